@@ -1,0 +1,399 @@
+"""ctypes bindings for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module, and only as the checker.  The product (visma_amd/) never
+does.
+
+Two libraries:
+  * libvisma_oracle.so  -- our C restatement (oracle/icp_oracle.c), always built.
+  * _ref/libvisma_ref.so -- the REAL reference path compiled from
+    /root/reference by oracle/Makefile `ref` (present only where it was built;
+    git-ignored; travels to the GPU box as a prebuilt file).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "libvisma_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libvisma_ref.so")
+REFERENCE_ROOT = "/root/reference"
+
+NSTATS = 38
+EST_POINT_TO_POINT = 1
+EST_POINT_TO_PLANE = 2
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def build(ref=True):
+    """Compile the oracle; compile oracle/_ref too when the reference is here."""
+    subprocess.check_call(["make", "-s", "-C", HERE])
+    if ref and os.path.isdir(REFERENCE_ROOT):
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+class VoResult(C.Structure):
+    _fields_ = [("T", C.c_double * 16), ("fitness", C.c_double),
+                ("rmse", C.c_double), ("k", C.c_int64), ("iters", C.c_int32)]
+
+
+class Result:
+    def __init__(self, T, fitness, rmse, k, iters=None, idx=None, trace=None):
+        self.T = np.array(T, dtype=np.float64).reshape(4, 4)
+        self.fitness = float(fitness)
+        self.rmse = float(rmse)
+        self.k = int(k)
+        self.iters = iters
+        self.idx = idx
+        self.trace = trace
+
+    def __repr__(self):
+        return "Result(k=%d fitness=%.6f rmse=%.6g iters=%s)" % (
+            self.k, self.fitness, self.rmse, self.iters)
+
+
+class Oracle:
+    """The C restatement (groups A `vo_*` and B `vk_*` of icp_oracle.h)."""
+
+    def __init__(self):
+        if not os.path.exists(ORACLE_SO):
+            build(ref=False)
+        self.lib = C.CDLL(ORACLE_SO)
+        L = self.lib
+        L.vo_nn_pass.restype = C.c_int64
+        L.vo_nn_pass_grid.restype = C.c_int64
+        L.vo_compute_rmse.restype = C.c_double
+        L.vk_nn_pass_f32.restype = C.c_int64
+        L.vk_nn_pass_f32_grid.restype = C.c_int64
+        L.vo_num_threads.restype = C.c_int
+
+    def num_threads(self):
+        return int(self.lib.vo_num_threads())
+
+    # ---- group A -------------------------------------------------------
+    def transform_points(self, xyz, T):
+        p = _f64(xyz, (-1, 3)).copy()
+        T = _f64(T, (16,))
+        self.lib.vo_transform_points(_ptr(p, _dp), C.c_int64(len(p)), _ptr(T, _dp))
+        return p
+
+    def transform_normals(self, nxyz, T):
+        p = _f64(nxyz, (-1, 3)).copy()
+        T = _f64(T, (16,))
+        self.lib.vo_transform_normals(_ptr(p, _dp), C.c_int64(len(p)), _ptr(T, _dp))
+        return p
+
+    def nn_pass(self, src, tgt, max_dist, grid=False):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        idx = np.empty(len(src), np.int32)
+        d2 = np.empty(len(src), np.float64)
+        e2 = C.c_double(0)
+        fn = self.lib.vo_nn_pass_grid if grid else self.lib.vo_nn_pass
+        k = fn(_ptr(src, _dp), C.c_int64(len(src)), _ptr(tgt, _dp),
+               C.c_int64(len(tgt)), C.c_double(max_dist), _ptr(idx, _ip),
+               _ptr(d2, _dp), C.byref(e2))
+        return int(k), idx, d2, e2.value
+
+    def nn_distance(self, src, tgt):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        d = np.empty(len(src), np.float64)
+        self.lib.vo_nn_distance(_ptr(src, _dp), C.c_int64(len(src)), _ptr(tgt, _dp),
+                                C.c_int64(len(tgt)), _ptr(d, _dp))
+        return d
+
+    def compute_rmse(self, src, tgt, corr):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+        return float(self.lib.vo_compute_rmse(_ptr(src, _dp), _ptr(tgt, _dp),
+                                              _ptr(corr, _ip), C.c_int64(len(corr))))
+
+    def umeyama(self, src, tgt, corr, with_scaling=False):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+        T = np.empty(16)
+        self.lib.vo_umeyama(_ptr(src, _dp), _ptr(tgt, _dp), _ptr(corr, _ip),
+                            C.c_int64(len(corr)), C.c_int(int(with_scaling)),
+                            _ptr(T, _dp))
+        return T.reshape(4, 4)
+
+    def jtj_jtr(self, src, tgt, corr, tgt_normals=None):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+        JTJ = np.empty(36); JTr = np.empty(6); r2 = C.c_double(0)
+        if tgt_normals is None:
+            self.lib.vo_jtj_jtr_point_to_point(
+                _ptr(src, _dp), _ptr(tgt, _dp), _ptr(corr, _ip),
+                C.c_int64(len(corr)), _ptr(JTJ, _dp), _ptr(JTr, _dp), C.byref(r2))
+        else:
+            n = _f64(tgt_normals, (-1, 3))
+            self.lib.vo_jtj_jtr_point_to_plane(
+                _ptr(src, _dp), _ptr(tgt, _dp), _ptr(n, _dp), _ptr(corr, _ip),
+                C.c_int64(len(corr)), _ptr(JTJ, _dp), _ptr(JTr, _dp), C.byref(r2))
+        return JTJ.reshape(6, 6), JTr, r2.value
+
+    def solve_jacobian_system(self, JTJ, JTr):
+        JTJ = _f64(JTJ, (36,)); JTr = _f64(JTr, (6,))
+        T = np.empty(16)
+        ok = self.lib.vo_solve_jacobian_system(_ptr(JTJ, _dp), _ptr(JTr, _dp), _ptr(T, _dp))
+        return bool(ok), T.reshape(4, 4)
+
+    def vector6d_to_matrix4d(self, x):
+        x = _f64(x, (6,)); T = np.empty(16)
+        self.lib.vo_vector6d_to_matrix4d(_ptr(x, _dp), _ptr(T, _dp))
+        return T.reshape(4, 4)
+
+    def point_to_plane_update(self, src, tgt, tgt_normals, corr):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3)); n = _f64(tgt_normals, (-1, 3))
+        corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+        T = np.empty(16)
+        self.lib.vo_point_to_plane_update(_ptr(src, _dp), _ptr(tgt, _dp), _ptr(n, _dp),
+                                          _ptr(corr, _ip), C.c_int64(len(corr)), _ptr(T, _dp))
+        return T.reshape(4, 4)
+
+    def _icp(self, fn, src, tgt, max_dist, init, max_iter, rel_fitness, rel_rmse,
+             with_scaling, grid, extra):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        init = _f64(np.eye(4) if init is None else init, (16,))
+        out = VoResult()
+        idx = np.empty(len(src), np.int32)
+        trace = np.full((max_iter + 1, 19), np.nan)
+        rc = fn(src, tgt, init, out, idx, trace)
+        res = Result(list(out.T), out.fitness, out.rmse, out.k, out.iters, idx,
+                     trace[:out.iters + 1])
+        res.rc = rc
+        return res
+
+    def registration_icp(self, src, tgt, max_dist, init=None, max_iter=30,
+                         rel_fitness=1e-6, rel_rmse=1e-6, estimator=EST_POINT_TO_POINT,
+                         with_scaling=False, tgt_normals=None, grid=True):
+        n = None if tgt_normals is None else _f64(tgt_normals, (-1, 3))
+
+        def call(s, t, i, out, idx, trace):
+            return self.lib.vo_registration_icp(
+                _ptr(s, _dp), C.c_int64(len(s)), _ptr(t, _dp), C.c_int64(len(t)),
+                _ptr(n, _dp), C.c_double(max_dist), _ptr(i, _dp), C.c_int(estimator),
+                C.c_int(int(with_scaling)), C.c_double(rel_fitness),
+                C.c_double(rel_rmse), C.c_int(max_iter), C.c_int(int(grid)),
+                C.byref(out), _ptr(idx, _ip), _ptr(trace, _dp))
+        return self._icp(call, src, tgt, max_dist, init, max_iter, rel_fitness,
+                         rel_rmse, with_scaling, grid, None)
+
+    def register_model_to_scene(self, model, scene, level, max_dist, max_iter=30,
+                                rel_fitness=1e-6, rel_rmse=1e-6, point_to_plane=False,
+                                scene_normals=None):
+        model = _f64(model, (-1, 3)); scene = _f64(scene, (-1, 3))
+        n = None if scene_normals is None else _f64(scene_normals, (-1, 3))
+        out = VoResult(); bl = C.c_int(-1)
+        self.lib.vo_register_model_to_scene(
+            _ptr(model, _dp), C.c_int64(len(model)), _ptr(scene, _dp),
+            C.c_int64(len(scene)), _ptr(n, _dp), C.c_int(level), C.c_double(max_dist),
+            C.c_int(int(point_to_plane)), C.c_double(rel_fitness), C.c_double(rel_rmse),
+            C.c_int(max_iter), C.byref(out), C.byref(bl))
+        r = Result(list(out.T), out.fitness, out.rmse, out.k, out.iters)
+        r.best_level = bl.value
+        return r
+
+    # SO(3)/SE(3)
+    def hat(self, u):
+        u = _f64(u, (3,)); M = np.empty(9)
+        self.lib.vo_hat(_ptr(u, _dp), _ptr(M, _dp))
+        return M.reshape(3, 3)
+
+    def rodrigues(self, w, jac=True):
+        w = _f64(w, (3,)); R = np.empty(9); D = np.empty(27) if jac else None
+        self.lib.vo_rodrigues(_ptr(w, _dp), _ptr(R, _dp), _ptr(D, _dp))
+        return R.reshape(3, 3), (D.reshape(9, 3) if jac else None)
+
+    def invrodrigues(self, R, jac=True):
+        R = _f64(R, (9,)); w = np.empty(3); D = np.empty(27) if jac else None
+        self.lib.vo_invrodrigues(_ptr(R, _dp), _ptr(w, _dp), _ptr(D, _dp))
+        return w, (D.reshape(3, 9) if jac else None)
+
+    def se3_compose(self, Ra, ta, Rb, tb):
+        Ra = _f64(Ra, (9,)); ta = _f64(ta, (3,)); Rb = _f64(Rb, (9,)); tb = _f64(tb, (3,))
+        R = np.empty(9); t = np.empty(3)
+        self.lib.vo_se3_compose(_ptr(Ra, _dp), _ptr(ta, _dp), _ptr(Rb, _dp), _ptr(tb, _dp),
+                                _ptr(R, _dp), _ptr(t, _dp))
+        return R.reshape(3, 3), t
+
+    def se3_act(self, R, t, v):
+        R = _f64(R, (9,)); t = _f64(t, (3,)); v = _f64(v, (3,)); o = np.empty(3)
+        self.lib.vo_se3_act(_ptr(R, _dp), _ptr(t, _dp), _ptr(v, _dp), _ptr(o, _dp))
+        return o
+
+    def se3_inv(self, R, t):
+        R = _f64(R, (9,)); t = _f64(t, (3,)); Ri = np.empty(9); ti = np.empty(3)
+        self.lib.vo_se3_inv(_ptr(R, _dp), _ptr(t, _dp), _ptr(Ri, _dp), _ptr(ti, _dp))
+        return Ri.reshape(3, 3), ti
+
+    def svd3(self, A):
+        A = _f64(A, (9,)); U = np.empty(9); s = np.empty(3); V = np.empty(9)
+        self.lib.vo_svd3(_ptr(A, _dp), _ptr(U, _dp), _ptr(s, _dp), _ptr(V, _dp))
+        return U.reshape(3, 3), s, V.reshape(3, 3)
+
+    # ---- group B (kernel specification) --------------------------------
+    def k_nn_pass(self, src32, tgt32, T32, r2f, grid=False):
+        src32 = np.ascontiguousarray(src32, np.float32)
+        tgt32 = np.ascontiguousarray(tgt32, np.float32)
+        T32 = np.ascontiguousarray(T32, np.float32).reshape(12)
+        ns, ss = src32.shape; nt, ts = tgt32.shape
+        idx = np.empty(ns, np.int32); d2 = np.empty(ns, np.float32)
+        fn = self.lib.vk_nn_pass_f32_grid if grid else self.lib.vk_nn_pass_f32
+        k = fn(_ptr(src32, _fp), C.c_int64(ns), C.c_int(ss), _ptr(tgt32, _fp),
+               C.c_int64(nt), C.c_int(ts), _ptr(T32, _fp), C.c_float(r2f),
+               _ptr(idx, _ip), _ptr(d2, _fp))
+        return int(k), idx, d2
+
+    def k_reduce_stats(self, src32, tgt32, idx, T64):
+        src32 = np.ascontiguousarray(src32, np.float32)
+        tgt32 = np.ascontiguousarray(tgt32, np.float32)
+        idx = np.ascontiguousarray(idx, np.int32)
+        T64 = _f64(T64, (-1,))[:12].copy()
+        st = np.empty(NSTATS)
+        self.lib.vk_reduce_stats(_ptr(src32, _fp), C.c_int64(src32.shape[0]),
+                                 C.c_int(src32.shape[1]), _ptr(tgt32, _fp),
+                                 C.c_int(tgt32.shape[1]), _ptr(idx, _ip),
+                                 _ptr(T64, _dp), _ptr(st, _dp))
+        return st
+
+    def k_solve_kabsch(self, stats, with_scaling=False):
+        st = _f64(stats, (NSTATS,)); T = np.empty(16)
+        self.lib.vk_solve_kabsch_from_stats(_ptr(st, _dp), C.c_int(int(with_scaling)),
+                                            _ptr(T, _dp))
+        return T.reshape(4, 4)
+
+    def k_solve_gn(self, stats):
+        st = _f64(stats, (NSTATS,)); T = np.empty(16)
+        ok = self.lib.vk_solve_gn_from_stats(_ptr(st, _dp), _ptr(T, _dp))
+        return bool(ok), T.reshape(4, 4)
+
+    def k_registration_icp(self, src, tgt, max_dist, init=None, max_iter=30,
+                           rel_fitness=1e-6, rel_rmse=1e-6, with_scaling=False,
+                           grid=True):
+        def call(s, t, i, out, idx, trace):
+            return self.lib.vk_registration_icp(
+                _ptr(s, _dp), C.c_int64(len(s)), _ptr(t, _dp), C.c_int64(len(t)),
+                C.c_double(max_dist), _ptr(i, _dp), C.c_int(int(with_scaling)),
+                C.c_double(rel_fitness), C.c_double(rel_rmse), C.c_int(max_iter),
+                C.c_int(int(grid)), C.byref(out), _ptr(idx, _ip), _ptr(trace, _dp))
+        return self._icp(call, src, tgt, max_dist, init, max_iter, rel_fitness,
+                         rel_rmse, with_scaling, grid, None)
+
+
+class Ref:
+    """The real reference (Open3D 0.3.0 RegistrationICP et al.), when built."""
+
+    @staticmethod
+    def available():
+        return os.path.exists(REF_SO)
+
+    def __init__(self):
+        if not os.path.exists(REF_SO):
+            raise FileNotFoundError(REF_SO + " (run `make -C oracle ref` where "
+                                    "/root/reference exists)")
+        self.lib = C.CDLL(REF_SO)
+        self.lib.ref_compute_rmse.restype = C.c_double
+
+    def registration_icp(self, src, tgt, max_dist, init=None, max_iter=30,
+                         rel_fitness=1e-6, rel_rmse=1e-6, estimator=EST_POINT_TO_POINT,
+                         with_scaling=False, src_normals=None, tgt_normals=None):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        sn = None if src_normals is None else _f64(src_normals, (-1, 3))
+        tn = None if tgt_normals is None else _f64(tgt_normals, (-1, 3))
+        init = _f64(np.eye(4) if init is None else init, (16,))
+        T = np.empty(16); fit = C.c_double(); rmse = C.c_double(); k = C.c_int64()
+        idx = np.empty(len(src), np.int32)
+        self.lib.ref_registration_icp(
+            _ptr(src, _dp), C.c_int64(len(src)), _ptr(sn, _dp), _ptr(tgt, _dp),
+            C.c_int64(len(tgt)), _ptr(tn, _dp), C.c_double(max_dist), _ptr(init, _dp),
+            C.c_int(estimator), C.c_int(int(with_scaling)), C.c_double(rel_fitness),
+            C.c_double(rel_rmse), C.c_int(max_iter), _ptr(T, _dp), C.byref(fit),
+            C.byref(rmse), _ptr(idx, _ip), C.byref(k))
+        return Result(T, fit.value, rmse.value, k.value, None, idx)
+
+    def evaluate_registration(self, src, tgt, max_dist, T=None):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        T = _f64(np.eye(4) if T is None else T, (16,))
+        fit = C.c_double(); rmse = C.c_double(); k = C.c_int64()
+        idx = np.empty(len(src), np.int32)
+        self.lib.ref_evaluate_registration(
+            _ptr(src, _dp), C.c_int64(len(src)), _ptr(tgt, _dp), C.c_int64(len(tgt)),
+            C.c_double(max_dist), _ptr(T, _dp), C.byref(fit), C.byref(rmse),
+            _ptr(idx, _ip), C.byref(k))
+        return Result(T, fit.value, rmse.value, k.value, None, idx)
+
+    def transform_points(self, xyz, T, normals=None):
+        p = _f64(xyz, (-1, 3)).copy()
+        n = None if normals is None else _f64(normals, (-1, 3)).copy()
+        T = _f64(T, (16,))
+        self.lib.ref_transform_points(_ptr(p, _dp), C.c_int64(len(p)), _ptr(n, _dp),
+                                      _ptr(T, _dp))
+        return (p, n) if normals is not None else p
+
+    def nn_distance(self, src, tgt):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        d = np.empty(len(src))
+        self.lib.ref_nn_distance(_ptr(src, _dp), C.c_int64(len(src)), _ptr(tgt, _dp),
+                                 C.c_int64(len(tgt)), _ptr(d, _dp))
+        return d
+
+    def compute_rmse(self, src, tgt, corr, estimator=EST_POINT_TO_POINT, tgt_normals=None):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        tn = None if tgt_normals is None else _f64(tgt_normals, (-1, 3))
+        corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+        return float(self.lib.ref_compute_rmse(
+            _ptr(src, _dp), C.c_int64(len(src)), _ptr(tgt, _dp), C.c_int64(len(tgt)),
+            _ptr(tn, _dp), _ptr(corr, _ip), C.c_int64(len(corr)), C.c_int(estimator)))
+
+    def compute_transformation(self, src, tgt, corr, estimator=EST_POINT_TO_POINT,
+                               with_scaling=False, tgt_normals=None):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        tn = None if tgt_normals is None else _f64(tgt_normals, (-1, 3))
+        corr = np.ascontiguousarray(corr, np.int32).reshape(-1, 2)
+        T = np.empty(16)
+        self.lib.ref_compute_transformation(
+            _ptr(src, _dp), C.c_int64(len(src)), _ptr(tgt, _dp), C.c_int64(len(tgt)),
+            _ptr(tn, _dp), _ptr(corr, _ip), C.c_int64(len(corr)), C.c_int(estimator),
+            C.c_int(int(with_scaling)), _ptr(T, _dp))
+        return T.reshape(4, 4)
+
+    def solve_jacobian_system(self, JTJ, JTr):
+        JTJ = _f64(JTJ, (36,)); JTr = _f64(JTr, (6,)); T = np.empty(16)
+        ok = self.lib.ref_solve_jacobian_system(_ptr(JTJ, _dp), _ptr(JTr, _dp), _ptr(T, _dp))
+        return bool(ok), T.reshape(4, 4)
+
+    def vector6d_to_matrix4d(self, x):
+        x = _f64(x, (6,)); T = np.empty(16)
+        self.lib.ref_vector6d_to_matrix4d(_ptr(x, _dp), _ptr(T, _dp))
+        return T.reshape(4, 4)
+
+    def hat(self, u):
+        u = _f64(u, (3,)); M = np.empty(9)
+        self.lib.ref_hat(_ptr(u, _dp), _ptr(M, _dp))
+        return M.reshape(3, 3)
+
+    def rodrigues(self, w, jac=True):
+        w = _f64(w, (3,)); R = np.empty(9); D = np.empty(27) if jac else None
+        self.lib.ref_rodrigues(_ptr(w, _dp), _ptr(R, _dp), _ptr(D, _dp))
+        return R.reshape(3, 3), (D.reshape(9, 3) if jac else None)
+
+    def invrodrigues(self, R, jac=True):
+        R = _f64(R, (9,)); w = np.empty(3); D = np.empty(27) if jac else None
+        self.lib.ref_invrodrigues(_ptr(R, _dp), _ptr(w, _dp), _ptr(D, _dp))
+        return w, (D.reshape(3, 9) if jac else None)
