@@ -1,0 +1,267 @@
+/*
+ * visma_icp.h -- C ABI of the MI355X-native ICP registration path.
+ *
+ * This is the drop-in boundary under the C++ shim (include/constrained_ICP.h,
+ * include/Core/Registration/Registration.h).  The reference has no C ABI or
+ * FFI for this path (it is a C++ virtual plugin called from a C++ free
+ * function), so each entry point cites the reference C++ interface it
+ * replaces.  Paths are relative to the reference root;
+ * O3D = thirdparty/Open3D/src.
+ *
+ * Conventions: every function returns a visma_icp_status (0 = OK) and never
+ * throws; 4x4 matrices are ROW-MAJOR double[16]; point arrays are AoS with a
+ * caller-given stride in elements; the caller owns every pointer it passes
+ * and the library copies what it keeps.  One ctx per host thread per GPU
+ * (thread-compatible, not thread-safe).
+ */
+#ifndef VISMA_ICP_H
+#define VISMA_ICP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define VISMA_ICP_API __attribute__((visibility("default")))
+#else
+#define VISMA_ICP_API
+#endif
+
+typedef struct visma_icp_ctx visma_icp_ctx;
+
+typedef enum {
+    VISMA_ICP_OK = 0,
+    VISMA_ICP_ERR_INVALID = 1,   /* bad argument                              */
+    VISMA_ICP_ERR_NO_DEVICE = 2, /* no usable gfx950 device / HIP unavailable */
+    VISMA_ICP_ERR_HIP = 3,       /* a HIP call failed (see last_error)        */
+    VISMA_ICP_ERR_RCCL = 4,      /* RCCL unavailable or a collective failed   */
+    VISMA_ICP_ERR_STATE = 5,     /* call order violated (e.g. no clouds set)  */
+    VISMA_ICP_ERR_ENGINE = 6     /* an injected engine callback failed        */
+} visma_icp_status;
+
+/* Per-iteration solve.  KABSCH is the reference's arithmetic
+ * (src/constrained_ICP.cpp:25-37 -> Eigen umeyama); the GN modes are single
+ * Gauss-Newton steps on the 6x6 normal equations
+ * (O3D/Core/Utility/Eigen.cpp:88-106; exp-map update via core/rodrigues.h:143). */
+typedef enum {
+    VISMA_ICP_SOLVER_KABSCH = 0,
+    VISMA_ICP_SOLVER_GN_EULER = 1,
+    VISMA_ICP_SOLVER_GN_EXPMAP = 2
+} visma_icp_solver;
+
+/* Nearest-neighbour search implementation (results are identical). */
+typedef enum {
+    VISMA_ICP_NN_AUTO = 0,
+    VISMA_ICP_NN_BRUTE = 1, /* brute force over the whole target           */
+    VISMA_ICP_NN_GRID = 2   /* radius-cell uniform grid (exact, radius-limited) */
+} visma_icp_nn_mode;
+
+#define VISMA_ICP_NSTATS 38
+/* Layout of the reduced statistics (one ICP iteration's normal equations):
+ *   [0]      K            number of correspondences
+ *   [1]      sum |p-q|^2
+ *   [2..22]  upper triangle of J^T J (6x6), row by row
+ *   [23..28] J^T r
+ *   [29..37] sum q p^T   (3x3 row-major, q = row)
+ * rows J = [p x e_k | e_k], r_k = (p-q).e_k (k = x,y,z), parameter order
+ * x = [alpha beta gamma tx ty tz] -- the convention of
+ * O3D/Core/Registration/TransformationEstimation.cpp:82-92 and
+ * O3D/Core/Utility/Eigen.cpp:137-182 (ComputeJTJandJTr). */
+
+/* Mirrors open3d::RegistrationResult (O3D/Core/Registration/Registration.h:81-94)
+ * plus bookkeeping. */
+typedef struct {
+    double transformation[16]; /* transformation_  (row-major)              */
+    double fitness;            /* fitness_                                  */
+    double inlier_rmse;        /* inlier_rmse_                              */
+    int64_t num_correspondences; /* correspondence_set_.size()              */
+    int32_t iterations;        /* solves performed                          */
+    int32_t nn_passes;         /* NN passes performed (= iterations + 1)    */
+} visma_icp_result;
+
+/* Kernel timing accumulated since the last reset (HIP events on the ctx's
+ * stream; only collected while profiling is enabled). */
+typedef struct {
+    double nn_ms;        /* total time in the NN-correspondence kernel       */
+    int64_t nn_launches;
+    double reduce_ms;    /* total time in the Jacobian/residual reduction    */
+    int64_t reduce_launches;
+    double aux_ms;       /* grid build / refine / other kernels              */
+    int64_t aux_launches;
+} visma_icp_timing;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Create a context on HIP device `device`.  Fails with NO_DEVICE (never falls
+ * back to the CPU) when there is no GPU.  Replaces the per-call state of
+ * open3d::RegistrationICP (KD-tree + source copy, Registration.cpp:159-165). */
+VISMA_ICP_API int visma_icp_create(visma_icp_ctx **out, int device);
+VISMA_ICP_API int visma_icp_destroy(visma_icp_ctx *ctx);
+/* Message of the last failure on ctx (or of the last failed create if NULL). */
+VISMA_ICP_API const char *visma_icp_last_error(const visma_icp_ctx *ctx);
+VISMA_ICP_API const char *visma_icp_version(void);
+
+/* ---- clouds ------------------------------------------------------------ */
+
+/* Upload both clouds from the reference's own storage: AoS float64 xyz
+ * (open3d::PointCloud::points_, O3D/Core/Geometry/PointCloud.h:86; stride 3).
+ * Centres both on the target centroid in f64, rounds to fp32 (design rule R2),
+ * and remembers the centre so every transform in this API stays in the
+ * caller's frame.  Replaces KDTreeFlann::SetGeometry + `PointCloud pcd = source`
+ * (Registration.cpp:160-162). */
+VISMA_ICP_API int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src_xyz,
+                                           int64_t ns, int src_stride,
+                                           const double *tgt_xyz, int64_t nt,
+                                           int tgt_stride);
+/* fp32 uploads, no centring (the caller's coordinates are used as they are). */
+VISMA_ICP_API int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt,
+                                       int stride_floats);
+VISMA_ICP_API int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns,
+                                       int stride_floats);
+/* Same from DEVICE memory (float4 xyzw per point, w ignored), copied D2D. */
+VISMA_ICP_API int visma_icp_set_target_device(visma_icp_ctx *ctx, const void *d_xyzw,
+                                              int64_t nt);
+VISMA_ICP_API int visma_icp_set_source_device(visma_icp_ctx *ctx, const void *d_xyzw,
+                                              int64_t ns);
+/* Target normals (AoS f64, stride 3) for the point-to-plane estimator. */
+VISMA_ICP_API int visma_icp_set_target_normals_f64(visma_icp_ctx *ctx,
+                                                   const double *nxyz, int64_t nt,
+                                                   int stride);
+
+/* ---- the three kernels, individually ----------------------------------- */
+
+/* Fused PointCloud::Transform (O3D/Core/Geometry/PointCloud.cpp:75-80) +
+ * GetRegistrationResultAndCorrespondences (Registration.cpp:41-96): apply T
+ * (caller frame) to the pristine source and find, per source point, the
+ * nearest target point with d^2 < (float)(max_dist^2).  Results stay on the
+ * device. */
+VISMA_ICP_API int visma_icp_nn_pass(visma_icp_ctx *ctx, const double T[16],
+                                    double max_dist);
+/* Per-correspondence Jacobian/residual + wavefront-shuffle reduction to the
+ * statistics above for the last nn_pass (replaces ComputeJTJandJTr,
+ * O3D/Core/Utility/Eigen.cpp:137-182, and the gathers of
+ * src/constrained_ICP.cpp:30-35).  Statistics are in the CENTRED frame. */
+VISMA_ICP_API int visma_icp_reduce(visma_icp_ctx *ctx,
+                                   double out_stats[VISMA_ICP_NSTATS]);
+/* Correspondences of the last nn_pass, sorted by source index
+ * (RegistrationResult::correspondence_set_).  Buffers hold >= ns entries;
+ * d2 may be NULL. */
+VISMA_ICP_API int visma_icp_get_correspondences(visma_icp_ctx *ctx, int32_t *src_idx,
+                                                int32_t *tgt_idx, float *d2,
+                                                int64_t *k);
+
+/* ---- host solves (pure functions; no ctx, no GPU) ----------------------- */
+
+/* Update from the statistics.  KABSCH: closed-form Umeyama
+ * (Eigen/src/Geometry/Umeyama.h:118-159) from the moments; GN_*: solve
+ * J^T J x = -J^T r with the |det| < 1e-6 guard (Eigen.cpp:35-56) and map x to
+ * SE(3) by Rz*Ry*Rx (Eigen.cpp:58-68) or by the exponential map
+ * (core/rodrigues.h:143-182).  Identity when K = 0 or the solve is rejected
+ * (src/constrained_ICP.cpp:29; TransformationEstimation.cpp:102). */
+VISMA_ICP_API int visma_icp_solve_from_stats(const double stats[VISMA_ICP_NSTATS],
+                                             int solver, int with_scaling,
+                                             double T_update[16]);
+
+/* ---- the full loop ------------------------------------------------------ */
+
+/* open3d::RegistrationICP (O3D/Core/Registration/Registration.h:102-107,
+ * .cpp:141-186) with estimator = cicp::TransformationEstimationPointToPoint4DoF
+ * (include/constrained_ICP.h:14-30).  Same iteration/termination semantics:
+ * max_iter+1 NN passes at most, stop when |dfitness| < rel_fitness and
+ * |drmse| < rel_rmse, result fields from the last NN pass.  max_dist <= 0
+ * returns OK with transformation = init and everything else 0
+ * (Registration.cpp:148-151). */
+VISMA_ICP_API int visma_icp_run(visma_icp_ctx *ctx, const double init[16],
+                                double max_dist, int max_iter, double rel_fitness,
+                                double rel_rmse, int solver, int with_scaling,
+                                visma_icp_result *out);
+/* Point-to-plane estimator (TransformationEstimation.cpp:61-103) on the same
+ * reduction; needs set_target_normals_f64, else returns OK with
+ * transformation = init (Registration.cpp:152-157). */
+VISMA_ICP_API int visma_icp_run_point_to_plane(visma_icp_ctx *ctx, const double init[16],
+                                               double max_dist, int max_iter,
+                                               double rel_fitness, double rel_rmse,
+                                               visma_icp_result *out);
+
+/* feh::RegisterModelToScene (include/tool.h:40-42, src/annotation.cpp:29-64):
+ * `level` yaw initialisations R_y(2 pi i / level), a full ICP from each (all
+ * in flight together on the GPU), keep the first with strictly the most
+ * correspondences.  per_level (may be NULL) receives all `level` results. */
+VISMA_ICP_API int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist,
+                                          int max_iter, double rel_fitness,
+                                          double rel_rmse, int solver,
+                                          visma_icp_result *best, int *best_level,
+                                          visma_icp_result *per_level);
+
+/* ---- batched small problems (AnnotationTool loop, src/annotation.cpp:103-168) */
+
+typedef struct {
+    const double *src_xyz; int64_t ns; /* AoS f64, stride 3 */
+    const double *tgt_xyz; int64_t nt;
+    double init[16];
+    double max_dist;
+} visma_icp_problem;
+
+/* n independent ICPs advanced in lock step, one grid launch per iteration. */
+VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs,
+                                      int n, int max_iter, double rel_fitness,
+                                      double rel_rmse, int solver,
+                                      visma_icp_result *out);
+
+/* ---- options / measurement --------------------------------------------- */
+VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
+VISMA_ICP_API int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled);
+VISMA_ICP_API int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out,
+                                       int reset);
+/* Compile-time tile constants, for roofline accounting: S_TILE source points
+ * per workgroup, target chunk staged per LDS fill, workgroup size. */
+VISMA_ICP_API int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block);
+/* Launch geometry of the last nn_pass: source tiles x target splits. */
+VISMA_ICP_API int visma_icp_get_launch_config(visma_icp_ctx *ctx, int *src_tiles,
+                                              int *tgt_splits);
+
+/* ---- multi-GPU (one process per GPU; source-sharded) -------------------- */
+
+#define VISMA_ICP_UNIQUE_ID_BYTES 128
+/* Rank 0 creates the id, the host program broadcasts it (any transport), every
+ * rank calls comm_init.  After that visma_icp_reduce / visma_icp_run sum the
+ * per-shard statistics with ONE ncclAllReduce(38 x f64) per iteration over
+ * xGMI; every rank solves the same system and holds the same transform.
+ * RCCL is loaded at run time (dlopen) -- a single-GPU build needs none. */
+VISMA_ICP_API int visma_icp_comm_unique_id(void *out_id /* 128 bytes */);
+VISMA_ICP_API int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks,
+                                      const void *unique_id);
+/* Alternative to RCCL: the host supplies the all-reduce (used by the CPU
+ * `gloo` tests).  fn must sum `n` doubles in place across ranks. */
+typedef int (*visma_icp_allreduce_fn)(void *user, double *inout, int n);
+VISMA_ICP_API int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn,
+                                          void *user, int rank, int nranks);
+/* Total source points over all ranks (fitness denominator); 0 = local ns. */
+VISMA_ICP_API int visma_icp_set_global_source_count(visma_icp_ctx *ctx, int64_t ns_total);
+
+/* ---- engine injection (test seam) --------------------------------------- */
+
+/* The driver (centring, loop, solve, stop test, sharding) runs over an
+ * "engine" that owns the clouds and produces statistics.  visma_icp_create
+ * installs the HIP engine, the only one the product ships.  This entry point
+ * lets the CPU test-suite drive the same host logic with an engine of its
+ * own; the product never calls it. */
+typedef struct {
+    int (*set_source)(void *user, const float *xyzw, int64_t ns);
+    int (*set_target)(void *user, const float *xyzw, int64_t nt);
+    int (*set_target_normals)(void *user, const float *nxyzw, int64_t nt);
+    int (*nn_pass)(void *user, const double T_centred[16], double max_dist);
+    int (*reduce)(void *user, const double T_centred[16], int point_to_plane,
+                  double stats[VISMA_ICP_NSTATS]);
+    int (*get_correspondences)(void *user, int32_t *tgt_idx_per_src, float *d2);
+} visma_icp_engine;
+VISMA_ICP_API int visma_icp_create_with_engine(visma_icp_ctx **out,
+                                               const visma_icp_engine *engine,
+                                               void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VISMA_ICP_H */

@@ -1,0 +1,166 @@
+"""GPU parity tests for the HIP kernels, through the C ABI (pytest -m gpu).
+
+The checker is the CPU oracle (oracle/icp_oracle.c): correspondences and fp32
+distances must match its kernel specification BIT FOR BIT; the f64 statistics
+to summation-order accuracy; the final SE(3) within 1e-5 relative Frobenius
+of the f64 reference algorithm (north_star tolerance).
+"""
+import numpy as np
+import pytest
+
+from visma_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+TOL_T = 1e-5  # north_star: final SE(3) within 1e-5 relative Frobenius of the CPU reference
+
+
+def _rand_T(rng, ang=0.2, tr=0.1):
+    w = rng.standard_normal(3)
+    w *= ang / np.linalg.norm(w)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    return synth.make_T(R, rng.standard_normal(3) * tr)
+
+
+def _clouds(rng, ns, nt, spread=1.0):
+    tgt = (rng.random((nt, 3)) * 2 - 1) * spread
+    src = (rng.random((ns, 3)) * 2 - 1) * spread
+    return src.astype(np.float32), tgt.astype(np.float32)
+
+
+@pytest.mark.parametrize("ns,nt,radius", [
+    (1000, 777, 0.3),       # ragged, single chunk tail
+    (5000, 20000, 0.075),   # C1/C2 shape
+    (257, 513, 0.5),        # just past tile / chunk boundaries
+    (70000, 3000, 0.1),     # large-source path (8 points per thread)
+    (1, 1, 10.0),
+    (3, 100000, 0.05),
+])
+def test_nn_bit_exact(gpu_ctx, oracle, ns, nt, radius):
+    rng = np.random.default_rng(ns * 31 + nt)
+    src, tgt = _clouds(rng, ns, nt)
+    T = _rand_T(rng, 0.1, 0.05)
+    gpu_ctx.set_target(tgt)
+    gpu_ctx.set_source(src)
+    gpu_ctx.nn_pass(T, radius)
+    st = gpu_ctx.reduce()
+    idx = gpu_ctx.correspondence_index()
+    si, ti, d2 = gpu_ctx.get_correspondences()
+    T32 = T[:3, :].astype(np.float32)
+    r2f = np.float32(radius * radius)
+    k, oidx, od2 = oracle.k_nn_pass(src, tgt, T32, r2f, grid=(ns * nt > 5e7))
+    assert np.array_equal(idx, oidx)
+    assert k == len(si) == int(round(st[0]))
+    assert np.array_equal(d2.view(np.uint32), od2[oidx >= 0].view(np.uint32))
+    ost = oracle.k_reduce_stats(src, tgt, oidx, T[:3, :])
+    scale = np.maximum(np.abs(ost), 1.0)
+    assert np.max(np.abs(st - ost) / scale) < 1e-9
+
+
+def test_nn_ties_lowest_index_and_strict_radius(gpu_ctx, oracle):
+    # duplicated targets -> exact ties; a target exactly at distance r -> rejected
+    tgt = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 0], [1, 0, 0], [0.5, 0, 0]] * 200, np.float32)
+    src = np.array([[0.01, 0, 0], [0.99, 0, 0], [0.25, 0, 0], [5, 5, 5]], np.float32)
+    gpu_ctx.set_target(tgt)
+    gpu_ctx.set_source(src)
+    gpu_ctx.nn_pass(np.eye(4), 0.25)
+    gpu_ctx.reduce()
+    idx = gpu_ctx.correspondence_index()
+    _, oidx, _ = oracle.k_nn_pass(src, tgt, np.eye(4)[:3].astype(np.float32), np.float32(0.0625))
+    assert np.array_equal(idx, oidx)
+    assert idx[0] == 0 and idx[1] == 1 and idx[3] == -1
+    # |0.25 - 0.5|^2 == 0.0625 == r^2 -> strict '<' rejects both neighbours of src[2]
+    assert idx[2] == -1
+
+
+def test_no_correspondences_and_bad_radius(gpu_ctx):
+    rng = np.random.default_rng(5)
+    src, tgt = _clouds(rng, 500, 800)
+    gpu_ctx.set_clouds_f64(src.astype(np.float64) + 100.0, tgt.astype(np.float64))
+    r = gpu_ctx.run(None, 0.01, 5, 0, 0)
+    assert r.num_correspondences == 0 and r.fitness_ == 0.0 and r.inlier_rmse_ == 0.0
+    assert np.allclose(r.transformation_, np.eye(4), atol=1e-12)   # identity updates
+    init = _rand_T(rng)
+    r = gpu_ctx.run(init, 0.0, 5)                                   # Registration.cpp:148-151
+    assert np.array_equal(r.transformation_, init) and r.iterations == 0
+
+
+def test_empty_clouds(gpu_ctx):
+    rng = np.random.default_rng(6)
+    src, tgt = _clouds(rng, 10, 10)
+    gpu_ctx.set_clouds_f64(src.astype(np.float64), np.zeros((0, 3)))
+    r = gpu_ctx.run(None, 0.5, 3, 0, 0)
+    assert r.num_correspondences == 0
+    gpu_ctx.set_clouds_f64(np.zeros((0, 3)), tgt.astype(np.float64))
+    r = gpu_ctx.run(None, 0.5, 3, 0, 0)
+    assert r.num_correspondences == 0
+
+
+@pytest.mark.parametrize("offset", [None, (3.0, -2.0, 1.5)])
+def test_run_parity_5k_20k(gpu_ctx, oracle, offset):
+    src, tgt, Tgt, _ = synth.make_pair(5000, 20000, offset=offset)
+    gpu_ctx.set_clouds_f64(src, tgt)
+    r = gpu_ctx.run(None, 0.075, 20, 0, 0)
+    o = oracle.registration_icp(src, tgt, 0.075, max_iter=20, rel_fitness=0, rel_rmse=0)
+    k = oracle.k_registration_icp(src, tgt, 0.075, max_iter=20, rel_fitness=0, rel_rmse=0)
+    assert r.iterations == 20 and r.nn_passes == 21
+    assert synth.rel_frobenius(r.transformation_, o.T) < TOL_T
+    assert synth.rel_frobenius(r.transformation_, k.T) < 1e-9      # same arithmetic
+    assert r.num_correspondences == o.k
+    idx = gpu_ctx.correspondence_index()
+    assert np.mean(idx == o.idx) >= 0.9999
+    assert abs(r.fitness_ - o.fitness) < 1e-12 and abs(r.inlier_rmse_ - o.rmse) < 1e-6
+
+
+def test_run_parity_64k_256k(gpu_ctx, oracle):
+    src, tgt, Tgt, radius = synth.make_pair(65536, 262144)
+    gpu_ctx.set_clouds_f64(src, tgt)
+    r = gpu_ctx.run(None, radius, 10, 0, 0)
+    o = oracle.registration_icp(src, tgt, radius, max_iter=10, rel_fitness=0, rel_rmse=0, grid=True)
+    assert synth.rel_frobenius(r.transformation_, o.T) < TOL_T
+    assert abs(r.num_correspondences - o.k) <= max(2, int(1e-4 * o.k))
+
+
+def test_termination_semantics(gpu_ctx, oracle):
+    src, tgt, _, _ = synth.make_pair(4000, 8000)
+    gpu_ctx.set_clouds_f64(src, tgt)
+    r = gpu_ctx.run(None, 0.075, 60, 1e-6, 1e-6)
+    o = oracle.registration_icp(src, tgt, 0.075, max_iter=60, rel_fitness=1e-6, rel_rmse=1e-6)
+    assert r.iterations < 60
+    assert abs(r.iterations - o.iters) <= 1
+    assert synth.rel_frobenius(r.transformation_, o.T) < 1e-4
+
+
+def test_solver_modes_converge_to_same_fixed_point(gpu_ctx):
+    src, tgt, _, _ = synth.make_pair(3000, 9000)
+    gpu_ctx.set_clouds_f64(src, tgt)
+    a = gpu_ctx.run(None, 0.075, 150, 0, 0, solver=0)
+    b = gpu_ctx.run(None, 0.075, 150, 0, 0, solver=1)
+    c = gpu_ctx.run(None, 0.075, 150, 0, 0, solver=2)
+    assert synth.rel_frobenius(b.transformation_, a.transformation_) < 1e-6
+    assert synth.rel_frobenius(c.transformation_, a.transformation_) < 1e-6
+
+
+def test_with_scaling(gpu_ctx, oracle):
+    src, tgt, _, _ = synth.make_pair(3000, 9000)
+    src = src * 1.02
+    gpu_ctx.set_clouds_f64(src, tgt)
+    r = gpu_ctx.run(None, 0.1, 15, 0, 0, with_scaling=True)
+    o = oracle.registration_icp(src, tgt, 0.1, max_iter=15, rel_fitness=0, rel_rmse=0, with_scaling=True)
+    assert synth.rel_frobenius(r.transformation_, o.T) < TOL_T
+
+
+def test_repeatable_bitwise(gpu_ctx):
+    src, tgt, _, _ = synth.make_pair(6000, 15000)
+    gpu_ctx.set_clouds_f64(src, tgt)
+    a = gpu_ctx.run(None, 0.075, 10, 0, 0)
+    b = gpu_ctx.run(None, 0.075, 10, 0, 0)
+    assert np.array_equal(a.transformation_, b.transformation_)
+    assert a.inlier_rmse_ == b.inlier_rmse_
+
+
+def test_create_fails_loudly_on_bad_device(lib):
+    with pytest.raises(lib.IcpError):
+        lib.Context(99)

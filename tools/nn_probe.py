@@ -1,0 +1,43 @@
+"""Time the NN-correspondence and reduction kernels at several sizes (GPU box)."""
+import sys
+import os
+import time
+import json
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from visma_amd import _lib, synth
+
+
+def main():
+    sizes = [(5000, 20000), (16384, 65536), (65536, 262144), (65536, 1048576),
+             (65536, 4194304), (262144, 4194304)]
+    if len(sys.argv) > 1:
+        sizes = [tuple(int(x) for x in a.split("x")) for a in sys.argv[1:]]
+    ctx = _lib.Context(0)
+    ctx.set_profiling(True)
+    out = []
+    for ns, nt in sizes:
+        src, tgt, T, r = synth.make_pair(ns, nt)
+        ctx.set_clouds_f64(src, tgt)
+        ctx.run(None, r, 1, 0, 0)            # warm
+        ctx.get_timing(reset=True)
+        iters = 5 if ns * nt > 1e11 else 10
+        t0 = time.time()
+        res = ctx.run(None, r, iters, 0, 0)
+        wall = time.time() - t0
+        tm = ctx.get_timing(reset=True)
+        nn = tm["nn_ms"] / tm["nn_launches"]
+        rd = tm["reduce_ms"] / tm["reduce_launches"]
+        pairs = ns * nt
+        rec = dict(ns=ns, nt=nt, radius=r, launch=ctx.launch_config(), nn_ms=nn, reduce_ms=rd,
+                   gpairs_per_s=pairs / nn / 1e6, tflops_8=8 * pairs / nn / 1e9,
+                   iter_ms_wall=wall / (iters + 1) * 1e3, K=res.num_correspondences,
+                   err_vs_gt=synth.rel_frobenius(res.transformation_, T))
+        print(json.dumps(rec), flush=True)
+        out.append(rec)
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,338 @@
+"""ctypes binding of the C ABI in include/visma_icp.h (libvisma_icp.so).
+
+The library is the product: HIP kernels for gfx950 + the C++ host driver.
+There is no Python or CPU implementation behind it -- if the shared library
+is missing, or no GPU is visible when a context is created, this module
+raises; it never falls back.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libvisma_icp.so")
+
+NSTATS = 38
+UNIQUE_ID_BYTES = 128
+SOLVER_KABSCH, SOLVER_GN_EULER, SOLVER_GN_EXPMAP = 0, 1, 2
+NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
+OK = 0
+ERR_NAMES = {1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "RCCL", 5: "STATE", 6: "ENGINE"}
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+class IcpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("visma_icp error %d (%s): %s" % (code, ERR_NAMES.get(code, "?"), msg))
+        self.code = code
+
+
+class CResult(C.Structure):
+    _fields_ = [("transformation", C.c_double * 16), ("fitness", C.c_double),
+                ("inlier_rmse", C.c_double), ("num_correspondences", C.c_int64),
+                ("iterations", C.c_int32), ("nn_passes", C.c_int32)]
+
+
+class CTiming(C.Structure):
+    _fields_ = [("nn_ms", C.c_double), ("nn_launches", C.c_int64),
+                ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
+                ("aux_ms", C.c_double), ("aux_launches", C.c_int64)]
+
+
+class CProblem(C.Structure):
+    _fields_ = [("src_xyz", _dp), ("ns", C.c_int64), ("tgt_xyz", _dp), ("nt", C.c_int64),
+                ("init", C.c_double * 16), ("max_dist", C.c_double)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
+ENG_SET = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int64)
+ENG_NN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_double)
+ENG_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int, _dp)
+ENG_CORR = C.CFUNCTYPE(C.c_int, C.c_void_p, _ip, _fp)
+
+
+class CEngine(C.Structure):
+    _fields_ = [("set_source", ENG_SET), ("set_target", ENG_SET),
+                ("set_target_normals", ENG_SET), ("nn_pass", ENG_NN),
+                ("reduce", ENG_REDUCE), ("get_correspondences", ENG_CORR)]
+
+
+_lib = None
+
+
+def load():
+    """Load libvisma_icp.so (raises if it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m visma_amd.build` (hipcc, gfx950). "
+            "visma_amd has no non-HIP implementation." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.visma_icp_last_error.restype = C.c_char_p
+    L.visma_icp_last_error.argtypes = [C.c_void_p]
+    L.visma_icp_version.restype = C.c_char_p
+    L.visma_icp_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.visma_icp_create_with_engine.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CEngine), C.c_void_p]
+    L.visma_icp_destroy.argtypes = [C.c_void_p]
+    L.visma_icp_set_clouds_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int]
+    L.visma_icp_set_target.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
+    L.visma_icp_set_source.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
+    L.visma_icp_set_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.visma_icp_set_source_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.visma_icp_set_target_normals_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int]
+    L.visma_icp_nn_pass.argtypes = [C.c_void_p, _dp, C.c_double]
+    L.visma_icp_reduce.argtypes = [C.c_void_p, _dp]
+    L.visma_icp_get_correspondences.argtypes = [C.c_void_p, _ip, _ip, _fp, C.POINTER(C.c_int64)]
+    L.visma_icp_solve_from_stats.argtypes = [_dp, C.c_int, C.c_int, _dp]
+    L.visma_icp_run.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_double, C.c_double,
+                                C.c_int, C.c_int, C.POINTER(CResult)]
+    L.visma_icp_run_point_to_plane.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_double,
+                                               C.c_double, C.POINTER(CResult)]
+    L.visma_icp_run_yaw_sweep.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double,
+                                          C.c_double, C.c_int, C.POINTER(CResult),
+                                          C.POINTER(C.c_int), C.POINTER(CResult)]
+    L.visma_icp_run_batch.argtypes = [C.c_void_p, C.POINTER(CProblem), C.c_int, C.c_int,
+                                      C.c_double, C.c_double, C.c_int, C.POINTER(CResult)]
+    L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_get_timing.argtypes = [C.c_void_p, C.POINTER(CTiming), C.c_int]
+    L.visma_icp_get_tile_config.argtypes = [C.POINTER(C.c_int)] * 3
+    L.visma_icp_get_launch_config.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.visma_icp_comm_unique_id.argtypes = [C.c_void_p]
+    L.visma_icp_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.visma_icp_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]
+    L.visma_icp_set_global_source_count.argtypes = [C.c_void_p, C.c_int64]
+    _lib = L
+    return L
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if shape is None else a.reshape(shape)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Result:
+    """Mirror of open3d::RegistrationResult (+ iteration counts)."""
+
+    def __init__(self, c):
+        self.transformation_ = np.array(list(c.transformation), dtype=np.float64).reshape(4, 4)
+        self.fitness_ = float(c.fitness)
+        self.inlier_rmse_ = float(c.inlier_rmse)
+        self.num_correspondences = int(c.num_correspondences)
+        self.iterations = int(c.iterations)
+        self.nn_passes = int(c.nn_passes)
+        self.correspondence_set_ = None
+
+    def __repr__(self):
+        return ("RegistrationResult(fitness=%.6f, inlier_rmse=%.6g, K=%d, iterations=%d)" %
+                (self.fitness_, self.inlier_rmse_, self.num_correspondences, self.iterations))
+
+
+class Context:
+    """One ICP context = one HIP stream on one GPU (visma_icp_ctx)."""
+
+    def __init__(self, device=0, engine=None):
+        self.L = load()
+        self._h = C.c_void_p()
+        self._keep = []
+        if engine is None:
+            rc = self.L.visma_icp_create(C.byref(self._h), int(device))
+        else:
+            self._keep.append(engine)
+            rc = self.L.visma_icp_create_with_engine(C.byref(self._h), C.byref(engine), None)
+        if rc != OK:
+            msg = self.L.visma_icp_last_error(None)
+            raise IcpError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.L.visma_icp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != OK:
+            msg = self.L.visma_icp_last_error(self._h)
+            raise IcpError(rc, msg.decode() if msg else "")
+
+    # ---- clouds ----
+    def set_clouds_f64(self, src, tgt):
+        src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
+        self._chk(self.L.visma_icp_set_clouds_f64(self._h, _p(src, _dp), len(src), 3,
+                                                  _p(tgt, _dp), len(tgt), 3))
+        self.ns, self.nt = len(src), len(tgt)
+
+    def set_target(self, xyz):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        self._chk(self.L.visma_icp_set_target(self._h, _p(a, _fp), a.shape[0], a.shape[1]))
+        self.nt = a.shape[0]
+
+    def set_source(self, xyz):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        self._chk(self.L.visma_icp_set_source(self._h, _p(a, _fp), a.shape[0], a.shape[1]))
+        self.ns = a.shape[0]
+
+    def set_target_device(self, ptr, n):
+        self._chk(self.L.visma_icp_set_target_device(self._h, C.c_void_p(ptr), n))
+        self.nt = n
+
+    def set_source_device(self, ptr, n):
+        self._chk(self.L.visma_icp_set_source_device(self._h, C.c_void_p(ptr), n))
+        self.ns = n
+
+    def set_target_normals_f64(self, n):
+        n = _f64(n, (-1, 3))
+        self._chk(self.L.visma_icp_set_target_normals_f64(self._h, _p(n, _dp), len(n), 3))
+
+    # ---- kernels ----
+    def nn_pass(self, T, max_dist):
+        T = _f64(T, (16,))
+        self._chk(self.L.visma_icp_nn_pass(self._h, _p(T, _dp), float(max_dist)))
+
+    def reduce(self):
+        st = np.empty(NSTATS)
+        self._chk(self.L.visma_icp_reduce(self._h, _p(st, _dp)))
+        return st
+
+    def get_correspondences(self):
+        si = np.empty(max(self.ns, 1), np.int32); ti = np.empty(max(self.ns, 1), np.int32)
+        d2 = np.empty(max(self.ns, 1), np.float32); k = C.c_int64(0)
+        self._chk(self.L.visma_icp_get_correspondences(self._h, _p(si, _ip), _p(ti, _ip),
+                                                       _p(d2, _fp), C.byref(k)))
+        k = k.value
+        return si[:k].copy(), ti[:k].copy(), d2[:k].copy()
+
+    def correspondence_index(self):
+        """Per-source-point target index (-1 = none), like the oracle's idx."""
+        si, ti, _ = self.get_correspondences()
+        idx = np.full(self.ns, -1, np.int32)
+        idx[si] = ti
+        return idx
+
+    # ---- loops ----
+    def run(self, init=None, max_dist=0.05, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+            solver=SOLVER_KABSCH, with_scaling=False):
+        init = _f64(np.eye(4) if init is None else init, (16,))
+        out = CResult()
+        self._chk(self.L.visma_icp_run(self._h, _p(init, _dp), float(max_dist), int(max_iter),
+                                       float(rel_fitness), float(rel_rmse), int(solver),
+                                       int(bool(with_scaling)), C.byref(out)))
+        return Result(out)
+
+    def run_point_to_plane(self, init=None, max_dist=0.05, max_iter=30, rel_fitness=1e-6,
+                           rel_rmse=1e-6):
+        init = _f64(np.eye(4) if init is None else init, (16,))
+        out = CResult()
+        self._chk(self.L.visma_icp_run_point_to_plane(self._h, _p(init, _dp), float(max_dist),
+                                                      int(max_iter), float(rel_fitness),
+                                                      float(rel_rmse), C.byref(out)))
+        return Result(out)
+
+    def run_yaw_sweep(self, level, max_dist, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                      solver=SOLVER_KABSCH):
+        best = CResult(); bl = C.c_int(-1); per = (CResult * level)()
+        self._chk(self.L.visma_icp_run_yaw_sweep(self._h, int(level), float(max_dist),
+                                                 int(max_iter), float(rel_fitness),
+                                                 float(rel_rmse), int(solver), C.byref(best),
+                                                 C.byref(bl), per))
+        return Result(best), bl.value, [Result(p) for p in per]
+
+    def run_batch(self, problems, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                  solver=SOLVER_KABSCH):
+        n = len(problems)
+        arr = (CProblem * max(n, 1))(); keep = []
+        for i, (src, tgt, init, r) in enumerate(problems):
+            s = _f64(src, (-1, 3)); t = _f64(tgt, (-1, 3)); keep += [s, t]
+            arr[i].src_xyz = _p(s, _dp); arr[i].ns = len(s)
+            arr[i].tgt_xyz = _p(t, _dp); arr[i].nt = len(t)
+            arr[i].init = (C.c_double * 16)(*_f64(np.eye(4) if init is None else init, (16,)))
+            arr[i].max_dist = float(r)
+        out = (CResult * max(n, 1))()
+        self._chk(self.L.visma_icp_run_batch(self._h, arr, n, int(max_iter), float(rel_fitness),
+                                             float(rel_rmse), int(solver), out))
+        return [Result(out[i]) for i in range(n)]
+
+    # ---- options ----
+    def set_nn_mode(self, mode):
+        self._chk(self.L.visma_icp_set_nn_mode(self._h, int(mode)))
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.visma_icp_set_profiling(self._h, int(bool(on))))
+
+    def get_timing(self, reset=False):
+        t = CTiming()
+        self._chk(self.L.visma_icp_get_timing(self._h, C.byref(t), int(bool(reset))))
+        return {k: getattr(t, k) for k, _ in CTiming._fields_}
+
+    def launch_config(self):
+        a = C.c_int(); b = C.c_int()
+        self._chk(self.L.visma_icp_get_launch_config(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    # ---- multi-GPU ----
+    def comm_init(self, rank, nranks, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        self._chk(self.L.visma_icp_comm_init(self._h, int(rank), int(nranks), buf))
+
+    def set_allreduce(self, fn, rank, nranks):
+        """fn(np.ndarray[38]) must sum in place across ranks (host all-reduce)."""
+        def tramp(_user, ptr, n):
+            try:
+                a = np.ctypeslib.as_array(ptr, shape=(n,))
+                fn(a)
+                return 0
+            except Exception:
+                return 1
+        cb = ALLREDUCE_FN(tramp)
+        self._keep.append(cb)
+        self._chk(self.L.visma_icp_set_allreduce(self._h, cb, None, int(rank), int(nranks)))
+
+    def set_global_source_count(self, n):
+        self._chk(self.L.visma_icp_set_global_source_count(self._h, int(n)))
+
+
+def comm_unique_id():
+    L = load()
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = L.visma_icp_comm_unique_id(buf)
+    if rc != OK:
+        msg = L.visma_icp_last_error(None)
+        raise IcpError(rc, msg.decode() if msg else "")
+    return bytes(buf.raw)
+
+
+def tile_config():
+    L = load()
+    a = C.c_int(); b = C.c_int(); c = C.c_int()
+    L.visma_icp_get_tile_config(C.byref(a), C.byref(b), C.byref(c))
+    return {"s_tile": a.value, "t_chunk": b.value, "block": c.value}
+
+
+def solve_from_stats(stats, solver=SOLVER_KABSCH, with_scaling=False):
+    L = load()
+    st = _f64(stats, (NSTATS,)); T = np.empty(16)
+    rc = L.visma_icp_solve_from_stats(_p(st, _dp), int(solver), int(bool(with_scaling)), _p(T, _dp))
+    if rc != OK:
+        raise IcpError(rc, "solve_from_stats")
+    return T.reshape(4, 4)

@@ -1,0 +1,44 @@
+"""Build the gfx950 shared library (HIP kernels + C ABI) in-tree with hipcc."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libvisma_icp.so")
+SOURCES = ["kernels.hip", "driver.cpp"]
+HEADERS = ["kernels.h", "so3.h", "host_math.hpp", os.path.join("..", "..", "include", "visma_icp.h")]
+
+
+def hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found (need ROCm; this package has no other backend)")
+    return exe
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_lib(force=False, verbose=False):
+    """Compile visma_amd/lib/libvisma_icp.so for gfx950 (cross-compiles without a GPU)."""
+    if not force and not is_stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
+           "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

@@ -1,0 +1,838 @@
+// driver.cpp -- host side of the MI355X-native ICP path and its C ABI.
+//
+// Structure:
+//   Engine        owns the clouds and produces the per-iteration statistics
+//     HipEngine   the product engine: gfx950 kernels on one HIP stream
+//     HookEngine  engine injected through visma_icp_create_with_engine (tests)
+//   visma_icp_ctx the driver: centring, the RegistrationICP loop
+//                 (O3D/Core/Registration/Registration.cpp:141-186), the tiny f64
+//                 solves, yaw sweep, batching, multi-GPU reduction.
+// No CPU fallback exists: without a GPU visma_icp_create fails.
+#include "../../include/visma_icp.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "host_math.hpp"
+#include "kernels.h"
+
+using namespace visma;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            err_ = std::string(#expr) + ": " + hipGetErrorString(e__);             \
+            return VISMA_ICP_ERR_HIP;                                              \
+        }                                                                          \
+    } while (0)
+
+// ---- RCCL, loaded at run time ------------------------------------------------
+struct NcclId { char internal[VISMA_ICP_UNIQUE_ID_BYTES]; };
+typedef void *NcclComm;
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(NcclComm *, int, NcclId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string error;
+    bool load()
+    {
+        if (handle) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (handle) break;
+        }
+        if (!handle) { error = std::string("dlopen(librccl): ") + dlerror(); return false; }
+        GetUniqueId = (decltype(GetUniqueId))dlsym(handle, "ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))dlsym(handle, "ncclCommInitRank");
+        AllReduce = (decltype(AllReduce))dlsym(handle, "ncclAllReduce");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllReduce || !CommDestroy) {
+            error = "librccl: missing symbols";
+            return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+constexpr int kNcclFloat64 = 8;  // ncclFloat64 / ncclDouble (rccl.h)
+constexpr int kNcclSum = 0;      // ncclSum
+
+// ---- engines --------------------------------------------------------------------
+class Engine {
+public:
+    virtual ~Engine() {}
+    virtual int set_source(const float *xyzw, int64_t ns) = 0;
+    virtual int set_target(const float *xyzw, int64_t nt) = 0;
+    virtual int set_target_normals(const float *nxyzw, int64_t nt) = 0;
+    virtual int set_source_device(const void *, int64_t) { err_ = "not supported by this engine"; return VISMA_ICP_ERR_STATE; }
+    virtual int set_target_device(const void *, int64_t) { err_ = "not supported by this engine"; return VISMA_ICP_ERR_STATE; }
+    virtual int nn_pass(const Mat4 &Tc, double max_dist) = 0;
+    virtual int reduce(const Mat4 &Tc, bool plane, double *stats) = 0;
+    virtual int get_correspondences(int32_t *idx, float *d2) = 0;
+    virtual int comm_init(int, int, const void *) { err_ = "RCCL needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    virtual void set_profiling(bool) {}
+    virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
+    virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
+    virtual bool has_device_allreduce() const { return false; }
+    const std::string &error() const { return err_; }
+    int64_t ns() const { return ns_; }
+    int64_t nt() const { return nt_; }
+    bool has_normals() const { return has_normals_; }
+
+protected:
+    std::string err_;
+    int64_t ns_ = 0, nt_ = 0;
+    bool has_normals_ = false;
+};
+
+class HipEngine : public Engine {
+public:
+    explicit HipEngine(int device) : device_(device) {}
+    ~HipEngine() override
+    {
+        (void)hipSetDevice(device_);
+        if (comm_) g_rccl.CommDestroy(comm_);
+        for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+        free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_);
+        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
+        if (h_stats_) (void)hipHostFree(h_stats_);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+
+    int init()
+    {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            err_ = "no HIP device visible (this library has no CPU fallback)";
+            return VISMA_ICP_ERR_NO_DEVICE;
+        }
+        if (device_ < 0 || device_ >= count) {
+            err_ = "device index out of range";
+            return VISMA_ICP_ERR_INVALID;
+        }
+        HIP_TRY(hipSetDevice(device_));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            err_ = std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only";
+            return VISMA_ICP_ERR_NO_DEVICE;
+        }
+        HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * reduce_max_blocks()));
+        HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
+        HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * kNStats, hipHostMallocDefault));
+        return VISMA_ICP_OK;
+    }
+
+    int set_source(const float *xyzw, int64_t ns) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_source(ns);
+        if (rc) return rc;
+        if (ns > 0) HIP_TRY(hipMemcpyAsync(d_src_, xyzw, sizeof(float4) * ns, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_source_device(const void *d, int64_t ns) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_source(ns);
+        if (rc) return rc;
+        if (ns > 0) HIP_TRY(hipMemcpyAsync(d_src_, d, sizeof(float4) * ns, hipMemcpyDeviceToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_target(const float *xyzw, int64_t nt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_target(nt);
+        if (rc) return rc;
+        if (nt > 0) HIP_TRY(hipMemcpyAsync(d_tgt_, xyzw, sizeof(float4) * nt, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_target_device(const void *d, int64_t nt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_target(nt);
+        if (rc) return rc;
+        if (nt > 0) HIP_TRY(hipMemcpyAsync(d_tgt_, d, sizeof(float4) * nt, hipMemcpyDeviceToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_target_normals(const float *nxyzw, int64_t nt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (nt != nt_) { err_ = "normals count != target count"; return VISMA_ICP_ERR_INVALID; }
+        free_dev(d_nrm_);
+        HIP_TRY(hipMalloc(&d_nrm_, sizeof(float4) * (nt > 0 ? nt : 1)));
+        if (nt > 0) HIP_TRY(hipMemcpy(d_nrm_, nxyzw, sizeof(float4) * nt, hipMemcpyHostToDevice));
+        has_normals_ = true;
+        return VISMA_ICP_OK;
+    }
+
+    int nn_pass(const Mat4 &Tc, double max_dist) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+        plan_ = nn_plan(ns_, nt_pad_);
+        const int64_t ns_pad = (int64_t)plan_.src_tiles * kBlock * plan_.spt;
+        const size_t need = sizeof(unsigned long long) * (size_t)ns_pad * plan_.tgt_splits;
+        if (need > keys_bytes_) {
+            free_dev(d_keys_);
+            HIP_TRY(hipMalloc(&d_keys_, need));
+            keys_bytes_ = need;
+        }
+        if (ns_pad > aux_cap_) {
+            free_dev(d_idx_); free_dev(d_d2_);
+            HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * ns_pad));
+            HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * ns_pad));
+            aux_cap_ = ns_pad;
+        }
+        ns_pad_ = ns_pad;
+        for (int i = 0; i < 12; i++) T32_.m[i] = (float)Tc.m[i];
+        r2f_ = (float)(max_dist * max_dist);
+        int e0 = -1;
+        if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+        HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_, T32_,
+                                r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, stream_));
+        if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+        have_pass_ = true;
+        return VISMA_ICP_OK;
+    }
+
+    int reduce(const Mat4 &Tc, bool plane, double *stats) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (!have_pass_) { err_ = "reduce before nn_pass"; return VISMA_ICP_ERR_STATE; }
+        if (plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
+        Xform64 T64;
+        for (int i = 0; i < 12; i++) T64.m[i] = Tc.m[i];
+        int e0 = -1;
+        if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+        HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
+                              (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
+                              plan_.tgt_splits, ns_pad_, T32_, T64, r2f_, plane ? 1 : 0,
+                              (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
+                              reduce_max_blocks(), (double *)d_stats_, stream_));
+        if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+        if (comm_) {
+            // ONE all-reduce of the 38 f64 accumulators per ICP iteration
+            int rc = g_rccl.AllReduce(d_stats_, d_stats_, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
+            if (rc != 0) {
+                err_ = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+                return VISMA_ICP_ERR_RCCL;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(h_stats_, d_stats_, sizeof(double) * kNStats, hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        std::memcpy(stats, h_stats_, sizeof(double) * kNStats);
+        return collect_timing();
+    }
+
+    int get_correspondences(int32_t *idx, float *d2) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (!have_pass_) { err_ = "no nn_pass yet"; return VISMA_ICP_ERR_STATE; }
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (ns_ > 0) {
+            HIP_TRY(hipMemcpy(idx, d_idx_, sizeof(int32_t) * ns_, hipMemcpyDeviceToHost));
+            if (d2) HIP_TRY(hipMemcpy(d2, d_d2_, sizeof(float) * ns_, hipMemcpyDeviceToHost));
+        }
+        return VISMA_ICP_OK;
+    }
+
+    int comm_init(int rank, int nranks, const void *id) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (!g_rccl.load()) { err_ = g_rccl.error; return VISMA_ICP_ERR_RCCL; }
+        NcclId nid;
+        std::memcpy(&nid, id, sizeof(nid));
+        int rc = g_rccl.CommInitRank(&comm_, nranks, nid, rank);
+        if (rc != 0) {
+            err_ = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+            comm_ = nullptr;
+            return VISMA_ICP_ERR_RCCL;
+        }
+        return VISMA_ICP_OK;
+    }
+    bool has_device_allreduce() const override { return comm_ != nullptr; }
+
+    void set_profiling(bool on) override { profiling_ = on; }
+    void get_timing(visma_icp_timing *t, bool reset) override
+    {
+        *t = timing_;
+        if (reset) std::memset(&timing_, 0, sizeof(timing_));
+    }
+    void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }
+
+private:
+    void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+    int ensure_source(int64_t ns)
+    {
+        if (ns < 0) { err_ = "negative point count"; return VISMA_ICP_ERR_INVALID; }
+        if (ns > 0x7fffffff - 4096) { err_ = "source too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
+        free_dev(d_src_);
+        HIP_TRY(hipMalloc(&d_src_, sizeof(float4) * (ns > 0 ? ns : 1)));
+        ns_ = ns;
+        have_pass_ = false;
+        return VISMA_ICP_OK;
+    }
+    int ensure_target(int64_t nt)
+    {
+        if (nt < 0) { err_ = "negative point count"; return VISMA_ICP_ERR_INVALID; }
+        if (nt > 0x7fffffff - 4096) { err_ = "target too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
+        free_dev(d_tgt_); free_dev(d_nrm_);
+        has_normals_ = false;
+        // pad to a whole number of LDS chunks with +inf points (never accepted)
+        nt_pad_ = ((nt + kTChunk - 1) / kTChunk) * kTChunk;
+        if (nt_pad_ == 0) nt_pad_ = kTChunk;
+        HIP_TRY(hipMalloc(&d_tgt_, sizeof(float4) * nt_pad_));
+        HIP_TRY(launch_fill_inf((float4 *)d_tgt_ + nt, nt_pad_ - nt, stream_));
+        nt_ = nt;
+        have_pass_ = false;
+        return VISMA_ICP_OK;
+    }
+    int next_event_pair()
+    {
+        if (ev_used_ + 2 > (int)ev_.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return 0;
+                ev_.push_back(e);
+            }
+        }
+        int r = ev_used_;
+        ev_used_ += 2;
+        return r;
+    }
+    int collect_timing()
+    {
+        for (const auto &p : pending_) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev_[p.first], ev_[p.first + 1]));
+            if (p.second == 0) { timing_.nn_ms += ms; timing_.nn_launches++; }
+            else { timing_.reduce_ms += ms; timing_.reduce_launches++; }
+        }
+        pending_.clear();
+        ev_used_ = 0;
+        return VISMA_ICP_OK;
+    }
+
+    int device_;
+    hipStream_t stream_ = nullptr;
+    void *d_src_ = nullptr, *d_tgt_ = nullptr, *d_nrm_ = nullptr, *d_keys_ = nullptr;
+    void *d_idx_ = nullptr, *d_d2_ = nullptr, *d_partials_ = nullptr, *d_stats_ = nullptr;
+    double *h_stats_ = nullptr;
+    int64_t nt_pad_ = 0, ns_pad_ = 0, aux_cap_ = 0;
+    size_t keys_bytes_ = 0;
+    NNLaunch plan_{0, 0, 0};
+    Xform32 T32_{};
+    float r2f_ = 0.f;
+    bool have_pass_ = false, profiling_ = false;
+    std::vector<hipEvent_t> ev_;
+    int ev_used_ = 0;
+    std::vector<std::pair<int, int>> pending_;
+    visma_icp_timing timing_{};
+    NcclComm comm_ = nullptr;
+};
+
+class HookEngine : public Engine {
+public:
+    HookEngine(const visma_icp_engine &vt, void *user) : vt_(vt), user_(user) {}
+    int set_source(const float *p, int64_t n) override { ns_ = n; return wrap(vt_.set_source(user_, p, n)); }
+    int set_target(const float *p, int64_t n) override { nt_ = n; has_normals_ = false; return wrap(vt_.set_target(user_, p, n)); }
+    int set_target_normals(const float *p, int64_t n) override
+    {
+        if (!vt_.set_target_normals) { err_ = "engine has no normals support"; return VISMA_ICP_ERR_ENGINE; }
+        has_normals_ = true;
+        return wrap(vt_.set_target_normals(user_, p, n));
+    }
+    int nn_pass(const Mat4 &Tc, double r) override { return wrap(vt_.nn_pass(user_, Tc.m, r)); }
+    int reduce(const Mat4 &Tc, bool plane, double *st) override { return wrap(vt_.reduce(user_, Tc.m, plane ? 1 : 0, st)); }
+    int get_correspondences(int32_t *idx, float *d2) override
+    {
+        std::vector<float> tmp;
+        if (!d2) { tmp.resize((size_t)(ns_ > 0 ? ns_ : 1)); d2 = tmp.data(); }
+        return wrap(vt_.get_correspondences(user_, idx, d2));
+    }
+
+private:
+    int wrap(int rc)
+    {
+        if (rc == 0) return VISMA_ICP_OK;
+        err_ = "engine callback returned " + std::to_string(rc);
+        return VISMA_ICP_ERR_ENGINE;
+    }
+    visma_icp_engine vt_;
+    void *user_;
+};
+
+}  // namespace
+
+// ---- the driver -----------------------------------------------------------------
+struct visma_icp_ctx {
+    std::unique_ptr<Engine> eng;
+    std::string err;
+    double centre[3] = {0, 0, 0};
+    bool have_src = false, have_tgt = false;
+    visma_icp_allreduce_fn host_allreduce = nullptr;
+    void *host_allreduce_user = nullptr;
+    int rank = 0, nranks = 1;
+    int64_t ns_total = 0;
+    Mat4 last_Tc = Mat4::identity();
+    bool last_plane = false;
+
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+    int eng_fail(int code) { err = eng->error(); return code; }
+
+    // one NN pass + reduction (+ cross-rank sum); fills stats, fitness, rmse
+    int pass(const Mat4 &Tc, double max_dist, bool plane, double *stats, double *fit, double *rmse, int64_t *k)
+    {
+        int rc = eng->nn_pass(Tc, max_dist);
+        if (rc) return eng_fail(rc);
+        last_Tc = Tc;
+        last_plane = plane;
+        rc = eng->reduce(Tc, plane, stats);
+        if (rc) return eng_fail(rc);
+        if (host_allreduce && !eng->has_device_allreduce()) {
+            if (host_allreduce(host_allreduce_user, stats, VISMA_ICP_NSTATS) != 0)
+                return fail(VISMA_ICP_ERR_ENGINE, "host all-reduce callback failed");
+        }
+        const double K = stats[0];
+        const int64_t denom = ns_total > 0 ? ns_total : eng->ns();
+        *k = (int64_t)std::llround(K);
+        if (K > 0.0) {  // Registration.cpp:87-94
+            *fit = K / (double)denom;
+            *rmse = std::sqrt(stats[1] / K);
+        } else {
+            *fit = 0.0;
+            *rmse = 0.0;
+        }
+        return VISMA_ICP_OK;
+    }
+
+    Mat4 solve(const double *stats, int solver, bool scaling, bool plane) const
+    {
+        bool ok;
+        if (plane) return gn_from_stats(stats, false, &ok);  // TransformationEstimation.cpp:94-102
+        switch (solver) {
+        case VISMA_ICP_SOLVER_GN_EULER: return gn_from_stats(stats, false, &ok);
+        case VISMA_ICP_SOLVER_GN_EXPMAP: return gn_from_stats(stats, true, &ok);
+        default: return kabsch_from_stats(stats, scaling);
+        }
+    }
+
+    int run(const double *init, double max_dist, int max_iter, double rel_fit, double rel_rmse,
+            int solver, bool scaling, bool plane, visma_icp_result *out)
+    {
+        std::memset(out, 0, sizeof(*out));
+        std::memcpy(out->transformation, init, sizeof(double) * 16);
+        if (!(max_dist > 0.0)) return VISMA_ICP_OK;                 // Registration.cpp:148-151
+        if (plane && !eng->has_normals()) return VISMA_ICP_OK;      // Registration.cpp:152-157
+        if (!have_src || !have_tgt) return fail(VISMA_ICP_ERR_STATE, "clouds not set");
+        Mat4 Tc = to_centred(Mat4::from(init), centre);
+        double stats[VISMA_ICP_NSTATS], fit, rmse;
+        int64_t k;
+        int rc = pass(Tc, max_dist, plane, stats, &fit, &rmse, &k);  // Registration.cpp:166-168
+        if (rc) return rc;
+        int it = 0;
+        for (int i = 0; i < max_iter; i++) {                          // Registration.cpp:169-184
+            const Mat4 upd = solve(stats, solver, scaling, plane);
+            Tc = upd * Tc;
+            const double bfit = fit, brmse = rmse;
+            rc = pass(Tc, max_dist, plane, stats, &fit, &rmse, &k);
+            if (rc) return rc;
+            it = i + 1;
+            if (std::fabs(bfit - fit) < rel_fit && std::fabs(brmse - rmse) < rel_rmse) break;
+        }
+        const Mat4 T = from_centred(Tc, centre);
+        std::memcpy(out->transformation, T.m, sizeof(T.m));
+        out->fitness = fit;
+        out->inlier_rmse = rmse;
+        out->num_correspondences = k;
+        out->iterations = it;
+        out->nn_passes = it + 1;
+        return VISMA_ICP_OK;
+    }
+};
+
+namespace {
+
+int pack_f64(const double *xyz, int64_t n, int stride, const double c[3], std::vector<float> &out)
+{
+    out.resize((size_t)(n > 0 ? n : 1) * 4);
+    for (int64_t i = 0; i < n; i++) {
+        const double *p = xyz + (size_t)i * stride;
+        out[4 * i + 0] = (float)(p[0] - c[0]);
+        out[4 * i + 1] = (float)(p[1] - c[1]);
+        out[4 * i + 2] = (float)(p[2] - c[2]);
+        out[4 * i + 3] = 0.f;
+    }
+    return 0;
+}
+
+void pack_f32(const float *xyz, int64_t n, int stride, std::vector<float> &out)
+{
+    out.resize((size_t)(n > 0 ? n : 1) * 4);
+    for (int64_t i = 0; i < n; i++) {
+        const float *p = xyz + (size_t)i * stride;
+        out[4 * i + 0] = p[0];
+        out[4 * i + 1] = p[1];
+        out[4 * i + 2] = p[2];
+        out[4 * i + 3] = 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *visma_icp_version(void) { return "visma-icp-mi355x 0.1 (gfx950)"; }
+
+int visma_icp_create(visma_icp_ctx **out, int device)
+{
+    if (!out) { g_create_error = "out is NULL"; return VISMA_ICP_ERR_INVALID; }
+    *out = nullptr;
+    std::unique_ptr<HipEngine> e(new HipEngine(device));
+    int rc = e->init();
+    if (rc) { g_create_error = e->error(); return rc; }
+    visma_icp_ctx *c = new visma_icp_ctx();
+    c->eng = std::move(e);
+    *out = c;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_create_with_engine(visma_icp_ctx **out, const visma_icp_engine *engine, void *user)
+{
+    if (!out || !engine || !engine->set_source || !engine->set_target || !engine->nn_pass ||
+        !engine->reduce || !engine->get_correspondences) {
+        g_create_error = "incomplete engine table";
+        return VISMA_ICP_ERR_INVALID;
+    }
+    visma_icp_ctx *c = new visma_icp_ctx();
+    c->eng.reset(new HookEngine(*engine, user));
+    *out = c;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_destroy(visma_icp_ctx *ctx)
+{
+    delete ctx;
+    return VISMA_ICP_OK;
+}
+
+const char *visma_icp_last_error(const visma_icp_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+#define CTX_CHECK()                                                             \
+    if (!ctx) { g_create_error = "ctx is NULL"; return VISMA_ICP_ERR_INVALID; }
+
+int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride,
+                             const double *tgt, int64_t nt, int tstride)
+{
+    CTX_CHECK();
+    if (ns < 0 || nt < 0 || sstride < 3 || tstride < 3 || (ns > 0 && !src) || (nt > 0 && !tgt))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad cloud arguments");
+    // centre on the target centroid: sequential f64 sum in index order
+    double c[3] = {0, 0, 0};
+    for (int64_t j = 0; j < nt; j++)
+        for (int a = 0; a < 3; a++) c[a] += tgt[(size_t)j * tstride + a];
+    if (nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)nt;
+    std::vector<float> buf;
+    pack_f64(tgt, nt, tstride, c, buf);
+    int rc = ctx->eng->set_target(buf.data(), nt);
+    if (rc) return ctx->eng_fail(rc);
+    pack_f64(src, ns, sstride, c, buf);
+    rc = ctx->eng->set_source(buf.data(), ns);
+    if (rc) return ctx->eng_fail(rc);
+    std::memcpy(ctx->centre, c, sizeof(c));
+    ctx->have_src = ctx->have_tgt = true;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt, int stride)
+{
+    CTX_CHECK();
+    if (nt < 0 || stride < 3 || (nt > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad target arguments");
+    std::vector<float> buf;
+    pack_f32(xyz, nt, stride, buf);
+    int rc = ctx->eng->set_target(buf.data(), nt);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->centre[0] = ctx->centre[1] = ctx->centre[2] = 0.0;
+    ctx->have_tgt = true;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns, int stride)
+{
+    CTX_CHECK();
+    if (ns < 0 || stride < 3 || (ns > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
+    std::vector<float> buf;
+    pack_f32(xyz, ns, stride, buf);
+    int rc = ctx->eng->set_source(buf.data(), ns);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->have_src = true;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_target_device(visma_icp_ctx *ctx, const void *d, int64_t nt)
+{
+    CTX_CHECK();
+    if (nt < 0 || (nt > 0 && !d)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad target arguments");
+    int rc = ctx->eng->set_target_device(d, nt);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->centre[0] = ctx->centre[1] = ctx->centre[2] = 0.0;
+    ctx->have_tgt = true;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_source_device(visma_icp_ctx *ctx, const void *d, int64_t ns)
+{
+    CTX_CHECK();
+    if (ns < 0 || (ns > 0 && !d)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
+    int rc = ctx->eng->set_source_device(d, ns);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->have_src = true;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_target_normals_f64(visma_icp_ctx *ctx, const double *n, int64_t nt, int stride)
+{
+    CTX_CHECK();
+    if (!ctx->have_tgt) return ctx->fail(VISMA_ICP_ERR_STATE, "set the target first");
+    if (nt != ctx->eng->nt() || stride < 3 || (nt > 0 && !n))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad normals arguments");
+    std::vector<float> buf;
+    const double zero[3] = {0, 0, 0};
+    pack_f64(n, nt, stride, zero, buf);
+    int rc = ctx->eng->set_target_normals(buf.data(), nt);
+    if (rc) return ctx->eng_fail(rc);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_nn_pass(visma_icp_ctx *ctx, const double T[16], double max_dist)
+{
+    CTX_CHECK();
+    if (!T) return ctx->fail(VISMA_ICP_ERR_INVALID, "T is NULL");
+    if (!ctx->have_src || !ctx->have_tgt) return ctx->fail(VISMA_ICP_ERR_STATE, "clouds not set");
+    if (!(max_dist > 0.0)) return ctx->fail(VISMA_ICP_ERR_INVALID, "max_dist must be > 0");
+    ctx->last_Tc = to_centred(Mat4::from(T), ctx->centre);
+    int rc = ctx->eng->nn_pass(ctx->last_Tc, max_dist);
+    if (rc) return ctx->eng_fail(rc);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_reduce(visma_icp_ctx *ctx, double out_stats[VISMA_ICP_NSTATS])
+{
+    CTX_CHECK();
+    if (!out_stats) return ctx->fail(VISMA_ICP_ERR_INVALID, "out_stats is NULL");
+    int rc = ctx->eng->reduce(ctx->last_Tc, false, out_stats);
+    if (rc) return ctx->eng_fail(rc);
+    if (ctx->host_allreduce && !ctx->eng->has_device_allreduce())
+        if (ctx->host_allreduce(ctx->host_allreduce_user, out_stats, VISMA_ICP_NSTATS) != 0)
+            return ctx->fail(VISMA_ICP_ERR_ENGINE, "host all-reduce callback failed");
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_correspondences(visma_icp_ctx *ctx, int32_t *src_idx, int32_t *tgt_idx, float *d2,
+                                  int64_t *k)
+{
+    CTX_CHECK();
+    if (!src_idx || !tgt_idx || !k) return ctx->fail(VISMA_ICP_ERR_INVALID, "NULL output buffer");
+    const int64_t ns = ctx->eng->ns();
+    std::vector<int32_t> idx((size_t)(ns > 0 ? ns : 1));
+    std::vector<float> dd((size_t)(ns > 0 ? ns : 1));
+    int rc = ctx->eng->get_correspondences(idx.data(), dd.data());
+    if (rc) return ctx->eng_fail(rc);
+    int64_t c = 0;
+    for (int64_t i = 0; i < ns; i++)
+        if (idx[i] >= 0) {
+            src_idx[c] = (int32_t)i;
+            tgt_idx[c] = idx[i];
+            if (d2) d2[c] = dd[i];
+            ++c;
+        }
+    *k = c;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_solve_from_stats(const double stats[VISMA_ICP_NSTATS], int solver, int with_scaling,
+                               double T_update[16])
+{
+    if (!stats || !T_update) return VISMA_ICP_ERR_INVALID;
+    Mat4 T;
+    bool ok = true;
+    switch (solver) {
+    case VISMA_ICP_SOLVER_KABSCH: T = kabsch_from_stats(stats, with_scaling != 0); break;
+    case VISMA_ICP_SOLVER_GN_EULER: T = gn_from_stats(stats, false, &ok); break;
+    case VISMA_ICP_SOLVER_GN_EXPMAP: T = gn_from_stats(stats, true, &ok); break;
+    default: return VISMA_ICP_ERR_INVALID;
+    }
+    std::memcpy(T_update, T.m, sizeof(T.m));
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_run(visma_icp_ctx *ctx, const double init[16], double max_dist, int max_iter,
+                  double rel_fitness, double rel_rmse, int solver, int with_scaling,
+                  visma_icp_result *out)
+{
+    CTX_CHECK();
+    if (!init || !out || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad run arguments");
+    if (solver < 0 || solver > VISMA_ICP_SOLVER_GN_EXPMAP) return ctx->fail(VISMA_ICP_ERR_INVALID, "unknown solver");
+    return ctx->run(init, max_dist, max_iter, rel_fitness, rel_rmse, solver, with_scaling != 0, false, out);
+}
+
+int visma_icp_run_point_to_plane(visma_icp_ctx *ctx, const double init[16], double max_dist,
+                                 int max_iter, double rel_fitness, double rel_rmse,
+                                 visma_icp_result *out)
+{
+    CTX_CHECK();
+    if (!init || !out || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad run arguments");
+    return ctx->run(init, max_dist, max_iter, rel_fitness, rel_rmse, VISMA_ICP_SOLVER_GN_EULER, false, true, out);
+}
+
+int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int max_iter,
+                            double rel_fitness, double rel_rmse, int solver, visma_icp_result *best,
+                            int *best_level, visma_icp_result *per_level)
+{
+    CTX_CHECK();
+    if (level <= 0 || !best || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad sweep arguments");
+    // src/annotation.cpp:35-61
+    const double interval = 2.0 * M_PI / (double)level;
+    visma_icp_result b;
+    std::memset(&b, 0, sizeof(b));
+    const Mat4 I = Mat4::identity();
+    std::memcpy(b.transformation, I.m, sizeof(I.m));
+    int bl = -1;
+    for (int i = 0; i < level; i++) {
+        const double a = interval * i, c = std::cos(a), s = std::sin(a);
+        Mat4 init = Mat4::identity();
+        init(0, 0) = c; init(0, 2) = s; init(2, 0) = -s; init(2, 2) = c;
+        visma_icp_result r;
+        int rc = ctx->run(init.m, max_dist, max_iter, rel_fitness, rel_rmse, solver, false, false, &r);
+        if (rc) return rc;
+        if (per_level) per_level[i] = r;
+        if (r.num_correspondences > b.num_correspondences) { b = r; bl = i; }
+    }
+    *best = b;
+    if (best_level) *best_level = bl;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int n, int max_iter,
+                        double rel_fitness, double rel_rmse, int solver, visma_icp_result *out)
+{
+    CTX_CHECK();
+    if (n < 0 || (n > 0 && (!probs || !out)) || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch arguments");
+    for (int i = 0; i < n; i++) {
+        int rc = visma_icp_set_clouds_f64(ctx, probs[i].src_xyz, probs[i].ns, 3, probs[i].tgt_xyz, probs[i].nt, 3);
+        if (rc) return rc;
+        rc = ctx->run(probs[i].init, probs[i].max_dist, max_iter, rel_fitness, rel_rmse, solver, false, false, &out[i]);
+        if (rc) return rc;
+    }
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode)
+{
+    CTX_CHECK();
+    if (nn_mode != VISMA_ICP_NN_AUTO && nn_mode != VISMA_ICP_NN_BRUTE)
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "nn mode not available in this build");
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled)
+{
+    CTX_CHECK();
+    ctx->eng->set_profiling(enabled != 0);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out, int reset)
+{
+    CTX_CHECK();
+    if (!out) return ctx->fail(VISMA_ICP_ERR_INVALID, "out is NULL");
+    ctx->eng->get_timing(out, reset != 0);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block)
+{
+    if (s_tile) *s_tile = kSTile;
+    if (t_chunk) *t_chunk = kTChunk;
+    if (block) *block = kBlock;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_launch_config(visma_icp_ctx *ctx, int *src_tiles, int *tgt_splits)
+{
+    CTX_CHECK();
+    int a = 0, b = 0;
+    ctx->eng->launch_config(&a, &b);
+    if (src_tiles) *src_tiles = a;
+    if (tgt_splits) *tgt_splits = b;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_comm_unique_id(void *out_id)
+{
+    if (!out_id) return VISMA_ICP_ERR_INVALID;
+    if (!g_rccl.load()) { g_create_error = g_rccl.error; return VISMA_ICP_ERR_RCCL; }
+    NcclId id;
+    int rc = g_rccl.GetUniqueId(&id);
+    if (rc != 0) { g_create_error = "ncclGetUniqueId failed"; return VISMA_ICP_ERR_RCCL; }
+    std::memcpy(out_id, &id, sizeof(id));
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks, const void *unique_id)
+{
+    CTX_CHECK();
+    if (!unique_id || nranks < 1 || rank < 0 || rank >= nranks) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad comm arguments");
+    int rc = ctx->eng->comm_init(rank, nranks, unique_id);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn, void *user, int rank, int nranks)
+{
+    CTX_CHECK();
+    if (nranks < 1 || rank < 0 || rank >= nranks) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad rank arguments");
+    ctx->host_allreduce = fn;
+    ctx->host_allreduce_user = user;
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_global_source_count(visma_icp_ctx *ctx, int64_t ns_total)
+{
+    CTX_CHECK();
+    if (ns_total < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "negative count");
+    ctx->ns_total = ns_total;
+    return VISMA_ICP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,285 @@
+// host_math.hpp -- the tiny f64 solves of the ICP loop (host side).
+//
+// The reference does these with Eigen (umeyama / JacobiSVD / LDLT).  Eigen is
+// not a dependency of this library (there is none on the target image), so the
+// few fixed-size operations needed are written out here:
+//   kabsch_from_stats   Eigen/src/Geometry/Umeyama.h:118-159 evaluated from the
+//                       reduced moments instead of from gathered 3xK matrices
+//   gn_from_stats       O3D/Core/Utility/Eigen.cpp:35-56,88-106 (6x6 solve with
+//                       the |det| < 1e-6 guard) + :58-68 (Euler ZYX) or the
+//                       exponential map of core/rodrigues.h:143-182
+// All matrices row-major.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "so3.h"
+
+namespace visma {
+
+struct Mat4 {
+    double m[16];
+    static Mat4 identity()
+    {
+        Mat4 r;
+        std::memset(r.m, 0, sizeof(r.m));
+        r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0;
+        return r;
+    }
+    static Mat4 from(const double *p)
+    {
+        Mat4 r;
+        std::memcpy(r.m, p, sizeof(r.m));
+        return r;
+    }
+    double &operator()(int i, int j) { return m[i * 4 + j]; }
+    double operator()(int i, int j) const { return m[i * 4 + j]; }
+};
+
+inline Mat4 operator*(const Mat4 &a, const Mat4 &b)
+{
+    Mat4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            double s = 0.0;
+            for (int k = 0; k < 4; k++) s += a(i, k) * b(k, j);
+            r(i, j) = s;
+        }
+    return r;
+}
+
+// x' = x - c  ==>  [R | t]  <->  [R | R c + t - c]
+inline Mat4 to_centred(const Mat4 &T, const double c[3])
+{
+    Mat4 r = T;
+    for (int i = 0; i < 3; i++)
+        r(i, 3) = T(i, 0) * c[0] + T(i, 1) * c[1] + T(i, 2) * c[2] + T(i, 3) - c[i];
+    return r;
+}
+
+inline Mat4 from_centred(const Mat4 &Tc, const double c[3])
+{
+    Mat4 r = Tc;
+    for (int i = 0; i < 3; i++)
+        r(i, 3) = Tc(i, 3) - (Tc(i, 0) * c[0] + Tc(i, 1) * c[1] + Tc(i, 2) * c[2]) + c[i];
+    return r;
+}
+
+inline double det3(const double A[9])
+{
+    return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
+           A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+
+// Singular value decomposition of a 3x3 by one-sided Jacobi rotations on the
+// columns (A V = U S); singular values sorted descending, U completed to a
+// full orthonormal basis when A is rank deficient.
+struct Svd3 {
+    double U[9], s[3], V[9];
+};
+
+inline Svd3 svd3(const double A[9])
+{
+    double G[3][3], W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) G[i][j] = A[i * 3 + j];
+    static const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 64; sweep++) {
+        bool any = false;
+        for (const auto &pq : pairs) {
+            const int p = pq[0], q = pq[1];
+            double a = 0, b = 0, g = 0;
+            for (int r = 0; r < 3; r++) {
+                a += G[r][p] * G[r][p];
+                b += G[r][q] * G[r][q];
+                g += G[r][p] * G[r][q];
+            }
+            if (g == 0.0 || std::fabs(g) <= 1e-17 * std::sqrt(a * b)) continue;
+            any = true;
+            const double zeta = (b - a) / (2.0 * g);
+            const double t = std::copysign(1.0, zeta) / (std::fabs(zeta) + std::hypot(1.0, zeta));
+            const double c = 1.0 / std::hypot(1.0, t), s = c * t;
+            for (int r = 0; r < 3; r++) {
+                const double gp = G[r][p], gq = G[r][q];
+                G[r][p] = c * gp - s * gq;
+                G[r][q] = s * gp + c * gq;
+                const double wp = W[r][p], wq = W[r][q];
+                W[r][p] = c * wp - s * wq;
+                W[r][q] = s * wp + c * wq;
+            }
+        }
+        if (!any) break;
+    }
+    double n[3];
+    int o[3] = {0, 1, 2};
+    for (int j = 0; j < 3; j++) n[j] = std::sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+    std::sort(o, o + 3, [&](int x, int y) { return n[x] > n[y]; });
+    Svd3 out;
+    double u[3][3];
+    int rank = 0;
+    for (int j = 0; j < 3; j++) {
+        out.s[j] = n[o[j]];
+        for (int r = 0; r < 3; r++) out.V[r * 3 + j] = W[r][o[j]];
+        if (n[o[j]] > 1e-300 && n[o[j]] > 1e-15 * n[o[0]]) {
+            for (int r = 0; r < 3; r++) u[j][r] = G[r][o[j]] / n[o[j]];
+            rank = j + 1;
+        }
+    }
+    auto cross = [](const double *a, const double *b, double *c) {
+        c[0] = a[1] * b[2] - a[2] * b[1];
+        c[1] = a[2] * b[0] - a[0] * b[2];
+        c[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    if (rank == 0) { u[0][0] = 1; u[0][1] = 0; u[0][2] = 0; rank = 1; }
+    if (rank == 1) {
+        int m = 0;
+        for (int r = 1; r < 3; r++) if (std::fabs(u[0][r]) < std::fabs(u[0][m])) m = r;
+        double e[3] = {0, 0, 0};
+        e[m] = 1.0;
+        cross(u[0], e, u[1]);
+        const double l = std::sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+        for (int r = 0; r < 3; r++) u[1][r] /= l;
+        rank = 2;
+    }
+    if (rank == 2) cross(u[0], u[1], u[2]);
+    for (int j = 0; j < 3; j++)
+        for (int r = 0; r < 3; r++) out.U[r * 3 + j] = u[j][r];
+    return out;
+}
+
+struct NormalEq {
+    double K, r2;
+    double JTJ[36];
+    double JTr[6];
+    double M[9];  // sum q p^T
+};
+
+inline NormalEq unpack_stats(const double *st)
+{
+    NormalEq e;
+    e.K = st[0];
+    e.r2 = st[1];
+    int o = 2;
+    for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) {
+            e.JTJ[a * 6 + b] = st[o];
+            e.JTJ[b * 6 + a] = st[o];
+            ++o;
+        }
+    for (int a = 0; a < 6; a++) e.JTr[a] = st[o++];
+    for (int a = 0; a < 9; a++) e.M[a] = st[o++];
+    return e;
+}
+
+// Closed-form least-squares rigid (optionally similarity) update for the
+// fixed correspondence set, from the moments.
+inline Mat4 kabsch_from_stats(const double *st, bool with_scaling)
+{
+    const NormalEq e = unpack_stats(st);
+    if (!(e.K > 0.0)) return Mat4::identity();
+    // the cross block of J^T J is hat(sum p); J^T r's tail is sum p - sum q
+    const double P[3] = {e.JTJ[2 * 6 + 4], e.JTJ[0 * 6 + 5], e.JTJ[1 * 6 + 3]};
+    const double Q[3] = {P[0] - e.JTr[3], P[1] - e.JTr[4], P[2] - e.JTr[5]};
+    const double inv = 1.0 / e.K;
+    double pm[3], qm[3], sigma[9];
+    for (int a = 0; a < 3; a++) { pm[a] = P[a] * inv; qm[a] = Q[a] * inv; }
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) sigma[a * 3 + b] = e.M[a * 3 + b] * inv - qm[a] * pm[b];
+    const Svd3 d = svd3(sigma);
+    double S[3] = {1.0, 1.0, 1.0};
+    if (det3(d.U) * det3(d.V) < 0.0) S[2] = -1.0;
+    double R[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[i * 3 + j] = d.U[i * 3] * S[0] * d.V[j * 3] + d.U[i * 3 + 1] * S[1] * d.V[j * 3 + 1] +
+                           d.U[i * 3 + 2] * S[2] * d.V[j * 3 + 2];
+    double c = 1.0;
+    if (with_scaling) {
+        // tr(sum(|p|^2 I - p p^T)) = 2 sum |p|^2
+        const double sum_p2 = 0.5 * (e.JTJ[0] + e.JTJ[7] + e.JTJ[14]);
+        const double var = sum_p2 * inv - (pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
+        c = (d.s[0] * S[0] + d.s[1] * S[1] + d.s[2] * S[2]) / var;
+    }
+    Mat4 T = Mat4::identity();
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T(i, j) = c * R[i * 3 + j];
+        T(i, 3) = qm[i] - c * (R[i * 3] * pm[0] + R[i * 3 + 1] * pm[1] + R[i * 3 + 2] * pm[2]);
+    }
+    return T;
+}
+
+// Solve A x = b (6x6, partial pivoting); returns det(A).
+inline double solve6(const double A[36], const double b[6], double x[6])
+{
+    double M[6][7];
+    for (int i = 0; i < 6; i++) {
+        for (int j = 0; j < 6; j++) M[i][j] = A[i * 6 + j];
+        M[i][6] = b[i];
+    }
+    double det = 1.0;
+    for (int c = 0; c < 6; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 6; r++)
+            if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+        if (M[piv][c] == 0.0) {
+            for (int i = 0; i < 6; i++) x[i] = 0.0;
+            return 0.0;
+        }
+        if (piv != c) {
+            for (int j = 0; j < 7; j++) std::swap(M[c][j], M[piv][j]);
+            det = -det;
+        }
+        det *= M[c][c];
+        for (int r = c + 1; r < 6; r++) {
+            const double f = M[r][c] / M[c][c];
+            for (int j = c; j < 7; j++) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int r = 5; r >= 0; r--) {
+        double s = M[r][6];
+        for (int j = r + 1; j < 6; j++) s -= M[r][j] * x[j];
+        x[r] = s / M[r][r];
+    }
+    return det;
+}
+
+inline Mat4 euler_zyx_to_mat4(const double x[6])
+{
+    const double ca = std::cos(x[0]), sa = std::sin(x[0]);
+    const double cb = std::cos(x[1]), sb = std::sin(x[1]);
+    const double cg = std::cos(x[2]), sg = std::sin(x[2]);
+    Mat4 T = Mat4::identity();
+    // Rz(g) * Ry(b) * Rx(a), written out
+    T(0, 0) = cg * cb; T(0, 1) = cg * sb * sa - sg * ca; T(0, 2) = cg * sb * ca + sg * sa;
+    T(1, 0) = sg * cb; T(1, 1) = sg * sb * sa + cg * ca; T(1, 2) = sg * sb * ca - cg * sa;
+    T(2, 0) = -sb;     T(2, 1) = cb * sa;                T(2, 2) = cb * ca;
+    T(0, 3) = x[3]; T(1, 3) = x[4]; T(2, 3) = x[5];
+    return T;
+}
+
+// One Gauss-Newton step on J^T J x = -J^T r.  ok=false (Identity) when the
+// determinant guard rejects the system.
+inline Mat4 gn_from_stats(const double *st, bool expmap, bool *ok)
+{
+    const NormalEq e = unpack_stats(st);
+    *ok = false;
+    if (!(e.K > 0.0)) return Mat4::identity();
+    double nb[6], x[6];
+    for (int i = 0; i < 6; i++) nb[i] = -e.JTr[i];
+    const double det = solve6(e.JTJ, nb, x);
+    if (std::fabs(det) < 1e-6 || std::isnan(det) || std::isinf(det)) return Mat4::identity();
+    *ok = true;
+    if (!expmap) return euler_zyx_to_mat4(x);
+    double R[9];
+    rodrigues(x, R);
+    Mat4 T = Mat4::identity();
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T(i, j) = R[i * 3 + j];
+        T(i, 3) = x[3 + i];
+    }
+    return T;
+}
+
+}  // namespace visma

@@ -1,0 +1,64 @@
+// kernels.h -- launch interface of the gfx950 ICP kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace visma {
+
+// ---- compile-time tile constants (reported by visma_icp_get_tile_config) ----
+constexpr int kBlock = 256;         // threads per workgroup (4 wave64)
+constexpr int kSptLarge = 8;        // source points per thread, large clouds
+constexpr int kSptSmall = 2;        // ... small clouds (more workgroups)
+constexpr int kSTile = kBlock * kSptLarge;  // S_TILE = 2048 source points / workgroup
+constexpr int kTChunk = 512;        // target points staged per LDS fill
+constexpr int kSub = 64;            // sub-chunk whose winner id is tracked
+constexpr int kReduceAcc = 29;      // per-thread f64 accumulators (max over modes)
+constexpr int kNStats = 38;
+
+struct Xform32 { float m[12]; };    // row-major 3x4, fp32 (NN search)
+struct Xform64 { double m[12]; };   // row-major 3x4, f64  (statistics)
+
+struct NNLaunch {
+    int src_tiles;
+    int tgt_splits;
+    int spt;
+};
+
+// Pick the launch geometry for ns source points against nt_pad/kTChunk chunks.
+NNLaunch nn_plan(int64_t ns, int64_t nt_pad);
+
+// Fused transform + brute-force nearest neighbour.  tgt must be padded to a
+// multiple of kTChunk with +inf points.  keys: [splits][ns_pad] 64-bit
+// (d2 bits << 32 | sub-chunk id), no initialisation needed.
+hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
+                           int64_t nt_pad, const Xform32 &T, float r2f,
+                           unsigned long long *keys, int64_t ns_pad,
+                           const NNLaunch &plan, hipStream_t stream);
+
+// Merge the per-split keys, recover the exact target index inside the winning
+// sub-chunk, then accumulate the per-correspondence Jacobian/residual
+// statistics; per-workgroup partials go to `partials`, `finalize` folds them
+// (fixed order) into the 38 statistics at `stats_out` (device or mapped host).
+// idx_out/d2_out (ns) receive the final correspondence per source point.
+hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
+                         const float4 *tgt_normals, const unsigned long long *keys,
+                         int nsplits, int64_t ns_pad, const Xform32 &T32,
+                         const Xform64 &T64, float r2f, int point_to_plane,
+                         int32_t *idx_out, float *d2_out, double *partials,
+                         int max_partial_blocks, double *stats_out,
+                         hipStream_t stream);
+
+int reduce_max_blocks();
+
+// fill n float4 with +inf (target padding)
+hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);
+// AoS stride-s floats -> float4 (w = 0)
+hipError_t launch_pack_float4(const float *src, int stride, float4 *dst, int64_t n,
+                              hipStream_t stream);
+
+// SO(3) self-test kernel: R = rodrigues(w), w2 = invrodrigues(R), v2 = g*v
+hipError_t launch_so3_selftest(const double *w, double *R, double *w2, int n,
+                               hipStream_t stream);
+
+}  // namespace visma

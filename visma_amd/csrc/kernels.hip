@@ -1,0 +1,452 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ICP path.
+//
+//  nn_brute_kernel   fused source transform + brute-force nearest neighbour
+//                    (replaces PointCloud::Transform + the KDTreeFlann lookups of
+//                    O3D/Core/Registration/Registration.cpp:41-96, 175-178)
+//  reduce_kernel     per-correspondence SE(3) Jacobian/residual + wavefront
+//                    shuffle reduction (replaces the gathers of
+//                    src/constrained_ICP.cpp:30-35 and ComputeJTJandJTr,
+//                    O3D/Core/Utility/Eigen.cpp:137-182)
+//  finalize_kernel   fixed-order fold of the workgroup partials into the 38
+//                    statistics (6x6 J^T J, 6x1 J^T r, cross-covariance, K, r^2)
+//
+// Arithmetic contract (checked bit-for-bit against oracle/icp_oracle.c vk_*):
+//   p  = fmaf(r0,sx, fmaf(r1,sy, fmaf(r2,sz, t)))          fp32, per row
+//   d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx)),  d = q - p        fp32
+//   accept iff d2 < r2f; lowest target index wins exact ties.
+// Statistics are accumulated in f64 from p = T64 * (double)s and q widened.
+#include "kernels.h"
+#include "so3.h"
+
+#include <math.h>
+
+namespace visma {
+
+// ------------------------------------------------------------------------
+// shared device helpers
+// ------------------------------------------------------------------------
+__device__ __forceinline__ void xform_point_f32(const Xform32 &T, const float4 s,
+                                                float &px, float &py, float &pz)
+{
+    px = __builtin_fmaf(T.m[0], s.x, __builtin_fmaf(T.m[1], s.y, __builtin_fmaf(T.m[2], s.z, T.m[3])));
+    py = __builtin_fmaf(T.m[4], s.x, __builtin_fmaf(T.m[5], s.y, __builtin_fmaf(T.m[6], s.z, T.m[7])));
+    pz = __builtin_fmaf(T.m[8], s.x, __builtin_fmaf(T.m[9], s.y, __builtin_fmaf(T.m[10], s.z, T.m[11])));
+}
+
+__device__ __forceinline__ float sqdist_f32(const float4 q, float px, float py, float pz)
+{
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+// one VALU op: min of three (v_min3_f32); inputs are never NaN-producing here
+__device__ __forceinline__ float min3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// ------------------------------------------------------------------------
+// NN: fused transform + brute force
+// ------------------------------------------------------------------------
+// Each thread keeps SPT transformed source points in registers; the workgroup
+// streams its share of the target through a double-buffered LDS tile (one
+// coalesced 16-B global load per lane per 256 targets, broadcast ds_read_b128
+// in the inner loop).  The inner loop only tracks the running minimum
+// (v_min3_f32 over two targets); which 64-target sub-chunk produced it is
+// recorded once per sub-chunk, and the exact index is recovered by the
+// reduction kernel, which re-evaluates that one sub-chunk.
+template <int SPT>
+__global__ __launch_bounds__(kBlock) void nn_brute_kernel(
+    const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
+    int chunks_total, int chunks_per_split, int src_tiles, int nsplits, Xform32 T,
+    float r2f, unsigned long long *__restrict__ keys, long long ns_pad)
+{
+    __shared__ float4 lds[2][kTChunk];
+    const int tid = threadIdx.x;
+
+    // XCD-aware (tile, split) decode: workgroup b runs on XCD b % 8, so give
+    // each XCD its own residue class of target splits -- its L2 then streams
+    // 1/8 of the target instead of all of it.
+    int tile, split;
+    {
+        const int b = blockIdx.x;
+        if ((nsplits & 7) == 0) {
+            const int xcd = b & 7, s = b >> 3;
+            tile = s % src_tiles;
+            split = xcd + 8 * (s / src_tiles);
+        } else {
+            tile = b % src_tiles;
+            split = b / src_tiles;
+        }
+    }
+
+    float px[SPT], py[SPT], pz[SPT], best[SPT];
+    unsigned win[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const int i = tile * (kBlock * SPT) + k * kBlock + tid;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < ns) s = src[i];
+        xform_point_f32(T, s, px[k], py[k], pz[k]);
+        best[k] = r2f;          // strict d2 < r2f acceptance is built in
+        win[k] = 0xFFFFFFFFu;   // "no correspondence"
+    }
+
+    const int c0 = split * chunks_per_split;
+    int c1 = c0 + chunks_per_split;
+    if (c1 > chunks_total) c1 = chunks_total;
+
+    if (c0 < c1) {
+        const float4 *g = tgt + (long long)c0 * kTChunk;
+        float4 r0 = g[tid], r1 = g[tid + kBlock];
+        lds[0][tid] = r0;
+        lds[0][tid + kBlock] = r1;
+        __syncthreads();
+        int buf = 0;
+        for (int c = c0; c < c1; ++c) {
+            const bool has_next = (c + 1 < c1);
+            if (has_next) {  // issue the next chunk's global loads early
+                g += kTChunk;
+                r0 = g[tid];
+                r1 = g[tid + kBlock];
+            }
+#pragma unroll 1
+            for (int sb = 0; sb < kTChunk / kSub; ++sb) {
+                float before[SPT];
+#pragma unroll
+                for (int k = 0; k < SPT; k++) before[k] = best[k];
+                const float4 *t = &lds[buf][sb * kSub];
+#pragma unroll 8
+                for (int j = 0; j < kSub; j += 2) {
+                    const float4 qa = t[j], qb = t[j + 1];
+#pragma unroll
+                    for (int k = 0; k < SPT; k++) {
+                        const float da = sqdist_f32(qa, px[k], py[k], pz[k]);
+                        const float db = sqdist_f32(qb, px[k], py[k], pz[k]);
+                        best[k] = min3_f32(best[k], da, db);
+                    }
+                }
+                const unsigned sid = (unsigned)(c * (kTChunk / kSub) + sb);
+#pragma unroll
+                for (int k = 0; k < SPT; k++)
+                    win[k] = (best[k] < before[k]) ? sid : win[k];
+            }
+            if (has_next) {
+                lds[buf ^ 1][tid] = r0;
+                lds[buf ^ 1][tid + kBlock] = r1;
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    unsigned long long *out = keys + (long long)split * ns_pad;
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const long long i = (long long)tile * (kBlock * SPT) + k * kBlock + tid;
+        out[i] = ((unsigned long long)__float_as_uint(best[k]) << 32) | win[k];
+    }
+}
+
+NNLaunch nn_plan(int64_t ns, int64_t nt_pad)
+{
+    NNLaunch p;
+    const int64_t chunks = nt_pad / kTChunk;
+    // small clouds: fewer points per thread so that more workgroups exist
+    p.spt = (ns >= 64 * 1024) ? kSptLarge : kSptSmall;
+    const int64_t tile = (int64_t)kBlock * p.spt;
+    p.src_tiles = (int)((ns + tile - 1) / tile);
+    if (p.src_tiles < 1) p.src_tiles = 1;
+    // aim for ~8 workgroups per CU (256 CUs) so the tail is short
+    const int64_t want = 2048;
+    int64_t splits = (want + p.src_tiles - 1) / p.src_tiles;
+    if (splits > chunks) splits = chunks;
+    if (splits >= 8) splits = (splits / 8) * 8;  // XCD-aware decode needs %8
+    if (splits < 1) splits = 1;
+    // every split must own at least one chunk
+    int64_t per = (chunks + splits - 1) / splits;
+    splits = (chunks + per - 1) / per;
+    if (splits >= 8 && (splits & 7)) {
+        // re-balance to a multiple of 8 when possible without empty splits
+        int64_t s8 = (splits / 8) * 8;
+        int64_t per8 = (chunks + s8 - 1) / s8;
+        if ((chunks + per8 - 1) / per8 == s8) splits = s8;
+    }
+    p.tgt_splits = (int)(splits < 1 ? 1 : splits);
+    return p;
+}
+
+hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
+                           int64_t nt_pad, const Xform32 &T, float r2f,
+                           unsigned long long *keys, int64_t ns_pad,
+                           const NNLaunch &plan, hipStream_t stream)
+{
+    const int chunks = (int)(nt_pad / kTChunk);
+    const int per = (chunks + plan.tgt_splits - 1) / plan.tgt_splits;
+    const dim3 grid((unsigned)(plan.src_tiles * plan.tgt_splits));
+    if (plan.spt == kSptLarge)
+        hipLaunchKernelGGL(nn_brute_kernel<kSptLarge>, grid, dim3(kBlock), 0, stream, src,
+                           (int)ns, tgt, chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f,
+                           keys, (long long)ns_pad);
+    else
+        hipLaunchKernelGGL(nn_brute_kernel<kSptSmall>, grid, dim3(kBlock), 0, stream, src,
+                           (int)ns, tgt, chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f,
+                           keys, (long long)ns_pad);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// Reduction: merge + refine + Jacobian/residual + wave-shuffle reduce
+// ------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Accumulator layouts
+//  point-to-point (23): 0 K | 1 r2 | 2-4 sum p | 5-7 sum q |
+//                       8-13 sum pp^T (xx xy xz yy yz zz) | 14-22 sum q p^T
+//  point-to-plane (29): 0 K | 1 r2 | 2-22 upper J^T J | 23-28 J^T r
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void reduce_kernel(
+    const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
+    const float4 *__restrict__ nrm, const unsigned long long *__restrict__ keys,
+    int nsplits, long long ns_pad, Xform32 T32, Xform64 T64, float r2f,
+    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
+{
+    constexpr int NACC = PLANE ? 29 : 23;
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        // (1) merge the per-split candidates: smallest (d2, sub-chunk id)
+        unsigned long long key = keys[i];
+        for (int s = 1; s < nsplits; s++) {
+            const unsigned long long k2 = keys[(long long)s * ns_pad + i];
+            key = (k2 < key) ? k2 : key;
+        }
+        const unsigned win = (unsigned)(key & 0xFFFFFFFFull);
+        const float best = __uint_as_float((unsigned)(key >> 32));
+        const float4 s4 = src[i];
+        int idx = -1;
+        float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (win != 0xFFFFFFFFu) {
+            // (2) recover the exact index: first j of the winning sub-chunk
+            // whose distance (same fp32 arithmetic) equals the minimum
+            float px, py, pz;
+            xform_point_f32(T32, s4, px, py, pz);
+            const float4 *t = tgt + (long long)win * kSub;
+#pragma unroll 4
+            for (int j = kSub - 1; j >= 0; --j) {
+                const float4 q = t[j];
+                if (sqdist_f32(q, px, py, pz) == best) {
+                    idx = (int)(win * kSub) + j;
+                    q4 = q;
+                }
+            }
+        }
+        idx_out[i] = idx;
+        d2_out[i] = best;
+        if (idx >= 0) {
+            // (3) Jacobian / residual rows in f64 (design rule R1/R2)
+            const double sx = s4.x, sy = s4.y, sz = s4.z;
+            const double p[3] = {
+                T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3],
+                T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7],
+                T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11]};
+            const double q[3] = {(double)q4.x, (double)q4.y, (double)q4.z};
+            const double r[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+            acc[0] += 1.0;
+            if (!PLANE) {
+                acc[1] += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+                acc[2] += p[0]; acc[3] += p[1]; acc[4] += p[2];
+                acc[5] += q[0]; acc[6] += q[1]; acc[7] += q[2];
+                acc[8] += p[0] * p[0]; acc[9] += p[0] * p[1]; acc[10] += p[0] * p[2];
+                acc[11] += p[1] * p[1]; acc[12] += p[1] * p[2]; acc[13] += p[2] * p[2];
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) acc[14 + a * 3 + b] += q[a] * p[b];
+            } else {
+                const float4 n4 = nrm[idx];
+                const double n[3] = {(double)n4.x, (double)n4.y, (double)n4.z};
+                const double rr = r[0] * n[0] + r[1] * n[1] + r[2] * n[2];
+                // J = [p x n | n]  (TransformationEstimation.cpp:87-89)
+                double J[6];
+                double H[9];
+                hat(p, H);  // p x n = hat(p) n
+                J[0] = H[0] * n[0] + H[1] * n[1] + H[2] * n[2];
+                J[1] = H[3] * n[0] + H[4] * n[1] + H[5] * n[2];
+                J[2] = H[6] * n[0] + H[7] * n[1] + H[8] * n[2];
+                J[3] = n[0]; J[4] = n[1]; J[5] = n[2];
+                acc[1] += rr * rr;
+                int o = 2;
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = a; b < 6; b++) acc[o++] += J[a] * J[b];
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[23 + a] += J[a] * rr;
+            }
+        }
+    }
+
+    // (4) wavefront shuffle reduction -> LDS across the 4 waves -> partials
+    __shared__ double wsum[kBlock / 64][NACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const double v = wave_sum(acc[a]);
+        if (lane == 0) wsum[wave][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double v = wsum[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; w++) v += wsum[w][threadIdx.x];
+        partials[(long long)blockIdx.x * kReduceAcc + threadIdx.x] = v;
+    }
+}
+
+// One workgroup; folds `nblocks` partial rows in a fixed order and expands the
+// compact point-to-point moments into the 6x6 / 6x1 normal equations.
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restrict__ partials,
+                                                          int nblocks,
+                                                          double *__restrict__ stats)
+{
+    constexpr int NACC = PLANE ? 29 : 23;
+    __shared__ double part[8][32];
+    __shared__ double tot[32];
+    const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double v = 0.0;
+    if (a < NACC)
+        for (int b = g; b < nblocks; b += 8) v += partials[(long long)b * kReduceAcc + a];
+    part[g][a] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < 8; gg++) t += part[gg][threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (PLANE) {
+            for (int i = 0; i < 29; i++) stats[i] = tot[i];
+            for (int i = 29; i < kNStats; i++) stats[i] = 0.0;
+        } else {
+            const double K = tot[0];
+            const double Px = tot[2], Py = tot[3], Pz = tot[4];
+            const double Qx = tot[5], Qy = tot[6], Qz = tot[7];
+            const double Sxx = tot[8], Sxy = tot[9], Sxz = tot[10];
+            const double Syy = tot[11], Syz = tot[12], Szz = tot[13];
+            const double *M = &tot[14];
+            stats[0] = K;
+            stats[1] = tot[1];
+            double *J = stats + 2;  // upper triangle, row by row
+            // row 0: sum(|p|^2 I - p p^T) | hat(sum p)
+            J[0] = Syy + Szz; J[1] = -Sxy; J[2] = -Sxz; J[3] = 0.0; J[4] = -Pz; J[5] = Py;
+            J[6] = Sxx + Szz; J[7] = -Syz; J[8] = Pz; J[9] = 0.0; J[10] = -Px;
+            J[11] = Sxx + Syy; J[12] = -Py; J[13] = Px; J[14] = 0.0;
+            J[15] = K; J[16] = 0.0; J[17] = 0.0;
+            J[18] = K; J[19] = 0.0;
+            J[20] = K;
+            double *r = stats + 23;  // J^T r = [ -vee(sum q p^T) ; sum p - sum q ]
+            double v3[3];
+            vee(M, v3);
+            r[0] = -v3[0]; r[1] = -v3[1]; r[2] = -v3[2];
+            r[3] = Px - Qx; r[4] = Py - Qy; r[5] = Pz - Qz;
+            for (int i = 0; i < 9; i++) stats[29 + i] = M[i];
+        }
+    }
+}
+
+int reduce_max_blocks() { return 1024; }
+
+hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
+                         const float4 *tgt_normals, const unsigned long long *keys,
+                         int nsplits, int64_t ns_pad, const Xform32 &T32,
+                         const Xform64 &T64, float r2f, int point_to_plane,
+                         int32_t *idx_out, float *d2_out, double *partials,
+                         int max_partial_blocks, double *stats_out, hipStream_t stream)
+{
+    int nblocks = (int)((ns + kBlock - 1) / kBlock);
+    if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
+    if (nblocks < 1) nblocks = 1;
+    if (point_to_plane) {
+        hipLaunchKernelGGL(reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
+                           (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
+                           T64, r2f, idx_out, d2_out, partials);
+        hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(kBlock), 0, stream, partials,
+                           nblocks, stats_out);
+    } else {
+        hipLaunchKernelGGL(reduce_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src,
+                           (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
+                           T64, r2f, idx_out, d2_out, partials);
+        hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(kBlock), 0, stream, partials,
+                           nblocks, stats_out);
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------
+__global__ void fill_inf_kernel(float4 *dst, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);
+}
+
+hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(fill_inf_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                       dst, (long long)n);
+    return hipGetLastError();
+}
+
+__global__ void pack_float4_kernel(const float *src, int stride, float4 *dst, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float *s = src + i * stride;
+        dst[i] = make_float4(s[0], s[1], s[2], 0.f);
+    }
+}
+
+hipError_t launch_pack_float4(const float *src, int stride, float4 *dst, int64_t n,
+                              hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_float4_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       stream, src, stride, dst, (long long)n);
+    return hipGetLastError();
+}
+
+__global__ void so3_selftest_kernel(const double *w, double *R, double *w2, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double wi[3] = {w[3 * i], w[3 * i + 1], w[3 * i + 2]}, Ri[9], wo[3];
+    rodrigues(wi, Ri);
+    invrodrigues(Ri, wo);
+    for (int a = 0; a < 9; a++) R[9 * i + a] = Ri[a];
+    for (int a = 0; a < 3; a++) w2[3 * i + a] = wo[a];
+}
+
+hipError_t launch_so3_selftest(const double *w, double *R, double *w2, int n,
+                               hipStream_t stream)
+{
+    hipLaunchKernelGGL(so3_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w, R, w2,
+                       n);
+    return hipGetLastError();
+}
+
+}  // namespace visma
