@@ -177,6 +177,14 @@ VISMA_ICP_API int visma_icp_run(visma_icp_ctx *ctx, const double init[16],
                                 double max_dist, int max_iter, double rel_fitness,
                                 double rel_rmse, int solver, int with_scaling,
                                 visma_icp_result *out);
+/* Exactly `steps` fixed ICP iterations with no stop test: each step = one NN
+ * pass at T, one reduction, one solve, T <- update * T (the body of the loop
+ * at Registration.cpp:169-178).  T_inout is updated in place; out (may be NULL)
+ * reports fitness / rmse / K of the LAST pass (taken at the T before the
+ * final update).  This is the unit bench.py times. */
+VISMA_ICP_API int visma_icp_iterate(visma_icp_ctx *ctx, double T_inout[16], double max_dist,
+                                    int steps, int solver, int with_scaling,
+                                    visma_icp_result *out);
 /* Point-to-plane estimator (TransformationEstimation.cpp:61-103) on the same
  * reduction; needs set_target_normals_f64, else returns OK with
  * transformation = init (Registration.cpp:152-157). */

@@ -92,6 +92,8 @@ def load():
     L.visma_icp_solve_from_stats.argtypes = [_dp, C.c_int, C.c_int, _dp]
     L.visma_icp_run.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_double, C.c_double,
                                 C.c_int, C.c_int, C.POINTER(CResult)]
+    L.visma_icp_iterate.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(CResult)]
     L.visma_icp_run_point_to_plane.argtypes = [C.c_void_p, _dp, C.c_double, C.c_int, C.c_double,
                                                C.c_double, C.POINTER(CResult)]
     L.visma_icp_run_yaw_sweep.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double,
@@ -239,6 +241,14 @@ class Context:
                                        float(rel_fitness), float(rel_rmse), int(solver),
                                        int(bool(with_scaling)), C.byref(out)))
         return Result(out)
+
+    def iterate(self, T, max_dist, steps, solver=SOLVER_KABSCH, with_scaling=False):
+        """Exactly `steps` fixed iterations from T; returns (T_new, Result of last pass)."""
+        T = _f64(np.eye(4) if T is None else T, (16,)).copy()
+        out = CResult()
+        self._chk(self.L.visma_icp_iterate(self._h, _p(T, _dp), float(max_dist), int(steps),
+                                           int(solver), int(bool(with_scaling)), C.byref(out)))
+        return T.reshape(4, 4), Result(out)
 
     def run_point_to_plane(self, init=None, max_dist=0.05, max_iter=30, rel_fitness=1e-6,
                            rel_rmse=1e-6):

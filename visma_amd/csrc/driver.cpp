@@ -702,6 +702,35 @@ int visma_icp_run(visma_icp_ctx *ctx, const double init[16], double max_dist, in
     return ctx->run(init, max_dist, max_iter, rel_fitness, rel_rmse, solver, with_scaling != 0, false, out);
 }
 
+int visma_icp_iterate(visma_icp_ctx *ctx, double T_inout[16], double max_dist, int steps, int solver,
+                      int with_scaling, visma_icp_result *out)
+{
+    CTX_CHECK();
+    if (!T_inout || steps < 0 || !(max_dist > 0.0)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad iterate arguments");
+    if (solver < 0 || solver > VISMA_ICP_SOLVER_GN_EXPMAP) return ctx->fail(VISMA_ICP_ERR_INVALID, "unknown solver");
+    if (!ctx->have_src || !ctx->have_tgt) return ctx->fail(VISMA_ICP_ERR_STATE, "clouds not set");
+    Mat4 Tc = to_centred(Mat4::from(T_inout), ctx->centre);
+    double stats[VISMA_ICP_NSTATS], fit = 0, rmse = 0;
+    int64_t k = 0;
+    for (int i = 0; i < steps; i++) {
+        int rc = ctx->pass(Tc, max_dist, false, stats, &fit, &rmse, &k);
+        if (rc) return rc;
+        Tc = ctx->solve(stats, solver, with_scaling != 0, false) * Tc;
+    }
+    const Mat4 T = from_centred(Tc, ctx->centre);
+    std::memcpy(T_inout, T.m, sizeof(T.m));
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        std::memcpy(out->transformation, T.m, sizeof(T.m));
+        out->fitness = fit;
+        out->inlier_rmse = rmse;
+        out->num_correspondences = k;
+        out->iterations = steps;
+        out->nn_passes = steps;
+    }
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_run_point_to_plane(visma_icp_ctx *ctx, const double init[16], double max_dist,
                                  int max_iter, double rel_fitness, double rel_rmse,
                                  visma_icp_result *out)

@@ -107,17 +107,26 @@ def default_radius(nt):
     return float(min(0.075, max(0.005, 3.0 * math.sqrt(SURFACE_AREA / nt))))
 
 
-def make_pair(ns, nt, seed_t=1234, seed_s=5678, noise=1e-3, offset=None):
+def T_gt_scaled(radius):
+    """A motion of about one search radius: the large-cloud workloads use it so
+    that radius-limited ICP (r shrinks with the target density) still converges
+    within the fixed iteration budget."""
+    a = radius / 1.5
+    return make_T(rot_y(a) @ rot_x(a / 5.0), np.array([0.6, -0.3, 0.45]) * radius)
+
+
+def make_pair(ns, nt, seed_t=1234, seed_s=5678, noise=1e-3, offset=None, motion="fixed"):
     """Return (source, target, T_gt, radius); clouds are float32-rounded f64.
 
     target = S-surf(nt, seed_t) + N(0, noise); source = T_gt^-1 * S-surf(ns, seed_s).
     `offset` (3-vector) shifts the whole scene away from the origin.
+    motion = "fixed": T_gt() (5 deg yaw, ~3 cm);  "radius": T_gt_scaled(radius).
     """
     tgt = surface_points(nt, seed_t)
     rng = np.random.Generator(np.random.Philox(seed_t + 1))
     tgt += rng.standard_normal(tgt.shape) * noise
     src = surface_points(ns, seed_s)
-    T = T_gt()
+    T = T_gt() if motion == "fixed" else T_gt_scaled(default_radius(nt))
     if offset is not None:
         off = np.asarray(offset, dtype=np.float64)
         tgt += off
