@@ -249,6 +249,12 @@ VISMA_ICP_API int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduc
 /* Total source points over all ranks (fitness denominator); 0 = local ns. */
 VISMA_ICP_API int visma_icp_set_global_source_count(visma_icp_ctx *ctx, int64_t ns_total);
 
+/* Device self-test of the SO(3) math the kernels are built on (restatement of
+ * core/rodrigues.h:143-226 in visma_amd/csrc/so3.h): for n axis-angle vectors
+ * w (3n doubles) computes, ON THE GPU, R = rodrigues(w) (9n) and
+ * w_back = invrodrigues(R) (3n). */
+VISMA_ICP_API int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n);
+
 /* ---- engine injection (test seam) --------------------------------------- */
 
 /* The driver (centring, loop, solve, stop test, sharding) runs over an
@@ -261,8 +267,9 @@ typedef struct {
     int (*set_target)(void *user, const float *xyzw, int64_t nt);
     int (*set_target_normals)(void *user, const float *nxyzw, int64_t nt);
     int (*nn_pass)(void *user, const double T_centred[16], double max_dist);
-    int (*reduce)(void *user, const double T_centred[16], int point_to_plane,
-                  double stats[VISMA_ICP_NSTATS]);
+    /* statistics of p + frame_offset, q + frame_offset (0 = centred frame) */
+    int (*reduce)(void *user, const double T_centred[16], const double frame_offset[3],
+                  int point_to_plane, double stats[VISMA_ICP_NSTATS]);
     int (*get_correspondences)(void *user, int32_t *tgt_idx_per_src, float *d2);
 } visma_icp_engine;
 VISMA_ICP_API int visma_icp_create_with_engine(visma_icp_ctx **out,

@@ -386,8 +386,12 @@ void vo_svd3(const double A[9], double U[9], double s[3], double V[9])
     }
     /* complete U to an orthonormal basis when rank deficient */
     if (rank == 0) {
-        u[0][0] = 1; u[0][1] = 0; u[0][2] = 0;
-        rank = 1;
+        /* zero matrix: Eigen's JacobiSVD performs no rotation and returns
+         * U = V = I (so Umeyama yields R = I); do the same */
+        memset(U, 0, 9 * sizeof(double));
+        memset(V, 0, 9 * sizeof(double));
+        U[0] = U[4] = U[8] = V[0] = V[4] = V[8] = 1.0;
+        return;
     }
     if (rank == 1) {
         double e[3] = {0, 0, 0};
@@ -934,8 +938,11 @@ int64_t vk_nn_pass_f32_grid(const float *src, int64_t ns, int sstride,
 
 void vk_reduce_stats(const float *src, int64_t ns, int sstride,
                      const float *tgt, int tstride, const int32_t *idx,
-                     const double T64[12], double stats[VK_NSTATS])
+                     const double T64[12], const double *offset,
+                     double stats[VK_NSTATS])
 {
+    const double off[3] = {offset ? offset[0] : 0.0, offset ? offset[1] : 0.0,
+                           offset ? offset[2] : 0.0};
     double JTJ[36], JTr[6], qp[9], r2 = 0.0;
     memset(JTJ, 0, sizeof(JTJ));
     memset(JTr, 0, sizeof(JTr));
@@ -948,8 +955,8 @@ void vk_reduce_stats(const float *src, int64_t ns, int sstride,
         double p[3], q[3];
         for (int a = 0; a < 3; a++) {
             p[a] = T64[a * 4] * (double)s[0] + T64[a * 4 + 1] * (double)s[1] +
-                   T64[a * 4 + 2] * (double)s[2] + T64[a * 4 + 3];
-            q[a] = (double)qf[a];
+                   T64[a * 4 + 2] * (double)s[2] + T64[a * 4 + 3] + off[a];
+            q[a] = (double)qf[a] + off[a];
         }
         for (int a = 0; a < 3; a++) {
             double n[3] = {0, 0, 0}, J[6];
@@ -1059,7 +1066,7 @@ int vk_registration_icp(const double *src, int64_t ns, const double *tgt,
         for (int a = 0; a < 12; a++) T32[a] = (float)Tc[a];                    \
         k = use_grid ? vk_nn_pass_f32_grid(s32, ns, 4, t32, nt, 4, T32, r2f, idx, NULL) \
                      : vk_nn_pass_f32(s32, ns, 4, t32, nt, 4, T32, r2f, idx, NULL);    \
-        vk_reduce_stats(s32, ns, 4, t32, 4, idx, Tc, stats);                   \
+        vk_reduce_stats(s32, ns, 4, t32, 4, idx, Tc, NULL, stats);                   \
         if (k == 0) { fit = 0; rmse = 0; }                                     \
         else { fit = (double)k / (double)ns; rmse = sqrt(stats[1] / (double)k); } \
     } while (0)

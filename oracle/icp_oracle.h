@@ -163,10 +163,12 @@ int64_t vk_nn_pass_f32_grid(const float *src, int64_t ns, int sstride,
                             const float T32[12], float r2f, int32_t *idx,
                             float *d2);
 
-/* Statistics over the accepted pairs (idx >= 0). T64 = row-major 3x4 f64. */
+/* Statistics over the accepted pairs (idx >= 0). T64 = row-major 3x4 f64.
+ * offset (3 doubles, may be NULL = 0) shifts the frame: p+offset, q+offset. */
 void vk_reduce_stats(const float *src, int64_t ns, int sstride,
                      const float *tgt, int tstride, const int32_t *idx,
-                     const double T64[12], double stats[VK_NSTATS]);
+                     const double T64[12], const double *offset,
+                     double stats[VK_NSTATS]);
 
 /* Closed-form Kabsch/Umeyama update from the statistics (design rule R1). */
 void vk_solve_kabsch_from_stats(const double stats[VK_NSTATS], int with_scaling,

@@ -260,7 +260,7 @@ class Oracle:
                _ptr(idx, _ip), _ptr(d2, _fp))
         return int(k), idx, d2
 
-    def k_reduce_stats(self, src32, tgt32, idx, T64):
+    def k_reduce_stats(self, src32, tgt32, idx, T64, offset=None):
         src32 = np.ascontiguousarray(src32, np.float32)
         tgt32 = np.ascontiguousarray(tgt32, np.float32)
         idx = np.ascontiguousarray(idx, np.int32)
@@ -269,7 +269,9 @@ class Oracle:
         self.lib.vk_reduce_stats(_ptr(src32, _fp), C.c_int64(src32.shape[0]),
                                  C.c_int(src32.shape[1]), _ptr(tgt32, _fp),
                                  C.c_int(tgt32.shape[1]), _ptr(idx, _ip),
-                                 _ptr(T64, _dp), _ptr(st, _dp))
+                                 _ptr(T64, _dp),
+                                 None if offset is None else _ptr(_f64(offset, (3,)), _dp),
+                                 _ptr(st, _dp))
         return st
 
     def k_solve_kabsch(self, stats, with_scaling=False):

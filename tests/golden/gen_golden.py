@@ -1,0 +1,313 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference.
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/gen_golden.py
+
+Every expected value below is an OUTPUT of the reference's own compiled code
+(oracle/_ref/libvisma_ref.so = Open3D 0.3.0 RegistrationICP / estimators /
+PointCloud / Eigen utilities + VISMA core/rodrigues.h), or a literal the
+reference's unit tests hold (the two Open3D known-answer tests).  Inputs are
+stored float32-rounded so every implementation sees bit-identical points.
+Only data is written: no reference source travels.
+"""
+import ctypes
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.oracle import Ref, EST_POINT_TO_PLANE, EST_POINT_TO_POINT  # noqa: E402
+
+REF = "/root/reference"
+O3D_DATA = REF + "/thirdparty/Open3D/examples/TestData"
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float64).astype(np.float32)
+
+
+def load_obj(path):
+    V, F = [], []
+    for line in open(path):
+        p = line.split()
+        if not p:
+            continue
+        if p[0] == "v":
+            V.append([float(x) for x in p[1:4]])
+        elif p[0] == "f":
+            F.append([int(x.split("/")[0]) - 1 for x in p[1:4]])
+    return np.array(V), np.array(F)
+
+
+def sample_mesh(V, F, n, seed):
+    """Seeded area-uniform surface sampling (our own sampler: the reference's
+    include/geometry.h:29-64 is time-seeded, so both sides are fed these points)."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    a, b, c = V[F[:, 0]], V[F[:, 1]], V[F[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+    tri = rng.choice(len(F), size=n, p=area / area.sum())
+    u, v = rng.random(n), rng.random(n)
+    flip = u + v > 1
+    u[flip], v[flip] = 1 - u[flip], 1 - v[flip]
+    return a[tri] + u[:, None] * (b[tri] - a[tri]) + v[:, None] * (c[tri] - a[tri])
+
+
+def load_pcd_xyz_normals(path):
+    raw = open(path, "rb").read()
+    head_end = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+    header = raw[:head_end].decode("ascii", "replace")
+    n = int([l for l in header.splitlines() if l.startswith("POINTS")][0].split()[1])
+    fields = [l for l in header.splitlines() if l.startswith("FIELDS")][0].split()[1:]
+    arr = np.frombuffer(raw[head_end:head_end + n * 4 * len(fields)], dtype=np.float32)
+    arr = arr.reshape(n, len(fields))
+    xyz = arr[:, :3].astype(np.float64)
+    nrm = arr[:, 3:6].astype(np.float64)
+    ok = np.isfinite(xyz).all(1) & np.isfinite(nrm).all(1)
+    return xyz[ok], nrm[ok]
+
+
+def rot_y(a):
+    c, s = math.cos(a), math.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+
+def make_T(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def trace(ref, src, tgt, r, init, iters, **kw):
+    """Per-iteration (T, fitness, rmse, K): RegistrationICP with max_iter = 0..iters."""
+    rows = []
+    last = None
+    for m in range(iters + 1):
+        last = ref.registration_icp(src, tgt, r, init=init, max_iter=m, rel_fitness=0.0,
+                                    rel_rmse=0.0, **kw)
+        rows.append(np.concatenate([last.T.ravel(), [last.fitness, last.rmse, last.k]]))
+    return np.array(rows), last
+
+
+def glibc_rand_points(n, lo=0.0, hi=1000.0):
+    """UnitTest::Rand (O3D/UnitTest/UnitTest.cpp:76-95): srand(0); x,y,z = rand()."""
+    libc = ctypes.CDLL("libc.so.6")
+    libc.srand(0)
+    RAND_MAX = 2147483647
+    f = (hi - lo) / RAND_MAX
+    out = np.empty((n, 3))
+    for i in range(n):
+        for a in range(3):
+            out[i, a] = lo + libc.rand() * f
+    return out
+
+
+def main():
+    os.environ.setdefault("OMP_NUM_THREADS", "8")
+    ref = Ref()
+    V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
+
+    # ---- C1/C2: chair CAD 5k samples -> 20k partial noisy scan ------------
+    src = f32(sample_mesh(V, F, 5000, 11)).astype(np.float64)
+    dense = sample_mesh(V, F, 60000, 12)
+    view = np.array([math.cos(0.6), 0.25, math.sin(0.6)])
+    keep = np.argsort(-(dense @ view))[:20000]          # the half facing the "camera"
+    keep.sort()
+    rng = np.random.Generator(np.random.Philox(13))
+    scan = dense[keep] + rng.standard_normal((20000, 3)) * 0.002
+    T_true = make_T(rot_y(math.radians(10.0)), [0.03, 0.0, -0.02])
+    tgt = f32(scan @ T_true[:3, :3].T + T_true[:3, 3]).astype(np.float64)
+    tr, last = trace(ref, src, tgt, 0.075, np.eye(4), 20)
+    np.savez_compressed(os.path.join(HERE, "chair_5k_20k.npz"), src=f32(src), tgt=f32(tgt),
+                        radius=0.075, init=np.eye(4), trace=tr, final_idx=last.idx,
+                        T_true=T_true)
+    print("chair_5k_20k: K=%d fitness=%.4f rmse=%.5f" % (last.k, last.fitness, last.rmse))
+
+    # same scene 3 m away from the origin (fp32 cancellation stress)
+    off = np.array([3.0, -1.0, 2.5])
+    src_o = f32(src + off).astype(np.float64)
+    tgt_o = f32(tgt + off).astype(np.float64)
+    init_o = make_T(rot_y(math.radians(2.0)), [0.005, 0.0, 0.004])
+    tr_o, last_o = trace(ref, src_o, tgt_o, 0.075, init_o, 20)
+    np.savez_compressed(os.path.join(HERE, "chair_offset3m.npz"), src=f32(src_o), tgt=f32(tgt_o),
+                        radius=0.075, init=init_o, trace=tr_o[[0, 1, 5, 10, 20]],
+                        trace_iters=np.array([0, 1, 5, 10, 20]), final_idx=last_o.idx)
+
+    # default criteria (1e-6, 1e-6, 30): termination semantics
+    term = ref.registration_icp(src, tgt, 0.075, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6)
+    # with scaling (7-DoF Umeyama)
+    src_s = f32(src * 1.03).astype(np.float64)
+    sc = ref.registration_icp(src_s, tgt, 0.075, max_iter=15, rel_fitness=0, rel_rmse=0,
+                              with_scaling=True)
+
+    # ---- orientation-constrained sweep: 24 yaw inits (src/annotation.cpp:29-64)
+    model = f32(sample_mesh(V, F, 4000, 21)).astype(np.float64)
+    scene_dense = sample_mesh(V, F, 30000, 22)
+    keep = np.argsort(-(scene_dense @ view))[:8000]
+    keep.sort()
+    rng = np.random.Generator(np.random.Philox(23))
+    T_scene = make_T(rot_y(math.radians(97.0)), [0.01, 0.0, -0.015])
+    scene = scene_dense[keep] + rng.standard_normal((8000, 3)) * 0.002
+    scene = f32(scene @ T_scene[:3, :3].T + T_scene[:3, 3]).astype(np.float64)
+    sweep_T, sweep_k, sweep_fit, sweep_rmse = [], [], [], []
+    for i in range(24):
+        a = 2 * math.pi / 24 * i
+        r = ref.registration_icp(model, scene, 0.02, init=make_T(rot_y(a), [0, 0, 0]), max_iter=30,
+                                 rel_fitness=1e-6, rel_rmse=1e-6)
+        sweep_T.append(r.T); sweep_k.append(r.k); sweep_fit.append(r.fitness); sweep_rmse.append(r.rmse)
+    sweep_k = np.array(sweep_k)
+    best = int(np.argmax(sweep_k))   # np.argmax = first maximum = "strictly greater" rule
+    np.savez_compressed(os.path.join(HERE, "yaw_sweep.npz"), model=f32(model), scene=f32(scene),
+                        radius=0.02, level=24, T=np.array(sweep_T), k=sweep_k,
+                        fitness=np.array(sweep_fit), rmse=np.array(sweep_rmse), best=best,
+                        T_scene=T_scene)
+    print("yaw sweep: best level %d K=%d (K range %d..%d)" % (best, sweep_k[best], sweep_k.min(), sweep_k.max()))
+
+    # ---- real scan fragments with normals (Open3D TestData/Feature) --------
+    a_xyz, a_n = load_pcd_xyz_normals(O3D_DATA + "/Feature/cloud_bin_0.pcd")
+    b_xyz, b_n = load_pcd_xyz_normals(O3D_DATA + "/Feature/cloud_bin_1.pcd")
+    a_xyz, a_n, b_xyz, b_n = [f32(x).astype(np.float64) for x in (a_xyz, a_n, b_xyz, b_n)]
+    init_f = make_T(rot_y(0.02), [0.01, -0.005, 0.0])
+    p2p, _ = trace(ref, a_xyz, b_xyz, 0.25, init_f, 10)
+    p2l_rows = []
+    for m in range(11):
+        r = ref.registration_icp(a_xyz, b_xyz, 0.25, init=init_f, max_iter=m, rel_fitness=0,
+                                 rel_rmse=0, estimator=EST_POINT_TO_PLANE, src_normals=a_n,
+                                 tgt_normals=b_n)
+        p2l_rows.append(np.concatenate([r.T.ravel(), [r.fitness, r.rmse, r.k]]))
+    np.savez_compressed(os.path.join(HERE, "fragments.npz"), src=f32(a_xyz), src_normals=f32(a_n),
+                        tgt=f32(b_xyz), tgt_normals=f32(b_n), radius=0.25, init=init_f,
+                        trace_p2p=p2p, trace_p2plane=np.array(p2l_rows))
+    print("fragments: p2p K=%d  p2plane K=%d" % (p2p[-1][18], p2l_rows[-1][18]))
+
+    # ---- estimator-level vectors ------------------------------------------
+    rng = np.random.default_rng(31)
+    K = 700
+    corr = np.stack([rng.integers(0, len(a_xyz), K), rng.integers(0, len(b_xyz), K)], 1).astype(np.int32)
+    est = dict(corr=corr)
+    est["rmse_p2p"] = ref.compute_rmse(a_xyz, b_xyz, corr)
+    est["T_p2p"] = ref.compute_transformation(a_xyz, b_xyz, corr)
+    est["T_p2p_scaled"] = ref.compute_transformation(a_xyz, b_xyz, corr, with_scaling=True)
+    est["T_p2plane"] = ref.compute_transformation(a_xyz, b_xyz, corr, estimator=EST_POINT_TO_PLANE,
+                                                  tgt_normals=b_n)
+    est["T_empty"] = ref.compute_transformation(a_xyz, b_xyz, corr[:0])
+    est["rmse_empty"] = ref.compute_rmse(a_xyz, b_xyz, corr[:0])
+    # near-aligned correspondences (small residuals) for the 6x6 path
+    idx = rng.integers(0, len(b_xyz), K)
+    Tn = make_T(rot_y(0.01), [0.002, -0.001, 0.003])
+    near = b_xyz[idx] @ np.linalg.inv(Tn)[:3, :3].T + np.linalg.inv(Tn)[:3, 3]
+    near = f32(near + rng.standard_normal(near.shape) * 1e-3).astype(np.float64)
+    corr_n = np.stack([np.arange(K), idx], 1).astype(np.int32)
+    est["near_src"] = f32(near)
+    est["near_corr"] = corr_n
+    est["near_T_p2p"] = ref.compute_transformation(near, b_xyz, corr_n)
+    est["near_T_p2plane"] = ref.compute_transformation(near, b_xyz, corr_n,
+                                                       estimator=EST_POINT_TO_PLANE, tgt_normals=b_n)
+    # 6x6 solves: a regular system, and a singular one that must be rejected
+    A = rng.standard_normal((6, 6)); A = A @ A.T + 6 * np.eye(6); b6 = rng.standard_normal(6) * 0.01
+    ok, X = ref.solve_jacobian_system(A, b6)
+    As = A.copy(); As[5] = As[4]; As[:, 5] = As[:, 4]
+    ok_s, X_s = ref.solve_jacobian_system(As, b6)
+    est.update(jtj=A, jtr=b6, solve_ok=ok, solve_T=X, jtj_singular=As, solve_singular_ok=ok_s,
+               solve_singular_T=X_s)
+    xs = rng.standard_normal((8, 6)) * np.array([1.5, 0.7, 2.0, 1, 1, 1])
+    est["euler_x"] = xs
+    est["euler_T"] = np.array([ref.vector6d_to_matrix4d(x) for x in xs])
+    est["termination_T"] = term.T
+    est["termination"] = np.array([term.fitness, term.rmse, term.k])
+    est["scaled_src"] = f32(src_s)
+    est["scaled_T"] = sc.T
+    est["scaled"] = np.array([sc.fitness, sc.rmse, sc.k])
+    np.savez_compressed(os.path.join(HERE, "estimators.npz"), **est)
+
+    # ---- edge cases ---------------------------------------------------------
+    e_src = f32(sample_mesh(V, F, 300, 41)).astype(np.float64)
+    e_tgt = f32(sample_mesh(V, F, 500, 42)).astype(np.float64)
+    dup = np.concatenate([e_tgt, e_tgt[:50]], 0)        # exact duplicate targets
+    edge = dict(src=f32(e_src), tgt=f32(e_tgt), tgt_dup=f32(dup))
+    cases = {
+        "none": (e_src + 50.0, e_tgt, 0.01, 5),          # no correspondences at all
+        "tiny_radius": (e_src, e_tgt, 1e-4, 5),
+        "dup": (e_src, dup, 0.05, 8),
+        "one_src": (e_src[:1], e_tgt, 0.5, 4),
+        "one_tgt": (e_src, e_tgt[:1], 2.0, 4),
+        "huge_radius": (e_src, e_tgt, 1e3, 6),
+        "zero_iter": (e_src, e_tgt, 0.05, 0),
+    }
+    for name, (s, t, r, m) in cases.items():
+        res = ref.registration_icp(s, t, r, max_iter=m, rel_fitness=0, rel_rmse=0)
+        edge[name + "_T"] = res.T
+        edge[name + "_frk"] = np.array([res.fitness, res.rmse, res.k])
+        edge[name + "_args"] = np.array([r, m])
+    bad = ref.registration_icp(e_src, e_tgt, 0.0, init=make_T(rot_y(0.3), [1, 2, 3]), max_iter=5)
+    edge["bad_radius_T"] = bad.T
+    edge["bad_radius_frk"] = np.array([bad.fitness, bad.rmse, bad.k])
+    noN = ref.registration_icp(e_src, e_tgt, 0.05, init=make_T(rot_y(0.3), [1, 2, 3]), max_iter=5,
+                               estimator=EST_POINT_TO_PLANE)
+    edge["plane_without_normals_T"] = noN.T
+    ev = ref.evaluate_registration(e_src, e_tgt, 0.05, make_T(rot_y(0.05), [0.01, 0, 0]))
+    edge["evaluate_frk"] = np.array([ev.fitness, ev.rmse, ev.k])
+    edge["evaluate_idx"] = ev.idx
+    edge["evaluate_T"] = make_T(rot_y(0.05), [0.01, 0, 0])
+    np.savez_compressed(os.path.join(HERE, "edge_cases.npz"), **edge)
+
+    # ---- Open3D known-answer unit tests (literals held by the reference tests) --
+    pts = glibc_rand_points(100)
+    ka = dict(rand_points=pts)
+    # O3D/UnitTest/Core/Geometry/PointCloud.cpp:172-232 (PointCloud.Transform)
+    ka["transform_T"] = np.array([[0.10, 0.20, 0.30, 0.40], [0.50, 0.60, 0.70, 0.80],
+                                  [0.90, 0.10, 0.11, 0.12], [0.13, 0.14, 0.15, 0.16]])
+    ka["transform_ref_points"] = np.array([
+        [398.225124, 1205.693071, 881.868153], [321.838886, 1085.294390, 831.611417],
+        [270.900608, 823.791432, 409.198658], [339.937683, 1004.432856, 615.608467],
+        [425.227547, 1157.793590, 484.511386], [434.350931, 1342.432421, 967.169396],
+        [140.844202, 447.193004, 190.052250], [293.388019, 767.506059, 320.900694],
+        [135.193922, 410.559494, 195.502569], [276.542855, 807.338946, 221.948633]])
+    ka["transform_ref_normals"] = np.array([
+        [397.825124, 1204.893071, 881.748153], [321.438886, 1084.494390, 831.491417],
+        [270.500608, 822.991432, 409.078658], [339.537683, 1003.632856, 615.488467],
+        [424.827547, 1156.993590, 484.391386], [433.950931, 1341.632421, 967.049396],
+        [140.444202, 446.393004, 189.932250], [292.988019, 766.706059, 320.780694],
+        [134.793922, 409.759494, 195.382569], [276.142855, 806.538946, 221.828633]])
+    # O3D/UnitTest/Core/Geometry/PointCloud.cpp:1074-1111
+    ka["nn_distance_ref"] = np.array([
+        155.013456, 126.672493, 114.606722, 190.747153, 133.079840, 121.137276, 106.805907,
+        226.190750, 131.745147, 172.069584, 247.822223, 119.390962, 21.209580, 68.624498,
+        136.386737, 149.981320, 206.445708, 191.876431, 140.127314, 131.657386, 183.471289,
+        221.094822, 178.447628, 126.081556, 29.338770, 111.453558, 102.236849, 304.969947,
+        40.823263, 227.787078, 169.129676, 197.146871, 167.494524, 174.795150, 142.910946,
+        263.053174, 122.803815, 238.740548, 116.243401, 180.230879, 91.863637, 96.241462,
+        24.547707, 174.705689, 65.612463, 148.994593, 158.758879, 345.655903, 251.182091,
+        182.235820])
+    # sanity: the compiled reference reproduces its own literals from these inputs
+    p10, n10 = ref.transform_points(pts[:10], ka["transform_T"], normals=pts[:10])
+    assert np.abs(p10 - ka["transform_ref_points"]).max() < 1e-6
+    assert np.abs(n10 - ka["transform_ref_normals"]).max() < 1e-6
+    d = ref.nn_distance(pts[:50], pts[50:100])
+    assert np.abs(d - ka["nn_distance_ref"]).max() < 1e-6
+    np.savez_compressed(os.path.join(HERE, "open3d_known_answers.npz"), **ka)
+
+    # ---- SO(3): core/rodrigues.h outputs -----------------------------------
+    rng = np.random.default_rng(51)
+    ws = np.concatenate([rng.standard_normal((12, 3)), rng.standard_normal((3, 3)) * 1e-10,
+                         np.zeros((1, 3)), rng.standard_normal((2, 3)) * 1e-4])
+    Rs, dRs, w2, dws, hats = [], [], [], [], []
+    for w in ws:
+        R, dR = ref.rodrigues(w)
+        wb, dw = ref.invrodrigues(R)
+        Rs.append(R); dRs.append(dR); w2.append(wb); dws.append(dw); hats.append(ref.hat(w))
+    np.savez_compressed(os.path.join(HERE, "rodrigues.npz"), w=ws, R=np.array(Rs),
+                        dR_dw=np.array(dRs), w_back=np.array(w2), dw_dR=np.array(dws),
+                        hat=np.array(hats))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -48,13 +48,14 @@ class OracleEngine:
             self.calls["nn"] += 1
             return 0
 
-        def reduce(_u, T, plane, out):
+        def reduce(_u, T, off, plane, out):
             Tc = np.ctypeslib.as_array(T, shape=(16,)).copy()
+            off = np.ctypeslib.as_array(off, shape=(3,)).copy()
             if plane:
-                st = self._plane_stats(Tc)
+                st = self._plane_stats(Tc, off)
             else:
                 st = self.o.k_reduce_stats(self.src, self.tgt if len(self.tgt) else np.zeros((1, 4), np.float32),
-                                           self.idx, Tc)
+                                           self.idx, Tc, offset=off)
             np.ctypeslib.as_array(out, shape=(38,))[:] = st
             self.calls["reduce"] += 1
             return 0
@@ -70,12 +71,12 @@ class OracleEngine:
                      _lib.ENG_NN(nn_pass), _lib.ENG_REDUCE(reduce), _lib.ENG_CORR(get_corr)]
         self.table = _lib.CEngine(*self._cbs)
 
-    def _plane_stats(self, Tc):
+    def _plane_stats(self, Tc, off):
         """Point-to-plane rows in f64 from the fp32 clouds (same layout as the kernel)."""
         m = self.idx >= 0
         s = self.src[m, :3].astype(np.float64)
-        p = s @ Tc.reshape(4, 4)[:3, :3].T + Tc.reshape(4, 4)[:3, 3]
-        q = self.tgt[self.idx[m], :3].astype(np.float64)
+        p = s @ Tc.reshape(4, 4)[:3, :3].T + Tc.reshape(4, 4)[:3, 3] + off
+        q = self.tgt[self.idx[m], :3].astype(np.float64) + off
         n = self.nrm[self.idx[m], :3].astype(np.float64)
         corr = np.stack([np.arange(len(p)), np.arange(len(p))], 1).astype(np.int32)
         JTJ, JTr, r2 = self.o.jtj_jtr(p, q, corr, tgt_normals=n)

@@ -1,0 +1,220 @@
+"""CPU: the product's host logic and C ABI, without a GPU.
+
+The shared library is the real one (built by hipcc); only its kernels need a
+GPU.  The driver (centring, RegistrationICP loop, closed-form / GN solves,
+stop test, yaw sweep, batching, all-reduce hook) is exercised through
+visma_icp_create_with_engine with the oracle standing in for the kernels --
+that seam exists for exactly this test-suite.  No compute call reaches HIP.
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle_engine import OracleEngine
+from visma_amd import synth
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def rel(A, B):
+    return synth.rel_frobenius(A, B)
+
+
+@pytest.fixture()
+def hctx(lib, oracle):
+    eng = OracleEngine(oracle)
+    ctx = eng.context()
+    ctx.engine = eng
+    yield ctx
+    ctx.close()
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    """Every VISMA_ICP_API function of include/visma_icp.h is exported."""
+    hdr = open(os.path.join(ROOT, "include", "visma_icp.h")).read()
+    names = sorted(set(re.findall(r"VISMA_ICP_API\s+[\w\s\*]+?\b(visma_icp_\w+)\s*\(", hdr)))
+    assert len(names) >= 25
+    L = ctypes.CDLL(lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    L.visma_icp_version.restype = ctypes.c_char_p
+    assert b"gfx950" in L.visma_icp_version()
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU the product refuses to create a context (no silent fallback)."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    with pytest.raises(lib.IcpError) as e:
+        lib.Context(0)
+    assert e.value.code in (2, 3)
+
+
+def test_tile_config(lib):
+    t = lib.tile_config()
+    assert t == {"s_tile": 2048, "t_chunk": 512, "block": 256}
+
+
+def test_solve_from_stats_matches_reference_estimators(lib, oracle):
+    e = load("estimators.npz")
+    f = load("fragments.npz")
+    tgt = f["tgt"].astype(np.float32)
+    near = e["near_src"].astype(np.float32)
+    idx = e["near_corr"][:, 1].astype(np.int32)
+    st = oracle.k_reduce_stats(near, tgt, idx, np.eye(4)[:3])
+    T = lib.solve_from_stats(st, lib.SOLVER_KABSCH)
+    assert rel(T, e["near_T_p2p"]) < 1e-9          # == reference ComputeTransformation
+    assert rel(T, oracle.k_solve_kabsch(st)) < 1e-13
+    Tg = lib.solve_from_stats(st, lib.SOLVER_GN_EULER)
+    assert rel(Tg, oracle.k_solve_gn(st)[1]) < 1e-13
+    Tx = lib.solve_from_stats(st, lib.SOLVER_GN_EXPMAP)
+    assert rel(Tx, Tg) < 1e-4 and np.allclose(Tx[:3, :3] @ Tx[:3, :3].T, np.eye(3), atol=1e-12)
+    Ts = lib.solve_from_stats(st, lib.SOLVER_KABSCH, with_scaling=True)
+    assert rel(Ts, oracle.k_solve_kabsch(st, with_scaling=True)) < 1e-13
+    # K = 0 -> identity (src/constrained_ICP.cpp:29)
+    assert np.array_equal(lib.solve_from_stats(np.zeros(38)), np.eye(4))
+    # the reference's own 6x6 systems, packed into the statistics layout
+    for A, ok_ref, T_ref in ((e["jtj"], True, e["solve_T"]), (e["jtj_singular"], False, np.eye(4))):
+        s = np.zeros(38); s[0] = 1.0
+        s[2:23] = A[np.triu_indices(6)]; s[23:29] = e["jtr"]
+        assert rel(lib.solve_from_stats(s, lib.SOLVER_GN_EULER), T_ref) < 1e-12
+
+
+def test_chair_golden_through_the_driver(hctx):
+    g = load("chair_5k_20k.npz")
+    hctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    for it in (0, 1, 7, 20):
+        r = hctx.run(g["init"], float(g["radius"]), it, 0.0, 0.0)
+        row = g["trace"][it]
+        assert r.iterations == it and r.nn_passes == it + 1
+        assert rel(r.transformation_, row[:16].reshape(4, 4)) < 1e-6
+        assert r.num_correspondences == row[18]
+        assert abs(r.fitness_ - row[16]) < 1e-12 and abs(r.inlier_rmse_ - row[17]) < 1e-7
+    assert rel(r.transformation_, g["trace"][20, :16].reshape(4, 4)) < 1e-7
+    assert np.mean(hctx.correspondence_index() == g["final_idx"]) >= 0.9999
+    si, ti, d2 = hctx.get_correspondences()
+    assert np.all(np.diff(si) > 0) and len(si) == r.num_correspondences   # sorted by source index
+
+
+def test_driver_equals_kernel_spec_loop(hctx, oracle):
+    """Same arithmetic as oracle vk_registration_icp, step for step."""
+    g = load("chair_offset3m.npz")
+    src, tgt = g["src"].astype(np.float64), g["tgt"].astype(np.float64)
+    hctx.set_clouds_f64(src, tgt)
+    r = hctx.run(g["init"], float(g["radius"]), 20, 0.0, 0.0)
+    k = oracle.k_registration_icp(src, tgt, float(g["radius"]), init=g["init"], max_iter=20,
+                                  rel_fitness=0, rel_rmse=0)
+    assert rel(r.transformation_, k.T) < 1e-12
+    assert rel(r.transformation_, g["trace"][-1][:16].reshape(4, 4)) < 1e-6   # 3 m offset, R2
+    assert np.array_equal(hctx.correspondence_index(), k.idx)
+
+
+def test_termination_semantics(hctx):
+    g = load("chair_5k_20k.npz")
+    e = load("estimators.npz")
+    hctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    r = hctx.run(None, 0.075, 30, 1e-6, 1e-6)
+    assert rel(r.transformation_, e["termination_T"]) < 1e-5
+    assert abs(r.num_correspondences - e["termination"][2]) <= 2
+    assert hctx.engine.calls["nn"] == r.nn_passes == r.iterations + 1
+
+
+def test_bad_arguments_follow_the_reference(hctx):
+    g = load("edge_cases.npz")
+    src, tgt = g["src"].astype(np.float64), g["tgt"].astype(np.float64)
+    hctx.set_clouds_f64(src, tgt)
+    init = g["bad_radius_T"]
+    r = hctx.run(init, 0.0, 5)                       # Registration.cpp:148-151
+    assert np.array_equal(r.transformation_, init) and r.num_correspondences == 0
+    assert r.fitness_ == 0 and r.inlier_rmse_ == 0 and hctx.engine.calls["nn"] == 0
+    r = hctx.run_point_to_plane(g["plane_without_normals_T"], 0.05, 5)   # :152-157
+    assert np.array_equal(r.transformation_, g["plane_without_normals_T"])
+    assert hctx.engine.calls["nn"] == 0
+    with pytest.raises(Exception):
+        hctx.run(None, 0.05, -1)
+
+
+def test_edge_cases_through_the_driver(hctx):
+    g = load("edge_cases.npz")
+    src, tgt, dup = (g[k].astype(np.float64) for k in ("src", "tgt", "tgt_dup"))
+    cases = {"none": (src + 50.0, tgt), "tiny_radius": (src, tgt), "dup": (src, dup),
+             "one_src": (src[:1], tgt), "one_tgt": (src, tgt[:1]), "huge_radius": (src, tgt),
+             "zero_iter": (src, tgt)}
+    for name, (s, t) in cases.items():
+        r_, m = g[name + "_args"]
+        hctx.set_clouds_f64(s, t)
+        r = hctx.run(None, float(r_), int(m), 0.0, 0.0)
+        assert r.num_correspondences == g[name + "_frk"][2], name
+        assert abs(r.fitness_ - g[name + "_frk"][0]) < 1e-12, name
+        assert abs(r.inlier_rmse_ - g[name + "_frk"][1]) < 1e-6 * max(1.0, g[name + "_frk"][1]), name
+        if name not in ("one_tgt", "one_src"):
+            assert rel(r.transformation_, g[name + "_T"]) < 1e-5, name
+    # empty clouds: no correspondences, identity updates
+    hctx.set_clouds_f64(np.zeros((0, 3)), tgt)
+    assert hctx.run(None, 0.1, 3, 0, 0).num_correspondences == 0
+    hctx.set_clouds_f64(src, np.zeros((0, 3)))
+    r = hctx.run(None, 0.1, 3, 0, 0)
+    assert r.num_correspondences == 0 and np.array_equal(r.transformation_, np.eye(4))
+
+
+def test_with_scaling(hctx):
+    g = load("chair_5k_20k.npz")
+    e = load("estimators.npz")
+    hctx.set_clouds_f64(e["scaled_src"].astype(np.float64), g["tgt"].astype(np.float64))
+    r = hctx.run(None, 0.075, 15, 0.0, 0.0, with_scaling=True)
+    assert rel(r.transformation_, e["scaled_T"]) < 1e-6
+    assert r.num_correspondences == e["scaled"][2]
+
+
+def test_point_to_plane(hctx):
+    g = load("fragments.npz")
+    hctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    hctx.set_target_normals_f64(g["tgt_normals"].astype(np.float64))
+    for it in (1, 10):
+        r = hctx.run_point_to_plane(g["init"], float(g["radius"]), it, 0.0, 0.0)
+        row = g["trace_p2plane"][it]
+        assert rel(r.transformation_, row[:16].reshape(4, 4)) < 1e-5
+        assert abs(r.num_correspondences - row[18]) <= 2
+    r = hctx.run(g["init"], float(g["radius"]), 10, 0.0, 0.0)
+    assert rel(r.transformation_, g["trace_p2p"][10][:16].reshape(4, 4)) < 1e-6
+
+
+def test_yaw_sweep(hctx):
+    g = load("yaw_sweep.npz")
+    hctx.set_clouds_f64(g["model"].astype(np.float64), g["scene"].astype(np.float64))
+    best, level, per = hctx.run_yaw_sweep(int(g["level"]), float(g["radius"]))
+    assert level == int(g["best"])
+    assert best.num_correspondences == g["k"][level]
+    assert rel(best.transformation_, g["T"][level]) < 1e-5
+    ks = np.array([p.num_correspondences for p in per])
+    # individual levels can stop one iteration apart (fp32 search vs f64), K within a few points
+    assert np.all(np.abs(ks - g["k"]) <= np.maximum(3, 0.01 * g["k"]))
+
+
+def test_batch(hctx, oracle):
+    g = load("edge_cases.npz")
+    src, tgt = g["src"].astype(np.float64), g["tgt"].astype(np.float64)
+    probs = [(src, tgt, None, 0.05), (src[:100], tgt, synth.make_T(synth.rot_y(0.05), [0.01, 0, 0]), 0.08),
+             (src + 50, tgt, None, 0.01)]
+    out = hctx.run_batch(probs, max_iter=6, rel_fitness=0, rel_rmse=0)
+    for (s, t, init, r), res in zip(probs, out):
+        o = oracle.registration_icp(s, t, r, init=init, max_iter=6, rel_fitness=0, rel_rmse=0)
+        assert res.num_correspondences == o.k
+        assert rel(res.transformation_, o.T) < 1e-6
+
+
+def test_iterate_is_k_fixed_steps(hctx):
+    g = load("chair_5k_20k.npz")
+    hctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    T, last = hctx.iterate(None, 0.075, 5)
+    assert hctx.engine.calls["nn"] == 5 and hctx.engine.calls["reduce"] == 5
+    assert rel(T, g["trace"][5, :16].reshape(4, 4)) < 1e-6
+    assert last.num_correspondences == g["trace"][4, 18]     # last pass was taken at T_4

@@ -51,7 +51,7 @@ class CProblem(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
 ENG_SET = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int64)
 ENG_NN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_double)
-ENG_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int, _dp)
+ENG_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, _dp, C.c_int, _dp)
 ENG_CORR = C.CFUNCTYPE(C.c_int, C.c_void_p, _ip, _fp)
 
 

@@ -84,7 +84,9 @@ public:
     virtual int set_source_device(const void *, int64_t) { err_ = "not supported by this engine"; return VISMA_ICP_ERR_STATE; }
     virtual int set_target_device(const void *, int64_t) { err_ = "not supported by this engine"; return VISMA_ICP_ERR_STATE; }
     virtual int nn_pass(const Mat4 &Tc, double max_dist) = 0;
-    virtual int reduce(const Mat4 &Tc, bool plane, double *stats) = 0;
+    // `offset` shifts the frame the statistics are expressed in (p+offset,
+    // q+offset): zero = centred frame, the cloud centre = the caller's frame.
+    virtual int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) = 0;
     virtual int get_correspondences(int32_t *idx, float *d2) = 0;
     virtual int comm_init(int, int, const void *) { err_ = "RCCL needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     virtual void set_profiling(bool) {}
@@ -218,7 +220,7 @@ public:
         return VISMA_ICP_OK;
     }
 
-    int reduce(const Mat4 &Tc, bool plane, double *stats) override
+    int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) override
     {
         HIP_TRY(hipSetDevice(device_));
         if (!have_pass_) { err_ = "reduce before nn_pass"; return VISMA_ICP_ERR_STATE; }
@@ -229,7 +231,7 @@ public:
         if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
         HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
                               (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
-                              plan_.tgt_splits, ns_pad_, T32_, T64, r2f_, plane ? 1 : 0,
+                              plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
                               (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
                               reduce_max_blocks(), (double *)d_stats_, stream_));
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
@@ -366,7 +368,11 @@ public:
         return wrap(vt_.set_target_normals(user_, p, n));
     }
     int nn_pass(const Mat4 &Tc, double r) override { return wrap(vt_.nn_pass(user_, Tc.m, r)); }
-    int reduce(const Mat4 &Tc, bool plane, double *st) override { return wrap(vt_.reduce(user_, Tc.m, plane ? 1 : 0, st)); }
+    int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *st) override
+    {
+        const double zero[3] = {0, 0, 0};
+        return wrap(vt_.reduce(user_, Tc.m, offset ? offset : zero, plane ? 1 : 0, st));
+    }
     int get_correspondences(int32_t *idx, float *d2) override
     {
         std::vector<float> tmp;
@@ -404,13 +410,18 @@ struct visma_icp_ctx {
     int eng_fail(int code) { err = eng->error(); return code; }
 
     // one NN pass + reduction (+ cross-rank sum); fills stats, fitness, rmse
-    int pass(const Mat4 &Tc, double max_dist, bool plane, double *stats, double *fit, double *rmse, int64_t *k)
+    // world_frame: express the statistics in the caller's frame (needed by the
+    // Gauss-Newton updates, whose Euler / exp-map retraction is not invariant to
+    // the choice of origin); the closed-form solve uses the centred frame.
+    int pass(const Mat4 &Tc, double max_dist, bool plane, bool world_frame, double *stats,
+             double *fit, double *rmse, int64_t *k)
     {
         int rc = eng->nn_pass(Tc, max_dist);
         if (rc) return eng_fail(rc);
         last_Tc = Tc;
         last_plane = plane;
-        rc = eng->reduce(Tc, plane, stats);
+        const double zero[3] = {0, 0, 0};
+        rc = eng->reduce(Tc, plane, world_frame ? centre : zero, stats);
         if (rc) return eng_fail(rc);
         if (host_allreduce && !eng->has_device_allreduce()) {
             if (host_allreduce(host_allreduce_user, stats, VISMA_ICP_NSTATS) != 0)
@@ -427,6 +438,15 @@ struct visma_icp_ctx {
             *rmse = 0.0;
         }
         return VISMA_ICP_OK;
+    }
+
+    static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }
+
+    // T_centred <- update o T_centred, with the update expressed in `world` or centred frame
+    Mat4 apply_update(const Mat4 &upd, const Mat4 &Tc, bool world_frame) const
+    {
+        if (!world_frame) return upd * Tc;
+        return to_centred(upd * from_centred(Tc, centre), centre);
     }
 
     Mat4 solve(const double *stats, int solver, bool scaling, bool plane) const
@@ -449,16 +469,17 @@ struct visma_icp_ctx {
         if (plane && !eng->has_normals()) return VISMA_ICP_OK;      // Registration.cpp:152-157
         if (!have_src || !have_tgt) return fail(VISMA_ICP_ERR_STATE, "clouds not set");
         Mat4 Tc = to_centred(Mat4::from(init), centre);
+        const bool world = wants_world_frame(solver, plane);
         double stats[VISMA_ICP_NSTATS], fit, rmse;
         int64_t k;
-        int rc = pass(Tc, max_dist, plane, stats, &fit, &rmse, &k);  // Registration.cpp:166-168
+        int rc = pass(Tc, max_dist, plane, world, stats, &fit, &rmse, &k);  // Registration.cpp:166-168
         if (rc) return rc;
         int it = 0;
         for (int i = 0; i < max_iter; i++) {                          // Registration.cpp:169-184
             const Mat4 upd = solve(stats, solver, scaling, plane);
-            Tc = upd * Tc;
+            Tc = apply_update(upd, Tc, world);
             const double bfit = fit, brmse = rmse;
-            rc = pass(Tc, max_dist, plane, stats, &fit, &rmse, &k);
+            rc = pass(Tc, max_dist, plane, world, stats, &fit, &rmse, &k);
             if (rc) return rc;
             it = i + 1;
             if (std::fabs(bfit - fit) < rel_fit && std::fabs(brmse - rmse) < rel_rmse) break;
@@ -646,7 +667,8 @@ int visma_icp_reduce(visma_icp_ctx *ctx, double out_stats[VISMA_ICP_NSTATS])
 {
     CTX_CHECK();
     if (!out_stats) return ctx->fail(VISMA_ICP_ERR_INVALID, "out_stats is NULL");
-    int rc = ctx->eng->reduce(ctx->last_Tc, false, out_stats);
+    const double zero[3] = {0, 0, 0};
+    int rc = ctx->eng->reduce(ctx->last_Tc, false, zero, out_stats);
     if (rc) return ctx->eng_fail(rc);
     if (ctx->host_allreduce && !ctx->eng->has_device_allreduce())
         if (ctx->host_allreduce(ctx->host_allreduce_user, out_stats, VISMA_ICP_NSTATS) != 0)
@@ -712,10 +734,11 @@ int visma_icp_iterate(visma_icp_ctx *ctx, double T_inout[16], double max_dist, i
     Mat4 Tc = to_centred(Mat4::from(T_inout), ctx->centre);
     double stats[VISMA_ICP_NSTATS], fit = 0, rmse = 0;
     int64_t k = 0;
+    const bool world = visma_icp_ctx::wants_world_frame(solver, false);
     for (int i = 0; i < steps; i++) {
-        int rc = ctx->pass(Tc, max_dist, false, stats, &fit, &rmse, &k);
+        int rc = ctx->pass(Tc, max_dist, false, world, stats, &fit, &rmse, &k);
         if (rc) return rc;
-        Tc = ctx->solve(stats, solver, with_scaling != 0, false) * Tc;
+        Tc = ctx->apply_update(ctx->solve(stats, solver, with_scaling != 0, false), Tc, world);
     }
     const Mat4 T = from_centred(Tc, ctx->centre);
     std::memcpy(T_inout, T.m, sizeof(T.m));
@@ -854,6 +877,24 @@ int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn, void 
     ctx->rank = rank;
     ctx->nranks = nranks;
     return VISMA_ICP_OK;
+}
+
+int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n)
+{
+    if (!w || !R || !w_back || n <= 0) return VISMA_ICP_ERR_INVALID;
+    double *dw = nullptr, *dR = nullptr, *dw2 = nullptr;
+    int rc = VISMA_ICP_ERR_HIP;
+    if (hipMalloc(&dw, sizeof(double) * 3 * n) == hipSuccess &&
+        hipMalloc(&dR, sizeof(double) * 9 * n) == hipSuccess &&
+        hipMalloc(&dw2, sizeof(double) * 3 * n) == hipSuccess &&
+        hipMemcpy(dw, w, sizeof(double) * 3 * n, hipMemcpyHostToDevice) == hipSuccess &&
+        launch_so3_selftest(dw, dR, dw2, n, nullptr) == hipSuccess &&
+        hipMemcpy(R, dR, sizeof(double) * 9 * n, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(w_back, dw2, sizeof(double) * 3 * n, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = VISMA_ICP_OK;
+    if (rc != VISMA_ICP_OK) g_create_error = "so3 selftest: HIP call failed (no GPU?)";
+    (void)hipFree(dw); (void)hipFree(dR); (void)hipFree(dw2);
+    return rc;
 }
 
 int visma_icp_set_global_source_count(visma_icp_ctx *ctx, int64_t ns_total)

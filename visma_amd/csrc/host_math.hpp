@@ -132,7 +132,12 @@ inline Svd3 svd3(const double A[9])
         c[1] = a[2] * b[0] - a[0] * b[2];
         c[2] = a[0] * b[1] - a[1] * b[0];
     };
-    if (rank == 0) { u[0][0] = 1; u[0][1] = 0; u[0][2] = 0; rank = 1; }
+    if (rank == 0) {
+        // zero matrix: no rotation is needed; U = V = I, which is also what the
+        // reference's JacobiSVD returns (so the update is a pure translation)
+        for (int i = 0; i < 9; i++) out.U[i] = out.V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        return out;
+    }
     if (rank == 1) {
         int m = 0;
         for (int r = 1; r < 3; r++) if (std::fabs(u[0][r]) < std::fabs(u[0][m])) m = r;

@@ -18,6 +18,7 @@ constexpr int kNStats = 38;
 
 struct Xform32 { float m[12]; };    // row-major 3x4, fp32 (NN search)
 struct Xform64 { double m[12]; };   // row-major 3x4, f64  (statistics)
+struct Offset64 { double v[3]; };   // frame shift applied to p and q in the statistics
 
 struct NNLaunch {
     int src_tiles;
@@ -44,7 +45,8 @@ hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
 hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const float4 *tgt_normals, const unsigned long long *keys,
                          int nsplits, int64_t ns_pad, const Xform32 &T32,
-                         const Xform64 &T64, float r2f, int point_to_plane,
+                         const Xform64 &T64, const double frame_offset[3], float r2f,
+                         int point_to_plane,
                          int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out,
                          hipStream_t stream);

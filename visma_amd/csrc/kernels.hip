@@ -215,7 +215,7 @@ template <bool PLANE>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
     const float4 *__restrict__ nrm, const unsigned long long *__restrict__ keys,
-    int nsplits, long long ns_pad, Xform32 T32, Xform64 T64, float r2f,
+    int nsplits, long long ns_pad, Xform32 T32, Xform64 T64, Offset64 off, float r2f,
     int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
 {
     constexpr int NACC = PLANE ? 29 : 23;
@@ -256,10 +256,11 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
             // (3) Jacobian / residual rows in f64 (design rule R1/R2)
             const double sx = s4.x, sy = s4.y, sz = s4.z;
             const double p[3] = {
-                T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3],
-                T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7],
-                T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11]};
-            const double q[3] = {(double)q4.x, (double)q4.y, (double)q4.z};
+                T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3] + off.v[0],
+                T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7] + off.v[1],
+                T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11] + off.v[2]};
+            const double q[3] = {(double)q4.x + off.v[0], (double)q4.y + off.v[1],
+                                 (double)q4.z + off.v[2]};
             const double r[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
             acc[0] += 1.0;
             if (!PLANE) {
@@ -372,23 +373,26 @@ int reduce_max_blocks() { return 1024; }
 hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const float4 *tgt_normals, const unsigned long long *keys,
                          int nsplits, int64_t ns_pad, const Xform32 &T32,
-                         const Xform64 &T64, float r2f, int point_to_plane,
+                         const Xform64 &T64, const double frame_offset[3], float r2f,
+                         int point_to_plane,
                          int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out, hipStream_t stream)
 {
+    Offset64 off;
+    for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
     int nblocks = (int)((ns + kBlock - 1) / kBlock);
     if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
     if (nblocks < 1) nblocks = 1;
     if (point_to_plane) {
         hipLaunchKernelGGL(reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
-                           T64, r2f, idx_out, d2_out, partials);
+                           T64, off, r2f, idx_out, d2_out, partials);
         hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(kBlock), 0, stream, partials,
                            nblocks, stats_out);
     } else {
         hipLaunchKernelGGL(reduce_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
-                           T64, r2f, idx_out, d2_out, partials);
+                           T64, off, r2f, idx_out, d2_out, partials);
         hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(kBlock), 0, stream, partials,
                            nblocks, stats_out);
     }
