@@ -1,0 +1,421 @@
+// visma_icp_open3d.hpp -- header-only C++/Eigen adapter between Open3D-shaped
+// callers and the C ABI (visma_icp.h).
+//
+// It is written against the NAMES the reference's callers use
+// (open3d::PointCloud::points_/normals_, CorrespondenceSet, RegistrationResult,
+// ICPConvergenceCriteria, TransformationEstimation and its enum), so it
+// compiles against the real Open3D 0.3.0 headers or against the stand-alone
+// set in include/Core/.  Include one of them first.
+//
+//   open3d::cicp::RegistrationICP      same signature as open3d::RegistrationICP
+//                                      (O3D/Core/Registration/Registration.h:102-107)
+//   open3d::cicp::EvaluateRegistration (Registration.h:96-99)
+//   open3d::cicp::RegisterModelToScene feh::RegisterModelToScene
+//                                      (include/tool.h:40-42, src/annotation.cpp:29-64)
+//   open3d::cicp::ICPRefinement        the ICP call of feh::ICPRefinement
+//                                      (src/evaluation.cpp:258-271)
+//
+// No Eigen type crosses a binary boundary: the C ABI takes raw row-major
+// doubles, so a translation unit built with -DEIGEN_DEFAULT_TO_ROW_MAJOR (as
+// VISMA's CMakeLists.txt:11-12 does) and one built without it can both use
+// this header.  Infrastructure failures (no GPU, HIP error) throw
+// std::runtime_error; argument errors follow the reference (message on stderr,
+// RegistrationResult(init) returned, Registration.cpp:148-157).
+#pragma once
+
+#include <Eigen/Core>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "visma_icp.h"
+
+namespace open3d {
+namespace cicp {
+
+// The plugin of include/constrained_ICP.h:14-30, made concrete: the reference
+// class never overrides the pure virtual GetTransformationEstimationType()
+// (O3D/Core/Registration/TransformationEstimation.h:58-59) and so cannot be
+// instantiated against the vendored Open3D; this one can.
+class TransformationEstimationPointToPoint4DoF : public TransformationEstimation {
+public:
+    TransformationEstimationPointToPoint4DoF(bool with_scaling = false)
+        : with_scaling_(with_scaling) {}
+    ~TransformationEstimationPointToPoint4DoF() override {}
+    TransformationEstimationType GetTransformationEstimationType() const override
+    {
+        return TransformationEstimationType::PointToPoint;
+    }
+    inline double ComputeRMSE(const PointCloud &source, const PointCloud &target,
+                              const CorrespondenceSet &corres) const override;
+    inline Eigen::Matrix4d ComputeTransformation(const PointCloud &source,
+                                                 const PointCloud &target,
+                                                 const CorrespondenceSet &corres) const override;
+    bool with_scaling_ = false;
+};
+
+namespace detail {
+
+inline void to_rowmajor(const Eigen::Matrix4d &M, double T[16])
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) T[i * 4 + j] = M(i, j);
+}
+
+inline Eigen::Matrix4d from_rowmajor(const double T[16])
+{
+    Eigen::Matrix4d M;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) M(i, j) = T[i * 4 + j];
+    return M;
+}
+
+// One context per host thread (the ABI is thread-compatible, not thread-safe).
+class ThreadContext {
+public:
+    ~ThreadContext() { if (ctx_) visma_icp_destroy(ctx_); }
+    visma_icp_ctx *get()
+    {
+        if (!ctx_) {
+            int device = 0;
+            if (const char *e = std::getenv("VISMA_ICP_DEVICE")) device = std::atoi(e);
+            const int rc = visma_icp_create(&ctx_, device);
+            if (rc != VISMA_ICP_OK)
+                throw std::runtime_error(std::string("visma_icp_create failed: ") +
+                                         visma_icp_last_error(nullptr));
+        }
+        return ctx_;
+    }
+    static ThreadContext &instance()
+    {
+        static thread_local ThreadContext tc;
+        return tc;
+    }
+
+private:
+    visma_icp_ctx *ctx_ = nullptr;
+};
+
+inline void check(visma_icp_ctx *ctx, int rc, const char *what)
+{
+    if (rc != VISMA_ICP_OK)
+        throw std::runtime_error(std::string(what) + ": " + visma_icp_last_error(ctx));
+}
+
+// std::vector<Eigen::Vector3d> is contiguous AoS f64 with stride 3
+inline const double *xyz(const std::vector<Eigen::Vector3d> &v)
+{
+    return v.empty() ? nullptr : v[0].data();
+}
+
+template <typename Cloud>
+inline visma_icp_ctx *upload(const Cloud &source, const Cloud &target, bool normals)
+{
+    visma_icp_ctx *ctx = ThreadContext::instance().get();
+    check(ctx, visma_icp_set_clouds_f64(ctx, xyz(source.points_), (int64_t)source.points_.size(), 3,
+                                        xyz(target.points_), (int64_t)target.points_.size(), 3),
+          "visma_icp_set_clouds_f64");
+    if (normals)
+        check(ctx, visma_icp_set_target_normals_f64(ctx, xyz(target.normals_),
+                                                    (int64_t)target.normals_.size(), 3),
+              "visma_icp_set_target_normals_f64");
+    return ctx;
+}
+
+template <typename Result>
+inline void fill_result(visma_icp_ctx *ctx, const visma_icp_result &r, size_t ns, Result &out)
+{
+    out.transformation_ = from_rowmajor(r.transformation);
+    out.fitness_ = r.fitness;
+    out.inlier_rmse_ = r.inlier_rmse;
+    std::vector<int32_t> si(ns ? ns : 1), ti(ns ? ns : 1);
+    int64_t k = 0;
+    check(ctx, visma_icp_get_correspondences(ctx, si.data(), ti.data(), nullptr, &k),
+          "visma_icp_get_correspondences");
+    out.correspondence_set_.resize((size_t)k);
+    for (int64_t i = 0; i < k; i++) out.correspondence_set_[i] = Eigen::Vector2i(si[i], ti[i]);
+}
+
+// 38 statistics of explicit correspondences, accumulated on the host in f64
+// (same layout the reduction kernel produces; see visma_icp.h).
+template <typename Cloud, typename Corr>
+inline void host_stats(const Cloud &source, const Cloud &target, const Corr &corres, bool plane,
+                       double st[VISMA_ICP_NSTATS])
+{
+    double JTJ[6][6] = {{0}}, JTr[6] = {0}, M[3][3] = {{0}}, r2 = 0.0;
+    for (const auto &c : corres) {
+        const Eigen::Vector3d &p = source.points_[c[0]];
+        const Eigen::Vector3d &q = target.points_[c[1]];
+        const int rows = plane ? 1 : 3;
+        for (int k = 0; k < rows; k++) {
+            Eigen::Vector3d n = plane ? Eigen::Vector3d(target.normals_[c[1]]) : Eigen::Vector3d::Zero();
+            if (!plane) n[k] = 1.0;
+            const Eigen::Vector3d a(p[1] * n[2] - p[2] * n[1], p[2] * n[0] - p[0] * n[2],
+                                    p[0] * n[1] - p[1] * n[0]);  // p x n
+            const double J[6] = {a[0], a[1], a[2], n[0], n[1], n[2]};
+            const double r = (p - q).dot(n);
+            for (int i = 0; i < 6; i++) {
+                for (int j = 0; j < 6; j++) JTJ[i][j] += J[i] * J[j];
+                JTr[i] += J[i] * r;
+            }
+            r2 += r * r;
+        }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) M[i][j] += q[i] * p[j];
+    }
+    int o = 0;
+    st[o++] = (double)corres.size();
+    st[o++] = r2;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) st[o++] = JTJ[i][j];
+    for (int i = 0; i < 6; i++) st[o++] = JTr[i];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) st[o++] = M[i][j];
+}
+
+template <typename Cloud, typename Corr>
+inline Eigen::Matrix4d host_update(const Cloud &s, const Cloud &t, const Corr &corres, bool plane,
+                                   bool with_scaling)
+{
+    if (corres.empty()) return Eigen::Matrix4d::Identity();
+    double st[VISMA_ICP_NSTATS], T[16];
+    host_stats(s, t, corres, plane, st);
+    visma_icp_solve_from_stats(st, plane ? VISMA_ICP_SOLVER_GN_EULER : VISMA_ICP_SOLVER_KABSCH,
+                               with_scaling ? 1 : 0, T);
+    return from_rowmajor(T);
+}
+
+template <typename Cloud, typename Corr>
+inline double host_rmse_point_to_point(const Cloud &s, const Cloud &t, const Corr &corres)
+{
+    if (corres.empty()) return 0.0;
+    double e = 0.0;
+    for (const auto &c : corres) e += (s.points_[c[0]] - t.points_[c[1]]).squaredNorm();
+    return std::sqrt(e / (double)corres.size());
+}
+
+}  // namespace detail
+
+// ---------------------------------------------------------------------------
+// One NN pass at a given transformation: fitness / inlier_rmse / correspondences.
+inline RegistrationResult EvaluateRegistration(
+    const PointCloud &source, const PointCloud &target, double max_correspondence_distance,
+    const Eigen::Matrix4d &transformation = Eigen::Matrix4d::Identity())
+{
+    RegistrationResult result(transformation);
+    if (max_correspondence_distance <= 0.0) return result;
+    visma_icp_ctx *ctx = detail::upload(source, target, false);
+    double T[16];
+    detail::to_rowmajor(transformation, T);
+    visma_icp_result r;
+    // zero iterations of the loop == exactly one NN pass at T
+    detail::check(ctx, visma_icp_run(ctx, T, max_correspondence_distance, 0, 0.0, 0.0,
+                                     VISMA_ICP_SOLVER_KABSCH, 0, &r), "visma_icp_run");
+    detail::fill_result(ctx, r, source.points_.size(), result);
+    return result;
+}
+
+// ---------------------------------------------------------------------------
+// The ICP driver.  Point-to-point estimators (Open3D's stock one and the 4DoF
+// class above -- identical arithmetic) and the point-to-plane estimator run
+// fully on the GPU.  Any OTHER subclass of TransformationEstimation still
+// works: the NN passes run on the GPU and the plugin's own virtual
+// ComputeTransformation is called on the host each iteration, exactly as
+// Registration.cpp:169-184 does.
+inline RegistrationResult RegistrationICP(
+    const PointCloud &source, const PointCloud &target, double max_correspondence_distance,
+    const Eigen::Matrix4d &init = Eigen::Matrix4d::Identity(),
+    const TransformationEstimation &estimation = TransformationEstimationPointToPoint4DoF(false),
+    const ICPConvergenceCriteria &criteria = ICPConvergenceCriteria())
+{
+    if (max_correspondence_distance <= 0.0) {
+        std::fprintf(stderr, "Error: Invalid max_correspondence_distance.\n");
+        return RegistrationResult(init);
+    }
+    const TransformationEstimationType type = estimation.GetTransformationEstimationType();
+    const bool plane = type == TransformationEstimationType::PointToPlane;
+    if (plane && (!source.HasNormals() || !target.HasNormals())) {
+        std::fprintf(stderr, "Error: TransformationEstimationPointToPlane requires "
+                             "pre-computed normal vectors.\n");
+        return RegistrationResult(init);
+    }
+    RegistrationResult result(init);
+    visma_icp_ctx *ctx = detail::upload(source, target, plane);
+    double T[16];
+    detail::to_rowmajor(init, T);
+    visma_icp_result r;
+
+    const auto *four = dynamic_cast<const TransformationEstimationPointToPoint4DoF *>(&estimation);
+    const auto *p2p = dynamic_cast<const TransformationEstimationPointToPoint *>(&estimation);
+    const auto *p2l = dynamic_cast<const TransformationEstimationPointToPlane *>(&estimation);
+    if (four || p2p) {
+        const bool scaling = four ? four->with_scaling_ : p2p->with_scaling_;
+        detail::check(ctx, visma_icp_run(ctx, T, max_correspondence_distance, criteria.max_iteration_,
+                                         criteria.relative_fitness_, criteria.relative_rmse_,
+                                         VISMA_ICP_SOLVER_KABSCH, scaling ? 1 : 0, &r),
+                      "visma_icp_run");
+        detail::fill_result(ctx, r, source.points_.size(), result);
+        return result;
+    }
+    if (p2l) {
+        detail::check(ctx, visma_icp_run_point_to_plane(ctx, T, max_correspondence_distance,
+                                                        criteria.max_iteration_,
+                                                        criteria.relative_fitness_,
+                                                        criteria.relative_rmse_, &r),
+                      "visma_icp_run_point_to_plane");
+        detail::fill_result(ctx, r, source.points_.size(), result);
+        return result;
+    }
+
+    // Generic plugin: GPU NN passes + the plugin's host-side solve.
+    Eigen::Matrix4d transformation = init;
+    PointCloud pcd = source;
+    if (!init.isIdentity()) pcd.Transform(init);
+    auto nn = [&](RegistrationResult &out) {
+        detail::to_rowmajor(transformation, T);
+        detail::check(ctx, visma_icp_run(ctx, T, max_correspondence_distance, 0, 0.0, 0.0,
+                                         VISMA_ICP_SOLVER_KABSCH, 0, &r), "visma_icp_run");
+        detail::fill_result(ctx, r, source.points_.size(), out);
+        out.transformation_ = transformation;
+    };
+    nn(result);
+    for (int i = 0; i < criteria.max_iteration_; i++) {
+        const Eigen::Matrix4d update =
+            estimation.ComputeTransformation(pcd, target, result.correspondence_set_);
+        transformation = update * transformation;
+        pcd.Transform(update);
+        const double bf = result.fitness_, br = result.inlier_rmse_;
+        nn(result);
+        if (std::abs(bf - result.fitness_) < criteria.relative_fitness_ &&
+            std::abs(br - result.inlier_rmse_) < criteria.relative_rmse_)
+            break;
+    }
+    return result;
+}
+
+// feh::RegisterModelToScene (src/annotation.cpp:29-64) with its JSON options
+// as plain arguments: rotation_level yaw initialisations about +Y, a full ICP
+// from each, the first result with strictly the most correspondences wins.
+inline Eigen::Matrix4d RegisterModelToScene(const PointCloud &model, const PointCloud &scene,
+                                            int rotation_level, double distance_threshold,
+                                            bool point_to_plane = false,
+                                            RegistrationResult *best_out = nullptr)
+{
+    RegistrationResult best;
+    if (!point_to_plane && rotation_level > 0 && distance_threshold > 0.0) {
+        // all levels in one library call (the sweep is advanced on the GPU)
+        visma_icp_ctx *ctx = detail::upload(model, scene, false);
+        visma_icp_result b;
+        int level = -1;
+        const ICPConvergenceCriteria c;
+        detail::check(ctx, visma_icp_run_yaw_sweep(ctx, rotation_level, distance_threshold,
+                                                   c.max_iteration_, c.relative_fitness_,
+                                                   c.relative_rmse_, VISMA_ICP_SOLVER_KABSCH, &b,
+                                                   &level, nullptr),
+                      "visma_icp_run_yaw_sweep");
+        best.transformation_ = detail::from_rowmajor(b.transformation);
+        best.fitness_ = b.fitness;
+        best.inlier_rmse_ = b.inlier_rmse;
+        if (best_out) {
+            // re-evaluate at the winning transform to materialise its correspondences
+            *best_out = level >= 0 ? cicp::EvaluateRegistration(model, scene, distance_threshold,
+                                                          best.transformation_)
+                                   : best;
+        }
+        return best.transformation_;
+    }
+    const double interval = 2.0 * M_PI / rotation_level;
+    for (int i = 0; i < rotation_level; ++i) {
+        const double a = interval * i, c = std::cos(a), s = std::sin(a);
+        Eigen::Matrix4d init = Eigen::Matrix4d::Identity();
+        init(0, 0) = c; init(0, 2) = s; init(2, 0) = -s; init(2, 2) = c;
+        RegistrationResult r;
+        if (point_to_plane)
+            r = cicp::RegistrationICP(model, scene, distance_threshold, init,
+                                TransformationEstimationPointToPlane(), ICPConvergenceCriteria());
+        else
+            r = cicp::RegistrationICP(model, scene, distance_threshold, init,
+                                TransformationEstimationPointToPoint4DoF(), ICPConvergenceCriteria());
+        if (r.correspondence_set_.size() > best.correspondence_set_.size()) best = r;
+    }
+    if (best_out) *best_out = best;
+    return best.transformation_;
+}
+
+// The registration call of feh::ICPRefinement (src/evaluation.cpp:258-271):
+// scene already down-sampled by the caller, source = sampled CAD models.
+inline RegistrationResult ICPRefinement(const PointCloud &scene, const PointCloud &scene_est,
+                                        const Eigen::Matrix4d &T_scene_src, double max_distance,
+                                        bool use_point_to_plane)
+{
+    if (use_point_to_plane)
+        return cicp::RegistrationICP(scene_est, scene, max_distance, T_scene_src,
+                               TransformationEstimationPointToPlane());
+    return cicp::RegistrationICP(scene_est, scene, max_distance, T_scene_src);
+}
+
+// ---- 4DoF estimator methods (explicit-correspondence entry points) ----------
+inline double TransformationEstimationPointToPoint4DoF::ComputeRMSE(
+    const PointCloud &source, const PointCloud &target, const CorrespondenceSet &corres) const
+{
+    return detail::host_rmse_point_to_point(source, target, corres);
+}
+
+inline Eigen::Matrix4d TransformationEstimationPointToPoint4DoF::ComputeTransformation(
+    const PointCloud &source, const PointCloud &target, const CorrespondenceSet &corres) const
+{
+    return detail::host_update(source, target, corres, false, with_scaling_);
+}
+
+}  // namespace cicp
+
+#ifdef VISMA_ICP_STANDALONE_OPEN3D_TYPES
+// Stand-alone header set: give the stock names their bodies too.
+inline double TransformationEstimationPointToPoint::ComputeRMSE(
+    const PointCloud &s, const PointCloud &t, const CorrespondenceSet &c) const
+{
+    return cicp::detail::host_rmse_point_to_point(s, t, c);
+}
+inline Eigen::Matrix4d TransformationEstimationPointToPoint::ComputeTransformation(
+    const PointCloud &s, const PointCloud &t, const CorrespondenceSet &c) const
+{
+    return cicp::detail::host_update(s, t, c, false, with_scaling_);
+}
+// NB the reference's point-to-plane ComputeRMSE assigns `err = r * r` instead of
+// accumulating (TransformationEstimation.cpp:70), i.e. it returns
+// sqrt(r_last^2 / K).  RegistrationICP never calls it; we keep its value.
+inline double TransformationEstimationPointToPlane::ComputeRMSE(
+    const PointCloud &s, const PointCloud &t, const CorrespondenceSet &c) const
+{
+    if (c.empty() || !t.HasNormals()) return 0.0;
+    const auto &l = c.back();
+    const double r = (s.points_[l[0]] - t.points_[l[1]]).dot(t.normals_[l[1]]);
+    return std::sqrt(r * r / (double)c.size());
+}
+inline Eigen::Matrix4d TransformationEstimationPointToPlane::ComputeTransformation(
+    const PointCloud &s, const PointCloud &t, const CorrespondenceSet &c) const
+{
+    if (c.empty() || !t.HasNormals()) return Eigen::Matrix4d::Identity();
+    return cicp::detail::host_update(s, t, c, true, false);
+}
+inline RegistrationResult EvaluateRegistration(const PointCloud &source, const PointCloud &target,
+                                               double max_correspondence_distance,
+                                               const Eigen::Matrix4d &transformation)
+{
+    return cicp::EvaluateRegistration(source, target, max_correspondence_distance, transformation);
+}
+inline RegistrationResult RegistrationICP(const PointCloud &source, const PointCloud &target,
+                                          double max_correspondence_distance,
+                                          const Eigen::Matrix4d &init,
+                                          const TransformationEstimation &estimation,
+                                          const ICPConvergenceCriteria &criteria)
+{
+    return cicp::RegistrationICP(source, target, max_correspondence_distance, init, estimation,
+                                 criteria);
+}
+#endif
+
+}  // namespace open3d

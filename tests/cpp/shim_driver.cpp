@@ -1,0 +1,113 @@
+// shim_driver.cpp -- exercises the C++/Eigen shim the way the reference's
+// callers do (src/evaluation.cpp:260-271, src/annotation.cpp:35-61).
+// Usage: shim_driver <mode> <in.bin> <out.bin>
+//   in : int64 ns, int64 nt, double radius, int32 iters, int32 level, double init[16],
+//        ns*3 doubles, nt*3 doubles, [nt*3 target normals, ns*3 source normals]
+//   out: double T[16], fitness, rmse, K, extra
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "constrained_ICP.h"
+
+using namespace open3d;
+
+// a user-defined estimator plugin: the generic path must keep working
+class MyEstimator : public TransformationEstimation {
+public:
+    TransformationEstimationType GetTransformationEstimationType() const override
+    {
+        return TransformationEstimationType::Unspecified;
+    }
+    double ComputeRMSE(const PointCloud &s, const PointCloud &t, const CorrespondenceSet &c) const override
+    {
+        return inner.ComputeRMSE(s, t, c);
+    }
+    Eigen::Matrix4d ComputeTransformation(const PointCloud &s, const PointCloud &t,
+                                          const CorrespondenceSet &c) const override
+    {
+        ++calls;
+        return inner.ComputeTransformation(s, t, c);
+    }
+    cicp::TransformationEstimationPointToPoint4DoF inner;
+    mutable int calls = 0;
+};
+
+static void read_cloud(FILE *f, std::vector<Eigen::Vector3d> &v, int64_t n)
+{
+    v.resize((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        double p[3];
+        if (fread(p, sizeof(double), 3, f) != 3) { std::fprintf(stderr, "short read\n"); std::exit(2); }
+        v[i] = Eigen::Vector3d(p[0], p[1], p[2]);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    const std::string mode = argv[1];
+    FILE *f = std::fopen(argv[2], "rb");
+    if (!f) return 2;
+    int64_t ns, nt; double radius; int32_t iters, level; double init_rm[16];
+    if (fread(&ns, 8, 1, f) != 1 || fread(&nt, 8, 1, f) != 1 || fread(&radius, 8, 1, f) != 1 ||
+        fread(&iters, 4, 1, f) != 1 || fread(&level, 4, 1, f) != 1 || fread(init_rm, 8, 16, f) != 16)
+        return 2;
+    auto model = std::make_shared<PointCloud>();
+    auto scene = std::make_shared<PointCloud>();
+    read_cloud(f, model->points_, ns);
+    read_cloud(f, scene->points_, nt);
+    if (mode == "plane") { read_cloud(f, scene->normals_, nt); read_cloud(f, model->normals_, ns); }
+    std::fclose(f);
+    Eigen::Matrix4d init;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) init(i, j) = init_rm[i * 4 + j];
+
+    RegistrationResult result;
+    double extra = 0.0;
+    try {
+        if (mode == "icp4dof") {            // src/annotation.cpp:51-56 call shape
+            result = open3d::RegistrationICP(*model, *scene, radius, init,
+                                             open3d::cicp::TransformationEstimationPointToPoint4DoF(),
+                                             open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
+        } else if (mode == "default") {     // src/evaluation.cpp:267-270 call shape
+            result = open3d::RegistrationICP(*model, *scene, radius, init);
+        } else if (mode == "plane") {       // src/evaluation.cpp:261-265
+            result = open3d::RegistrationICP(*model, *scene, radius, init,
+                                             open3d::TransformationEstimationPointToPlane(),
+                                             open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
+        } else if (mode == "plugin") {
+            MyEstimator est;
+            result = open3d::RegistrationICP(*model, *scene, radius, init, est,
+                                             open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
+            extra = est.calls;
+        } else if (mode == "sweep") {       // src/annotation.cpp:29-64
+            RegistrationResult best;
+            result.transformation_ = cicp::RegisterModelToScene(*model, *scene, level, radius, false, &best);
+            result.fitness_ = best.fitness_; result.inlier_rmse_ = best.inlier_rmse_;
+            result.correspondence_set_ = best.correspondence_set_;
+        } else if (mode == "evaluate") {
+            result = open3d::EvaluateRegistration(*model, *scene, radius, init);
+        } else if (mode == "estimator") {   // host-only: explicit correspondences, no GPU needed
+            CorrespondenceSet cs;
+            for (int64_t i = 0; i < ns; i++) cs.push_back(Eigen::Vector2i((int)i, (int)((i * 7919) % nt)));
+            cicp::TransformationEstimationPointToPoint4DoF est(level != 0);
+            result.transformation_ = est.ComputeTransformation(*model, *scene, cs);
+            result.inlier_rmse_ = est.ComputeRMSE(*model, *scene, cs);
+            result.correspondence_set_ = cs;
+        } else {
+            return 2;
+        }
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "shim_driver: %s\n", e.what());
+        return 3;
+    }
+    FILE *o = std::fopen(argv[3], "wb");
+    double out[20];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out[i * 4 + j] = result.transformation_(i, j);
+    out[16] = result.fitness_; out[17] = result.inlier_rmse_;
+    out[18] = (double)result.correspondence_set_.size(); out[19] = extra;
+    std::fwrite(out, sizeof(double), 20, o);
+    std::fclose(o);
+    return 0;
+}

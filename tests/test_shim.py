@@ -1,0 +1,121 @@
+"""The C++/Eigen shim (include/constrained_ICP.h, include/Core/, visma_icp_open3d.hpp).
+
+tests/cpp/shim_driver.cpp calls it exactly the way the reference's callers do
+(`open3d::RegistrationICP(*model, *scene, threshold, init,
+open3d::cicp::TransformationEstimationPointToPoint4DoF(), criteria)`,
+src/annotation.cpp:51-56; src/evaluation.cpp:260-271).  It is compiled twice --
+with and without -DEIGEN_DEFAULT_TO_ROW_MAJOR (VISMA's CMakeLists.txt:11-12) --
+to show that the Eigen storage order of the caller cannot leak through the
+C ABI.  Binaries are prebuilt where Eigen headers exist (tests/cpp/build_shim.py).
+"""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from visma_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = os.path.join(HERE, "golden")
+sys.path.insert(0, os.path.join(HERE, "cpp"))
+import build_shim  # noqa: E402
+
+BINS = ["shim_driver", "shim_driver_rowmajor"]
+
+
+@pytest.fixture(scope="module")
+def bins(lib):
+    if build_shim.eigen_dir() is not None:
+        build_shim.build()
+    paths = [os.path.join(HERE, "cpp", "_build", b) for b in BINS]
+    if not all(os.path.exists(p) for p in paths):
+        pytest.skip("shim driver not prebuilt and no Eigen headers here")
+    return paths
+
+
+def run(binary, mode, tmp_path, src, tgt, radius, iters=0, level=0, init=None, tn=None, sn=None):
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    init = np.eye(4) if init is None else np.asarray(init, np.float64)
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<qqdii", len(src), len(tgt), float(radius), int(iters), int(level)))
+        f.write(init.astype("<f8").tobytes())
+        f.write(np.ascontiguousarray(src, "<f8").tobytes())
+        f.write(np.ascontiguousarray(tgt, "<f8").tobytes())
+        if tn is not None:
+            f.write(np.ascontiguousarray(tn, "<f8").tobytes())
+            f.write(np.ascontiguousarray(sn, "<f8").tobytes())
+    p = subprocess.run([binary, mode, inp, outp], capture_output=True, text=True, timeout=300)
+    if p.returncode != 0:
+        return p.returncode, p.stderr, None
+    o = np.fromfile(outp, "<f8")
+    return 0, p.stderr, dict(T=o[:16].reshape(4, 4), fitness=o[16], rmse=o[17], k=int(o[18]), extra=o[19])
+
+
+def test_estimator_entry_points_host_only(bins, tmp_path):
+    """ComputeTransformation / ComputeRMSE with explicit correspondences need no GPU."""
+    from oracle.oracle import Oracle
+    o = Oracle()
+    f = np.load(os.path.join(G, "fragments.npz"))
+    src, tgt = f["src"].astype(np.float64)[:900], f["tgt"].astype(np.float64)
+    corr = np.stack([np.arange(len(src)), (np.arange(len(src)) * 7919) % len(tgt)], 1).astype(np.int32)
+    for scaling in (0, 1):
+        want = o.umeyama(src, tgt, corr, with_scaling=bool(scaling))
+        for b in bins:
+            rc, err, r = run(b, "estimator", tmp_path, src, tgt, 0.1, level=scaling)
+            assert rc == 0, err
+            assert synth.rel_frobenius(r["T"], want) < 1e-9
+            assert abs(r["rmse"] - o.compute_rmse(src, tgt, corr)) < 1e-12
+
+
+def test_shim_without_gpu_fails_loudly(bins, tmp_path):
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU present")
+    g = np.load(os.path.join(G, "edge_cases.npz"))
+    rc, err, _ = run(bins[0], "icp4dof", tmp_path, g["src"], g["tgt"], 0.05, iters=3)
+    assert rc == 3 and "visma_icp_create failed" in err       # no silent CPU path
+
+
+@pytest.mark.gpu
+def test_shim_registration_icp_matches_reference(bins, tmp_path):
+    g = np.load(os.path.join(G, "chair_5k_20k.npz"))
+    src, tgt = g["src"].astype(np.float64), g["tgt"].astype(np.float64)
+    for b in bins:   # column-major and row-major Eigen callers
+        rc, err, r = run(b, "icp4dof", tmp_path, src, tgt, float(g["radius"]), iters=20)
+        assert rc == 0, err
+        row = g["trace"][20]
+        assert synth.rel_frobenius(r["T"], row[:16].reshape(4, 4)) < 1e-5
+        assert r["k"] == row[18] and abs(r["fitness"] - row[16]) < 1e-12
+        # a user-defined estimator plugin: GPU NN passes + host virtual solve
+        rc, err, p = run(b, "plugin", tmp_path, src, tgt, float(g["radius"]), iters=6)
+        assert rc == 0, err
+        assert p["extra"] == 6
+        assert synth.rel_frobenius(p["T"], g["trace"][6][:16].reshape(4, 4)) < 1e-5
+        assert p["k"] == g["trace"][6][18]
+    e = np.load(os.path.join(G, "estimators.npz"))
+    rc, err, r = run(bins[0], "default", tmp_path, src, tgt, 0.075)   # default estimator + criteria
+    assert rc == 0, err
+    assert synth.rel_frobenius(r["T"], e["termination_T"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_shim_point_to_plane_sweep_evaluate(bins, tmp_path):
+    f = np.load(os.path.join(G, "fragments.npz"))
+    src, tgt = f["src"].astype(np.float64), f["tgt"].astype(np.float64)
+    rc, err, r = run(bins[1], "plane", tmp_path, src, tgt, float(f["radius"]), iters=10, init=f["init"],
+                     tn=f["tgt_normals"].astype(np.float64), sn=f["src_normals"].astype(np.float64))
+    assert rc == 0, err
+    assert synth.rel_frobenius(r["T"], f["trace_p2plane"][10][:16].reshape(4, 4)) < 1e-5
+    y = np.load(os.path.join(G, "yaw_sweep.npz"))
+    rc, err, r = run(bins[0], "sweep", tmp_path, y["model"].astype(np.float64),
+                     y["scene"].astype(np.float64), float(y["radius"]), level=int(y["level"]))
+    assert rc == 0, err
+    assert synth.rel_frobenius(r["T"], y["T"][int(y["best"])]) < 1e-5
+    assert r["k"] == y["k"][int(y["best"])]
+    g = np.load(os.path.join(G, "edge_cases.npz"))
+    rc, err, r = run(bins[0], "evaluate", tmp_path, g["src"].astype(np.float64),
+                     g["tgt"].astype(np.float64), 0.05, init=g["evaluate_T"])
+    assert rc == 0, err
+    assert r["k"] == g["evaluate_frk"][2] and abs(r["rmse"] - g["evaluate_frk"][1]) < 1e-6
