@@ -219,7 +219,12 @@ VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_proble
                                       visma_icp_result *out);
 
 /* ---- options / measurement --------------------------------------------- */
+/* AUTO (default) uses the radius-cell grid whenever the target/radius make it
+ * worthwhile and the LDS-tiled brute-force kernel otherwise; BRUTE / GRID force
+ * one.  The grid is (re)built on the GPU when the target or the radius changes. */
 VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
+/* Which search the last nn_pass used (VISMA_ICP_NN_BRUTE or VISMA_ICP_NN_GRID). */
+VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
 VISMA_ICP_API int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out,
                                        int reset);

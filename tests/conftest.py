@@ -43,6 +43,23 @@ def _gpu_present():
 
 
 @pytest.fixture(scope="session")
-def gpu_ctx(lib):
+def _gpu_ctx_session(lib):
     """A HIP context on device 0.  On a GPU box a failure here is a FAILURE, not a skip."""
     return lib.Context(0)
+
+
+@pytest.fixture(params=["brute", "grid"])
+def gpu_ctx(request, lib, _gpu_ctx_session):
+    """The session context with the NN search forced to each implementation in
+    turn: the brute-force kernel and the radius-cell grid must give identical answers."""
+    ctx = _gpu_ctx_session
+    ctx.set_nn_mode({"brute": lib.NN_BRUTE, "grid": lib.NN_GRID}[request.param])
+    ctx.nn_mode_name = request.param
+    yield ctx
+    ctx.set_nn_mode(lib.NN_AUTO)
+
+
+@pytest.fixture()
+def gpu_ctx_auto(lib, _gpu_ctx_session):
+    _gpu_ctx_session.set_nn_mode(lib.NN_AUTO)
+    return _gpu_ctx_session

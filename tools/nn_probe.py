@@ -18,24 +18,27 @@ def main():
     ctx.set_profiling(True)
     out = []
     for ns, nt in sizes:
-        src, tgt, T, r = synth.make_pair(ns, nt)
+        src, tgt, T, r = synth.make_pair(ns, nt, motion="radius")
         ctx.set_clouds_f64(src, tgt)
-        ctx.run(None, r, 1, 0, 0)            # warm
-        ctx.get_timing(reset=True)
-        iters = 5 if ns * nt > 1e11 else 10
-        t0 = time.time()
-        res = ctx.run(None, r, iters, 0, 0)
-        wall = time.time() - t0
-        tm = ctx.get_timing(reset=True)
-        nn = tm["nn_ms"] / tm["nn_launches"]
-        rd = tm["reduce_ms"] / tm["reduce_launches"]
-        pairs = ns * nt
-        rec = dict(ns=ns, nt=nt, radius=r, launch=ctx.launch_config(), nn_ms=nn, reduce_ms=rd,
-                   gpairs_per_s=pairs / nn / 1e6, tflops_8=8 * pairs / nn / 1e9,
-                   iter_ms_wall=wall / (iters + 1) * 1e3, K=res.num_correspondences,
-                   err_vs_gt=synth.rel_frobenius(res.transformation_, T))
-        print(json.dumps(rec), flush=True)
-        out.append(rec)
+        for mode, name in ((_lib.NN_BRUTE, "brute"), (_lib.NN_GRID, "grid")):
+            ctx.set_nn_mode(mode)
+            ctx.run(None, r, 1, 0, 0)            # warm (+ grid build)
+            tb = ctx.get_timing(reset=True)
+            iters = 5 if (ns * nt > 1e11 and name == "brute") else 20
+            t0 = time.time()
+            res = ctx.run(None, r, iters, 0, 0)
+            wall = time.time() - t0
+            tm = ctx.get_timing(reset=True)
+            nn = tm["nn_ms"] / tm["nn_launches"]
+            rd = tm["reduce_ms"] / tm["reduce_launches"]
+            pairs = ns * nt
+            rec = dict(mode=name, ns=ns, nt=nt, radius=r, nn_ms=nn, reduce_ms=rd,
+                       build_ms=tb["aux_ms"], gpairs_per_s=pairs / nn / 1e6,
+                       iter_ms_wall=wall / (iters + 1) * 1e3, K=res.num_correspondences,
+                       T_hash=float(res.transformation_.sum()),
+                       err_vs_gt=synth.rel_frobenius(res.transformation_, T))
+            print(json.dumps(rec), flush=True)
+            out.append(rec)
     return out
 
 

@@ -102,6 +102,7 @@ def load():
     L.visma_icp_run_batch.argtypes = [C.c_void_p, C.POINTER(CProblem), C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.POINTER(CResult)]
     L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_timing.argtypes = [C.c_void_p, C.POINTER(CTiming), C.c_int]
     L.visma_icp_get_tile_config.argtypes = [C.POINTER(C.c_int)] * 3
@@ -286,6 +287,11 @@ class Context:
     # ---- options ----
     def set_nn_mode(self, mode):
         self._chk(self.L.visma_icp_set_nn_mode(self._h, int(mode)))
+
+    def nn_mode_used(self):
+        m = C.c_int(0)
+        self._chk(self.L.visma_icp_get_nn_mode_used(self._h, C.byref(m)))
+        return m.value
 
     def set_profiling(self, on=True):
         self._chk(self.L.visma_icp_set_profiling(self._h, int(bool(on))))

@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvisma_icp.so")
-SOURCES = ["kernels.hip", "driver.cpp"]
-HEADERS = ["kernels.h", "so3.h", "host_math.hpp", os.path.join("..", "..", "include", "visma_icp.h")]
+SOURCES = ["kernels.hip", "grid.hip", "driver.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "so3.h", "host_math.hpp", os.path.join("..", "..", "include", "visma_icp.h")]
 
 
 def hipcc():

@@ -1,0 +1,122 @@
+// device_common.h -- device helpers shared by the NN and reduction kernels.
+//
+// Arithmetic contract (checked bit-for-bit against oracle/icp_oracle.c vk_*):
+//   p  = fmaf(r0,sx, fmaf(r1,sy, fmaf(r2,sz, t)))          fp32, per row
+//   d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx)),  d = q - p        fp32
+//   accept iff d2 < r2f; lowest target index wins exact ties.
+// Statistics are accumulated in f64 from p = T64 * (double)s and q widened.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "so3.h"
+
+namespace visma {
+
+__device__ __forceinline__ void xform_point_f32(const Xform32 &T, const float4 s,
+                                                float &px, float &py, float &pz)
+{
+    px = __builtin_fmaf(T.m[0], s.x, __builtin_fmaf(T.m[1], s.y, __builtin_fmaf(T.m[2], s.z, T.m[3])));
+    py = __builtin_fmaf(T.m[4], s.x, __builtin_fmaf(T.m[5], s.y, __builtin_fmaf(T.m[6], s.z, T.m[7])));
+    pz = __builtin_fmaf(T.m[8], s.x, __builtin_fmaf(T.m[9], s.y, __builtin_fmaf(T.m[10], s.z, T.m[11])));
+}
+
+__device__ __forceinline__ float sqdist_f32(const float4 q, float px, float py, float pz)
+{
+    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+
+// one VALU op: min of three (v_min3_f32); inputs are never NaN-producing here
+__device__ __forceinline__ float min3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Accumulator layouts
+//  point-to-point (23): 0 K | 1 r2 | 2-4 sum p | 5-7 sum q |
+//                       8-13 sum pp^T (xx xy xz yy yz zz) | 14-22 sum q p^T
+//  point-to-plane (29): 0 K | 1 r2 | 2-22 upper J^T J | 23-28 J^T r
+template <bool PLANE>
+struct Acc {
+    static constexpr int N = PLANE ? 29 : 23;
+};
+
+// Jacobian / residual rows of ONE correspondence, in f64 (design rules R1/R2):
+// p = T64 * s (+ frame offset), q = target point (+ frame offset).
+template <bool PLANE>
+__device__ __forceinline__ void accumulate_pair(double *acc, const float4 s4, const float4 q4,
+                                                const float4 n4, const Xform64 &T64,
+                                                const Offset64 &off)
+{
+    const double sx = s4.x, sy = s4.y, sz = s4.z;
+    const double p[3] = {T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3] + off.v[0],
+                         T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7] + off.v[1],
+                         T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11] + off.v[2]};
+    const double q[3] = {(double)q4.x + off.v[0], (double)q4.y + off.v[1], (double)q4.z + off.v[2]};
+    const double r[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
+    acc[0] += 1.0;
+    if (!PLANE) {
+        // rows J_k = [p x e_k | e_k] = k-th row of [-hat(p) | I]: only their
+        // moments are kept here; finalize_kernel expands them to J^T J / J^T r
+        acc[1] += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+        acc[2] += p[0]; acc[3] += p[1]; acc[4] += p[2];
+        acc[5] += q[0]; acc[6] += q[1]; acc[7] += q[2];
+        acc[8] += p[0] * p[0]; acc[9] += p[0] * p[1]; acc[10] += p[0] * p[2];
+        acc[11] += p[1] * p[1]; acc[12] += p[1] * p[2]; acc[13] += p[2] * p[2];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) acc[14 + a * 3 + b] += q[a] * p[b];
+    } else {
+        const double n[3] = {(double)n4.x, (double)n4.y, (double)n4.z};
+        const double rr = r[0] * n[0] + r[1] * n[1] + r[2] * n[2];
+        // J = [p x n | n]  (TransformationEstimation.cpp:87-89); p x n = hat(p) n
+        double J[6], H[9];
+        hat(p, H);
+        J[0] = H[0] * n[0] + H[1] * n[1] + H[2] * n[2];
+        J[1] = H[3] * n[0] + H[4] * n[1] + H[5] * n[2];
+        J[2] = H[6] * n[0] + H[7] * n[1] + H[8] * n[2];
+        J[3] = n[0]; J[4] = n[1]; J[5] = n[2];
+        acc[1] += rr * rr;
+        int o = 2;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) acc[o++] += J[a] * J[b];
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[23 + a] += J[a] * rr;
+    }
+}
+
+// wavefront shuffle reduction -> LDS across the 4 waves -> one partial row
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(const double *acc, double *partials)
+{
+    __shared__ double wsum[kBlock / 64][NACC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < NACC; a++) {
+        const double v = wave_sum(acc[a]);
+        if (lane == 0) wsum[wave][a] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        double v = wsum[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; w++) v += wsum[w][threadIdx.x];
+        partials[(long long)blockIdx.x * kReduceAcc + threadIdx.x] = v;
+    }
+}
+
+}  // namespace visma

@@ -89,6 +89,8 @@ public:
     virtual int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) = 0;
     virtual int get_correspondences(int32_t *idx, float *d2) = 0;
     virtual int comm_init(int, int, const void *) { err_ = "RCCL needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    virtual int set_nn_mode(int mode) { return mode == VISMA_ICP_NN_AUTO ? VISMA_ICP_OK : VISMA_ICP_ERR_STATE; }
+    virtual int nn_mode_used() const { return VISMA_ICP_NN_AUTO; }
     virtual void set_profiling(bool) {}
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
@@ -114,6 +116,8 @@ public:
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
+        free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
+        free_dev(d_start_); free_dev(d_bsum_);
         if (h_stats_) (void)hipHostFree(h_stats_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -194,6 +198,20 @@ public:
     {
         HIP_TRY(hipSetDevice(device_));
         if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+        const int64_t ns_min_pad = ((ns_ + kBlock - 1) / kBlock) * kBlock;
+        for (int i = 0; i < 12; i++) T32_.m[i] = (float)Tc.m[i];
+        r2f_ = (float)(max_dist * max_dist);
+        int rc = choose_mode(max_dist);
+        if (rc) return rc;
+        if (use_grid_) {
+            // the grid search is fused with the reduction: it runs in reduce()
+            // (or in get_correspondences() if no reduction is asked for)
+            rc = ensure_aux(ns_min_pad);
+            if (rc) return rc;
+            grid_pending_ = true;
+            have_pass_ = true;
+            return VISMA_ICP_OK;
+        }
         plan_ = nn_plan(ns_, nt_pad_);
         const int64_t ns_pad = (int64_t)plan_.src_tiles * kBlock * plan_.spt;
         const size_t need = sizeof(unsigned long long) * (size_t)ns_pad * plan_.tgt_splits;
@@ -202,20 +220,16 @@ public:
             HIP_TRY(hipMalloc(&d_keys_, need));
             keys_bytes_ = need;
         }
-        if (ns_pad > aux_cap_) {
-            free_dev(d_idx_); free_dev(d_d2_);
-            HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * ns_pad));
-            HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * ns_pad));
-            aux_cap_ = ns_pad;
-        }
+        rc = ensure_aux(ns_pad);
+        if (rc) return rc;
         ns_pad_ = ns_pad;
-        for (int i = 0; i < 12; i++) T32_.m[i] = (float)Tc.m[i];
-        r2f_ = (float)(max_dist * max_dist);
         int e0 = -1;
         if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
         HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_, T32_,
                                 r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, stream_));
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+        grid_pending_ = false;
+        brute_reduced_ = false;
         have_pass_ = true;
         return VISMA_ICP_OK;
     }
@@ -228,13 +242,30 @@ public:
         Xform64 T64;
         for (int i = 0; i < 12; i++) T64.m[i] = Tc.m[i];
         int e0 = -1;
-        if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-        HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
-                              (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
-                              plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
-                              (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                              reduce_max_blocks(), (double *)d_stats_, stream_));
-        if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+        if (use_grid_) {
+            int nblocks = 1;
+            if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+            HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
+                                          (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
+                                          T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
+                                          (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
+                                          &nblocks, stream_));
+            if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+            if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+            HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
+                                    (double *)d_stats_, stream_));
+            if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            grid_pending_ = false;
+        } else {
+            if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+            HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
+                                  (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
+                                  plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
+                                  (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
+                                  reduce_max_blocks(), (double *)d_stats_, stream_));
+            if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            brute_reduced_ = true;
+        }
         if (comm_) {
             // ONE all-reduce of the 38 f64 accumulators per ICP iteration
             int rc = g_rccl.AllReduce(d_stats_, d_stats_, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
@@ -253,6 +284,29 @@ public:
     {
         HIP_TRY(hipSetDevice(device_));
         if (!have_pass_) { err_ = "no nn_pass yet"; return VISMA_ICP_ERR_STATE; }
+        if (use_grid_ && grid_pending_) {
+            // nn_pass without a reduction: run the fused kernel for its index output
+            Xform64 T64;
+            for (int i = 0; i < 12; i++) T64.m[i] = (double)T32_.m[i];
+            int nblocks = 1;
+            HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
+                                          (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
+                                          T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
+                                          (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
+                                          &nblocks, stream_));
+            grid_pending_ = false;
+        } else if (!use_grid_ && !brute_reduced_) {
+            // brute-force pass without a reduction yet: the index is recovered by
+            // the reduction kernel, run it for its index output
+            Xform64 T64;
+            for (int i = 0; i < 12; i++) T64.m[i] = (double)T32_.m[i];
+            HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
+                                  (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
+                                  plan_.tgt_splits, ns_pad_, T32_, T64, nullptr, r2f_, 0,
+                                  (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
+                                  reduce_max_blocks(), (double *)d_stats_, stream_));
+            brute_reduced_ = true;
+        }
         HIP_TRY(hipStreamSynchronize(stream_));
         if (ns_ > 0) {
             HIP_TRY(hipMemcpy(idx, d_idx_, sizeof(int32_t) * ns_, hipMemcpyDeviceToHost));
@@ -260,6 +314,17 @@ public:
         }
         return VISMA_ICP_OK;
     }
+
+    int set_nn_mode(int mode) override
+    {
+        if (mode != VISMA_ICP_NN_AUTO && mode != VISMA_ICP_NN_BRUTE && mode != VISMA_ICP_NN_GRID) {
+            err_ = "unknown nn mode";
+            return VISMA_ICP_ERR_INVALID;
+        }
+        nn_mode_ = mode;
+        return VISMA_ICP_OK;
+    }
+    int nn_mode_used() const override { return use_grid_ ? VISMA_ICP_NN_GRID : VISMA_ICP_NN_BRUTE; }
 
     int comm_init(int rank, int nranks, const void *id) override
     {
@@ -309,7 +374,66 @@ private:
         HIP_TRY(hipMalloc(&d_tgt_, sizeof(float4) * nt_pad_));
         HIP_TRY(launch_fill_inf((float4 *)d_tgt_ + nt, nt_pad_ - nt, stream_));
         nt_ = nt;
+        grid_valid_ = false;
         have_pass_ = false;
+        return VISMA_ICP_OK;
+    }
+    int ensure_aux(int64_t ns_pad)
+    {
+        if (ns_pad > aux_cap_) {
+            free_dev(d_idx_); free_dev(d_d2_);
+            HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * (ns_pad > 0 ? ns_pad : 1)));
+            HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * (ns_pad > 0 ? ns_pad : 1)));
+            aux_cap_ = ns_pad;
+        }
+        return VISMA_ICP_OK;
+    }
+    // Pick brute force or the grid for this (target, radius); build the grid if needed.
+    int choose_mode(double max_dist)
+    {
+        if (nn_mode_ == VISMA_ICP_NN_BRUTE || nt_ == 0) { use_grid_ = false; return VISMA_ICP_OK; }
+        if (!(grid_valid_ && grid_radius_ == max_dist)) {
+            int rc = build_grid(max_dist);
+            if (rc) return rc;
+        }
+        if (nn_mode_ == VISMA_ICP_NN_GRID) { use_grid_ = true; return VISMA_ICP_OK; }
+        // AUTO: the grid pays off when a 3x3x3 neighbourhood is a small part of the
+        // target; a degenerate grid (few cells) would scan most of the cloud per
+        // query without LDS tiling -- use the tiled brute-force kernel there.
+        use_grid_ = grid_.ncell >= 512 && nt_ >= 4096;
+        return VISMA_ICP_OK;
+    }
+    int build_grid(double max_dist)
+    {
+        int e0 = -1;
+        if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+        if (!d_box_) HIP_TRY(hipMalloc(&d_box_, sizeof(unsigned) * 8));
+        HIP_TRY(launch_grid_bbox((const float4 *)d_tgt_, nt_, (unsigned *)d_box_, stream_));
+        unsigned box[6];
+        HIP_TRY(hipMemcpyAsync(box, d_box_, sizeof(box), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        float mn[3], mx[3];
+        grid_decode_bbox(box, mn, mx);
+        grid_ = grid_plan(mn, mx, max_dist, kGridMaxCells);
+        if ((int64_t)nt_ > sorted_cap_) {
+            free_dev(d_sorted_); free_dev(d_cell_of_);
+            HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * nt_));
+            HIP_TRY(hipMalloc(&d_cell_of_, sizeof(unsigned) * nt_));
+            sorted_cap_ = nt_;
+        }
+        if (grid_.ncell + 1 > cell_cap_) {
+            free_dev(d_count_); free_dev(d_start_); free_dev(d_bsum_);
+            HIP_TRY(hipMalloc(&d_count_, sizeof(unsigned) * (grid_.ncell + 1)));
+            HIP_TRY(hipMalloc(&d_start_, sizeof(unsigned) * (grid_.ncell + 1)));
+            HIP_TRY(hipMalloc(&d_bsum_, sizeof(unsigned) * (grid_scan_blocks(grid_.ncell) + 1)));
+            cell_cap_ = grid_.ncell + 1;
+        }
+        HIP_TRY(launch_grid_build((const float4 *)d_tgt_, nt_, grid_, (unsigned *)d_cell_of_,
+                                  (unsigned *)d_count_, (unsigned *)d_bsum_, (unsigned *)d_start_,
+                                  (float4 *)d_sorted_, stream_));
+        if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
+        grid_valid_ = true;
+        grid_radius_ = max_dist;
         return VISMA_ICP_OK;
     }
     int next_event_pair()
@@ -331,7 +455,8 @@ private:
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ev_[p.first], ev_[p.first + 1]));
             if (p.second == 0) { timing_.nn_ms += ms; timing_.nn_launches++; }
-            else { timing_.reduce_ms += ms; timing_.reduce_launches++; }
+            else if (p.second == 1) { timing_.reduce_ms += ms; timing_.reduce_launches++; }
+            else { timing_.aux_ms += ms; timing_.aux_launches++; }
         }
         pending_.clear();
         ev_used_ = 0;
@@ -354,6 +479,14 @@ private:
     std::vector<std::pair<int, int>> pending_;
     visma_icp_timing timing_{};
     NcclComm comm_ = nullptr;
+    // radius-cell grid (valid for one target + one radius)
+    int nn_mode_ = VISMA_ICP_NN_AUTO;
+    bool use_grid_ = false, grid_valid_ = false, grid_pending_ = false, brute_reduced_ = false;
+    double grid_radius_ = 0.0;
+    GridParams grid_{};
+    void *d_box_ = nullptr, *d_sorted_ = nullptr, *d_cell_of_ = nullptr, *d_count_ = nullptr;
+    void *d_start_ = nullptr, *d_bsum_ = nullptr;
+    int64_t sorted_cap_ = 0, cell_cap_ = 0;
 };
 
 class HookEngine : public Engine {
@@ -808,8 +941,16 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
 int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode)
 {
     CTX_CHECK();
-    if (nn_mode != VISMA_ICP_NN_AUTO && nn_mode != VISMA_ICP_NN_BRUTE)
-        return ctx->fail(VISMA_ICP_ERR_INVALID, "nn mode not available in this build");
+    int rc = ctx->eng->set_nn_mode(nn_mode);
+    if (rc) return ctx->eng_fail(rc);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode)
+{
+    CTX_CHECK();
+    if (!nn_mode) return ctx->fail(VISMA_ICP_ERR_INVALID, "nn_mode is NULL");
+    *nn_mode = ctx->eng->nn_mode_used();
     return VISMA_ICP_OK;
 }
 

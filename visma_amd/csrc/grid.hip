@@ -1,0 +1,335 @@
+// grid.hip -- radius-cell uniform grid: exact radius-limited nearest neighbour
+// in O(NS * 27 cells) instead of O(NS * NT)  (SURVEY.md 8f row 1).
+//
+// Same answers as the brute-force kernel, bit for bit: the candidate set of a
+// query is every target point in the 3x3x3 block of cells around it, the cell
+// edge h = 1.001 * max_dist (>= max_dist with room for fp32 rounding of the
+// cell coordinate), so every point with fp32 d2 < (float)(max_dist^2) is a
+// candidate; candidates are ranked by (d2, original index), i.e. lowest index
+// on exact ties, with the same fp32 arithmetic (device_common.h).
+//
+// Replaces the reference's KD-tree (KDTreeFlann::SetRawData / SearchHybrid,
+// O3D/Core/Geometry/KDTreeFlann.cpp:164-208): build = bounding box ->
+// per-point cell id + histogram -> exclusive scan -> scatter (counting sort,
+// target points stored contiguously per cell with their original index in .w);
+// query = fused transform + 9 contiguous runs (x-adjacent cells are adjacent in
+// memory) + Jacobian/residual accumulation + wave-shuffle reduction, ONE kernel
+// per ICP iteration.
+#include "device_common.h"
+
+#include <math.h>
+#include <string.h>
+
+namespace visma {
+
+// ---- order-preserving float <-> uint map (for atomic min/max) --------------
+__device__ __forceinline__ unsigned f2ord(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void bbox_init_kernel(unsigned *box)
+{
+    if (threadIdx.x < 3) box[threadIdx.x] = 0xFFFFFFFFu;      // min x,y,z
+    else if (threadIdx.x < 6) box[threadIdx.x] = 0u;          // max x,y,z
+}
+
+__global__ __launch_bounds__(256) void bbox_kernel(const float4 *__restrict__ pts, int n,
+                                                   unsigned *__restrict__ box)
+{
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const float4 q = pts[i];
+        mn[0] = fminf(mn[0], q.x); mx[0] = fmaxf(mx[0], q.x);
+        mn[1] = fminf(mn[1], q.y); mx[1] = fmaxf(mx[1], q.y);
+        mn[2] = fminf(mn[2], q.z); mx[2] = fmaxf(mx[2], q.z);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_down(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&box[a], f2ord(mn[a]));
+            atomicMax(&box[3 + a], f2ord(mx[a]));
+        }
+    }
+}
+
+// The cell coordinate; build and query MUST use this same expression.
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int dim)
+{
+    float u = floorf((v - mn) * inv_h);
+    u = fminf(fmaxf(u, -2.0f), (float)dim + 1.0f);   // also tames inf / huge values
+    return (int)u;
+}
+
+__global__ __launch_bounds__(256) void cell_count_kernel(const float4 *__restrict__ pts, int n,
+                                                         GridParams g,
+                                                         unsigned *__restrict__ cell_of,
+                                                         unsigned *__restrict__ count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = pts[i];
+    int cx = cell_coord(q.x, g.mn[0], g.inv_h, g.dim[0]);
+    int cy = cell_coord(q.y, g.mn[1], g.inv_h, g.dim[1]);
+    int cz = cell_coord(q.z, g.mn[2], g.inv_h, g.dim[2]);
+    cx = min(max(cx, 0), g.dim[0] - 1);
+    cy = min(max(cy, 0), g.dim[1] - 1);
+    cz = min(max(cz, 0), g.dim[2] - 1);
+    const unsigned c = (unsigned)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+    cell_of[i] = c;
+    atomicAdd(&count[c], 1u);
+}
+
+// ---- exclusive scan of `count` (n entries) into `start` (n+1 entries) --------
+constexpr int kScanPerBlock = 2048;   // 256 threads x 8
+
+__global__ __launch_bounds__(256) void scan_block_sum_kernel(const unsigned *__restrict__ count,
+                                                             long long n,
+                                                             unsigned *__restrict__ bsum)
+{
+    __shared__ unsigned w[4];
+    const long long base = (long long)blockIdx.x * kScanPerBlock + threadIdx.x * 8;
+    unsigned s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        if (base + k < n) s += count[base + k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+
+// one workgroup: in-place exclusive scan of bsum[0..nb)
+__global__ __launch_bounds__(1024) void scan_top_kernel(unsigned *__restrict__ bsum, int nb)
+{
+    __shared__ unsigned part[1024];
+    const int per = (nb + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nb);
+    unsigned s = 0;
+    for (int i = lo; i < hi; i++) s += bsum[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan
+        unsigned v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - s;        // exclusive prefix of this thread's range
+    for (int i = lo; i < hi; i++) {
+        const unsigned v = bsum[i];
+        bsum[i] = run;
+        run += v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scan_apply_kernel(const unsigned *__restrict__ count,
+                                                         long long n,
+                                                         const unsigned *__restrict__ bsum,
+                                                         unsigned *__restrict__ start)
+{
+    __shared__ unsigned tsum[256];
+    const long long base = (long long)blockIdx.x * kScanPerBlock + threadIdx.x * 8;
+    unsigned v[8], s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        v[k] = (base + k < n) ? count[base + k] : 0u;
+        s += v[k];
+    }
+    tsum[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        unsigned t = (threadIdx.x >= off) ? tsum[threadIdx.x - off] : 0u;
+        __syncthreads();
+        tsum[threadIdx.x] += t;
+        __syncthreads();
+    }
+    unsigned run = bsum[blockIdx.x] + tsum[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (base + k < n) start[base + k] = run;
+        run += v[k];
+    }
+    // the last element of all: start[n] = total
+    if (base <= n - 1 && n - 1 < base + 8) start[n] = run;
+}
+
+__global__ __launch_bounds__(256) void cell_scatter_kernel(const float4 *__restrict__ pts, int n,
+                                                           const unsigned *__restrict__ cell_of,
+                                                           const unsigned *__restrict__ start,
+                                                           unsigned *__restrict__ cursor,
+                                                           float4 *__restrict__ sorted)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned c = cell_of[i];
+    const unsigned pos = start[c] + atomicAdd(&cursor[c], 1u);
+    const float4 q = pts[i];
+    sorted[pos] = make_float4(q.x, q.y, q.z, __uint_as_float((unsigned)i));
+}
+
+hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, stream, box6);
+    if (nt > 0) {
+        int blocks = (int)((nt + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, stream, tgt, (int)nt, box6);
+    }
+    return hipGetLastError();
+}
+
+void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3])
+{
+    for (int a = 0; a < 6; a++) {
+        const unsigned o = box6[a];
+        const unsigned u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+        float f;
+        memcpy(&f, &u, sizeof(f));
+        (a < 3 ? mn[a] : mx[a - 3]) = f;
+    }
+}
+
+GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells)
+{
+    GridParams g;
+    float h = (float)(max_dist * 1.001);
+    if (!(h > 0.f) || !isfinite(h)) h = 1.0f;
+    for (;;) {
+        double n = 1.0;
+        for (int a = 0; a < 3; a++) {
+            double ext = (double)mx[a] - (double)mn[a];
+            if (!(ext >= 0.0) || !isfinite(ext)) ext = 0.0;
+            double d = floor(ext / h) + 1.0;
+            if (d > 2.0e9) d = 2.0e9;
+            g.dim[a] = (int)d;
+            n *= d;
+        }
+        if (n <= (double)max_cells) break;
+        h *= 1.26f;
+    }
+    for (int a = 0; a < 3; a++) g.mn[a] = mn[a];
+    g.h = h;
+    g.inv_h = 1.0f / h;
+    g.ncell = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    return g;
+}
+
+hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
+                             unsigned *cell_of, unsigned *count, unsigned *bsum,
+                             unsigned *start, float4 *sorted, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned) * (size_t)g.ncell, stream);
+    if (e != hipSuccess) return e;
+    const int pblocks = (int)((nt + 255) / 256);
+    if (nt > 0)
+        hipLaunchKernelGGL(cell_count_kernel, dim3(pblocks), dim3(256), 0, stream, tgt, (int)nt, g,
+                           cell_of, count);
+    const int nb = (int)((g.ncell + kScanPerBlock - 1) / kScanPerBlock);
+    hipLaunchKernelGGL(scan_block_sum_kernel, dim3(nb), dim3(256), 0, stream, count,
+                       (long long)g.ncell, bsum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsum, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, count, (long long)g.ncell,
+                       bsum, start);
+    e = hipMemsetAsync(count, 0, sizeof(unsigned) * (size_t)g.ncell, stream);   // reuse as cursors
+    if (e != hipSuccess) return e;
+    if (nt > 0)
+        hipLaunchKernelGGL(cell_scatter_kernel, dim3(pblocks), dim3(256), 0, stream, tgt, (int)nt,
+                           cell_of, start, count, sorted);
+    return hipGetLastError();
+}
+
+int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) / kScanPerBlock); }
+
+// ------------------------------------------------------------------------
+// Query: fused transform + grid NN + Jacobian/residual + reduction
+// ------------------------------------------------------------------------
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
+    const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
+    const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
+    Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out, float *__restrict__ d2_out,
+    double *__restrict__ partials)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        const float4 s4 = src[i];
+        float px, py, pz;
+        xform_point_f32(T32, s4, px, py, pz);
+        const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
+        const int cy = cell_coord(py, g.mn[1], g.inv_h, g.dim[1]);
+        const int cz = cell_coord(pz, g.mn[2], g.inv_h, g.dim[2]);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
+        float best = r2f;
+        unsigned bi = 0xFFFFFFFFu;
+        float4 qb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (x0 <= x1) {
+            for (int z = z0; z <= z1; z++)
+                for (int y = y0; y <= y1; y++) {
+                    const long long row = ((long long)z * g.dim[1] + y) * g.dim[0];
+                    const unsigned b = start[row + x0], e = start[row + x1 + 1];
+                    for (unsigned j = b; j < e; j++) {
+                        const float4 q = sorted[j];
+                        const float d = sqdist_f32(q, px, py, pz);
+                        const unsigned id = __float_as_uint(q.w);
+                        // (d2, index) lexicographic minimum; strict d2 < r2f
+                        if (d < best || (d == best && bi != 0xFFFFFFFFu && id < bi)) {
+                            best = d;
+                            bi = id;
+                            qb = q;
+                        }
+                    }
+                }
+        }
+        idx_out[i] = (bi == 0xFFFFFFFFu) ? -1 : (int)bi;
+        d2_out[i] = best;
+        if (bi != 0xFFFFFFFFu) {
+            float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PLANE) n4 = nrm[bi];
+            accumulate_pair<PLANE>(acc, s4, qb, n4, T64, off);
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
+hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
+                                 const unsigned *start, const GridParams &g,
+                                 const float4 *tgt_normals, const Xform32 &T32, const Xform64 &T64,
+                                 const double frame_offset[3], float r2f, int point_to_plane,
+                                 int32_t *idx_out, float *d2_out, double *partials,
+                                 int max_partial_blocks, int *nblocks_out, hipStream_t stream)
+{
+    Offset64 off;
+    for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
+    int nblocks = (int)((ns + kBlock - 1) / kBlock);
+    if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
+    if (nblocks < 1) nblocks = 1;
+    if (point_to_plane)
+        hipLaunchKernelGGL(nn_grid_reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
+                           (int)ns, sorted, start, g, tgt_normals, T32, T64, off, r2f, idx_out,
+                           d2_out, partials);
+    else
+        hipLaunchKernelGGL(nn_grid_reduce_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src,
+                           (int)ns, sorted, start, g, tgt_normals, T32, T64, off, r2f, idx_out,
+                           d2_out, partials);
+    if (nblocks_out) *nblocks_out = nblocks;
+    return hipGetLastError();
+}
+
+}  // namespace visma

@@ -53,6 +53,36 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
 
 int reduce_max_blocks();
 
+// Fold `nblocks` partial rows into the 38 statistics (one workgroup, fixed order).
+hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
+                           double *stats_out, hipStream_t stream);
+
+// ---- radius-cell uniform grid (grid.hip) -------------------------------------
+struct GridParams {
+    float mn[3];      // lower corner of the target's bounding box
+    float h, inv_h;   // cell edge (>= 1.001 * max_dist) and its reciprocal
+    int dim[3];       // cells per axis
+    int64_t ncell;
+};
+constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;
+
+hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
+void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
+GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells);
+int grid_scan_blocks(int64_t ncell);
+// counting sort of the target by cell: start[ncell+1], sorted[nt] = (x,y,z, bits(orig index))
+hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
+                             unsigned *cell_of, unsigned *count, unsigned *bsum,
+                             unsigned *start, float4 *sorted, hipStream_t stream);
+// fused transform + grid NN + Jacobian/residual + reduction to partial rows
+// (launch_finalize folds them); also writes idx_out / d2_out.
+hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
+                                 const unsigned *start, const GridParams &g,
+                                 const float4 *tgt_normals, const Xform32 &T32, const Xform64 &T64,
+                                 const double frame_offset[3], float r2f, int point_to_plane,
+                                 int32_t *idx_out, float *d2_out, double *partials,
+                                 int max_partial_blocks, int *nblocks_out, hipStream_t stream);
+
 // fill n float4 with +inf (target padding)
 hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);
 // AoS stride-s floats -> float4 (w = 0)

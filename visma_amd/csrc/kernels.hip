@@ -15,37 +15,11 @@
 //   d2 = fmaf(dz,dz, fmaf(dy,dy, dx*dx)),  d = q - p        fp32
 //   accept iff d2 < r2f; lowest target index wins exact ties.
 // Statistics are accumulated in f64 from p = T64 * (double)s and q widened.
-#include "kernels.h"
-#include "so3.h"
+#include "device_common.h"
 
 #include <math.h>
 
 namespace visma {
-
-// ------------------------------------------------------------------------
-// shared device helpers
-// ------------------------------------------------------------------------
-__device__ __forceinline__ void xform_point_f32(const Xform32 &T, const float4 s,
-                                                float &px, float &py, float &pz)
-{
-    px = __builtin_fmaf(T.m[0], s.x, __builtin_fmaf(T.m[1], s.y, __builtin_fmaf(T.m[2], s.z, T.m[3])));
-    py = __builtin_fmaf(T.m[4], s.x, __builtin_fmaf(T.m[5], s.y, __builtin_fmaf(T.m[6], s.z, T.m[7])));
-    pz = __builtin_fmaf(T.m[8], s.x, __builtin_fmaf(T.m[9], s.y, __builtin_fmaf(T.m[10], s.z, T.m[11])));
-}
-
-__device__ __forceinline__ float sqdist_f32(const float4 q, float px, float py, float pz)
-{
-    const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-}
-
-// one VALU op: min of three (v_min3_f32); inputs are never NaN-producing here
-__device__ __forceinline__ float min3_f32(float a, float b, float c)
-{
-    float r;
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
 
 // ------------------------------------------------------------------------
 // NN: fused transform + brute force
@@ -200,17 +174,6 @@ hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
 // ------------------------------------------------------------------------
 // Reduction: merge + refine + Jacobian/residual + wave-shuffle reduce
 // ------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// Accumulator layouts
-//  point-to-point (23): 0 K | 1 r2 | 2-4 sum p | 5-7 sum q |
-//                       8-13 sum pp^T (xx xy xz yy yz zz) | 14-22 sum q p^T
-//  point-to-plane (29): 0 K | 1 r2 | 2-22 upper J^T J | 23-28 J^T r
 template <bool PLANE>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
@@ -218,7 +181,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
     int nsplits, long long ns_pad, Xform32 T32, Xform64 T64, Offset64 off, float r2f,
     int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
 {
-    constexpr int NACC = PLANE ? 29 : 23;
+    constexpr int NACC = Acc<PLANE>::N;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -253,65 +216,14 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
         idx_out[i] = idx;
         d2_out[i] = best;
         if (idx >= 0) {
-            // (3) Jacobian / residual rows in f64 (design rule R1/R2)
-            const double sx = s4.x, sy = s4.y, sz = s4.z;
-            const double p[3] = {
-                T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3] + off.v[0],
-                T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7] + off.v[1],
-                T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11] + off.v[2]};
-            const double q[3] = {(double)q4.x + off.v[0], (double)q4.y + off.v[1],
-                                 (double)q4.z + off.v[2]};
-            const double r[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
-            acc[0] += 1.0;
-            if (!PLANE) {
-                acc[1] += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
-                acc[2] += p[0]; acc[3] += p[1]; acc[4] += p[2];
-                acc[5] += q[0]; acc[6] += q[1]; acc[7] += q[2];
-                acc[8] += p[0] * p[0]; acc[9] += p[0] * p[1]; acc[10] += p[0] * p[2];
-                acc[11] += p[1] * p[1]; acc[12] += p[1] * p[2]; acc[13] += p[2] * p[2];
-#pragma unroll
-                for (int a = 0; a < 3; a++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) acc[14 + a * 3 + b] += q[a] * p[b];
-            } else {
-                const float4 n4 = nrm[idx];
-                const double n[3] = {(double)n4.x, (double)n4.y, (double)n4.z};
-                const double rr = r[0] * n[0] + r[1] * n[1] + r[2] * n[2];
-                // J = [p x n | n]  (TransformationEstimation.cpp:87-89)
-                double J[6];
-                double H[9];
-                hat(p, H);  // p x n = hat(p) n
-                J[0] = H[0] * n[0] + H[1] * n[1] + H[2] * n[2];
-                J[1] = H[3] * n[0] + H[4] * n[1] + H[5] * n[2];
-                J[2] = H[6] * n[0] + H[7] * n[1] + H[8] * n[2];
-                J[3] = n[0]; J[4] = n[1]; J[5] = n[2];
-                acc[1] += rr * rr;
-                int o = 2;
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b = a; b < 6; b++) acc[o++] += J[a] * J[b];
-#pragma unroll
-                for (int a = 0; a < 6; a++) acc[23 + a] += J[a] * rr;
-            }
+            // (3) Jacobian / residual rows in f64
+            float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PLANE) n4 = nrm[idx];
+            accumulate_pair<PLANE>(acc, s4, q4, n4, T64, off);
         }
     }
-
     // (4) wavefront shuffle reduction -> LDS across the 4 waves -> partials
-    __shared__ double wsum[kBlock / 64][NACC];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int a = 0; a < NACC; a++) {
-        const double v = wave_sum(acc[a]);
-        if (lane == 0) wsum[wave][a] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < NACC) {
-        double v = wsum[0][threadIdx.x];
-#pragma unroll
-        for (int w = 1; w < kBlock / 64; w++) v += wsum[w][threadIdx.x];
-        partials[(long long)blockIdx.x * kReduceAcc + threadIdx.x] = v;
-    }
+    block_reduce_store<NACC>(acc, partials);
 }
 
 // One workgroup; folds `nblocks` partial rows in a fixed order and expands the
@@ -321,13 +233,24 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restri
                                                           int nblocks,
                                                           double *__restrict__ stats)
 {
-    constexpr int NACC = PLANE ? 29 : 23;
+    constexpr int NACC = Acc<PLANE>::N;
     __shared__ double part[8][32];
     __shared__ double tot[32];
     const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
     double v = 0.0;
-    if (a < NACC)
-        for (int b = g; b < nblocks; b += 8) v += partials[(long long)b * kReduceAcc + a];
+    if (a < NACC) {
+        // rows g, g+8, g+16, ...: four independent load/add chains in flight
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int b = g;
+        for (; b + 24 < nblocks; b += 32) {
+            v0 += partials[(long long)b * kReduceAcc + a];
+            v1 += partials[(long long)(b + 8) * kReduceAcc + a];
+            v2 += partials[(long long)(b + 16) * kReduceAcc + a];
+            v3 += partials[(long long)(b + 24) * kReduceAcc + a];
+        }
+        for (; b < nblocks; b += 8) v0 += partials[(long long)b * kReduceAcc + a];
+        v = (v0 + v1) + (v2 + v3);
+    }
     part[g][a] = v;
     __syncthreads();
     if (threadIdx.x < 32) {
@@ -368,14 +291,25 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restri
     }
 }
 
-int reduce_max_blocks() { return 1024; }
+int reduce_max_blocks() { return 512; }
+
+hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
+                           double *stats_out, hipStream_t stream)
+{
+    if (point_to_plane)
+        hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(kBlock), 0, stream, partials,
+                           nblocks, stats_out);
+    else
+        hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(kBlock), 0, stream, partials,
+                           nblocks, stats_out);
+    return hipGetLastError();
+}
 
 hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const float4 *tgt_normals, const unsigned long long *keys,
                          int nsplits, int64_t ns_pad, const Xform32 &T32,
                          const Xform64 &T64, const double frame_offset[3], float r2f,
-                         int point_to_plane,
-                         int32_t *idx_out, float *d2_out, double *partials,
+                         int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out, hipStream_t stream)
 {
     Offset64 off;
@@ -383,20 +317,17 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
     int nblocks = (int)((ns + kBlock - 1) / kBlock);
     if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
     if (nblocks < 1) nblocks = 1;
-    if (point_to_plane) {
+    if (point_to_plane)
         hipLaunchKernelGGL(reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
                            T64, off, r2f, idx_out, d2_out, partials);
-        hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(kBlock), 0, stream, partials,
-                           nblocks, stats_out);
-    } else {
+    else
         hipLaunchKernelGGL(reduce_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
                            T64, off, r2f, idx_out, d2_out, partials);
-        hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(kBlock), 0, stream, partials,
-                           nblocks, stats_out);
-    }
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_finalize(partials, nblocks, point_to_plane, stats_out, stream);
 }
 
 // ------------------------------------------------------------------------
