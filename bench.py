@@ -100,8 +100,9 @@ def main():
                              % (args.gpus, args.gpus))
         args.gpus = world
 
+    force_comm = os.environ.get("VISMA_ICP_FORCE_COMM") == "1"   # exercise RCCL even at N=1
     dist = None
-    if world > 1:
+    if world > 1 or force_comm:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -124,7 +125,7 @@ def main():
     # (full) target centroid, which all ranks share.
     ctx.set_clouds_f64(src[lo:hi], tgt)
     ctx.set_global_source_count(ns)
-    if world > 1:
+    if dist is not None:
         import torch
         if rank == 0:
             uid = torch.tensor(list(_lib.comm_unique_id()), dtype=torch.uint8, device="cuda")

@@ -90,6 +90,7 @@ typedef struct {
     int64_t reduce_launches;
     double aux_ms;       /* grid build / refine / other kernels              */
     int64_t aux_launches;
+    double grid_candidates; /* target points examined by the grid search (sum) */
 } visma_icp_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -40,7 +40,8 @@ class CResult(C.Structure):
 class CTiming(C.Structure):
     _fields_ = [("nn_ms", C.c_double), ("nn_launches", C.c_int64),
                 ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
-                ("aux_ms", C.c_double), ("aux_launches", C.c_int64)]
+                ("aux_ms", C.c_double), ("aux_launches", C.c_int64),
+                ("grid_candidates", C.c_double)]
 
 
 class CProblem(C.Structure):

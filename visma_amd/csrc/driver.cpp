@@ -13,8 +13,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -117,7 +119,7 @@ public:
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
-        free_dev(d_start_); free_dev(d_bsum_);
+        free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_);
         if (h_stats_) (void)hipHostFree(h_stats_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -143,6 +145,12 @@ public:
         HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * reduce_max_blocks()));
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
+        HIP_TRY(hipMalloc(&d_cand_, sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d_cand_, 0, sizeof(unsigned long long)));
+        if (const char *e = std::getenv("VISMA_ICP_GRID_LANES")) {
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) grid_lanes_ = v;
+        }
         HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * kNStats, hipHostMallocDefault));
         return VISMA_ICP_OK;
     }
@@ -249,7 +257,8 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, stream_));
+                                          &nblocks, grid_lanes_,
+                                          profiling_ ? (unsigned long long *)d_cand_ : nullptr, stream_));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
             HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
@@ -293,7 +302,7 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, stream_));
+                                          &nblocks, grid_lanes_, nullptr, stream_));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -345,8 +354,16 @@ public:
     void set_profiling(bool on) override { profiling_ = on; }
     void get_timing(visma_icp_timing *t, bool reset) override
     {
+        unsigned long long c = 0;
+        (void)hipSetDevice(device_);
+        (void)hipStreamSynchronize(stream_);
+        (void)hipMemcpy(&c, d_cand_, sizeof(c), hipMemcpyDeviceToHost);
+        timing_.grid_candidates = (double)c;
         *t = timing_;
-        if (reset) std::memset(&timing_, 0, sizeof(timing_));
+        if (reset) {
+            std::memset(&timing_, 0, sizeof(timing_));
+            (void)hipMemset(d_cand_, 0, sizeof(unsigned long long));
+        }
     }
     void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }
 
@@ -485,7 +502,8 @@ private:
     double grid_radius_ = 0.0;
     GridParams grid_{};
     void *d_box_ = nullptr, *d_sorted_ = nullptr, *d_cell_of_ = nullptr, *d_count_ = nullptr;
-    void *d_start_ = nullptr, *d_bsum_ = nullptr;
+    void *d_start_ = nullptr, *d_bsum_ = nullptr, *d_cand_ = nullptr;
+    int grid_lanes_ = 8;   // lanes cooperating on one query (VISMA_ICP_GRID_LANES overrides)
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
 };
 
@@ -538,6 +556,7 @@ struct visma_icp_ctx {
     int64_t ns_total = 0;
     Mat4 last_Tc = Mat4::identity();
     bool last_plane = false;
+    std::vector<int32_t> src_order;   // engine position -> caller's source index (Morton order)
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
     int eng_fail(int code) { err = eng->error(); return code; }
@@ -655,6 +674,54 @@ void pack_f32(const float *xyz, int64_t n, int stride, std::vector<float> &out)
     }
 }
 
+// Spatial (Morton / Z-order) permutation of packed xyzw points.  Neighbouring
+// lanes then query neighbouring grid cells, so a wave's candidate runs overlap
+// in L1/L2.  Returns order[pos] = original index and permutes `pts` in place.
+inline uint32_t spread10(uint32_t v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+void morton_order(std::vector<float> &pts, int64_t n, std::vector<int32_t> &order)
+{
+    order.resize((size_t)n);
+    if (n <= 0) return;
+    float mn[3] = {pts[0], pts[1], pts[2]}, mx[3] = {pts[0], pts[1], pts[2]};
+    for (int64_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            const float v = pts[4 * i + a];
+            if (v < mn[a]) mn[a] = v;
+            if (v > mx[a]) mx[a] = v;
+        }
+    float ext = 0.f;
+    for (int a = 0; a < 3; a++) ext = std::max(ext, mx[a] - mn[a]);
+    const float scale = (ext > 0.f && std::isfinite(ext)) ? 1023.0f / ext : 0.f;
+    std::vector<std::pair<uint32_t, int32_t>> keys((size_t)n);
+    for (int64_t i = 0; i < n; i++) {
+        uint32_t q[3];
+        for (int a = 0; a < 3; a++) {
+            float u = (pts[4 * i + a] - mn[a]) * scale;
+            if (!(u >= 0.f)) u = 0.f;
+            if (u > 1023.f) u = 1023.f;
+            q[a] = (uint32_t)u;
+        }
+        keys[i] = {spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2), (int32_t)i};
+    }
+    std::sort(keys.begin(), keys.end());   // ties broken by original index: deterministic
+    std::vector<float> out((size_t)n * 4);
+    for (int64_t pos = 0; pos < n; pos++) {
+        const int32_t o = keys[pos].second;
+        order[pos] = o;
+        std::memcpy(&out[4 * pos], &pts[4 * (size_t)o], 4 * sizeof(float));
+    }
+    std::memcpy(pts.data(), out.data(), out.size() * sizeof(float));
+}
+
 }  // namespace
 
 extern "C" {
@@ -717,6 +784,7 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     int rc = ctx->eng->set_target(buf.data(), nt);
     if (rc) return ctx->eng_fail(rc);
     pack_f64(src, ns, sstride, c, buf);
+    morton_order(buf, ns, ctx->src_order);
     rc = ctx->eng->set_source(buf.data(), ns);
     if (rc) return ctx->eng_fail(rc);
     std::memcpy(ctx->centre, c, sizeof(c));
@@ -743,6 +811,7 @@ int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns, int s
     if (ns < 0 || stride < 3 || (ns > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
     std::vector<float> buf;
     pack_f32(xyz, ns, stride, buf);
+    morton_order(buf, ns, ctx->src_order);
     int rc = ctx->eng->set_source(buf.data(), ns);
     if (rc) return ctx->eng_fail(rc);
     ctx->have_src = true;
@@ -766,6 +835,7 @@ int visma_icp_set_source_device(visma_icp_ctx *ctx, const void *d, int64_t ns)
     if (ns < 0 || (ns > 0 && !d)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
     int rc = ctx->eng->set_source_device(d, ns);
     if (rc) return ctx->eng_fail(rc);
+    ctx->src_order.clear();   // device-resident source is used in the caller's order
     ctx->have_src = true;
     return VISMA_ICP_OK;
 }
@@ -819,6 +889,17 @@ int visma_icp_get_correspondences(visma_icp_ctx *ctx, int32_t *src_idx, int32_t 
     std::vector<float> dd((size_t)(ns > 0 ? ns : 1));
     int rc = ctx->eng->get_correspondences(idx.data(), dd.data());
     if (rc) return ctx->eng_fail(rc);
+    if ((int64_t)ctx->src_order.size() == ns && ns > 0) {
+        // the engine holds the source in Morton order: back to the caller's order
+        std::vector<int32_t> idx2((size_t)ns);
+        std::vector<float> dd2((size_t)ns);
+        for (int64_t pos = 0; pos < ns; pos++) {
+            idx2[ctx->src_order[pos]] = idx[pos];
+            dd2[ctx->src_order[pos]] = dd[pos];
+        }
+        idx.swap(idx2);
+        dd.swap(dd2);
+    }
     int64_t c = 0;
     for (int64_t i = 0; i < ns; i++)
         if (idx[i] >= 0) {

@@ -254,19 +254,28 @@ int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) /
 // ------------------------------------------------------------------------
 // Query: fused transform + grid NN + Jacobian/residual + reduction
 // ------------------------------------------------------------------------
-template <bool PLANE>
+// G consecutive lanes cooperate on one query: lane g takes candidates
+// j = b+g, b+g+G, ... of each contiguous run (G*16-byte coalesced segments), the
+// G partial minima are merged with G-lane butterfly shuffles on the
+// (d2, original index) key, and lane 0 of the group accumulates the
+// correspondence's Jacobian/residual rows.
+template <bool PLANE, int G>
 __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
     Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out, float *__restrict__ d2_out,
-    double *__restrict__ partials)
+    double *__restrict__ partials, unsigned long long *__restrict__ cand_count)
 {
     constexpr int NACC = Acc<PLANE>::N;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+    unsigned ncand = 0;
 
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+    const int sub = threadIdx.x % G;                       // lane within the query group
+    const int groups_per_block = kBlock / G;
+    for (int i = blockIdx.x * groups_per_block + threadIdx.x / G; i < ns;
+         i += gridDim.x * groups_per_block) {
         const float4 s4 = src[i];
         float px, py, pz;
         xform_point_f32(T32, s4, px, py, pz);
@@ -284,7 +293,8 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 for (int y = y0; y <= y1; y++) {
                     const long long row = ((long long)z * g.dim[1] + y) * g.dim[0];
                     const unsigned b = start[row + x0], e = start[row + x1 + 1];
-                    for (unsigned j = b; j < e; j++) {
+                    if (sub == 0) ncand += e - b;
+                    for (unsigned j = b + sub; j < e; j += G) {
                         const float4 q = sorted[j];
                         const float d = sqdist_f32(q, px, py, pz);
                         const unsigned id = __float_as_uint(q.w);
@@ -297,15 +307,46 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     }
                 }
         }
-        idx_out[i] = (bi == 0xFFFFFFFFu) ? -1 : (int)bi;
-        d2_out[i] = best;
-        if (bi != 0xFFFFFFFFu) {
-            float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PLANE) n4 = nrm[bi];
-            accumulate_pair<PLANE>(acc, s4, qb, n4, T64, off);
+        if (G > 1) {
+            // butterfly merge over the G lanes: smallest (d2, index) wins everywhere
+#pragma unroll
+            for (int m = G >> 1; m > 0; m >>= 1) {
+                const float ob = __shfl_xor(best, m, 64);
+                const unsigned oi = (unsigned)__shfl_xor((int)bi, m, 64);
+                const float ox = __shfl_xor(qb.x, m, 64), oy = __shfl_xor(qb.y, m, 64),
+                            oz = __shfl_xor(qb.z, m, 64);
+                const bool take = (ob < best) || (ob == best && oi < bi);
+                if (take) { best = ob; bi = oi; qb.x = ox; qb.y = oy; qb.z = oz; }
+            }
+        }
+        if (sub == 0) {
+            idx_out[i] = (bi == 0xFFFFFFFFu) ? -1 : (int)bi;
+            d2_out[i] = best;
+            if (bi != 0xFFFFFFFFu) {
+                float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (PLANE) n4 = nrm[bi];
+                accumulate_pair<PLANE>(acc, s4, qb, n4, T64, off);
+            }
         }
     }
     block_reduce_store<NACC>(acc, partials);
+    if (cand_count) {
+        unsigned long long c = ncand;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if ((threadIdx.x & 63) == 0 && c) atomicAdd(cand_count, c);
+    }
+}
+
+template <bool PLANE, int G>
+static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, int ns,
+                          const float4 *sorted, const unsigned *start, const GridParams &g,
+                          const float4 *nrm, const Xform32 &T32, const Xform64 &T64,
+                          const Offset64 &off, float r2f, int *idx_out, float *d2_out,
+                          double *partials, unsigned long long *cand)
+{
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G>), dim3(nblocks), dim3(kBlock), 0, stream, src,
+                       ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out, partials, cand);
 }
 
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -313,21 +354,35 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  const float4 *tgt_normals, const Xform32 &T32, const Xform64 &T64,
                                  const double frame_offset[3], float r2f, int point_to_plane,
                                  int32_t *idx_out, float *d2_out, double *partials,
-                                 int max_partial_blocks, int *nblocks_out, hipStream_t stream)
+                                 int max_partial_blocks, int *nblocks_out, int lanes_per_query,
+                                 unsigned long long *cand_count, hipStream_t stream)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
-    int nblocks = (int)((ns + kBlock - 1) / kBlock);
-    if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
+    const int G = lanes_per_query;
+    int64_t want = (ns * G + kBlock - 1) / kBlock;
+    int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
     if (nblocks < 1) nblocks = 1;
-    if (point_to_plane)
-        hipLaunchKernelGGL(nn_grid_reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
-                           (int)ns, sorted, start, g, tgt_normals, T32, T64, off, r2f, idx_out,
-                           d2_out, partials);
-    else
-        hipLaunchKernelGGL(nn_grid_reduce_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src,
-                           (int)ns, sorted, start, g, tgt_normals, T32, T64, off, r2f, idx_out,
-                           d2_out, partials);
+#define VISMA_GRID_CASE(GG)                                                                        \
+    case GG:                                                                                       \
+        if (point_to_plane)                                                                        \
+            launch_grid_t<true, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals,  \
+                                    T32, T64, off, r2f, idx_out, d2_out, partials, cand_count);    \
+        else                                                                                       \
+            launch_grid_t<false, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals, \
+                                     T32, T64, off, r2f, idx_out, d2_out, partials, cand_count);   \
+        break;
+    switch (G) {
+        VISMA_GRID_CASE(1)
+        VISMA_GRID_CASE(2)
+        VISMA_GRID_CASE(4)
+        VISMA_GRID_CASE(8)
+        VISMA_GRID_CASE(16)
+        VISMA_GRID_CASE(32)
+    default:
+        return hipErrorInvalidValue;
+    }
+#undef VISMA_GRID_CASE
     if (nblocks_out) *nblocks_out = nblocks;
     return hipGetLastError();
 }

@@ -81,7 +81,8 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  const float4 *tgt_normals, const Xform32 &T32, const Xform64 &T64,
                                  const double frame_offset[3], float r2f, int point_to_plane,
                                  int32_t *idx_out, float *d2_out, double *partials,
-                                 int max_partial_blocks, int *nblocks_out, hipStream_t stream);
+                                 int max_partial_blocks, int *nblocks_out, int lanes_per_query,
+                                 unsigned long long *cand_count, hipStream_t stream);
 
 // fill n float4 with +inf (target padding)
 hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restri
     }
 }
 
-int reduce_max_blocks() { return 512; }
+int reduce_max_blocks() { return 2048; }
 
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
                            double *stats_out, hipStream_t stream)
