@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- ICP iterations/s of the MI355X-native registration path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--nn auto|grid|brute]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json metric "ICP iterations/sec + corresp. M-pairs/sec,
 64k->4M-pt target"): synthetic S-surf clouds, source
 262,144 points -> target 4,194,304 points, fp32 search / f64 statistics.
-One STEP = one ICP iteration = one fused transform+NN pass over all
-NS x NT pairs, one Jacobian/residual reduction, one host solve, T <- update*T.
-Inputs are resident in HBM before the timed region.
+One STEP = one ICP iteration = one fused transform + nearest-neighbour pass of
+every source point against the target, one Jacobian/residual reduction, one
+host solve, T <- update*T.  Inputs are resident in HBM before the timed region
+(the radius-cell grid is built once per target/radius, outside the timed
+region, like the reference's KD-tree; its build time is reported).
+
+NN search: `auto` (default) = the radius-cell uniform grid (exact radius-limited
+1-NN; HBM-bound); `brute` = the LDS-tiled brute-force kernel north_star names
+(fp32-VALU-bound).  Both give bit-identical correspondences.  A few brute-force
+steps are always run after the timed region and reported under `brute_force`.
 
 N > 1: the SOURCE is sharded across ranks (each rank holds the full target),
 every rank reduces its shard to the 38 f64 normal-equation accumulators and
@@ -45,6 +52,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--ns", type=int, default=NS_DEFAULT)
     ap.add_argument("--nt", type=int, default=NT_DEFAULT)
+    ap.add_argument("--nn", choices=["auto", "grid", "brute"], default="auto")
+    ap.add_argument("--brute-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
     return ap.parse_args()
@@ -82,11 +91,60 @@ def cpu_baseline(src, tgt, radius, iters):
     return {
         "value": 1.0 / per_iter, "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
         "sample": "same clouds %d->%d, r=%.4g: %d steady-state iterations "
-                  "(t[%d its]-t[1 it]); setup+2 passes %.2fs"
+                  "(t[%d its]-t[1 it]); setup (KD-tree build) + 2 passes %.2fs"
                   % (len(src), len(tgt), radius, iters, iters + 1, t1),
         "ms_per_iter": per_iter * 1e3, "setup_plus_first_iter_s": t1,
         "T": np.asarray(res.T).tolist(),
     }
+
+
+def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
+    # ALGORITHMIC work of ONE brute-force NN launch on one rank:
+    #   flops = 8 * NS_local * NT        (3 sub, 1 mul, 2 fma = 8 flop per pair)
+    #   bytes = ceil(NS_local/S_TILE) * NT * 16  +  NS_local * 24
+    flops = 8.0 * ns_local * nt
+    s_tile = tile["block"] * (8 if ns_local >= 65536 else 2)
+    b_alg = math.ceil(ns_local / s_tile) * nt * 16.0 + ns_local * 24.0
+    tf = flops / (nn_ms * 1e-3) / 1e12
+    return {
+        "kernel": "nn_brute_kernel", "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+        "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
+        "note": "fp32 compute roof: the brute-force pair loop is VALU-bound (~1e5 flop/B); gfx950's "
+                "dense f32 MFMA peak equals its f32 vector peak (157.3 TF); the kernel issues VALU "
+                "ops, no MFMA",
+        "avg_launch_ms": nn_ms, "alg_flops_per_launch": flops,
+        "pairs_per_launch": float(ns_local) * nt,
+        "hbm_streamed": {"alg_bytes_per_launch": b_alg, "s_tile": s_tile,
+                         "achieved_gbps": b_alg / (nn_ms * 1e-3) / 1e9,
+                         "frac_of_8TBps": b_alg / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                         "compulsory_bytes": nt * 16.0 + ns_local * 24.0},
+    }
+
+
+def grid_roofline(ns_local, nt, nn_ms, cand_per_launch, traffic):
+    # ALGORITHMIC bytes of ONE grid launch on one rank: per query 16 B source +
+    # 18 x 4 B cell-range lookups + 8 B (index, d2) out, plus 16 B per candidate
+    # target point examined (the candidate count is measured by the kernel).
+    b_alg = ns_local * (16.0 + 72.0 + 8.0) + 16.0 * cand_per_launch
+    gbps = b_alg / (nn_ms * 1e-3) / 1e9
+    return {
+        "kernel": "nn_grid_reduce_kernel", "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
+        "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
+        "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_alg,
+        "candidates_per_query": cand_per_launch / max(ns_local, 1),
+        "compulsory_bytes": nt * 16.0 + ns_local * 24.0,
+        "note": "fused transform + grid NN + Jacobian/residual reduction; algorithmic bytes = what "
+                "the queries request (neighbouring queries share cells, so HBM-side traffic is lower)",
+    }
+
+
+def load_traffic(kind, ns_local, nt):
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(tpath))
+        return tj.get("%s:%dx%d" % (kind, ns_local, nt), {}).get("hbm_bytes_per_nn_launch")
+    except Exception:
+        return None
 
 
 def main():
@@ -120,6 +178,7 @@ def main():
     # source shard of this rank (contiguous slice; full target everywhere)
     lo = (ns * rank) // world
     hi = (ns * (rank + 1)) // world
+    ns_local = hi - lo
     ctx = _lib.Context(local_rank)
     # every rank must centre on the SAME point: set_clouds_f64 centres on the
     # (full) target centroid, which all ranks share.
@@ -140,83 +199,82 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    T = np.eye(4)
-    if args.warmup > 0:
-        T, _ = ctx.iterate(T, radius, args.warmup)
+    def reduce_max(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID, "brute": _lib.NN_BRUTE}[args.nn])
     ctx.set_profiling(True)
+    T = np.eye(4)
     ctx.get_timing(reset=True)
+    if args.warmup > 0:
+        T, _ = ctx.iterate(T, radius, args.warmup)       # also builds the grid (one-off)
+    setup = ctx.get_timing(reset=True)
+    mode = "grid" if ctx.nn_mode_used() == _lib.NN_GRID else "brute"
     sync_all()
     t0 = time.perf_counter()
     T, last = ctx.iterate(T, radius, args.steps)       # every step ends with a stream sync
     sync_all()
-    elapsed = time.perf_counter() - t0
+    elapsed = reduce_max(time.perf_counter() - t0)
     tm = ctx.get_timing(reset=True)
+    nn_ms = reduce_max(tm["nn_ms"] / max(tm["nn_launches"], 1))
+    cand = tm["grid_candidates"] / max(tm["nn_launches"], 1)
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([tm["nn_ms"] / max(tm["nn_launches"], 1)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        nn_ms = float(k.item())
-    else:
-        nn_ms = tm["nn_ms"] / max(tm["nn_launches"], 1)
+    # a few brute-force steps (outside the timed region) for the north_star kernel's own numbers
+    brute = None
+    if mode != "brute" and args.brute_steps > 0:
+        ctx.set_nn_mode(_lib.NN_BRUTE)
+        ctx.iterate(T, radius, 1)
+        ctx.get_timing(reset=True)
+        tb0 = time.perf_counter()
+        Tb, _ = ctx.iterate(np.eye(4), radius, args.brute_steps)
+        tb = time.perf_counter() - tb0
+        tmb = ctx.get_timing(reset=True)
+        # same answer as the grid from the same start (bit-identical correspondences)
+        Tg, _ = (ctx.set_nn_mode(_lib.NN_GRID), ctx.iterate(np.eye(4), radius, args.brute_steps))[1]
+        brute = {"steps": args.brute_steps, "ms_per_step": tb / args.brute_steps * 1e3,
+                 "nn_ms": reduce_max(tmb["nn_ms"] / max(tmb["nn_launches"], 1)),
+                 "T_equals_grid_T": bool(np.array_equal(Tb, Tg)),
+                 "rel_frobenius_vs_grid": synth.rel_frobenius(Tb, Tg)}
+        ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID}[args.nn])
 
     if rank == 0:
         tile = _lib.tile_config()
-        src_tiles, tgt_splits = ctx.launch_config()
-        ns_local = hi - lo
-        # ALGORITHMIC work of ONE NN launch on one rank:
-        #   flops = 8 * NS_local * NT        (3 sub, 1 mul, 2 fma = 8 flop per pair)
-        #   bytes = ceil(NS_local/S_TILE) * NT * 16  +  NS_local * 24
-        flops = 8.0 * ns_local * nt
-        s_tile = tile["block"] * (8 if ns_local >= 65536 else 2)
-        b_alg = math.ceil(ns_local / s_tile) * nt * 16.0 + ns_local * 24.0
-        b_min = nt * 16.0 + ns_local * 24.0
-        achieved_tf = flops / (nn_ms * 1e-3) / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "%dx%d" % (ns_local, nt)
-                traffic = tj.get(key, {}).get("hbm_bytes_per_nn_launch")
-            except Exception:
-                traffic = None
-        roofline = {
-            "kernel": "nn_brute_kernel", "bound": "mfma",
-            "achieved": achieved_tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved_tf / PEAK_FP32_TFLOPS, "traffic": traffic,
-            "note": "fp32 compute roof: the brute-force pair loop is VALU-bound (arithmetic "
-                    "intensity ~1e5 flop/B); gfx950's dense f32 MFMA peak equals its f32 vector "
-                    "peak (157.3 TF), the kernel issues VALU ops, no MFMA",
-            "avg_launch_ms": nn_ms, "launches": tm["nn_launches"],
-            "alg_flops_per_launch": flops, "pairs_per_launch": float(ns_local) * nt,
-            "hbm_streamed": {"alg_bytes_per_launch": b_alg, "s_tile": s_tile,
-                             "achieved_gbps": b_alg / (nn_ms * 1e-3) / 1e9,
-                             "frac_of_8TBps": b_alg / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-                             "compulsory_bytes": b_min},
-            "reduce_kernel": {"avg_launch_ms": tm["reduce_ms"] / max(tm["reduce_launches"], 1),
-                              "alg_bytes_per_launch": ns_local * 36.0 + 304.0},
-            "launch": {"src_tiles": src_tiles, "tgt_splits": tgt_splits},
-        }
+        if mode == "grid":
+            roofline = grid_roofline(ns_local, nt, nn_ms, cand, load_traffic("grid", ns_local, nt))
+        else:
+            roofline = brute_roofline(ns_local, nt, nn_ms, tile, load_traffic("brute", ns_local, nt))
+        roofline["launches"] = tm["nn_launches"]
+        roofline["reduce_finalize_avg_ms"] = tm["reduce_ms"] / max(tm["reduce_launches"], 1)
         out = {
             "metric": "icp_iterations_per_sec", "value": args.steps / elapsed,
             "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, brute-force NN, "
-                                   "%d fixed ICP iterations" % (ns, nt, args.steps),
-                       "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch",
+            "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, "
+                                   "nn=%s" % (ns, nt, args.steps, mode),
+                       "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode,
                        "parallelism": "source-sharded x%d, 1 ncclAllReduce(38 f64)/iter" % world},
             "mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
             "matched_corr_per_sec": last.num_correspondences * args.steps / elapsed,
             "fitness": last.fitness_, "inlier_rmse": last.inlier_rmse_,
             "err_vs_T_gt": synth.rel_frobenius(T, T_gt),
+            "setup_ms": {"grid_build_kernels": setup["aux_ms"]},
             "roofline": roofline,
         }
+        if brute is not None:
+            b = brute_roofline(ns_local, nt, brute["nn_ms"], tile, load_traffic("brute", ns_local, nt))
+            b.update(steps=brute["steps"], ms_per_step=brute["ms_per_step"],
+                     iterations_per_sec=1e3 / brute["ms_per_step"],
+                     mpairs_per_sec=float(ns) * nt / brute["ms_per_step"] / 1e3,
+                     T_equals_grid_T=brute["T_equals_grid_T"],
+                     rel_frobenius_vs_grid=brute["rel_frobenius_vs_grid"])
+            out["brute_force"] = b
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(src, tgt, radius, args.cpu_iters)
             # parity of the two paths on this workload, same iteration count

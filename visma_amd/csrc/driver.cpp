@@ -257,7 +257,7 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, grid_lanes_,
+                                          &nblocks, grid_lanes(),
                                           profiling_ ? (unsigned long long *)d_cand_ : nullptr, stream_));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -302,7 +302,7 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, grid_lanes_, nullptr, stream_));
+                                          &nblocks, grid_lanes(), nullptr, stream_));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -503,7 +503,13 @@ private:
     GridParams grid_{};
     void *d_box_ = nullptr, *d_sorted_ = nullptr, *d_cell_of_ = nullptr, *d_count_ = nullptr;
     void *d_start_ = nullptr, *d_bsum_ = nullptr, *d_cand_ = nullptr;
-    int grid_lanes_ = 8;   // lanes cooperating on one query (VISMA_ICP_GRID_LANES overrides)
+    int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
+    int grid_lanes() const
+    {
+        if (grid_lanes_ > 0) return grid_lanes_;
+        // measured on MI355X: small clouds need the extra parallelism, large ones the locality
+        return ns_ <= 16384 ? 8 : (ns_ <= 131072 ? 4 : 2);
+    }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
 };
 

@@ -283,29 +283,36 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         const int cy = cell_coord(py, g.mn[1], g.inv_h, g.dim[1]);
         const int cz = cell_coord(pz, g.mn[2], g.inv_h, g.dim[2]);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
-        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
         float best = r2f;
         unsigned bi = 0xFFFFFFFFu;
         float4 qb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (x0 <= x1) {
-            for (int z = z0; z <= z1; z++)
-                for (int y = y0; y <= y1; y++) {
-                    const long long row = ((long long)z * g.dim[1] + y) * g.dim[0];
-                    const unsigned b = start[row + x0], e = start[row + x1 + 1];
-                    if (sub == 0) ncand += e - b;
-                    for (unsigned j = b + sub; j < e; j += G) {
-                        const float4 q = sorted[j];
-                        const float d = sqdist_f32(q, px, py, pz);
-                        const unsigned id = __float_as_uint(q.w);
-                        // (d2, index) lexicographic minimum; strict d2 < r2f
-                        if (d < best || (d == best && bi != 0xFFFFFFFFu && id < bi)) {
-                            best = d;
-                            bi = id;
-                            qb = q;
-                        }
-                    }
+        // The 3 x-adjacent cells of a (y,z) row are adjacent in memory: 9 runs.
+        // Fetch all 9 (begin, end) pairs first -- 18 independent loads in flight
+        // instead of 9 dependent round trips to the (sparse, L2-cold) cell table.
+        unsigned rb[9], re[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int z = cz - 1 + k / 3, y = cy - 1 + k % 3;
+            const bool ok = (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+            const long long row = ((long long)(ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
+            rb[k] = ok ? start[row + x0] : 0u;
+            re[k] = ok ? start[row + x1 + 1] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const unsigned b = rb[k], e = re[k];
+            if (sub == 0) ncand += e - b;
+            for (unsigned j = b + sub; j < e; j += G) {
+                const float4 q = sorted[j];
+                const float d = sqdist_f32(q, px, py, pz);
+                const unsigned id = __float_as_uint(q.w);
+                // (d2, index) lexicographic minimum; strict d2 < r2f
+                if (d < best || (d == best && bi != 0xFFFFFFFFu && id < bi)) {
+                    best = d;
+                    bi = id;
+                    qb = q;
                 }
+            }
         }
         if (G > 1) {
             // butterfly merge over the G lanes: smallest (d2, index) wins everywhere

@@ -229,26 +229,27 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
 // One workgroup; folds `nblocks` partial rows in a fixed order and expands the
 // compact point-to-point moments into the 6x6 / 6x1 normal equations.
 template <bool PLANE>
-__global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restrict__ partials,
-                                                          int nblocks,
-                                                          double *__restrict__ stats)
+__global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ partials,
+                                                        int nblocks,
+                                                        double *__restrict__ stats)
 {
     constexpr int NACC = Acc<PLANE>::N;
-    __shared__ double part[8][32];
+    constexpr int NG = 32;                 // row groups (1024 threads = 32 stats x 32 groups)
+    __shared__ double part[NG][33];
     __shared__ double tot[32];
     const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
     double v = 0.0;
     if (a < NACC) {
-        // rows g, g+8, g+16, ...: four independent load/add chains in flight
+        // rows g, g+32, g+64, ...: four independent load/add chains in flight
         double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
         int b = g;
-        for (; b + 24 < nblocks; b += 32) {
+        for (; b + 3 * NG < nblocks; b += 4 * NG) {
             v0 += partials[(long long)b * kReduceAcc + a];
-            v1 += partials[(long long)(b + 8) * kReduceAcc + a];
-            v2 += partials[(long long)(b + 16) * kReduceAcc + a];
-            v3 += partials[(long long)(b + 24) * kReduceAcc + a];
+            v1 += partials[(long long)(b + NG) * kReduceAcc + a];
+            v2 += partials[(long long)(b + 2 * NG) * kReduceAcc + a];
+            v3 += partials[(long long)(b + 3 * NG) * kReduceAcc + a];
         }
-        for (; b < nblocks; b += 8) v0 += partials[(long long)b * kReduceAcc + a];
+        for (; b < nblocks; b += NG) v0 += partials[(long long)b * kReduceAcc + a];
         v = (v0 + v1) + (v2 + v3);
     }
     part[g][a] = v;
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restri
     if (threadIdx.x < 32) {
         double t = 0.0;
 #pragma unroll
-        for (int gg = 0; gg < 8; gg++) t += part[gg][threadIdx.x];
+        for (int gg = 0; gg < NG; gg++) t += part[gg][threadIdx.x];
         tot[threadIdx.x] = t;
     }
     __syncthreads();
@@ -291,16 +292,16 @@ __global__ __launch_bounds__(kBlock) void finalize_kernel(const double *__restri
     }
 }
 
-int reduce_max_blocks() { return 2048; }
+int reduce_max_blocks() { return 1024; }
 
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
                            double *stats_out, hipStream_t stream)
 {
     if (point_to_plane)
-        hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(kBlock), 0, stream, partials,
+        hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(1024), 0, stream, partials,
                            nblocks, stats_out);
     else
-        hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(kBlock), 0, stream, partials,
+        hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(1024), 0, stream, partials,
                            nblocks, stats_out);
     return hipGetLastError();
 }
