@@ -274,8 +274,19 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
 
     const int sub = threadIdx.x % G;                       // lane within the query group
     const int groups_per_block = kBlock / G;
-    for (int i = blockIdx.x * groups_per_block + threadIdx.x / G; i < ns;
-         i += gridDim.x * groups_per_block) {
+    // XCD-aware chunking: workgroup b runs on XCD b % 8.  Give each XCD ONE
+    // contiguous eighth of the (Morton-ordered) queries, so its private L2 holds
+    // one spatial region of the target instead of a slice of everything.
+    int vb = blockIdx.x;
+    if ((gridDim.x & 7) == 0) vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // consecutive virtual blocks take consecutive query chunks; a block strides by
+    // one over its own contiguous share
+    const int total_groups = gridDim.x * groups_per_block;
+    const int per_group = (ns + total_groups - 1) / total_groups;
+    const int gid = vb * groups_per_block + threadIdx.x / G;
+    const int i_begin = gid * per_group;
+    const int i_end = min(i_begin + per_group, ns);
+    for (int i = i_begin; i < i_end; i++) {
         const float4 s4 = src[i];
         float px, py, pz;
         xform_point_f32(T32, s4, px, py, pz);
@@ -302,15 +313,26 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         for (int k = 0; k < 9; k++) {
             const unsigned b = rb[k], e = re[k];
             if (sub == 0) ncand += e - b;
-            for (unsigned j = b + sub; j < e; j += G) {
-                const float4 q = sorted[j];
-                const float d = sqdist_f32(q, px, py, pz);
-                const unsigned id = __float_as_uint(q.w);
-                // (d2, index) lexicographic minimum; strict d2 < r2f
-                if (d < best || (d == best && bi != 0xFFFFFFFFu && id < bi)) {
-                    best = d;
-                    bi = id;
-                    qb = q;
+            // four candidates per lane in flight (the loads do not depend on each other)
+            for (unsigned j = b + sub; j < e; j += 4 * G) {
+                float4 q[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned ju = j + u * G;
+                    q[u] = sorted[ju < e ? ju : j];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (j + u * G < e) {
+                        const float d = sqdist_f32(q[u], px, py, pz);
+                        const unsigned id = __float_as_uint(q[u].w);
+                        // (d2, index) lexicographic minimum; strict d2 < r2f
+                        if (d < best || (d == best && bi != 0xFFFFFFFFu && id < bi)) {
+                            best = d;
+                            bi = id;
+                            qb = q[u];
+                        }
+                    }
                 }
             }
         }
