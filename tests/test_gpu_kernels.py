@@ -164,3 +164,37 @@ def test_repeatable_bitwise(gpu_ctx):
 def test_create_fails_loudly_on_bad_device(lib):
     with pytest.raises(lib.IcpError):
         lib.Context(99)
+
+
+def test_device_loop_equals_host_loop(gpu_ctx, oracle):
+    """The on-device loop (solve + stop test in a kernel epilogue) and the
+    synchronous host loop are the same algorithm: same iteration count, same K,
+    transforms equal to rounding (device vs host libm)."""
+    src, tgt, _, _ = synth.make_pair(6000, 15000)
+    gpu_ctx.set_clouds_f64(src, tgt)
+    for kw in (dict(max_iter=25, rel_fitness=1e-6, rel_rmse=1e-6),
+               dict(max_iter=12, rel_fitness=0.0, rel_rmse=0.0),
+               dict(max_iter=0, rel_fitness=0.0, rel_rmse=0.0),
+               dict(max_iter=9, rel_fitness=0.0, rel_rmse=0.0, solver=1),
+               dict(max_iter=9, rel_fitness=0.0, rel_rmse=0.0, solver=2)):
+        try:
+            gpu_ctx.set_device_loop(True)
+            a = gpu_ctx.run(None, 0.075, **kw)
+            ia = gpu_ctx.correspondence_index()
+            gpu_ctx.set_device_loop(False)
+            b = gpu_ctx.run(None, 0.075, **kw)
+            ib = gpu_ctx.correspondence_index()
+        finally:
+            gpu_ctx.set_device_loop(True)
+        assert a.iterations == b.iterations and a.nn_passes == b.nn_passes
+        assert a.num_correspondences == b.num_correspondences
+        assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
+        assert abs(a.inlier_rmse_ - b.inlier_rmse_) < 1e-12 and a.fitness_ == b.fitness_
+        assert np.array_equal(ia, ib)
+    Ta, la = gpu_ctx.iterate(None, 0.075, 7)
+    gpu_ctx.set_device_loop(False)
+    try:
+        Tb, lb = gpu_ctx.iterate(None, 0.075, 7)
+    finally:
+        gpu_ctx.set_device_loop(True)
+    assert synth.rel_frobenius(Ta, Tb) < 1e-12 and la.num_correspondences == lb.num_correspondences

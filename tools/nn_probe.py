@@ -32,7 +32,14 @@ def main():
             nn = tm["nn_ms"] / tm["nn_launches"]
             rd = tm["reduce_ms"] / tm["reduce_launches"]
             pairs = ns * nt
+            ctx.set_device_loop(False)
+            t0 = time.time()
+            ctx.run(None, r, iters, 0, 0)
+            wall_host = time.time() - t0
+            ctx.set_device_loop(True)
+            ctx.get_timing(reset=True)
             rec = dict(mode=name, ns=ns, nt=nt, radius=r, nn_ms=nn, reduce_ms=rd,
+                       iter_ms_wall_hostloop=wall_host / (iters + 1) * 1e3,
                        build_ms=tb["aux_ms"], gpairs_per_s=pairs / nn / 1e6,
                        iter_ms_wall=wall / (iters + 1) * 1e3, K=res.num_correspondences,
                        T_hash=float(res.transformation_.sum()),

@@ -105,6 +105,7 @@ def load():
     L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_set_device_loop.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_timing.argtypes = [C.c_void_p, C.POINTER(CTiming), C.c_int]
     L.visma_icp_get_tile_config.argtypes = [C.POINTER(C.c_int)] * 3
     L.visma_icp_get_launch_config.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -293,6 +294,9 @@ class Context:
         m = C.c_int(0)
         self._chk(self.L.visma_icp_get_nn_mode_used(self._h, C.byref(m)))
         return m.value
+
+    def set_device_loop(self, on=True):
+        self._chk(self.L.visma_icp_set_device_loop(self._h, int(bool(on))))
 
     def set_profiling(self, on=True):
         self._chk(self.L.visma_icp_set_profiling(self._h, int(bool(on))))

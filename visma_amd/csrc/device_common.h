@@ -22,6 +22,25 @@ __device__ __forceinline__ void xform_point_f32(const Xform32 &T, const float4 s
     pz = __builtin_fmaf(T.m[8], s.x, __builtin_fmaf(T.m[9], s.y, __builtin_fmaf(T.m[10], s.z, T.m[11])));
 }
 
+// Transform / radius of this launch: from the device-resident loop state when
+// one is given (asynchronous on-device loop), else from the kernel arguments.
+// Returns false when the loop has already finished (the launch is a no-op).
+__device__ __forceinline__ bool load_loop_state(const DevIcpState *st, Xform32 &T32, Xform64 &T64,
+                                                Offset64 &off, float &r2f)
+{
+    if (!st) return true;
+    if (!st->active) return false;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        T64.m[i] = st->Tc[i];
+        T32.m[i] = (float)st->Tc[i];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) off.v[a] = st->world_frame ? st->centre[a] : 0.0;
+    r2f = st->r2f;
+    return true;
+}
+
 __device__ __forceinline__ float sqdist_f32(const float4 q, float px, float py, float pz)
 {
     const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
@@ -118,5 +137,71 @@ __device__ __forceinline__ void block_reduce_store(const double *acc, double *pa
         partials[(long long)blockIdx.x * kReduceAcc + threadIdx.x] = v;
     }
 }
+
+// One workgroup; folds `nblocks` partial rows in a fixed order and expands the
+// compact point-to-point moments into the 6x6 / 6x1 normal equations.
+template <bool PLANE>
+__device__ __forceinline__ void fold_partials(const double *__restrict__ partials, int nblocks,
+                                              double *__restrict__ stats)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    constexpr int NG = 32;                 // row groups (1024 threads = 32 stats x 32 groups)
+    __shared__ double part[NG][33];
+    __shared__ double tot[32];
+    const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double v = 0.0;
+    if (a < NACC) {
+        // rows g, g+32, g+64, ...: four independent load/add chains in flight
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int b = g;
+        for (; b + 3 * NG < nblocks; b += 4 * NG) {
+            v0 += partials[(long long)b * kReduceAcc + a];
+            v1 += partials[(long long)(b + NG) * kReduceAcc + a];
+            v2 += partials[(long long)(b + 2 * NG) * kReduceAcc + a];
+            v3 += partials[(long long)(b + 3 * NG) * kReduceAcc + a];
+        }
+        for (; b < nblocks; b += NG) v0 += partials[(long long)b * kReduceAcc + a];
+        v = (v0 + v1) + (v2 + v3);
+    }
+    part[g][a] = v;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) t += part[gg][threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (PLANE) {
+            for (int i = 0; i < 29; i++) stats[i] = tot[i];
+            for (int i = 29; i < kNStats; i++) stats[i] = 0.0;
+        } else {
+            const double K = tot[0];
+            const double Px = tot[2], Py = tot[3], Pz = tot[4];
+            const double Qx = tot[5], Qy = tot[6], Qz = tot[7];
+            const double Sxx = tot[8], Sxy = tot[9], Sxz = tot[10];
+            const double Syy = tot[11], Syz = tot[12], Szz = tot[13];
+            const double *M = &tot[14];
+            stats[0] = K;
+            stats[1] = tot[1];
+            double *J = stats + 2;  // upper triangle, row by row
+            // row 0: sum(|p|^2 I - p p^T) | hat(sum p)
+            J[0] = Syy + Szz; J[1] = -Sxy; J[2] = -Sxz; J[3] = 0.0; J[4] = -Pz; J[5] = Py;
+            J[6] = Sxx + Szz; J[7] = -Syz; J[8] = Pz; J[9] = 0.0; J[10] = -Px;
+            J[11] = Sxx + Syy; J[12] = -Py; J[13] = Px; J[14] = 0.0;
+            J[15] = K; J[16] = 0.0; J[17] = 0.0;
+            J[18] = K; J[19] = 0.0;
+            J[20] = K;
+            double *r = stats + 23;  // J^T r = [ -vee(sum q p^T) ; sum p - sum q ]
+            double v3[3];
+            vee(M, v3);
+            r[0] = -v3[0]; r[1] = -v3[1]; r[2] = -v3[2];
+            r[3] = Px - Qx; r[4] = Py - Qy; r[5] = Pz - Qz;
+            for (int i = 0; i < 9; i++) stats[29 + i] = M[i];
+        }
+    }
+}
+
 
 }  // namespace visma

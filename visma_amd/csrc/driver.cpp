@@ -91,6 +91,23 @@ public:
     virtual int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) = 0;
     virtual int get_correspondences(int32_t *idx, float *d2) = 0;
     virtual int comm_init(int, int, const void *) { err_ = "RCCL needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    // The whole loop on the device (no per-iteration host round trip).
+    struct LoopParams {
+        Mat4 Tc0;
+        double centre[3];
+        double max_dist, rel_fit, rel_rmse;
+        int max_iter, solver, passes;   // passes = NN passes to enqueue at most
+        bool scaling, plane, world, check_stop;
+        int64_t ns_total;
+    };
+    struct LoopResult {
+        Mat4 Tc;
+        double fit, rmse;
+        int64_t k;
+        int iters, passes;
+    };
+    virtual bool supports_device_loop() const { return false; }
+    virtual int run_loop(const LoopParams &, LoopResult *) { err_ = "no device loop"; return VISMA_ICP_ERR_STATE; }
     virtual int set_nn_mode(int mode) { return mode == VISMA_ICP_NN_AUTO ? VISMA_ICP_OK : VISMA_ICP_ERR_STATE; }
     virtual int nn_mode_used() const { return VISMA_ICP_NN_AUTO; }
     virtual void set_profiling(bool) {}
@@ -119,7 +136,8 @@ public:
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
-        free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_);
+        free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
+        if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -234,7 +252,7 @@ public:
         int e0 = -1;
         if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
         HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_, T32_,
-                                r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, stream_));
+                                r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, nullptr, stream_));
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
         grid_pending_ = false;
         brute_reduced_ = false;
@@ -258,7 +276,8 @@ public:
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                           &nblocks, grid_lanes(),
-                                          profiling_ ? (unsigned long long *)d_cand_ : nullptr, stream_));
+                                          profiling_ ? (unsigned long long *)d_cand_ : nullptr, nullptr,
+                                          stream_));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
             HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
@@ -271,7 +290,7 @@ public:
                                   (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                   plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
                                   (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                                  reduce_max_blocks(), (double *)d_stats_, stream_));
+                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             brute_reduced_ = true;
         }
@@ -302,7 +321,7 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, grid_lanes(), nullptr, stream_));
+                                          &nblocks, grid_lanes(), nullptr, nullptr, stream_));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -313,7 +332,7 @@ public:
                                   (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                   plan_.tgt_splits, ns_pad_, T32_, T64, nullptr, r2f_, 0,
                                   (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                                  reduce_max_blocks(), (double *)d_stats_, stream_));
+                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_));
             brute_reduced_ = true;
         }
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -321,6 +340,115 @@ public:
             HIP_TRY(hipMemcpy(idx, d_idx_, sizeof(int32_t) * ns_, hipMemcpyDeviceToHost));
             if (d2) HIP_TRY(hipMemcpy(d2, d_d2_, sizeof(float) * ns_, hipMemcpyDeviceToHost));
         }
+        return VISMA_ICP_OK;
+    }
+
+    bool supports_device_loop() const override { return true; }
+
+    int run_loop(const LoopParams &lp, LoopResult *out) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+        if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
+        int rc = choose_mode(lp.max_dist);
+        if (rc) return rc;
+        r2f_ = (float)(lp.max_dist * lp.max_dist);
+        for (int i = 0; i < 12; i++) T32_.m[i] = (float)lp.Tc0.m[i];
+        if (use_grid_) {
+            rc = ensure_aux(((ns_ + kBlock - 1) / kBlock) * kBlock);
+            if (rc) return rc;
+        } else {
+            plan_ = nn_plan(ns_, nt_pad_);
+            ns_pad_ = (int64_t)plan_.src_tiles * kBlock * plan_.spt;
+            const size_t need = sizeof(unsigned long long) * (size_t)ns_pad_ * plan_.tgt_splits;
+            if (need > keys_bytes_) {
+                free_dev(d_keys_);
+                HIP_TRY(hipMalloc(&d_keys_, need));
+                keys_bytes_ = need;
+            }
+            rc = ensure_aux(ns_pad_);
+            if (rc) return rc;
+        }
+        if (!d_state_) {
+            HIP_TRY(hipMalloc(&d_state_, sizeof(DevIcpState)));
+            HIP_TRY(hipHostMalloc((void **)&h_state_, sizeof(DevIcpState), hipHostMallocDefault));
+        }
+        DevIcpState &h = *h_state_;
+        std::memset(&h, 0, sizeof(h));
+        for (int i = 0; i < 12; i++) h.Tc[i] = lp.Tc0.m[i];
+        for (int a = 0; a < 3; a++) h.centre[a] = lp.centre[a];
+        h.rel_fit = lp.rel_fit; h.rel_rmse = lp.rel_rmse;
+        h.ns_total = lp.ns_total > 0 ? lp.ns_total : ns_;
+        h.active = 1;
+        h.max_iter = lp.max_iter; h.solver = lp.solver; h.scaling = lp.scaling ? 1 : 0;
+        h.plane = lp.plane ? 1 : 0; h.world_frame = lp.world ? 1 : 0;
+        h.check_stop = lp.check_stop ? 1 : 0;
+        h.r2f = r2f_;
+        HIP_TRY(hipMemcpyAsync(d_state_, &h, sizeof(h), hipMemcpyHostToDevice, stream_));
+        DevIcpState *st = (DevIcpState *)d_state_;
+        const Xform64 T64{};   // ignored: the kernels read the transform from the state
+        const int plane = lp.plane ? 1 : 0;
+        // with a stop test the host looks at the state every `chunk` passes; launches
+        // after convergence are no-ops (the kernels return on !active)
+        const int chunk = lp.check_stop ? 8 : lp.passes;
+        int done = 0;
+        while (done < lp.passes) {
+            const int n = std::min(chunk, lp.passes - done);
+            for (int j = 0; j < n; j++) {
+                int nblocks = 1, e0 = -1;
+                if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                if (use_grid_) {
+                    HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
+                                                  (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
+                                                  T32_, T64, nullptr, r2f_, plane, (int32_t *)d_idx_,
+                                                  (float *)d_d2_, (double *)d_partials_,
+                                                  reduce_max_blocks(), &nblocks, grid_lanes(),
+                                                  profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
+                                                  stream_));
+                } else {
+                    HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
+                                            T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
+                                            stream_));
+                }
+                if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+                if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                if (!use_grid_) {
+                    HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
+                                          (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
+                                          plan_.tgt_splits, ns_pad_, T32_, T64, nullptr, r2f_, plane,
+                                          (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
+                                          reduce_max_blocks(), nullptr, st, &nblocks, stream_));
+                }
+                if (comm_) {
+                    HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
+                    // ONE all-reduce of the 38 f64 accumulators per ICP iteration
+                    int nrc = g_rccl.AllReduce(st->stats, st->stats, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
+                    if (nrc != 0) {
+                        err_ = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error");
+                        return VISMA_ICP_ERR_RCCL;
+                    }
+                    HIP_TRY(launch_solve_state(st, stream_));
+                } else {
+                    HIP_TRY(launch_finalize_solve((const double *)d_partials_, nblocks, st, plane, stream_));
+                }
+                if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            }
+            done += n;
+            HIP_TRY(hipMemcpyAsync(&h, d_state_, sizeof(h), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            rc = collect_timing();
+            if (rc) return rc;
+            if (!h.active) break;
+        }
+        out->Tc = Mat4::identity();
+        for (int i = 0; i < 12; i++) out->Tc.m[i] = h.Tc[i];
+        out->fit = h.fit; out->rmse = h.rmse;
+        out->k = (int64_t)std::llround(h.K);
+        out->iters = h.iter; out->passes = h.passes;
+        for (int i = 0; i < 12; i++) T32_.m[i] = (float)h.Tc[i];
+        have_pass_ = true;
+        grid_pending_ = false;
+        brute_reduced_ = true;
         return VISMA_ICP_OK;
     }
 
@@ -503,6 +631,8 @@ private:
     GridParams grid_{};
     void *d_box_ = nullptr, *d_sorted_ = nullptr, *d_cell_of_ = nullptr, *d_count_ = nullptr;
     void *d_start_ = nullptr, *d_bsum_ = nullptr, *d_cand_ = nullptr;
+    void *d_state_ = nullptr;
+    DevIcpState *h_state_ = nullptr;
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes() const
     {
@@ -598,6 +728,8 @@ struct visma_icp_ctx {
         return VISMA_ICP_OK;
     }
 
+    bool device_loop_enabled = true;
+    bool use_device_loop() const { return device_loop_enabled && eng->supports_device_loop() && !host_allreduce; }
     static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }
 
     // T_centred <- update o T_centred, with the update expressed in `world` or centred frame
@@ -628,6 +760,28 @@ struct visma_icp_ctx {
         if (!have_src || !have_tgt) return fail(VISMA_ICP_ERR_STATE, "clouds not set");
         Mat4 Tc = to_centred(Mat4::from(init), centre);
         const bool world = wants_world_frame(solver, plane);
+        if (use_device_loop()) {
+            Engine::LoopParams lp;
+            lp.Tc0 = Tc;
+            std::memcpy(lp.centre, centre, sizeof(centre));
+            lp.max_dist = max_dist; lp.rel_fit = rel_fit; lp.rel_rmse = rel_rmse;
+            lp.max_iter = max_iter; lp.solver = solver; lp.passes = max_iter + 1;
+            lp.scaling = scaling; lp.plane = plane; lp.world = world; lp.check_stop = true;
+            lp.ns_total = ns_total > 0 ? ns_total : eng->ns();
+            Engine::LoopResult r;
+            int rc = eng->run_loop(lp, &r);
+            if (rc) return eng_fail(rc);
+            last_Tc = r.Tc;
+            last_plane = plane;
+            const Mat4 T = from_centred(r.Tc, centre);
+            std::memcpy(out->transformation, T.m, sizeof(T.m));
+            out->fitness = r.fit;
+            out->inlier_rmse = r.rmse;
+            out->num_correspondences = r.k;
+            out->iterations = r.iters;
+            out->nn_passes = r.passes;
+            return VISMA_ICP_OK;
+        }
         double stats[VISMA_ICP_NSTATS], fit, rmse;
         int64_t k;
         int rc = pass(Tc, max_dist, plane, world, stats, &fit, &rmse, &k);  // Registration.cpp:166-168
@@ -955,6 +1109,31 @@ int visma_icp_iterate(visma_icp_ctx *ctx, double T_inout[16], double max_dist, i
     double stats[VISMA_ICP_NSTATS], fit = 0, rmse = 0;
     int64_t k = 0;
     const bool world = visma_icp_ctx::wants_world_frame(solver, false);
+    if (ctx->use_device_loop() && steps > 0) {
+        Engine::LoopParams lp;
+        lp.Tc0 = Tc;
+        std::memcpy(lp.centre, ctx->centre, sizeof(ctx->centre));
+        lp.max_dist = max_dist; lp.rel_fit = 0.0; lp.rel_rmse = 0.0;
+        lp.max_iter = steps; lp.solver = solver; lp.passes = steps;
+        lp.scaling = with_scaling != 0; lp.plane = false; lp.world = world; lp.check_stop = false;
+        lp.ns_total = ctx->ns_total > 0 ? ctx->ns_total : ctx->eng->ns();
+        Engine::LoopResult r;
+        int rc = ctx->eng->run_loop(lp, &r);
+        if (rc) return ctx->eng_fail(rc);
+        ctx->last_Tc = r.Tc;
+        const Mat4 T = from_centred(r.Tc, ctx->centre);
+        std::memcpy(T_inout, T.m, sizeof(T.m));
+        if (out) {
+            std::memset(out, 0, sizeof(*out));
+            std::memcpy(out->transformation, T.m, sizeof(T.m));
+            out->fitness = r.fit;
+            out->inlier_rmse = r.rmse;
+            out->num_correspondences = r.k;
+            out->iterations = r.iters;
+            out->nn_passes = r.passes;
+        }
+        return VISMA_ICP_OK;
+    }
     for (int i = 0; i < steps; i++) {
         int rc = ctx->pass(Tc, max_dist, false, world, stats, &fit, &rmse, &k);
         if (rc) return rc;
@@ -1038,6 +1217,13 @@ int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode)
     CTX_CHECK();
     if (!nn_mode) return ctx->fail(VISMA_ICP_ERR_INVALID, "nn_mode is NULL");
     *nn_mode = ctx->eng->nn_mode_used();
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled)
+{
+    CTX_CHECK();
+    ctx->device_loop_enabled = enabled != 0;
     return VISMA_ICP_OK;
 }
 

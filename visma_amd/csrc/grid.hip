@@ -264,9 +264,11 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
     Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out, float *__restrict__ d2_out,
-    double *__restrict__ partials, unsigned long long *__restrict__ cand_count)
+    double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
+    const DevIcpState *__restrict__ st)
 {
     constexpr int NACC = Acc<PLANE>::N;
+    if (!load_loop_state(st, T32, T64, off, r2f)) return;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -372,10 +374,11 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const float4 *sorted, const unsigned *start, const GridParams &g,
                           const float4 *nrm, const Xform32 &T32, const Xform64 &T64,
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
-                          double *partials, unsigned long long *cand)
+                          double *partials, unsigned long long *cand, const DevIcpState *st)
 {
     hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G>), dim3(nblocks), dim3(kBlock), 0, stream, src,
-                       ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out, partials, cand);
+                       ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out, partials, cand,
+                       st);
 }
 
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -384,7 +387,8 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  const double frame_offset[3], float r2f, int point_to_plane,
                                  int32_t *idx_out, float *d2_out, double *partials,
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
-                                 unsigned long long *cand_count, hipStream_t stream)
+                                 unsigned long long *cand_count, const DevIcpState *st,
+                                 hipStream_t stream)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
@@ -396,10 +400,12 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     case GG:                                                                                       \
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals,  \
-                                    T32, T64, off, r2f, idx_out, d2_out, partials, cand_count);    \
+                                    T32, T64, off, r2f, idx_out, d2_out, partials, cand_count, \
+                                    st);                                                   \
         else                                                                                       \
             launch_grid_t<false, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals, \
-                                     T32, T64, off, r2f, idx_out, d2_out, partials, cand_count);   \
+                                     T32, T64, off, r2f, idx_out, d2_out, partials, cand_count, \
+                                     st);                                                  \
         break;
     switch (G) {
         VISMA_GRID_CASE(1)

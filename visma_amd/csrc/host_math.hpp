@@ -1,4 +1,6 @@
-// host_math.hpp -- the tiny f64 solves of the ICP loop (host side).
+// host_math.hpp -- the tiny f64 solves of the ICP loop.  Every function is
+// host+device: the synchronous API solves on the host, the asynchronous
+// on-device loop (icp_loop.hip) runs the very same code in a one-thread kernel.
 //
 // The reference does these with Eigen (umeyama / JacobiSVD / LDLT).  Eigen is
 // not a dependency of this library (there is none on the target image), so the
@@ -11,9 +13,8 @@
 // All matrices row-major.
 #pragma once
 
-#include <algorithm>
-#include <cmath>
-#include <cstring>
+#include <math.h>
+#include <string.h>
 
 #include "so3.h"
 
@@ -21,24 +22,24 @@ namespace visma {
 
 struct Mat4 {
     double m[16];
-    static Mat4 identity()
+    VISMA_HD static Mat4 identity()
     {
         Mat4 r;
-        std::memset(r.m, 0, sizeof(r.m));
+        for (int i = 0; i < 16; i++) r.m[i] = 0.0;
         r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.0;
         return r;
     }
-    static Mat4 from(const double *p)
+    VISMA_HD static Mat4 from(const double *p)
     {
         Mat4 r;
-        std::memcpy(r.m, p, sizeof(r.m));
+        for (int i = 0; i < 16; i++) r.m[i] = p[i];
         return r;
     }
-    double &operator()(int i, int j) { return m[i * 4 + j]; }
-    double operator()(int i, int j) const { return m[i * 4 + j]; }
+    VISMA_HD double &operator()(int i, int j) { return m[i * 4 + j]; }
+    VISMA_HD double operator()(int i, int j) const { return m[i * 4 + j]; }
 };
 
-inline Mat4 operator*(const Mat4 &a, const Mat4 &b)
+VISMA_HD Mat4 operator*(const Mat4 &a, const Mat4 &b)
 {
     Mat4 r;
     for (int i = 0; i < 4; i++)
@@ -51,7 +52,7 @@ inline Mat4 operator*(const Mat4 &a, const Mat4 &b)
 }
 
 // x' = x - c  ==>  [R | t]  <->  [R | R c + t - c]
-inline Mat4 to_centred(const Mat4 &T, const double c[3])
+VISMA_HD Mat4 to_centred(const Mat4 &T, const double c[3])
 {
     Mat4 r = T;
     for (int i = 0; i < 3; i++)
@@ -59,7 +60,7 @@ inline Mat4 to_centred(const Mat4 &T, const double c[3])
     return r;
 }
 
-inline Mat4 from_centred(const Mat4 &Tc, const double c[3])
+VISMA_HD Mat4 from_centred(const Mat4 &Tc, const double c[3])
 {
     Mat4 r = Tc;
     for (int i = 0; i < 3; i++)
@@ -67,7 +68,7 @@ inline Mat4 from_centred(const Mat4 &Tc, const double c[3])
     return r;
 }
 
-inline double det3(const double A[9])
+VISMA_HD double det3(const double A[9])
 {
     return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) +
            A[2] * (A[3] * A[7] - A[4] * A[6]);
@@ -76,31 +77,38 @@ inline double det3(const double A[9])
 // Singular value decomposition of a 3x3 by one-sided Jacobi rotations on the
 // columns (A V = U S); singular values sorted descending, U completed to a
 // full orthonormal basis when A is rank deficient.
+VISMA_HD void cross3(const double *a, const double *b, double *c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
 struct Svd3 {
     double U[9], s[3], V[9];
 };
 
-inline Svd3 svd3(const double A[9])
+VISMA_HD Svd3 svd3(const double A[9])
 {
     double G[3][3], W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) G[i][j] = A[i * 3 + j];
-    static const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
     for (int sweep = 0; sweep < 64; sweep++) {
         bool any = false;
-        for (const auto &pq : pairs) {
-            const int p = pq[0], q = pq[1];
+        for (int pi = 0; pi < 3; pi++) {
+            const int p = pairs[pi][0], q = pairs[pi][1];
             double a = 0, b = 0, g = 0;
             for (int r = 0; r < 3; r++) {
                 a += G[r][p] * G[r][p];
                 b += G[r][q] * G[r][q];
                 g += G[r][p] * G[r][q];
             }
-            if (g == 0.0 || std::fabs(g) <= 1e-17 * std::sqrt(a * b)) continue;
+            if (g == 0.0 || fabs(g) <= 1e-17 * sqrt(a * b)) continue;
             any = true;
             const double zeta = (b - a) / (2.0 * g);
-            const double t = std::copysign(1.0, zeta) / (std::fabs(zeta) + std::hypot(1.0, zeta));
-            const double c = 1.0 / std::hypot(1.0, t), s = c * t;
+            const double t = copysign(1.0, zeta) / (fabs(zeta) + hypot(1.0, zeta));
+            const double c = 1.0 / hypot(1.0, t), s = c * t;
             for (int r = 0; r < 3; r++) {
                 const double gp = G[r][p], gq = G[r][q];
                 G[r][p] = c * gp - s * gq;
@@ -114,8 +122,10 @@ inline Svd3 svd3(const double A[9])
     }
     double n[3];
     int o[3] = {0, 1, 2};
-    for (int j = 0; j < 3; j++) n[j] = std::sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
-    std::sort(o, o + 3, [&](int x, int y) { return n[x] > n[y]; });
+    for (int j = 0; j < 3; j++) n[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
+    for (int a = 0; a < 2; a++)   // sort the three indices by descending norm
+        for (int b = a + 1; b < 3; b++)
+            if (n[o[b]] > n[o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
     Svd3 out;
     double u[3][3];
     int rank = 0;
@@ -127,11 +137,6 @@ inline Svd3 svd3(const double A[9])
             rank = j + 1;
         }
     }
-    auto cross = [](const double *a, const double *b, double *c) {
-        c[0] = a[1] * b[2] - a[2] * b[1];
-        c[1] = a[2] * b[0] - a[0] * b[2];
-        c[2] = a[0] * b[1] - a[1] * b[0];
-    };
     if (rank == 0) {
         // zero matrix: no rotation is needed; U = V = I, which is also what the
         // reference's JacobiSVD returns (so the update is a pure translation)
@@ -140,15 +145,15 @@ inline Svd3 svd3(const double A[9])
     }
     if (rank == 1) {
         int m = 0;
-        for (int r = 1; r < 3; r++) if (std::fabs(u[0][r]) < std::fabs(u[0][m])) m = r;
+        for (int r = 1; r < 3; r++) if (fabs(u[0][r]) < fabs(u[0][m])) m = r;
         double e[3] = {0, 0, 0};
         e[m] = 1.0;
-        cross(u[0], e, u[1]);
-        const double l = std::sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+        cross3(u[0], e, u[1]);
+        const double l = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
         for (int r = 0; r < 3; r++) u[1][r] /= l;
         rank = 2;
     }
-    if (rank == 2) cross(u[0], u[1], u[2]);
+    if (rank == 2) cross3(u[0], u[1], u[2]);
     for (int j = 0; j < 3; j++)
         for (int r = 0; r < 3; r++) out.U[r * 3 + j] = u[j][r];
     return out;
@@ -161,7 +166,7 @@ struct NormalEq {
     double M[9];  // sum q p^T
 };
 
-inline NormalEq unpack_stats(const double *st)
+VISMA_HD NormalEq unpack_stats(const double *st)
 {
     NormalEq e;
     e.K = st[0];
@@ -180,7 +185,7 @@ inline NormalEq unpack_stats(const double *st)
 
 // Closed-form least-squares rigid (optionally similarity) update for the
 // fixed correspondence set, from the moments.
-inline Mat4 kabsch_from_stats(const double *st, bool with_scaling)
+VISMA_HD Mat4 kabsch_from_stats(const double *st, bool with_scaling)
 {
     const NormalEq e = unpack_stats(st);
     if (!(e.K > 0.0)) return Mat4::identity();
@@ -216,7 +221,7 @@ inline Mat4 kabsch_from_stats(const double *st, bool with_scaling)
 }
 
 // Solve A x = b (6x6, partial pivoting); returns det(A).
-inline double solve6(const double A[36], const double b[6], double x[6])
+VISMA_HD double solve6(const double A[36], const double b[6], double x[6])
 {
     double M[6][7];
     for (int i = 0; i < 6; i++) {
@@ -227,13 +232,13 @@ inline double solve6(const double A[36], const double b[6], double x[6])
     for (int c = 0; c < 6; c++) {
         int piv = c;
         for (int r = c + 1; r < 6; r++)
-            if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+            if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
         if (M[piv][c] == 0.0) {
             for (int i = 0; i < 6; i++) x[i] = 0.0;
             return 0.0;
         }
         if (piv != c) {
-            for (int j = 0; j < 7; j++) std::swap(M[c][j], M[piv][j]);
+            for (int j = 0; j < 7; j++) { const double t = M[c][j]; M[c][j] = M[piv][j]; M[piv][j] = t; }
             det = -det;
         }
         det *= M[c][c];
@@ -250,11 +255,11 @@ inline double solve6(const double A[36], const double b[6], double x[6])
     return det;
 }
 
-inline Mat4 euler_zyx_to_mat4(const double x[6])
+VISMA_HD Mat4 euler_zyx_to_mat4(const double x[6])
 {
-    const double ca = std::cos(x[0]), sa = std::sin(x[0]);
-    const double cb = std::cos(x[1]), sb = std::sin(x[1]);
-    const double cg = std::cos(x[2]), sg = std::sin(x[2]);
+    const double ca = cos(x[0]), sa = sin(x[0]);
+    const double cb = cos(x[1]), sb = sin(x[1]);
+    const double cg = cos(x[2]), sg = sin(x[2]);
     Mat4 T = Mat4::identity();
     // Rz(g) * Ry(b) * Rx(a), written out
     T(0, 0) = cg * cb; T(0, 1) = cg * sb * sa - sg * ca; T(0, 2) = cg * sb * ca + sg * sa;
@@ -266,7 +271,7 @@ inline Mat4 euler_zyx_to_mat4(const double x[6])
 
 // One Gauss-Newton step on J^T J x = -J^T r.  ok=false (Identity) when the
 // determinant guard rejects the system.
-inline Mat4 gn_from_stats(const double *st, bool expmap, bool *ok)
+VISMA_HD Mat4 gn_from_stats(const double *st, bool expmap, bool *ok)
 {
     const NormalEq e = unpack_stats(st);
     *ok = false;
@@ -274,7 +279,7 @@ inline Mat4 gn_from_stats(const double *st, bool expmap, bool *ok)
     double nb[6], x[6];
     for (int i = 0; i < 6; i++) nb[i] = -e.JTr[i];
     const double det = solve6(e.JTJ, nb, x);
-    if (std::fabs(det) < 1e-6 || std::isnan(det) || std::isinf(det)) return Mat4::identity();
+    if (fabs(det) < 1e-6 || isnan(det) || isinf(det)) return Mat4::identity();
     *ok = true;
     if (!expmap) return euler_zyx_to_mat4(x);
     double R[9];

@@ -1,0 +1,111 @@
+// icp_loop.hip -- the ICP loop advanced on the device.
+//
+// The synchronous API pays one stream synchronisation + one 304-byte D2H copy +
+// one host solve per iteration (~25 us on MI355X, as much as the kernels of a
+// 5k x 20k problem).  Here the per-iteration solve, the compose T <- update * T
+// and the stop test of O3D/Core/Registration/Registration.cpp:169-184 run in a
+// one-thread epilogue of the fold kernel, on the state kept in HBM
+// (DevIcpState); the NN / reduction kernels read the transform from that state.
+// The host only enqueues launches and reads the state back once per chunk.
+//
+// The solve is the SAME code as the host's (host_math.hpp is host+device):
+// closed-form Kabsch/Umeyama from the reduced moments, or the 6x6 Gauss-Newton
+// step with Euler / exponential-map retraction.
+#include "device_common.h"
+#include "host_math.hpp"
+
+namespace visma {
+
+__device__ void advance_state(DevIcpState *st)
+{
+    const double *stats = st->stats;
+    const double K = stats[0];
+    // fitness / rmse of the pass just finished (Registration.cpp:87-94)
+    double fit = 0.0, rmse = 0.0;
+    if (K > 0.0) {
+        fit = K / (double)st->ns_total;
+        rmse = sqrt(stats[1] / K);
+    }
+    st->K = K;
+    st->fit = fit;
+    st->rmse = rmse;
+    st->passes += 1;
+    bool stop = false;
+    if (st->check_stop && st->passes >= 2 && fabs(st->fit_prev - fit) < st->rel_fit &&
+        fabs(st->rmse_prev - rmse) < st->rel_rmse)
+        stop = true;                                   // Registration.cpp:179-183
+    if (st->iter >= st->max_iter) stop = true;         // loop bound, :169
+    if (stop) {
+        st->active = 0;
+        return;
+    }
+    // update = estimation.ComputeTransformation(...)  (:172-173), from the moments
+    Mat4 upd;
+    bool ok = true;
+    if (st->plane || st->solver == 1)
+        upd = gn_from_stats(stats, false, &ok);
+    else if (st->solver == 2)
+        upd = gn_from_stats(stats, true, &ok);
+    else
+        upd = kabsch_from_stats(stats, st->scaling != 0);
+    // transformation = update * transformation  (:174), in f64
+    Mat4 Tc = Mat4::identity();
+    for (int i = 0; i < 12; i++) Tc.m[i] = st->Tc[i];
+    Mat4 Tn;
+    if (st->world_frame)
+        Tn = to_centred(upd * from_centred(Tc, st->centre), st->centre);
+    else
+        Tn = upd * Tc;
+    for (int i = 0; i < 12; i++) st->Tc[i] = Tn.m[i];
+    st->iter += 1;
+    st->fit_prev = fit;
+    st->rmse_prev = rmse;
+}
+
+template <bool PLANE>
+__global__ __launch_bounds__(1024) void finalize_solve_kernel(const double *__restrict__ partials,
+                                                              int nblocks, DevIcpState *st,
+                                                              int do_solve)
+{
+    if (!st->active) return;
+    fold_partials<PLANE>(partials, nblocks, st->stats);
+    if (do_solve && threadIdx.x == 0) advance_state(st);   // same thread wrote the stats
+}
+
+__global__ void solve_state_kernel(DevIcpState *st)
+{
+    if (threadIdx.x == 0 && st->active) advance_state(st);
+}
+
+// `plane` is a host copy of st->plane (chooses the accumulator layout)
+static hipError_t launch_fs(const double *partials, int nblocks, DevIcpState *st, int plane,
+                            int do_solve, hipStream_t stream)
+{
+    if (plane)
+        hipLaunchKernelGGL(finalize_solve_kernel<true>, dim3(1), dim3(1024), 0, stream, partials,
+                           nblocks, st, do_solve);
+    else
+        hipLaunchKernelGGL(finalize_solve_kernel<false>, dim3(1), dim3(1024), 0, stream, partials,
+                           nblocks, st, do_solve);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize_solve(const double *partials, int nblocks, DevIcpState *st, int plane,
+                                 hipStream_t stream)
+{
+    return launch_fs(partials, nblocks, st, plane, 1, stream);
+}
+
+hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpState *st, int plane,
+                                 hipStream_t stream)
+{
+    return launch_fs(partials, nblocks, st, plane, 0, stream);
+}
+
+hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream)
+{
+    hipLaunchKernelGGL(solve_state_kernel, dim3(1), dim3(64), 0, stream, st);
+    return hipGetLastError();
+}
+
+}  // namespace visma

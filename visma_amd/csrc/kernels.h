@@ -20,6 +20,24 @@ struct Xform32 { float m[12]; };    // row-major 3x4, fp32 (NN search)
 struct Xform64 { double m[12]; };   // row-major 3x4, f64  (statistics)
 struct Offset64 { double v[3]; };   // frame shift applied to p and q in the statistics
 
+// State of one ICP problem advanced entirely on the device (icp_loop.hip): the
+// NN / reduction kernels read the current transform from it, the one-thread
+// solve kernel updates it, the host only reads it back at the end.
+struct DevIcpState {
+    double Tc[12];       // current transform, centred frame (row-major 3x4)
+    double centre[3];    // cloud centre (frame offset of GN / point-to-plane statistics)
+    double stats[kNStats];
+    double fit, rmse, fit_prev, rmse_prev, K;
+    double rel_fit, rel_rmse;
+    long long ns_total;  // fitness denominator (all ranks)
+    int iter;            // solves performed
+    int passes;          // NN passes performed
+    int active;          // 1 while the loop is still running
+    int max_iter, solver, scaling, plane, world_frame, check_stop;
+    float r2f;
+    int pad_;
+};
+
 struct NNLaunch {
     int src_tiles;
     int tgt_splits;
@@ -35,7 +53,7 @@ NNLaunch nn_plan(int64_t ns, int64_t nt_pad);
 hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
                            int64_t nt_pad, const Xform32 &T, float r2f,
                            unsigned long long *keys, int64_t ns_pad,
-                           const NNLaunch &plan, hipStream_t stream);
+                           const NNLaunch &plan, const DevIcpState *st, hipStream_t stream);
 
 // Merge the per-split keys, recover the exact target index inside the winning
 // sub-chunk, then accumulate the per-correspondence Jacobian/residual
@@ -48,14 +66,23 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const Xform64 &T64, const double frame_offset[3], float r2f,
                          int point_to_plane,
                          int32_t *idx_out, float *d2_out, double *partials,
-                         int max_partial_blocks, double *stats_out,
-                         hipStream_t stream);
+                         int max_partial_blocks, double *stats_out, const DevIcpState *st,
+                         int *nblocks_out, hipStream_t stream);
 
 int reduce_max_blocks();
 
 // Fold `nblocks` partial rows into the 38 statistics (one workgroup, fixed order).
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
                            double *stats_out, hipStream_t stream);
+// On-device loop (icp_loop.hip): fold + solve + stop test, no host round trip.
+//  launch_finalize_solve : single GPU (fold partials, then advance the state)
+//  launch_finalize_state : fold partials into st->stats only (an all-reduce follows)
+//  launch_solve_state    : advance the state from st->stats
+hipError_t launch_finalize_solve(const double *partials, int nblocks, DevIcpState *st, int plane,
+                                 hipStream_t stream);
+hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpState *st, int plane,
+                                 hipStream_t stream);
+hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream);
 
 // ---- radius-cell uniform grid (grid.hip) -------------------------------------
 struct GridParams {
@@ -82,7 +109,8 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  const double frame_offset[3], float r2f, int point_to_plane,
                                  int32_t *idx_out, float *d2_out, double *partials,
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
-                                 unsigned long long *cand_count, hipStream_t stream);
+                                 unsigned long long *cand_count, const DevIcpState *st,
+                                 hipStream_t stream);
 
 // fill n float4 with +inf (target padding)
 hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);

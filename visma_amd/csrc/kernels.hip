@@ -35,10 +35,16 @@ template <int SPT>
 __global__ __launch_bounds__(kBlock) void nn_brute_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
     int chunks_total, int chunks_per_split, int src_tiles, int nsplits, Xform32 T,
-    float r2f, unsigned long long *__restrict__ keys, long long ns_pad)
+    float r2f, unsigned long long *__restrict__ keys, long long ns_pad,
+    const DevIcpState *__restrict__ st)
 {
     __shared__ float4 lds[2][kTChunk];
     const int tid = threadIdx.x;
+    {
+        Xform64 t64;
+        Offset64 o;
+        if (!load_loop_state(st, T, t64, o, r2f)) return;
+    }
 
     // XCD-aware (tile, split) decode: workgroup b runs on XCD b % 8, so give
     // each XCD its own residue class of target splits -- its L2 then streams
@@ -155,7 +161,7 @@ NNLaunch nn_plan(int64_t ns, int64_t nt_pad)
 hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
                            int64_t nt_pad, const Xform32 &T, float r2f,
                            unsigned long long *keys, int64_t ns_pad,
-                           const NNLaunch &plan, hipStream_t stream)
+                           const NNLaunch &plan, const DevIcpState *st, hipStream_t stream)
 {
     const int chunks = (int)(nt_pad / kTChunk);
     const int per = (chunks + plan.tgt_splits - 1) / plan.tgt_splits;
@@ -163,11 +169,11 @@ hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
     if (plan.spt == kSptLarge)
         hipLaunchKernelGGL(nn_brute_kernel<kSptLarge>, grid, dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f,
-                           keys, (long long)ns_pad);
+                           keys, (long long)ns_pad, st);
     else
         hipLaunchKernelGGL(nn_brute_kernel<kSptSmall>, grid, dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f,
-                           keys, (long long)ns_pad);
+                           keys, (long long)ns_pad, st);
     return hipGetLastError();
 }
 
@@ -179,9 +185,11 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
     const float4 *__restrict__ nrm, const unsigned long long *__restrict__ keys,
     int nsplits, long long ns_pad, Xform32 T32, Xform64 T64, Offset64 off, float r2f,
-    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
+    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials,
+    const DevIcpState *__restrict__ st)
 {
     constexpr int NACC = Acc<PLANE>::N;
+    if (!load_loop_state(st, T32, T64, off, r2f)) return;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -226,70 +234,12 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
     block_reduce_store<NACC>(acc, partials);
 }
 
-// One workgroup; folds `nblocks` partial rows in a fixed order and expands the
-// compact point-to-point moments into the 6x6 / 6x1 normal equations.
 template <bool PLANE>
 __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ partials,
                                                         int nblocks,
                                                         double *__restrict__ stats)
 {
-    constexpr int NACC = Acc<PLANE>::N;
-    constexpr int NG = 32;                 // row groups (1024 threads = 32 stats x 32 groups)
-    __shared__ double part[NG][33];
-    __shared__ double tot[32];
-    const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double v = 0.0;
-    if (a < NACC) {
-        // rows g, g+32, g+64, ...: four independent load/add chains in flight
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        int b = g;
-        for (; b + 3 * NG < nblocks; b += 4 * NG) {
-            v0 += partials[(long long)b * kReduceAcc + a];
-            v1 += partials[(long long)(b + NG) * kReduceAcc + a];
-            v2 += partials[(long long)(b + 2 * NG) * kReduceAcc + a];
-            v3 += partials[(long long)(b + 3 * NG) * kReduceAcc + a];
-        }
-        for (; b < nblocks; b += NG) v0 += partials[(long long)b * kReduceAcc + a];
-        v = (v0 + v1) + (v2 + v3);
-    }
-    part[g][a] = v;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        double t = 0.0;
-#pragma unroll
-        for (int gg = 0; gg < NG; gg++) t += part[gg][threadIdx.x];
-        tot[threadIdx.x] = t;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (PLANE) {
-            for (int i = 0; i < 29; i++) stats[i] = tot[i];
-            for (int i = 29; i < kNStats; i++) stats[i] = 0.0;
-        } else {
-            const double K = tot[0];
-            const double Px = tot[2], Py = tot[3], Pz = tot[4];
-            const double Qx = tot[5], Qy = tot[6], Qz = tot[7];
-            const double Sxx = tot[8], Sxy = tot[9], Sxz = tot[10];
-            const double Syy = tot[11], Syz = tot[12], Szz = tot[13];
-            const double *M = &tot[14];
-            stats[0] = K;
-            stats[1] = tot[1];
-            double *J = stats + 2;  // upper triangle, row by row
-            // row 0: sum(|p|^2 I - p p^T) | hat(sum p)
-            J[0] = Syy + Szz; J[1] = -Sxy; J[2] = -Sxz; J[3] = 0.0; J[4] = -Pz; J[5] = Py;
-            J[6] = Sxx + Szz; J[7] = -Syz; J[8] = Pz; J[9] = 0.0; J[10] = -Px;
-            J[11] = Sxx + Syy; J[12] = -Py; J[13] = Px; J[14] = 0.0;
-            J[15] = K; J[16] = 0.0; J[17] = 0.0;
-            J[18] = K; J[19] = 0.0;
-            J[20] = K;
-            double *r = stats + 23;  // J^T r = [ -vee(sum q p^T) ; sum p - sum q ]
-            double v3[3];
-            vee(M, v3);
-            r[0] = -v3[0]; r[1] = -v3[1]; r[2] = -v3[2];
-            r[3] = Px - Qx; r[4] = Py - Qy; r[5] = Pz - Qz;
-            for (int i = 0; i < 9; i++) stats[29 + i] = M[i];
-        }
-    }
+    fold_partials<PLANE>(partials, nblocks, stats);
 }
 
 int reduce_max_blocks() { return 1024; }
@@ -311,7 +261,8 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          int nsplits, int64_t ns_pad, const Xform32 &T32,
                          const Xform64 &T64, const double frame_offset[3], float r2f,
                          int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
-                         int max_partial_blocks, double *stats_out, hipStream_t stream)
+                         int max_partial_blocks, double *stats_out, const DevIcpState *st,
+                         int *nblocks_out, hipStream_t stream)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
@@ -321,13 +272,15 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
     if (point_to_plane)
         hipLaunchKernelGGL(reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
-                           T64, off, r2f, idx_out, d2_out, partials);
+                           T64, off, r2f, idx_out, d2_out, partials, st);
     else
         hipLaunchKernelGGL(reduce_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
-                           T64, off, r2f, idx_out, d2_out, partials);
+                           T64, off, r2f, idx_out, d2_out, partials, st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (nblocks_out) *nblocks_out = nblocks;
+    if (!stats_out) return hipSuccess;   // the caller folds the partial rows itself
     return launch_finalize(partials, nblocks, point_to_plane, stats_out, stream);
 }
 
