@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -130,6 +131,7 @@ public:
     explicit HipEngine(int device) : device_(device) {}
     ~HipEngine() override
     {
+        if (!inited_) { (void)hipGetLastError(); return; }   // never touched the device
         (void)hipSetDevice(device_);
         if (comm_) g_rccl.CommDestroy(comm_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
@@ -169,7 +171,11 @@ public:
             const int v = std::atoi(e);
             if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) grid_lanes_ = v;
         }
-        HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * kNStats, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * (kNStats + 2),
+                              hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h_stats_, 0, sizeof(double) * (kNStats + 2));
+        HIP_TRY(hipHostGetDevicePointer((void **)&h_stats_dev_, h_stats_, 0));
+        inited_ = true;
         return VISMA_ICP_OK;
     }
 
@@ -302,9 +308,26 @@ public:
                 return VISMA_ICP_ERR_RCCL;
             }
         }
-        HIP_TRY(hipMemcpyAsync(h_stats_, d_stats_, sizeof(double) * kNStats, hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
+        // publish to mapped host memory and spin on the sequence word (no DMA
+        // packet, no interrupt wake-up: ~10 us less per iteration than memcpy+sync)
+        const unsigned long long seq = ++pub_seq_;
+        HIP_TRY(launch_publish_stats((const double *)d_stats_, h_stats_dev_, seq, stream_));
+        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(h_stats_ + kNStats);
+        bool seen = false;
+        for (long long spin = 0; spin < 400000000ll; ++spin) {
+            if (*flag == seq) { seen = true; break; }
+            if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(stream_) != hipErrorNotReady) {
+                seen = (*flag == seq);
+                break;
+            }
+        }
+        if (!seen) {
+            HIP_TRY(hipStreamSynchronize(stream_));   // surfaces a kernel fault, if any
+            if (*flag != seq) { err_ = "statistics were not published"; return VISMA_ICP_ERR_HIP; }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(stats, h_stats_, sizeof(double) * kNStats);
+        if (profiling_) HIP_TRY(hipStreamSynchronize(stream_));   // events must have retired
         return collect_timing();
     }
 
@@ -612,7 +635,9 @@ private:
     hipStream_t stream_ = nullptr;
     void *d_src_ = nullptr, *d_tgt_ = nullptr, *d_nrm_ = nullptr, *d_keys_ = nullptr;
     void *d_idx_ = nullptr, *d_d2_ = nullptr, *d_partials_ = nullptr, *d_stats_ = nullptr;
-    double *h_stats_ = nullptr;
+    double *h_stats_ = nullptr, *h_stats_dev_ = nullptr;
+    unsigned long long pub_seq_ = 0;
+    bool inited_ = false;
     int64_t nt_pad_ = 0, ns_pad_ = 0, aux_cap_ = 0;
     size_t keys_bytes_ = 0;
     NNLaunch plan_{0, 0, 0};

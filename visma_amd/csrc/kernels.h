@@ -70,6 +70,9 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          int *nblocks_out, hipStream_t stream);
 
 int reduce_max_blocks();
+// stats (device) -> host_out[0..37] (mapped host memory), then host_out[38] = seq (u64 bits)
+hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned long long seq,
+                                hipStream_t stream);
 
 // Fold `nblocks` partial rows into the 38 statistics (one workgroup, fixed order).
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,

@@ -242,6 +242,28 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict
     fold_partials<PLANE>(partials, nblocks, stats);
 }
 
+// Copy the statistics into host-visible (mapped, coherent) memory and then raise
+// a sequence number there: the host spin-waits on it instead of paying a
+// DMA packet + stream-synchronise wake-up per ICP iteration.
+__global__ void publish_stats_kernel(const double *__restrict__ stats, double *host_out,
+                                     unsigned long long seq)
+{
+    if (threadIdx.x < kNStats) host_out[threadIdx.x] = stats[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(host_out + kNStats) = seq;
+    }
+}
+
+hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned long long seq,
+                                hipStream_t stream)
+{
+    hipLaunchKernelGGL(publish_stats_kernel, dim3(1), dim3(64), 0, stream, stats, host_out, seq);
+    return hipGetLastError();
+}
+
 int reduce_max_blocks() { return 1024; }
 
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
