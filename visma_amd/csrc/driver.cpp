@@ -108,7 +108,11 @@ public:
         int iters, passes;
     };
     virtual bool supports_device_loop() const { return false; }
-    virtual int run_loop(const LoopParams &, LoopResult *) { err_ = "no device loop"; return VISMA_ICP_ERR_STATE; }
+    // nprob problems over the SAME clouds (own initial transform each; lp.Tc0 is
+    // ignored when Tc0s is given).  select_problem() picks whose correspondences
+    // get_correspondences() returns afterwards.
+    virtual int run_loop(const LoopParams &, const Mat4 *, int, LoopResult *) { err_ = "no device loop"; return VISMA_ICP_ERR_STATE; }
+    virtual void select_problem(int) {}
     virtual int set_nn_mode(int mode) { return mode == VISMA_ICP_NN_AUTO ? VISMA_ICP_OK : VISMA_ICP_ERR_STATE; }
     virtual int nn_mode_used() const { return VISMA_ICP_NN_AUTO; }
     virtual void set_profiling(bool) {}
@@ -164,6 +168,7 @@ public:
         }
         HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
         HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * reduce_max_blocks()));
+        partial_rows_ = (size_t)reduce_max_blocks();
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
         HIP_TRY(hipMalloc(&d_cand_, sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d_cand_, 0, sizeof(unsigned long long)));
@@ -235,6 +240,7 @@ public:
         r2f_ = (float)(max_dist * max_dist);
         int rc = choose_mode(max_dist);
         if (rc) return rc;
+        view_offset_ = 0;
         if (use_grid_) {
             // the grid search is fused with the reduction: it runs in reduce()
             // (or in get_correspondences() if no reduction is asked for)
@@ -283,7 +289,7 @@ public:
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                           &nblocks, grid_lanes(),
                                           profiling_ ? (unsigned long long *)d_cand_ : nullptr, nullptr,
-                                          stream_));
+                                          1, 0, stream_));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
             HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
@@ -327,8 +333,7 @@ public:
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         std::memcpy(stats, h_stats_, sizeof(double) * kNStats);
-        if (profiling_) HIP_TRY(hipStreamSynchronize(stream_));   // events must have retired
-        return collect_timing();
+        return maybe_collect_timing();
     }
 
     int get_correspondences(int32_t *idx, float *d2) override
@@ -344,7 +349,7 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, grid_lanes(), nullptr, nullptr, stream_));
+                                          &nblocks, grid_lanes(), nullptr, nullptr, 1, 0, stream_));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -360,26 +365,42 @@ public:
         }
         HIP_TRY(hipStreamSynchronize(stream_));
         if (ns_ > 0) {
-            HIP_TRY(hipMemcpy(idx, d_idx_, sizeof(int32_t) * ns_, hipMemcpyDeviceToHost));
-            if (d2) HIP_TRY(hipMemcpy(d2, d_d2_, sizeof(float) * ns_, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(idx, (int32_t *)d_idx_ + view_offset_, sizeof(int32_t) * ns_, hipMemcpyDeviceToHost));
+            if (d2) HIP_TRY(hipMemcpy(d2, (float *)d_d2_ + view_offset_, sizeof(float) * ns_, hipMemcpyDeviceToHost));
         }
         return VISMA_ICP_OK;
     }
 
     bool supports_device_loop() const override { return true; }
 
-    int run_loop(const LoopParams &lp, LoopResult *out) override
+    void select_problem(int b) override { view_offset_ = (int64_t)b * loop_out_stride_; }
+
+    int run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopResult *out) override
     {
         HIP_TRY(hipSetDevice(device_));
+        if (nprob < 1) { err_ = "nprob < 1"; return VISMA_ICP_ERR_INVALID; }
         if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
         if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
         int rc = choose_mode(lp.max_dist);
         if (rc) return rc;
         r2f_ = (float)(lp.max_dist * lp.max_dist);
         for (int i = 0; i < 12; i++) T32_.m[i] = (float)lp.Tc0.m[i];
+        if (nprob > 1 && (!use_grid_ || comm_)) {
+            err_ = "batched loop needs the grid search on a single GPU";
+            return VISMA_ICP_ERR_STATE;
+        }
+        const int64_t ns_rounded = ((ns_ + kBlock - 1) / kBlock) * kBlock;
+        view_offset_ = 0;
+        loop_out_stride_ = ns_rounded;
         if (use_grid_) {
-            rc = ensure_aux(((ns_ + kBlock - 1) / kBlock) * kBlock);
+            rc = ensure_aux(ns_rounded * nprob);
             if (rc) return rc;
+            const size_t rows = (size_t)reduce_max_blocks() * nprob;
+            if (rows > partial_rows_) {
+                free_dev(d_partials_);
+                HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * rows));
+                partial_rows_ = rows;
+            }
         } else {
             plan_ = nn_plan(ns_, nt_pad_);
             ns_pad_ = (int64_t)plan_.src_tiles * kBlock * plan_.spt;
@@ -392,22 +413,28 @@ public:
             rc = ensure_aux(ns_pad_);
             if (rc) return rc;
         }
-        if (!d_state_) {
-            HIP_TRY(hipMalloc(&d_state_, sizeof(DevIcpState)));
-            HIP_TRY(hipHostMalloc((void **)&h_state_, sizeof(DevIcpState), hipHostMallocDefault));
+        if (nprob > state_cap_) {
+            free_dev(d_state_);
+            if (h_state_) { (void)hipHostFree(h_state_); h_state_ = nullptr; }
+            HIP_TRY(hipMalloc(&d_state_, sizeof(DevIcpState) * nprob));
+            HIP_TRY(hipHostMalloc((void **)&h_state_, sizeof(DevIcpState) * nprob, hipHostMallocDefault));
+            state_cap_ = nprob;
         }
-        DevIcpState &h = *h_state_;
-        std::memset(&h, 0, sizeof(h));
-        for (int i = 0; i < 12; i++) h.Tc[i] = lp.Tc0.m[i];
-        for (int a = 0; a < 3; a++) h.centre[a] = lp.centre[a];
-        h.rel_fit = lp.rel_fit; h.rel_rmse = lp.rel_rmse;
-        h.ns_total = lp.ns_total > 0 ? lp.ns_total : ns_;
-        h.active = 1;
-        h.max_iter = lp.max_iter; h.solver = lp.solver; h.scaling = lp.scaling ? 1 : 0;
-        h.plane = lp.plane ? 1 : 0; h.world_frame = lp.world ? 1 : 0;
-        h.check_stop = lp.check_stop ? 1 : 0;
-        h.r2f = r2f_;
-        HIP_TRY(hipMemcpyAsync(d_state_, &h, sizeof(h), hipMemcpyHostToDevice, stream_));
+        for (int b = 0; b < nprob; b++) {
+            DevIcpState &h = h_state_[b];
+            std::memset(&h, 0, sizeof(h));
+            const Mat4 &T0 = Tc0s ? Tc0s[b] : lp.Tc0;
+            for (int i = 0; i < 12; i++) h.Tc[i] = T0.m[i];
+            for (int a = 0; a < 3; a++) h.centre[a] = lp.centre[a];
+            h.rel_fit = lp.rel_fit; h.rel_rmse = lp.rel_rmse;
+            h.ns_total = lp.ns_total > 0 ? lp.ns_total : ns_;
+            h.active = 1;
+            h.max_iter = lp.max_iter; h.solver = lp.solver; h.scaling = lp.scaling ? 1 : 0;
+            h.plane = lp.plane ? 1 : 0; h.world_frame = lp.world ? 1 : 0;
+            h.check_stop = lp.check_stop ? 1 : 0;
+            h.r2f = r2f_;
+        }
+        HIP_TRY(hipMemcpyAsync(d_state_, h_state_, sizeof(DevIcpState) * nprob, hipMemcpyHostToDevice, stream_));
         DevIcpState *st = (DevIcpState *)d_state_;
         const Xform64 T64{};   // ignored: the kernels read the transform from the state
         const int plane = lp.plane ? 1 : 0;
@@ -427,7 +454,7 @@ public:
                                                   (float *)d_d2_, (double *)d_partials_,
                                                   reduce_max_blocks(), &nblocks, grid_lanes(),
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
-                                                  stream_));
+                                                  nprob, loop_out_stride_, stream_));
                 } else {
                     HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
                                             T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
@@ -452,23 +479,28 @@ public:
                     }
                     HIP_TRY(launch_solve_state(st, stream_));
                 } else {
-                    HIP_TRY(launch_finalize_solve((const double *)d_partials_, nblocks, st, plane, stream_));
+                    HIP_TRY(launch_finalize_solve((const double *)d_partials_, nblocks, st, plane, nprob, stream_));
                 }
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             }
             done += n;
-            HIP_TRY(hipMemcpyAsync(&h, d_state_, sizeof(h), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(h_state_, d_state_, sizeof(DevIcpState) * nprob, hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipStreamSynchronize(stream_));
-            rc = collect_timing();
+            rc = maybe_collect_timing();
             if (rc) return rc;
-            if (!h.active) break;
+            bool any = false;
+            for (int b = 0; b < nprob; b++) any = any || h_state_[b].active;
+            if (!any) break;
         }
-        out->Tc = Mat4::identity();
-        for (int i = 0; i < 12; i++) out->Tc.m[i] = h.Tc[i];
-        out->fit = h.fit; out->rmse = h.rmse;
-        out->k = (int64_t)std::llround(h.K);
-        out->iters = h.iter; out->passes = h.passes;
-        for (int i = 0; i < 12; i++) T32_.m[i] = (float)h.Tc[i];
+        for (int b = 0; b < nprob; b++) {
+            const DevIcpState &h = h_state_[b];
+            out[b].Tc = Mat4::identity();
+            for (int i = 0; i < 12; i++) out[b].Tc.m[i] = h.Tc[i];
+            out[b].fit = h.fit; out[b].rmse = h.rmse;
+            out[b].k = (int64_t)std::llround(h.K);
+            out[b].iters = h.iter; out[b].passes = h.passes;
+        }
+        for (int i = 0; i < 12; i++) T32_.m[i] = (float)h_state_[0].Tc[i];
         have_pass_ = true;
         grid_pending_ = false;
         brute_reduced_ = true;
@@ -508,6 +540,7 @@ public:
         unsigned long long c = 0;
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(stream_);
+        (void)collect_timing();
         (void)hipMemcpy(&c, d_cand_, sizeof(c), hipMemcpyDeviceToHost);
         timing_.grid_candidates = (double)c;
         *t = timing_;
@@ -617,6 +650,13 @@ private:
         ev_used_ += 2;
         return r;
     }
+    // event pairs are only read back in bulk (get_timing, or when many are pending)
+    int maybe_collect_timing()
+    {
+        if (pending_.size() < 2048) return VISMA_ICP_OK;
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return collect_timing();
+    }
     int collect_timing()
     {
         for (const auto &p : pending_) {
@@ -658,6 +698,9 @@ private:
     void *d_start_ = nullptr, *d_bsum_ = nullptr, *d_cand_ = nullptr;
     void *d_state_ = nullptr;
     DevIcpState *h_state_ = nullptr;
+    int state_cap_ = 0;
+    size_t partial_rows_ = 0;
+    int64_t view_offset_ = 0, loop_out_stride_ = 0;
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes() const
     {
@@ -794,7 +837,7 @@ struct visma_icp_ctx {
             lp.scaling = scaling; lp.plane = plane; lp.world = world; lp.check_stop = true;
             lp.ns_total = ns_total > 0 ? ns_total : eng->ns();
             Engine::LoopResult r;
-            int rc = eng->run_loop(lp, &r);
+            int rc = eng->run_loop(lp, nullptr, 1, &r);
             if (rc) return eng_fail(rc);
             last_Tc = r.Tc;
             last_plane = plane;
@@ -1143,7 +1186,7 @@ int visma_icp_iterate(visma_icp_ctx *ctx, double T_inout[16], double max_dist, i
         lp.scaling = with_scaling != 0; lp.plane = false; lp.world = world; lp.check_stop = false;
         lp.ns_total = ctx->ns_total > 0 ? ctx->ns_total : ctx->eng->ns();
         Engine::LoopResult r;
-        int rc = ctx->eng->run_loop(lp, &r);
+        int rc = ctx->eng->run_loop(lp, nullptr, 1, &r);
         if (rc) return ctx->eng_fail(rc);
         ctx->last_Tc = r.Tc;
         const Mat4 T = from_centred(r.Tc, ctx->centre);
@@ -1195,6 +1238,54 @@ int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int 
     if (level <= 0 || !best || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad sweep arguments");
     // src/annotation.cpp:35-61
     const double interval = 2.0 * M_PI / (double)level;
+    if (ctx->use_device_loop() && max_dist > 0.0 && ctx->have_src && ctx->have_tgt) {
+        // all `level` ICPs in flight together: one launch per iteration covers every
+        // (yaw, source point) pair over the shared grid, `level` solves run in parallel
+        std::vector<Mat4> inits((size_t)level), Tc0((size_t)level);
+        for (int i = 0; i < level; i++) {
+            const double a = interval * i, c = std::cos(a), s = std::sin(a);
+            Mat4 init = Mat4::identity();
+            init(0, 0) = c; init(0, 2) = s; init(2, 0) = -s; init(2, 2) = c;
+            inits[i] = init;
+            Tc0[i] = to_centred(init, ctx->centre);
+        }
+        Engine::LoopParams lp;
+        lp.Tc0 = Tc0[0];
+        std::memcpy(lp.centre, ctx->centre, sizeof(ctx->centre));
+        lp.max_dist = max_dist; lp.rel_fit = rel_fitness; lp.rel_rmse = rel_rmse;
+        lp.max_iter = max_iter; lp.solver = solver; lp.passes = max_iter + 1;
+        lp.scaling = false; lp.plane = false;
+        lp.world = visma_icp_ctx::wants_world_frame(solver, false);
+        lp.check_stop = true;
+        lp.ns_total = ctx->ns_total > 0 ? ctx->ns_total : ctx->eng->ns();
+        std::vector<Engine::LoopResult> rs((size_t)level);
+        int rc = ctx->eng->run_loop(lp, Tc0.data(), level, rs.data());
+        if (rc == VISMA_ICP_OK) {
+            visma_icp_result bb;
+            std::memset(&bb, 0, sizeof(bb));
+            const Mat4 I = Mat4::identity();
+            std::memcpy(bb.transformation, I.m, sizeof(I.m));
+            int bl = -1;
+            for (int i = 0; i < level; i++) {
+                visma_icp_result r;
+                std::memset(&r, 0, sizeof(r));
+                const Mat4 T = from_centred(rs[i].Tc, ctx->centre);
+                std::memcpy(r.transformation, T.m, sizeof(T.m));
+                r.fitness = rs[i].fit; r.inlier_rmse = rs[i].rmse;
+                r.num_correspondences = rs[i].k;
+                r.iterations = rs[i].iters; r.nn_passes = rs[i].passes;
+                if (per_level) per_level[i] = r;
+                if (r.num_correspondences > bb.num_correspondences) { bb = r; bl = i; }   // strict >
+            }
+            ctx->eng->select_problem(bl >= 0 ? bl : 0);
+            if (bl >= 0) ctx->last_Tc = rs[bl].Tc;
+            *best = bb;
+            if (best_level) *best_level = bl;
+            return VISMA_ICP_OK;
+        }
+        if (rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);
+        // (brute-force search selected, or RCCL attached): fall through to the sequential sweep
+    }
     visma_icp_result b;
     std::memset(&b, 0, sizeof(b));
     const Mat4 I = Mat4::identity();

@@ -265,10 +265,17 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
     Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out, float *__restrict__ d2_out,
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
-    const DevIcpState *__restrict__ st)
+    const DevIcpState *__restrict__ st, int bpp, long long out_stride)
 {
     constexpr int NACC = Acc<PLANE>::N;
+    // `bpp` workgroups per problem: problem b = blockIdx.x / bpp shares the
+    // clouds and the grid with the others but has its own transform / state
+    // (the yaw sweep of src/annotation.cpp:35-61 is 24 such problems).
+    const int prob = blockIdx.x / bpp, lb = blockIdx.x - prob * bpp;
+    if (st) st += prob;
     if (!load_loop_state(st, T32, T64, off, r2f)) return;
+    idx_out += (long long)prob * out_stride;
+    d2_out += (long long)prob * out_stride;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -279,11 +286,11 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     // XCD-aware chunking: workgroup b runs on XCD b % 8.  Give each XCD ONE
     // contiguous eighth of the (Morton-ordered) queries, so its private L2 holds
     // one spatial region of the target instead of a slice of everything.
-    int vb = blockIdx.x;
-    if ((gridDim.x & 7) == 0) vb = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    int vb = lb;
+    if ((bpp & 7) == 0) vb = (lb & 7) * (bpp >> 3) + (lb >> 3);
     // consecutive virtual blocks take consecutive query chunks; a block strides by
     // one over its own contiguous share
-    const int total_groups = gridDim.x * groups_per_block;
+    const int total_groups = bpp * groups_per_block;
     const int per_group = (ns + total_groups - 1) / total_groups;
     const int gid = vb * groups_per_block + threadIdx.x / G;
     const int i_begin = gid * per_group;
@@ -374,11 +381,12 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const float4 *sorted, const unsigned *start, const GridParams &g,
                           const float4 *nrm, const Xform32 &T32, const Xform64 &T64,
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
-                          double *partials, unsigned long long *cand, const DevIcpState *st)
+                          double *partials, unsigned long long *cand, const DevIcpState *st,
+                          int nprob, long long out_stride)
 {
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G>), dim3(nblocks), dim3(kBlock), 0, stream, src,
-                       ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out, partials, cand,
-                       st);
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G>), dim3(nblocks * nprob), dim3(kBlock), 0,
+                       stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
+                       partials, cand, st, nblocks, out_stride);
 }
 
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -388,7 +396,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int32_t *idx_out, float *d2_out, double *partials,
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
-                                 hipStream_t stream)
+                                 int nprob, int64_t out_stride, hipStream_t stream)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
@@ -401,11 +409,11 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals,  \
                                     T32, T64, off, r2f, idx_out, d2_out, partials, cand_count, \
-                                    st);                                                   \
+                                    st, nprob, (long long)out_stride);                     \
         else                                                                                       \
             launch_grid_t<false, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals, \
                                      T32, T64, off, r2f, idx_out, d2_out, partials, cand_count, \
-                                     st);                                                  \
+                                     st, nprob, (long long)out_stride);                    \
         break;
     switch (G) {
         VISMA_GRID_CASE(1)

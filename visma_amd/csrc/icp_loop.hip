@@ -67,6 +67,8 @@ __global__ __launch_bounds__(1024) void finalize_solve_kernel(const double *__re
                                                               int nblocks, DevIcpState *st,
                                                               int do_solve)
 {
+    st += blockIdx.x;                                        // one workgroup per problem
+    partials += (long long)blockIdx.x * nblocks * kReduceAcc;
     if (!st->active) return;
     fold_partials<PLANE>(partials, nblocks, st->stats);
     if (do_solve && threadIdx.x == 0) advance_state(st);   // same thread wrote the stats
@@ -79,27 +81,27 @@ __global__ void solve_state_kernel(DevIcpState *st)
 
 // `plane` is a host copy of st->plane (chooses the accumulator layout)
 static hipError_t launch_fs(const double *partials, int nblocks, DevIcpState *st, int plane,
-                            int do_solve, hipStream_t stream)
+                            int do_solve, int nprob, hipStream_t stream)
 {
     if (plane)
-        hipLaunchKernelGGL(finalize_solve_kernel<true>, dim3(1), dim3(1024), 0, stream, partials,
+        hipLaunchKernelGGL(finalize_solve_kernel<true>, dim3(nprob), dim3(1024), 0, stream, partials,
                            nblocks, st, do_solve);
     else
-        hipLaunchKernelGGL(finalize_solve_kernel<false>, dim3(1), dim3(1024), 0, stream, partials,
+        hipLaunchKernelGGL(finalize_solve_kernel<false>, dim3(nprob), dim3(1024), 0, stream, partials,
                            nblocks, st, do_solve);
     return hipGetLastError();
 }
 
 hipError_t launch_finalize_solve(const double *partials, int nblocks, DevIcpState *st, int plane,
-                                 hipStream_t stream)
+                                 int nprob, hipStream_t stream)
 {
-    return launch_fs(partials, nblocks, st, plane, 1, stream);
+    return launch_fs(partials, nblocks, st, plane, 1, nprob, stream);
 }
 
 hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpState *st, int plane,
                                  hipStream_t stream)
 {
-    return launch_fs(partials, nblocks, st, plane, 0, stream);
+    return launch_fs(partials, nblocks, st, plane, 0, 1, stream);
 }
 
 hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream)

@@ -81,8 +81,9 @@ hipError_t launch_finalize(const double *partials, int nblocks, int point_to_pla
 //  launch_finalize_solve : single GPU (fold partials, then advance the state)
 //  launch_finalize_state : fold partials into st->stats only (an all-reduce follows)
 //  launch_solve_state    : advance the state from st->stats
+// nprob problems: workgroup b folds rows [b*nblocks, (b+1)*nblocks) into st[b]
 hipError_t launch_finalize_solve(const double *partials, int nblocks, DevIcpState *st, int plane,
-                                 hipStream_t stream);
+                                 int nprob, hipStream_t stream);
 hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpState *st, int plane,
                                  hipStream_t stream);
 hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream);
@@ -113,7 +114,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int32_t *idx_out, float *d2_out, double *partials,
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
-                                 hipStream_t stream);
+                                 int nprob, int64_t out_stride, hipStream_t stream);
 
 // fill n float4 with +inf (target padding)
 hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);
