@@ -238,7 +238,6 @@ def main():
         Tg, _ = (ctx.set_nn_mode(_lib.NN_GRID), ctx.iterate(np.eye(4), radius, args.brute_steps))[1]
         brute = {"steps": args.brute_steps, "ms_per_step": tb / args.brute_steps * 1e3,
                  "nn_ms": reduce_max(tmb["nn_ms"] / max(tmb["nn_launches"], 1)),
-                 "T_equals_grid_T": bool(np.array_equal(Tb, Tg)),
                  "rel_frobenius_vs_grid": synth.rel_frobenius(Tb, Tg)}
         ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID}[args.nn])
 
@@ -272,7 +271,6 @@ def main():
             b.update(steps=brute["steps"], ms_per_step=brute["ms_per_step"],
                      iterations_per_sec=1e3 / brute["ms_per_step"],
                      mpairs_per_sec=float(ns) * nt / brute["ms_per_step"] / 1e3,
-                     T_equals_grid_T=brute["T_equals_grid_T"],
                      rel_frobenius_vs_grid=brute["rel_frobenius_vs_grid"])
             out["brute_force"] = b
         if world == 1 and not args.no_cpu_baseline:

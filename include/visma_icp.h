@@ -226,11 +226,13 @@ VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_proble
 VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
 /* Which search the last nn_pass used (VISMA_ICP_NN_BRUTE or VISMA_ICP_NN_GRID). */
 VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
-/* The loop of visma_icp_run / visma_icp_iterate normally runs ON THE DEVICE
- * (per-iteration solve, compose and stop test in a one-thread kernel epilogue;
- * the host reads the state back every 8 passes).  0 selects the synchronous
- * host loop (one stream sync + host solve per iteration); results agree to
- * rounding. */
+/* Where the ICP loop runs.  1: ON THE DEVICE (per-iteration solve, compose and
+ * stop test in a one-thread kernel epilogue, the host reads the state back
+ * every 8 passes); 0: on the host (statistics published to mapped host memory,
+ * host spin-waits, solves in f64, relaunches); -1 (default): automatic -- host
+ * loop for a single problem, device loop for visma_icp_run_yaw_sweep, whose
+ * `level` problems then advance together with one set of launches per
+ * iteration.  Results agree to rounding. */
 VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out,

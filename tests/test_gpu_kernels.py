@@ -185,16 +185,17 @@ def test_device_loop_equals_host_loop(gpu_ctx, oracle):
             b = gpu_ctx.run(None, 0.075, **kw)
             ib = gpu_ctx.correspondence_index()
         finally:
-            gpu_ctx.set_device_loop(True)
+            gpu_ctx.set_device_loop(None)
         assert a.iterations == b.iterations and a.nn_passes == b.nn_passes
         assert a.num_correspondences == b.num_correspondences
         assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
         assert abs(a.inlier_rmse_ - b.inlier_rmse_) < 1e-12 and a.fitness_ == b.fitness_
         assert np.array_equal(ia, ib)
+    gpu_ctx.set_device_loop(True)
     Ta, la = gpu_ctx.iterate(None, 0.075, 7)
     gpu_ctx.set_device_loop(False)
     try:
         Tb, lb = gpu_ctx.iterate(None, 0.075, 7)
     finally:
-        gpu_ctx.set_device_loop(True)
+        gpu_ctx.set_device_loop(None)
     assert synth.rel_frobenius(Ta, Tb) < 1e-12 and la.num_correspondences == lb.num_correspondences

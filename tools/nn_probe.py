@@ -22,6 +22,7 @@ def main():
         ctx.set_clouds_f64(src, tgt)
         for mode, name in ((_lib.NN_BRUTE, "brute"), (_lib.NN_GRID, "grid")):
             ctx.set_nn_mode(mode)
+            ctx.set_device_loop(True)
             ctx.run(None, r, 1, 0, 0)            # warm (+ grid build)
             tb = ctx.get_timing(reset=True)
             iters = 5 if (ns * nt > 1e11 and name == "brute") else 20
@@ -36,7 +37,7 @@ def main():
             t0 = time.time()
             ctx.run(None, r, iters, 0, 0)
             wall_host = time.time() - t0
-            ctx.set_device_loop(True)
+            ctx.set_device_loop(None)
             ctx.get_timing(reset=True)
             rec = dict(mode=name, ns=ns, nt=nt, radius=r, nn_ms=nn, reduce_ms=rd,
                        iter_ms_wall_hostloop=wall_host / (iters + 1) * 1e3,

@@ -11,7 +11,7 @@ src, tgt, _, _ = synth.make_pair(40000, 20000)
 cases.append(("S-surf 40k->20k r=0.02", src, tgt, 0.02))
 for name, s, t, r in cases:
     ctx.set_clouds_f64(s, t)
-    for label, dev in (("batched device loop", True), ("sequential host loop", False)):
+    for label, dev in (("batched device loop", None), ("sequential host loop", False)):
         ctx.set_device_loop(dev)
         ctx.run_yaw_sweep(24, r)
         t0 = time.time()
@@ -20,4 +20,4 @@ for name, s, t, r in cases:
         its = sum(p.iterations for p in per)
         print(json.dumps(dict(case=name, mode=label, ms=dt * 1e3, best_level=level, K=best.num_correspondences,
                               total_iterations=its, icp_iterations_per_s=its / dt)))
-    ctx.set_device_loop(True)
+    ctx.set_device_loop(None)

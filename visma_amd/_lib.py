@@ -296,7 +296,8 @@ class Context:
         return m.value
 
     def set_device_loop(self, on=True):
-        self._chk(self.L.visma_icp_set_device_loop(self._h, int(bool(on))))
+        """True: on-device loop, False: host loop, None: automatic (default)."""
+        self._chk(self.L.visma_icp_set_device_loop(self._h, -1 if on is None else int(bool(on))))
 
     def set_profiling(self, on=True):
         self._chk(self.L.visma_icp_set_profiling(self._h, int(bool(on))))

@@ -796,8 +796,14 @@ struct visma_icp_ctx {
         return VISMA_ICP_OK;
     }
 
-    bool device_loop_enabled = true;
-    bool use_device_loop() const { return device_loop_enabled && eng->supports_device_loop() && !host_allreduce; }
+    // 0 = synchronous host loop, 1 = on-device loop, 2 = auto: host loop for one
+    // problem (spin-wait on mapped memory beats a one-thread f64 SVD on the GPU:
+    // measured 46 vs 68 us per iteration at 5k x 20k), device loop for sweeps of
+    // many transforms (their solves run in parallel and nothing syncs per pass)
+    int loop_mode = 2;
+    bool device_loop_possible() const { return eng->supports_device_loop() && !host_allreduce; }
+    bool use_device_loop() const { return loop_mode == 1 && device_loop_possible(); }
+    bool use_device_loop_batched() const { return loop_mode != 0 && device_loop_possible(); }
     static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }
 
     // T_centred <- update o T_centred, with the update expressed in `world` or centred frame
@@ -1238,7 +1244,7 @@ int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int 
     if (level <= 0 || !best || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad sweep arguments");
     // src/annotation.cpp:35-61
     const double interval = 2.0 * M_PI / (double)level;
-    if (ctx->use_device_loop() && max_dist > 0.0 && ctx->have_src && ctx->have_tgt) {
+    if (ctx->use_device_loop_batched() && max_dist > 0.0 && ctx->have_src && ctx->have_tgt) {
         // all `level` ICPs in flight together: one launch per iteration covers every
         // (yaw, source point) pair over the shared grid, `level` solves run in parallel
         std::vector<Mat4> inits((size_t)level), Tc0((size_t)level);
@@ -1339,7 +1345,7 @@ int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode)
 int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled)
 {
     CTX_CHECK();
-    ctx->device_loop_enabled = enabled != 0;
+    ctx->loop_mode = enabled < 0 ? 2 : (enabled != 0 ? 1 : 0);
     return VISMA_ICP_OK;
 }
 
