@@ -199,3 +199,34 @@ def test_device_loop_equals_host_loop(gpu_ctx, oracle):
     finally:
         gpu_ctx.set_device_loop(None)
     assert synth.rel_frobenius(Ta, Tb) < 1e-12 and la.num_correspondences == lb.num_correspondences
+
+
+def test_batch_of_different_clouds_in_flight(gpu_ctx_auto, oracle):
+    """BASELINE config 3: many small ICPs with their own clouds advanced together
+    on the device == the same problems run one at a time."""
+    ctx = gpu_ctx_auto
+    rng = np.random.default_rng(17)
+    probs = []
+    for i in range(14):
+        ns, nt = int(rng.integers(300, 6000)), int(rng.integers(200, 9000))
+        src, tgt, _, _ = synth.make_pair(ns, nt, seed_t=100 + i, seed_s=200 + i)
+        init = synth.make_T(synth.rot_y(0.01 * i), [0.002 * i, 0, -0.001 * i])
+        probs.append((src + 0.1 * i, tgt + 0.1 * i, init, [0.05, 0.075, 0.02][i % 3]))
+    probs.append((probs[0][0] + 30.0, probs[0][1], None, 0.01))      # no correspondences at all
+    probs.append((probs[1][0][:1], probs[1][1], None, 0.5))           # a single source point
+    batched = ctx.run_batch(probs, max_iter=25, rel_fitness=1e-6, rel_rmse=1e-6)
+    ctx.set_device_loop(False)
+    try:
+        single = ctx.run_batch(probs, max_iter=25, rel_fitness=1e-6, rel_rmse=1e-6)
+    finally:
+        ctx.set_device_loop(None)
+    for i, (a, b) in enumerate(zip(batched, single)):
+        assert a.num_correspondences == b.num_correspondences, i
+        assert a.iterations == b.iterations and a.nn_passes == b.nn_passes, i
+        if i != 15:      # one source point: the rotation is undetermined
+            assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-9, i
+        assert abs(a.inlier_rmse_ - b.inlier_rmse_) < 1e-9 and a.fitness_ == b.fitness_
+    s0, t0, i0, r0 = probs[3]
+    o = oracle.registration_icp(s0, t0, r0, init=i0, max_iter=25)
+    assert synth.rel_frobenius(batched[3].transformation_, o.T) < TOL_T
+    assert batched[3].num_correspondences == o.k

@@ -113,6 +113,20 @@ public:
     // get_correspondences() returns afterwards.
     virtual int run_loop(const LoopParams &, const Mat4 *, int, LoopResult *) { err_ = "no device loop"; return VISMA_ICP_ERR_STATE; }
     virtual void select_problem(int) {}
+    // A batch of problems with their OWN clouds, advanced together on the device.
+    struct BatchProblem {
+        const float *src_xyzw; int64_t ns;
+        const float *tgt_xyzw; int64_t nt;
+        Mat4 Tc0;
+        double centre[3];
+        double max_dist;
+        float bb_min[3], bb_max[3];   // bounding box of the (centred) target
+    };
+    virtual int run_loop_batch(const LoopParams &, const std::vector<BatchProblem> &, LoopResult *)
+    {
+        err_ = "no batched device loop";
+        return VISMA_ICP_ERR_STATE;
+    }
     virtual int set_nn_mode(int mode) { return mode == VISMA_ICP_NN_AUTO ? VISMA_ICP_OK : VISMA_ICP_ERR_STATE; }
     virtual int nn_mode_used() const { return VISMA_ICP_NN_AUTO; }
     virtual void set_profiling(bool) {}
@@ -143,6 +157,8 @@ public:
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
+        free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
+        free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
         if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
         if (stream_) (void)hipStreamDestroy(stream_);
@@ -507,6 +523,148 @@ public:
         return VISMA_ICP_OK;
     }
 
+    int run_loop_batch(const LoopParams &lp, const std::vector<BatchProblem> &pb, LoopResult *out) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        const int B = (int)pb.size();
+        if (B < 1) return VISMA_ICP_OK;
+        if (comm_) { err_ = "batched loop is single-GPU"; return VISMA_ICP_ERR_STATE; }
+        // ---- layout of the concatenated arrays
+        std::vector<ProbDesc> descs((size_t)B);
+        int64_t src_tot = 0, tgt_tot = 0, cell_tot = 0, max_ncell = 0;
+        int total_blocks = 0;
+        const int G = 4;
+        for (int b = 0; b < B; b++) {
+            const BatchProblem &q = pb[b];
+            if (q.ns < 0 || q.nt < 0 || !(q.max_dist > 0.0)) { err_ = "bad batch problem"; return VISMA_ICP_ERR_INVALID; }
+            ProbDesc &d = descs[b];
+            std::memset(&d, 0, sizeof(d));
+            // a small cloud does not get a huge cell table: cap the grid, h grows (still exact)
+            const int64_t cap = std::min<int64_t>(kGridMaxCells, std::max<int64_t>(4096, 8 * q.nt));
+            float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+            if (q.nt > 0) for (int a = 0; a < 3; a++) { mn[a] = q.bb_min[a]; mx[a] = q.bb_max[a]; }
+            d.g = grid_plan(mn, mx, q.max_dist, cap);
+            d.src_off = src_tot; d.sorted_off = tgt_tot; d.start_off = cell_tot; d.out_off = src_tot;
+            d.ns = (int)q.ns;
+            d.first_block = total_blocks;
+            int64_t nb = (q.ns * G + kBlock - 1) / kBlock;
+            if (nb < 1) nb = 1;
+            if (nb > 256) nb = 256;
+            d.nblocks = (int)nb;
+            total_blocks += d.nblocks;
+            src_tot += q.ns; tgt_tot += q.nt; cell_tot += d.g.ncell + 1;
+            max_ncell = std::max(max_ncell, d.g.ncell);
+        }
+        // ---- device buffers
+        if (src_tot > bt_src_cap_) {
+            free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_);
+            HIP_TRY(hipMalloc(&bt_src_, sizeof(float4) * std::max<int64_t>(src_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(src_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_d2_, sizeof(float) * std::max<int64_t>(src_tot, 1)));
+            bt_src_cap_ = src_tot;
+        }
+        if (tgt_tot > bt_tgt_cap_) {
+            free_dev(bt_tgt_); free_dev(bt_sorted_); free_dev(bt_cell_of_);
+            HIP_TRY(hipMalloc(&bt_tgt_, sizeof(float4) * std::max<int64_t>(tgt_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_sorted_, sizeof(float4) * std::max<int64_t>(tgt_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_cell_of_, sizeof(unsigned) * std::max<int64_t>(tgt_tot, 1)));
+            bt_tgt_cap_ = tgt_tot;
+        }
+        if (cell_tot > bt_cell_cap_) {
+            free_dev(bt_count_); free_dev(bt_start_);
+            HIP_TRY(hipMalloc(&bt_count_, sizeof(unsigned) * cell_tot));
+            HIP_TRY(hipMalloc(&bt_start_, sizeof(unsigned) * cell_tot));
+            bt_cell_cap_ = cell_tot;
+        }
+        if (grid_scan_blocks(max_ncell) + 1 > bt_bsum_cap_) {
+            free_dev(bt_bsum_);
+            bt_bsum_cap_ = grid_scan_blocks(max_ncell) + 1;
+            HIP_TRY(hipMalloc(&bt_bsum_, sizeof(unsigned) * bt_bsum_cap_));
+        }
+        if (B > bt_desc_cap_) {
+            free_dev(bt_descs_);
+            HIP_TRY(hipMalloc(&bt_descs_, sizeof(ProbDesc) * B));
+            bt_desc_cap_ = B;
+        }
+        if ((size_t)total_blocks > partial_rows_) {
+            free_dev(d_partials_);
+            HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * (size_t)total_blocks));
+            partial_rows_ = (size_t)total_blocks;
+        }
+        if (B > state_cap_) {
+            free_dev(d_state_);
+            if (h_state_) { (void)hipHostFree(h_state_); h_state_ = nullptr; }
+            HIP_TRY(hipMalloc(&d_state_, sizeof(DevIcpState) * B));
+            HIP_TRY(hipHostMalloc((void **)&h_state_, sizeof(DevIcpState) * B, hipHostMallocDefault));
+            state_cap_ = B;
+        }
+        // ---- uploads + per-problem grid builds (stream ordered, no host sync)
+        int e0 = -1;
+        if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+        for (int b = 0; b < B; b++) {
+            const BatchProblem &q = pb[b];
+            const ProbDesc &d = descs[b];
+            if (q.ns > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_src_ + d.src_off, q.src_xyzw, sizeof(float4) * q.ns, hipMemcpyHostToDevice, stream_));
+            if (q.nt > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_tgt_ + d.sorted_off, q.tgt_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
+            HIP_TRY(launch_grid_build((const float4 *)bt_tgt_ + d.sorted_off, q.nt, d.g,
+                                      (unsigned *)bt_cell_of_ + d.sorted_off, (unsigned *)bt_count_ + d.start_off,
+                                      (unsigned *)bt_bsum_, (unsigned *)bt_start_ + d.start_off,
+                                      (float4 *)bt_sorted_ + d.sorted_off, stream_));
+        }
+        HIP_TRY(hipMemcpyAsync(bt_descs_, descs.data(), sizeof(ProbDesc) * B, hipMemcpyHostToDevice, stream_));
+        for (int b = 0; b < B; b++) {
+            DevIcpState &h = h_state_[b];
+            std::memset(&h, 0, sizeof(h));
+            for (int i = 0; i < 12; i++) h.Tc[i] = pb[b].Tc0.m[i];
+            for (int a = 0; a < 3; a++) h.centre[a] = pb[b].centre[a];
+            h.rel_fit = lp.rel_fit; h.rel_rmse = lp.rel_rmse;
+            h.ns_total = pb[b].ns;
+            h.active = 1;
+            h.max_iter = lp.max_iter; h.solver = lp.solver; h.scaling = lp.scaling ? 1 : 0;
+            h.plane = 0; h.world_frame = lp.world ? 1 : 0; h.check_stop = lp.check_stop ? 1 : 0;
+            h.r2f = (float)(pb[b].max_dist * pb[b].max_dist);
+        }
+        HIP_TRY(hipMemcpyAsync(d_state_, h_state_, sizeof(DevIcpState) * B, hipMemcpyHostToDevice, stream_));
+        // the staging memory of the caller must stay valid until the copies are done
+        HIP_TRY(hipStreamSynchronize(stream_));
+        if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
+        // ---- the loop: one NN launch + one fold/solve launch per pass for ALL problems
+        DevIcpState *st = (DevIcpState *)d_state_;
+        const int chunk = lp.check_stop ? 8 : lp.passes;
+        int done = 0;
+        while (done < lp.passes) {
+            const int n = std::min(chunk, lp.passes - done);
+            for (int j = 0; j < n; j++) {
+                if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                HIP_TRY(launch_nn_grid_reduce_batch((const float4 *)bt_src_, (const float4 *)bt_sorted_,
+                                                    (const unsigned *)bt_start_, (const ProbDesc *)bt_descs_, B,
+                                                    total_blocks, (int32_t *)bt_idx_, (float *)bt_d2_,
+                                                    (double *)d_partials_, G, st, stream_));
+                if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+                if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_));
+                if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            }
+            done += n;
+            HIP_TRY(hipMemcpyAsync(h_state_, d_state_, sizeof(DevIcpState) * B, hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            int rc = maybe_collect_timing();
+            if (rc) return rc;
+            bool any = false;
+            for (int b = 0; b < B; b++) any = any || h_state_[b].active;
+            if (!any) break;
+        }
+        for (int b = 0; b < B; b++) {
+            const DevIcpState &h = h_state_[b];
+            out[b].Tc = Mat4::identity();
+            for (int i = 0; i < 12; i++) out[b].Tc.m[i] = h.Tc[i];
+            out[b].fit = h.fit; out[b].rmse = h.rmse;
+            out[b].k = (int64_t)std::llround(h.K);
+            out[b].iters = h.iter; out[b].passes = h.passes;
+        }
+        return VISMA_ICP_OK;
+    }
+
     int set_nn_mode(int mode) override
     {
         if (mode != VISMA_ICP_NN_AUTO && mode != VISMA_ICP_NN_BRUTE && mode != VISMA_ICP_NN_GRID) {
@@ -700,6 +858,11 @@ private:
     DevIcpState *h_state_ = nullptr;
     int state_cap_ = 0;
     size_t partial_rows_ = 0;
+    // batch of problems with their own clouds (concatenated arrays)
+    void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
+    void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
+    int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0;
+    int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes() const
@@ -1317,6 +1480,64 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
 {
     CTX_CHECK();
     if (n < 0 || (n > 0 && (!probs || !out)) || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch arguments");
+    if (ctx->use_device_loop_batched() && n > 1) {
+        // every problem in flight together: concatenated clouds, one grid per problem,
+        // one NN launch + one fold/solve launch per pass for the whole batch
+        std::vector<std::vector<float>> sbuf((size_t)n), tbuf((size_t)n);
+        std::vector<Engine::BatchProblem> pb((size_t)n);
+        std::vector<int32_t> order;
+        bool ok = true;
+        for (int i = 0; i < n && ok; i++) {
+            const visma_icp_problem &q = probs[i];
+            if (q.ns < 0 || q.nt < 0 || (q.ns > 0 && !q.src_xyz) || (q.nt > 0 && !q.tgt_xyz))
+                return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch problem");
+            if (!(q.max_dist > 0.0)) { ok = false; break; }   // rare: handled by the sequential path
+            double c[3] = {0, 0, 0};
+            for (int64_t j = 0; j < q.nt; j++)
+                for (int a = 0; a < 3; a++) c[a] += q.tgt_xyz[(size_t)j * 3 + a];
+            if (q.nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)q.nt;
+            pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
+            pack_f64(q.src_xyz, q.ns, 3, c, sbuf[i]);
+            morton_order(sbuf[i], q.ns, order);
+            Engine::BatchProblem &b = pb[i];
+            b.src_xyzw = sbuf[i].data(); b.ns = q.ns;
+            b.tgt_xyzw = tbuf[i].data(); b.nt = q.nt;
+            b.Tc0 = to_centred(Mat4::from(q.init), c);
+            std::memcpy(b.centre, c, sizeof(c));
+            b.max_dist = q.max_dist;
+            for (int a = 0; a < 3; a++) { b.bb_min[a] = 0.f; b.bb_max[a] = 0.f; }
+            for (int64_t j = 0; j < q.nt; j++)
+                for (int a = 0; a < 3; a++) {
+                    const float v = tbuf[i][4 * j + a];
+                    if (j == 0 || v < b.bb_min[a]) b.bb_min[a] = v;
+                    if (j == 0 || v > b.bb_max[a]) b.bb_max[a] = v;
+                }
+        }
+        if (ok) {
+            Engine::LoopParams lp;
+            lp.Tc0 = Mat4::identity();
+            lp.centre[0] = lp.centre[1] = lp.centre[2] = 0.0;
+            lp.max_dist = 0.0; lp.rel_fit = rel_fitness; lp.rel_rmse = rel_rmse;
+            lp.max_iter = max_iter; lp.solver = solver; lp.passes = max_iter + 1;
+            lp.scaling = false; lp.plane = false;
+            lp.world = visma_icp_ctx::wants_world_frame(solver, false);
+            lp.check_stop = true; lp.ns_total = 0;
+            std::vector<Engine::LoopResult> rs((size_t)n);
+            int rc = ctx->eng->run_loop_batch(lp, pb, rs.data());
+            if (rc == VISMA_ICP_OK) {
+                for (int i = 0; i < n; i++) {
+                    std::memset(&out[i], 0, sizeof(out[i]));
+                    const Mat4 T = from_centred(rs[i].Tc, pb[i].centre);
+                    std::memcpy(out[i].transformation, T.m, sizeof(T.m));
+                    out[i].fitness = rs[i].fit; out[i].inlier_rmse = rs[i].rmse;
+                    out[i].num_correspondences = rs[i].k;
+                    out[i].iterations = rs[i].iters; out[i].nn_passes = rs[i].passes;
+                }
+                return VISMA_ICP_OK;
+            }
+            if (rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);
+        }
+    }
     for (int i = 0; i < n; i++) {
         int rc = visma_icp_set_clouds_f64(ctx, probs[i].src_xyz, probs[i].ns, 3, probs[i].tgt_xyz, probs[i].nt, 3);
         if (rc) return rc;

@@ -265,13 +265,38 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
     Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out, float *__restrict__ d2_out,
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
-    const DevIcpState *__restrict__ st, int bpp, long long out_stride)
+    const DevIcpState *__restrict__ st, int bpp, long long out_stride,
+    const ProbDesc *__restrict__ descs, int nprob)
 {
     constexpr int NACC = Acc<PLANE>::N;
-    // `bpp` workgroups per problem: problem b = blockIdx.x / bpp shares the
-    // clouds and the grid with the others but has its own transform / state
-    // (the yaw sweep of src/annotation.cpp:35-61 is 24 such problems).
-    const int prob = blockIdx.x / bpp, lb = blockIdx.x - prob * bpp;
+    int prob, lb;
+    if (descs) {
+        // batch of problems with their own clouds: find the problem this workgroup
+        // belongs to (largest p with first_block <= blockIdx.x; wave-uniform)
+        int lo = 0, hi = nprob - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        prob = lo;
+        const ProbDesc d = descs[prob];
+        lb = (int)blockIdx.x - d.first_block;
+        bpp = d.nblocks;
+        src += d.src_off;
+        ns = d.ns;
+        sorted += d.sorted_off;
+        start += d.start_off;
+        g = d.g;
+        out_stride = 0;
+        idx_out += d.out_off;
+        d2_out += d.out_off;
+    } else {
+        // `bpp` workgroups per problem: problem b = blockIdx.x / bpp shares the
+        // clouds and the grid with the others but has its own transform / state
+        // (the yaw sweep of src/annotation.cpp:35-61 is 24 such problems).
+        prob = blockIdx.x / bpp;
+        lb = blockIdx.x - prob * bpp;
+    }
     if (st) st += prob;
     if (!load_loop_state(st, T32, T64, off, r2f)) return;
     idx_out += (long long)prob * out_stride;
@@ -386,7 +411,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
 {
     hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G>), dim3(nblocks * nprob), dim3(kBlock), 0,
                        stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
-                       partials, cand, st, nblocks, out_stride);
+                       partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
 }
 
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -427,6 +452,36 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     }
 #undef VISMA_GRID_CASE
     if (nblocks_out) *nblocks_out = nblocks;
+    return hipGetLastError();
+}
+
+template <int G>
+static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const float4 *src,
+                                const float4 *sorted, const unsigned *start, const ProbDesc *descs,
+                                int nprob, int *idx_out, float *d2_out, double *partials,
+                                const DevIcpState *st)
+{
+    const Xform32 T32{};
+    const Xform64 T64{};
+    const Offset64 off{};
+    const GridParams g{};
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G>), dim3(total_blocks), dim3(kBlock), 0, stream,
+                       src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
+                       d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob);
+}
+
+hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
+                                       const ProbDesc *descs, int nprob, int total_blocks,
+                                       int32_t *idx_out, float *d2_out, double *partials,
+                                       int lanes_per_query, const DevIcpState *st, hipStream_t stream)
+{
+    if (!st || !descs) return hipErrorInvalidValue;
+    switch (lanes_per_query) {
+    case 2: launch_grid_batch_t<2>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st); break;
+    case 4: launch_grid_batch_t<4>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st); break;
+    case 8: launch_grid_batch_t<8>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

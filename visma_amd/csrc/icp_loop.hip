@@ -104,6 +104,25 @@ hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpStat
     return launch_fs(partials, nblocks, st, plane, 0, 1, stream);
 }
 
+__global__ __launch_bounds__(1024) void finalize_solve_batch_kernel(const double *__restrict__ partials,
+                                                                   const ProbDesc *__restrict__ descs,
+                                                                   DevIcpState *st)
+{
+    const ProbDesc d = descs[blockIdx.x];                    // one workgroup per problem
+    st += blockIdx.x;
+    if (!st->active) return;
+    fold_partials<false>(partials + (long long)d.first_block * kReduceAcc, d.nblocks, st->stats);
+    if (threadIdx.x == 0) advance_state(st);
+}
+
+hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
+                                       int nprob, hipStream_t stream)
+{
+    hipLaunchKernelGGL(finalize_solve_batch_kernel, dim3(nprob), dim3(1024), 0, stream, partials, descs,
+                       st);
+    return hipGetLastError();
+}
+
 hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream)
 {
     hipLaunchKernelGGL(solve_state_kernel, dim3(1), dim3(64), 0, stream, st);

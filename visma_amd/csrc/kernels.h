@@ -97,6 +97,13 @@ struct GridParams {
 };
 constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;
 
+// One problem of a batch with its OWN clouds (offsets into concatenated arrays).
+struct ProbDesc {
+    long long src_off, sorted_off, start_off, out_off;
+    int ns, first_block, nblocks, pad_;
+    GridParams g;
+};
+
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
 GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells);
@@ -115,6 +122,15 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream);
+// Batch of problems with different clouds: `descs` (device) gives every problem's
+// offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
+hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
+                                       const ProbDesc *descs, int nprob, int total_blocks,
+                                       int32_t *idx_out, float *d2_out, double *partials,
+                                       int lanes_per_query, const DevIcpState *st,
+                                       hipStream_t stream);
+hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
+                                       int nprob, hipStream_t stream);
 
 // fill n float4 with +inf (target padding)
 hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);
