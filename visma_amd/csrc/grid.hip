@@ -343,9 +343,32 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             rb[k] = ok ? start[row + x0] : 0u;
             re[k] = ok ? start[row + x1 + 1] : 0u;
         }
+        // Visit the centre row first, then the 4 edge rows, then the 4 corner rows,
+        // and SKIP a row whose slab cannot contain a better candidate: every point
+        // of row (dy,dz) is at least delta = |(dist to the slab in y, in z)| away.
+        // Margins: 1e-3 cell on each slab distance (fp32 binning of query and
+        // candidates) and 1e-5 relative on the squared bound (fp32 d2 rounding), so
+        // a skipped candidate has d2 > best strictly -- it could neither win nor tie.
+        const float fy = (py - g.mn[1]) * g.inv_h - (float)cy;     // position inside the cell, [0,1)
+        const float fz = (pz - g.mn[2]) * g.inv_h - (float)cz;
+        const float lo_y = fmaxf(fy - 1e-3f, 0.f), hi_y = fmaxf(1.0f - fy - 1e-3f, 0.f);
+        const float lo_z = fmaxf(fz - 1e-3f, 0.f), hi_z = fmaxf(1.0f - fz - 1e-3f, 0.f);
+        const float h2 = g.h * g.h * (1.0f - 1e-5f);
+        constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int kk = 0; kk < 9; kk++) {
+            const int k = order[kk];
             const unsigned b = rb[k], e = re[k];
+            if (kk > 0) {
+                const int dz = k / 3 - 1, dy = k % 3 - 1;
+                const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
+                const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
+                // the group's current best bounds what any lane still needs
+                float gbest = best;
+#pragma unroll
+                for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
+                if ((ey * ey + ez * ez) * h2 > gbest) continue;
+            }
             if (sub == 0) ncand += e - b;
             // four candidates per lane in flight (the loads do not depend on each other)
             for (unsigned j = b + sub; j < e; j += 4 * G) {
