@@ -121,20 +121,25 @@ def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
     }
 
 
-def grid_roofline(ns_local, nt, nn_ms, cand_per_launch, traffic):
+def grid_roofline(ns_local, nt, nn_ms, cand_per_launch, cand27_per_launch, traffic):
     # ALGORITHMIC bytes of ONE grid launch on one rank: per query 16 B source +
     # 18 x 4 B cell-range lookups + 8 B (index, d2) out, plus 16 B per candidate
-    # target point examined (the candidate count is measured by the kernel).
+    # target point EXAMINED (counted by the kernel; rows of cells that provably
+    # cannot hold a better candidate are skipped, so this is less than the full
+    # 3x3x3 neighbourhood, whose byte count is given for reference).
     b_alg = ns_local * (16.0 + 72.0 + 8.0) + 16.0 * cand_per_launch
+    b_27 = ns_local * (16.0 + 72.0 + 8.0) + 16.0 * cand27_per_launch
     gbps = b_alg / (nn_ms * 1e-3) / 1e9
     return {
         "kernel": "nn_grid_reduce_kernel", "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
         "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
         "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_alg,
         "candidates_per_query": cand_per_launch / max(ns_local, 1),
+        "full_27cell": {"bytes_per_launch": b_27, "gbps": b_27 / (nn_ms * 1e-3) / 1e9,
+                        "candidates_per_query": cand27_per_launch / max(ns_local, 1)},
         "compulsory_bytes": nt * 16.0 + ns_local * 24.0,
-        "note": "fused transform + grid NN + Jacobian/residual reduction; algorithmic bytes = what "
-                "the queries request (neighbouring queries share cells, so HBM-side traffic is lower)",
+        "note": "fused transform + grid NN + Jacobian/residual reduction; memory-LATENCY-limited "
+                "(scattered 16-B loads, 3-4 dependent round trips per query), not bandwidth-limited",
     }
 
 
@@ -223,6 +228,7 @@ def main():
     tm = ctx.get_timing(reset=True)
     nn_ms = reduce_max(tm["nn_ms"] / max(tm["nn_launches"], 1))
     cand = tm["grid_candidates"] / max(tm["nn_launches"], 1)
+    cand27 = tm["grid_candidates_27cell"] / max(tm["nn_launches"], 1)
 
     # a few brute-force steps (outside the timed region) for the north_star kernel's own numbers
     brute = None
@@ -244,7 +250,7 @@ def main():
     if rank == 0:
         tile = _lib.tile_config()
         if mode == "grid":
-            roofline = grid_roofline(ns_local, nt, nn_ms, cand, load_traffic("grid", ns_local, nt))
+            roofline = grid_roofline(ns_local, nt, nn_ms, cand, cand27, load_traffic("grid", ns_local, nt))
         else:
             roofline = brute_roofline(ns_local, nt, nn_ms, tile, load_traffic("brute", ns_local, nt))
         roofline["launches"] = tm["nn_launches"]

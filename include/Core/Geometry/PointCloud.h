@@ -2,6 +2,7 @@
 // (shape of O3D/Core/Geometry/PointCloud.h:42-89: AoS f64 points/normals/colors).
 #pragma once
 #include <Eigen/Core>
+#include <memory>
 #include <vector>
 
 namespace open3d {
@@ -45,5 +46,9 @@ public:
     std::vector<Eigen::Vector3d> normals_;
     std::vector<Eigen::Vector3d> colors_;
 };
+
+/// Down-sample with a voxel grid (shape of O3D/Core/Geometry/PointCloud.h:101-105);
+/// implemented on the GPU in visma_icp_open3d.hpp.
+inline std::shared_ptr<PointCloud> VoxelDownSample(const PointCloud &input, double voxel_size);
 
 }  // namespace open3d

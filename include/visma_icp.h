@@ -91,6 +91,7 @@ typedef struct {
     double aux_ms;       /* grid build / refine / other kernels              */
     int64_t aux_launches;
     double grid_candidates; /* target points examined by the grid search (sum) */
+    double grid_candidates_27cell; /* ... points in the full 3x3x3 cell blocks (before row pruning) */
 } visma_icp_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */
@@ -262,6 +263,20 @@ VISMA_ICP_API int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduc
                                           void *user, int rank, int nranks);
 /* Total source points over all ranks (fitness denominator); 0 = local ns. */
 VISMA_ICP_API int visma_icp_set_global_source_count(visma_icp_ctx *ctx, int64_t ns_total);
+
+/* open3d::VoxelDownSample (O3D/Core/Geometry/DownSample.cpp:179-220), the step
+ * both callers run right before ICP (src/annotation.cpp:112,
+ * src/evaluation.cpp:258).  AoS f64 in (stride 3; normals / colors may be NULL),
+ * AoS f64 out (buffers of n rows).  Every output value is bit-identical to the
+ * reference's (same f64 voxel index expression, sums taken in input order); the
+ * ORDER of the voxels is ascending (ix,iy,iz) here, hash-map order there.
+ * voxel_size <= 0, or voxel_size * INT_MAX < extent, give *n_out = 0 like the
+ * reference. */
+VISMA_ICP_API int visma_icp_voxel_down_sample(visma_icp_ctx *ctx, const double *xyz, int64_t n,
+                                              const double *normals, const double *colors,
+                                              double voxel_size, double *out_xyz,
+                                              double *out_normals, double *out_colors,
+                                              int64_t *n_out);
 
 /* Device self-test of the SO(3) math the kernels are built on (restatement of
  * core/rodrigues.h:143-226 in visma_amd/csrc/so3.h): for n axis-angle vectors

@@ -345,8 +345,46 @@ inline Eigen::Matrix4d RegisterModelToScene(const PointCloud &model, const Point
     return best.transformation_;
 }
 
-// The registration call of feh::ICPRefinement (src/evaluation.cpp:258-271):
-// scene already down-sampled by the caller, source = sampled CAD models.
+// open3d::VoxelDownSample (O3D/Core/Geometry/DownSample.cpp:179-220) on the GPU:
+// same points / normals / colours, bit for bit; voxels come out in ascending
+// (ix,iy,iz) order instead of the reference's hash-map iteration order.
+inline std::shared_ptr<PointCloud> VoxelDownSample(const PointCloud &input, double voxel_size)
+{
+    auto output = std::make_shared<PointCloud>();
+    const int64_t n = (int64_t)input.points_.size();
+    if (voxel_size <= 0.0 || n == 0) return output;
+    visma_icp_ctx *ctx = detail::ThreadContext::instance().get();
+    const bool hn = input.HasNormals(), hc = input.HasColors();
+    output->points_.resize((size_t)n);
+    if (hn) output->normals_.resize((size_t)n);
+    if (hc) output->colors_.resize((size_t)n);
+    int64_t m = 0;
+    detail::check(ctx, visma_icp_voxel_down_sample(
+                           ctx, detail::xyz(input.points_), n, hn ? detail::xyz(input.normals_) : nullptr,
+                           hc ? detail::xyz(input.colors_) : nullptr, voxel_size,
+                           output->points_[0].data(), hn ? output->normals_[0].data() : nullptr,
+                           hc ? output->colors_[0].data() : nullptr, &m),
+                  "visma_icp_voxel_down_sample");
+    output->points_.resize((size_t)m);
+    if (hn) output->normals_.resize((size_t)m);
+    if (hc) output->colors_.resize((size_t)m);
+    return output;
+}
+
+// feh::ICPRefinement (src/evaluation.cpp:258-271) from the down-sampling on:
+// scene = VoxelDownSample(scene, voxel_size); RegistrationICP(scene_est, scene, ...).
+inline RegistrationResult ICPRefinement(const PointCloud &scene_raw, const PointCloud &scene_est,
+                                        const Eigen::Matrix4d &T_scene_src, double voxel_size,
+                                        double max_distance, bool use_point_to_plane)
+{
+    const std::shared_ptr<PointCloud> scene = cicp::VoxelDownSample(scene_raw, voxel_size);
+    if (use_point_to_plane)
+        return cicp::RegistrationICP(scene_est, *scene, max_distance, T_scene_src,
+                                     TransformationEstimationPointToPlane());
+    return cicp::RegistrationICP(scene_est, *scene, max_distance, T_scene_src);
+}
+
+// The registration call alone (scene already down-sampled by the caller).
 inline RegistrationResult ICPRefinement(const PointCloud &scene, const PointCloud &scene_est,
                                         const Eigen::Matrix4d &T_scene_src, double max_distance,
                                         bool use_point_to_plane)
@@ -400,6 +438,10 @@ inline Eigen::Matrix4d TransformationEstimationPointToPlane::ComputeTransformati
 {
     if (c.empty() || !t.HasNormals()) return Eigen::Matrix4d::Identity();
     return cicp::detail::host_update(s, t, c, true, false);
+}
+inline std::shared_ptr<PointCloud> VoxelDownSample(const PointCloud &input, double voxel_size)
+{
+    return cicp::VoxelDownSample(input, voxel_size);
 }
 inline RegistrationResult EvaluateRegistration(const PointCloud &source, const PointCloud &target,
                                                double max_correspondence_distance,

@@ -699,6 +699,70 @@ int vo_register_model_to_scene(const double *model, int64_t ns,
     return 0;
 }
 
+/* ---- O3D/Core/Geometry/DownSample.cpp:179-220 -------------------------- */
+typedef struct { int32_t v[3]; int64_t i; } vox_key;
+static int vox_cmp(const void *a, const void *b)
+{
+    const vox_key *x = (const vox_key *)a, *y = (const vox_key *)b;
+    for (int k = 0; k < 3; k++)
+        if (x->v[k] != y->v[k]) return x->v[k] < y->v[k] ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i ? 1 : 0);   /* input order inside a voxel */
+}
+
+int64_t vo_voxel_down_sample(const double *xyz, const double *normals, const double *colors,
+                             int64_t n, double voxel_size, double *out_xyz,
+                             double *out_normals, double *out_colors)
+{
+    if (voxel_size <= 0.0 || n <= 0) return 0;               /* :183-186 */
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; a++) { mn[a] = mx[a] = xyz[a]; }
+    for (int64_t i = 1; i < n; i++)
+        for (int a = 0; a < 3; a++) {
+            if (xyz[3 * i + a] < mn[a]) mn[a] = xyz[3 * i + a];
+            if (xyz[3 * i + a] > mx[a]) mx[a] = xyz[3 * i + a];
+        }
+    double vmin[3], ext = 0.0;
+    for (int a = 0; a < 3; a++) {                            /* :189-190 */
+        vmin[a] = mn[a] - voxel_size * 0.5;
+        double e = (mx[a] + voxel_size * 0.5) - vmin[a];
+        if (e > ext) ext = e;
+    }
+    if (voxel_size * 2147483647.0 < ext) return 0;           /* :191-195 */
+    vox_key *k = (vox_key *)malloc((size_t)n * sizeof(vox_key));
+    for (int64_t i = 0; i < n; i++) {                        /* :200-205 */
+        for (int a = 0; a < 3; a++)
+            k[i].v[a] = (int32_t)floor((xyz[3 * i + a] - vmin[a]) / voxel_size);
+        k[i].i = i;
+    }
+    qsort(k, (size_t)n, sizeof(vox_key), vox_cmp);
+    int64_t m = 0;
+    for (int64_t s = 0; s < n;) {
+        int64_t e = s;
+        double p[3] = {0, 0, 0}, nn[3] = {0, 0, 0}, c[3] = {0, 0, 0};
+        while (e < n && k[e].v[0] == k[s].v[0] && k[e].v[1] == k[s].v[1] && k[e].v[2] == k[s].v[2]) {
+            const int64_t i = k[e].i;                        /* AddPoint, :50-65 */
+            for (int a = 0; a < 3; a++) p[a] += xyz[3 * i + a];
+            if (normals && !isnan(normals[3 * i]) && !isnan(normals[3 * i + 1]) && !isnan(normals[3 * i + 2]))
+                for (int a = 0; a < 3; a++) nn[a] += normals[3 * i + a];
+            if (colors) for (int a = 0; a < 3; a++) c[a] += colors[3 * i + a];
+            e++;
+        }
+        const double cnt = (double)(e - s);
+        for (int a = 0; a < 3; a++) out_xyz[3 * m + a] = p[a] / cnt;           /* :67-70 */
+        if (normals && out_normals) {                                          /* :72-75 normalized() */
+            const double z = nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2];
+            const double inv = z > 0.0 ? 1.0 / sqrt(z) : 1.0;
+            for (int a = 0; a < 3; a++) out_normals[3 * m + a] = z > 0.0 ? nn[a] / sqrt(z) : nn[a];
+            (void)inv;
+        }
+        if (colors && out_colors) for (int a = 0; a < 3; a++) out_colors[3 * m + a] = c[a] / cnt;
+        m++;
+        s = e;
+    }
+    free(k);
+    return m;
+}
+
 /* ---- core/rodrigues.h ------------------------------------------------ */
 void vo_hat(const double u[3], double M[9]) /* rodrigues.h:8-15 */
 {

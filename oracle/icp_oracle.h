@@ -132,6 +132,17 @@ void vo_se3_act(const double R[9], const double t[3], const double v[3],
 void vo_se3_inv(const double R[9], const double t[3], double Ri[9],
                 double ti[3]);
 
+/* O3D/Core/Geometry/DownSample.cpp:179-220 (VoxelDownSample): voxel index
+ * floor((p - (min_bound - voxel/2)) / voxel) in f64, per-voxel mean of points /
+ * colours, normalised sum of the non-NaN normals, accumulation in input order.
+ * The reference emits voxels in std::unordered_map iteration order; here they
+ * come sorted by (ix, iy, iz).  normals / colors may be NULL.  Returns the number
+ * of voxels (0 for voxel_size <= 0 or voxel_size * INT_MAX < extent). Outputs
+ * must hold n rows. */
+int64_t vo_voxel_down_sample(const double *xyz, const double *normals, const double *colors,
+                             int64_t n, double voxel_size, double *out_xyz,
+                             double *out_normals, double *out_colors);
+
 /* 3x3 SVD helper (one-sided Jacobi), exposed for tests. A = U diag(s) V^T,
  * s descending, row-major. */
 void vo_svd3(const double A[9], double U[9], double s[3], double V[9]);

@@ -242,6 +242,10 @@ class Oracle:
         self.lib.vo_se3_inv(_ptr(R, _dp), _ptr(t, _dp), _ptr(Ri, _dp), _ptr(ti, _dp))
         return Ri.reshape(3, 3), ti
 
+    def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):
+        """Returns (points, normals, colors) sorted by voxel index (ix, iy, iz)."""
+        return _voxel(self.lib.vo_voxel_down_sample, xyz, voxel_size, normals, colors)
+
     def svd3(self, A):
         A = _f64(A, (9,)); U = np.empty(9); s = np.empty(3); V = np.empty(9)
         self.lib.vo_svd3(_ptr(A, _dp), _ptr(U, _dp), _ptr(s, _dp), _ptr(V, _dp))
@@ -298,6 +302,17 @@ class Oracle:
                          rel_rmse, with_scaling, grid, None)
 
 
+def _voxel(fn, xyz, voxel_size, normals, colors):
+    fn.restype = C.c_int64
+    p = _f64(xyz, (-1, 3)); n = len(p)
+    nn = None if normals is None else _f64(normals, (-1, 3))
+    cc = None if colors is None else _f64(colors, (-1, 3))
+    op = np.empty((max(n, 1), 3)); on = np.empty((max(n, 1), 3)); oc = np.empty((max(n, 1), 3))
+    m = fn(_ptr(p, _dp), _ptr(nn, _dp), _ptr(cc, _dp), C.c_int64(n), C.c_double(voxel_size),
+           _ptr(op, _dp), _ptr(on, _dp), _ptr(oc, _dp))
+    return (op[:m].copy(), None if nn is None else on[:m].copy(), None if cc is None else oc[:m].copy())
+
+
 class Ref:
     """The real reference (Open3D 0.3.0 RegistrationICP et al.), when built."""
 
@@ -347,6 +362,10 @@ class Ref:
         self.lib.ref_transform_points(_ptr(p, _dp), C.c_int64(len(p)), _ptr(n, _dp),
                                       _ptr(T, _dp))
         return (p, n) if normals is not None else p
+
+    def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):
+        """In the reference's own (hash-map) output order."""
+        return _voxel(self.lib.ref_voxel_down_sample, xyz, voxel_size, normals, colors)
 
     def nn_distance(self, src, tgt):
         src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))

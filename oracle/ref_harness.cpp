@@ -11,6 +11,7 @@
 //   O3D/Core/Registration/TransformationEstimation.cpp:35-103
 //   O3D/Core/Geometry/PointCloud.cpp:75-87,122-142
 //   O3D/Core/Utility/Eigen.cpp:58-68,88-106
+//   O3D/Core/Geometry/DownSample.cpp:179-220        VoxelDownSample
 //
 // NOTE on VISMA's own src/constrained_ICP.cpp: it includes "Core/Core.h",
 // which includes the CMake-GENERATED "../Open3DConfig.h"; that header does
@@ -141,6 +142,29 @@ void ref_transform_points(double *xyz, int64_t n, double *normals,
             xyz[3 * i + a] = p.points_[i](a);
             if (normals) normals[3 * i + a] = p.normals_[i](a);
         }
+}
+
+// O3D/Core/Geometry/DownSample.cpp:179-220, in the reference's own output order
+int64_t ref_voxel_down_sample(const double *xyz, const double *normals, const double *colors,
+                              int64_t n, double voxel_size, double *out_xyz, double *out_normals,
+                              double *out_colors)
+{
+    PointCloud p;
+    fill_cloud(p, xyz, n, normals);
+    if (colors) {
+        p.colors_.resize((size_t)n);
+        for (int64_t i = 0; i < n; i++)
+            p.colors_[i] = Eigen::Vector3d(colors[3 * i], colors[3 * i + 1], colors[3 * i + 2]);
+    }
+    std::shared_ptr<PointCloud> o = open3d::VoxelDownSample(p, voxel_size);
+    const int64_t m = (int64_t)o->points_.size();
+    for (int64_t i = 0; i < m; i++)
+        for (int a = 0; a < 3; a++) {
+            out_xyz[3 * i + a] = o->points_[i](a);
+            if (normals && out_normals) out_normals[3 * i + a] = o->normals_[i](a);
+            if (colors && out_colors) out_colors[3 * i + a] = o->colors_[i](a);
+        }
+    return m;
 }
 
 void ref_nn_distance(const double *src, int64_t ns, const double *tgt,

@@ -86,6 +86,9 @@ int main(int argc, char **argv)
             result.transformation_ = cicp::RegisterModelToScene(*model, *scene, level, radius, false, &best);
             result.fitness_ = best.fitness_; result.inlier_rmse_ = best.inlier_rmse_;
             result.correspondence_set_ = best.correspondence_set_;
+        } else if (mode == "refine") {      // src/evaluation.cpp:258-271: down-sample the scene, then ICP
+            result = cicp::ICPRefinement(*scene, *model, init, /*voxel*/ 0.05, radius, false);
+            extra = (double)open3d::VoxelDownSample(*scene, 0.05)->points_.size();
         } else if (mode == "evaluate") {
             result = open3d::EvaluateRegistration(*model, *scene, radius, init);
         } else if (mode == "estimator") {   // host-only: explicit correspondences, no GPU needed

@@ -109,9 +109,38 @@ def glibc_rand_points(n, lo=0.0, hi=1000.0):
     return out
 
 
+def gen_voxel(ref):
+    """VoxelDownSample outputs of the reference, rows sorted lexicographically
+    (the reference's own order is its hash map's iteration order)."""
+    a_xyz, a_n = load_pcd_xyz_normals(O3D_DATA + "/Feature/cloud_bin_0.pcd")
+    a_xyz = f32(a_xyz).astype(np.float64); a_n = f32(a_n).astype(np.float64)
+    rng = np.random.default_rng(61)
+    col = rng.random(a_xyz.shape)
+    a_n[7] = np.nan                       # a NaN normal must be skipped (DownSample.cpp:53-58)
+    out = dict(xyz=a_xyz, normals=a_n, colors=col)
+    for name, v in (("v005", 0.05), ("v02", 0.2), ("v1em4", 1e-4)):
+        p, n, c = ref.voxel_down_sample(a_xyz, v, a_n, col)
+        k = np.lexsort((p[:, 2], p[:, 1], p[:, 0]))
+        out[name + "_size"] = v
+        out[name + "_p"], out[name + "_n"], out[name + "_c"] = p[k], n[k], c[k]
+    # O3D/UnitTest/Core/Geometry/PointCloud.cpp:677-783: 20 random points, voxel 0.5
+    pts = glibc_rand_points(20)
+    out["ka_points"] = pts
+    out["ka_ref_first"] = np.array([352.458347, 807.724520, 919.026474])   # literal ref_points[0]
+    p, _, _ = ref.voxel_down_sample(pts, 0.5)
+    # the literal is one of the output voxels (each point sits alone in its voxel);
+    # WHERE it appears depends on the hash map of the C++ library in use
+    assert np.abs(p - out["ka_ref_first"]).max(1).min() < 1e-6
+    out["ka_out_sorted"] = p[np.lexsort((p[:, 2], p[:, 1], p[:, 0]))]
+    np.savez_compressed(os.path.join(HERE, "voxel.npz"), **out)
+    print("voxel fixture:", {k: v.shape for k, v in out.items() if k.endswith("_p")})
+
+
 def main():
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Ref()
+    if len(sys.argv) > 1 and sys.argv[1] == "voxel":
+        return gen_voxel(ref)
     V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
 
     # ---- C1/C2: chair CAD 5k samples -> 20k partial noisy scan ------------
@@ -306,6 +335,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "rodrigues.npz"), w=ws, R=np.array(Rs),
                         dR_dw=np.array(dRs), w_back=np.array(w2), dw_dR=np.array(dws),
                         hat=np.array(hats))
+    gen_voxel(ref)
     print("golden fixtures written to", HERE)
 
 

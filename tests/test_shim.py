@@ -119,3 +119,18 @@ def test_shim_point_to_plane_sweep_evaluate(bins, tmp_path):
                      g["tgt"].astype(np.float64), 0.05, init=g["evaluate_T"])
     assert rc == 0, err
     assert r["k"] == g["evaluate_frk"][2] and abs(r["rmse"] - g["evaluate_frk"][1]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_shim_icp_refinement_with_voxel_down_sample(bins, tmp_path):
+    """cicp::ICPRefinement = VoxelDownSample(scene, 0.05) + RegistrationICP (src/evaluation.cpp:258-271)."""
+    from oracle.oracle import Oracle
+    o = Oracle()
+    f = np.load(os.path.join(G, "fragments.npz"))
+    model, scene = f["src"].astype(np.float64), f["tgt"].astype(np.float64)
+    down = o.voxel_down_sample(scene, 0.05)[0]
+    want = o.registration_icp(model, down, 0.25, init=f["init"], max_iter=30)
+    rc, err, r = run(bins[0], "refine", tmp_path, model, scene, 0.25, init=f["init"])
+    assert rc == 0, err
+    assert int(r["extra"]) == len(down)
+    assert synth.rel_frobenius(r["T"], want.T) < 1e-5 and abs(r["k"] - want.k) <= 2

@@ -41,7 +41,7 @@ class CTiming(C.Structure):
     _fields_ = [("nn_ms", C.c_double), ("nn_launches", C.c_int64),
                 ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
                 ("aux_ms", C.c_double), ("aux_launches", C.c_int64),
-                ("grid_candidates", C.c_double)]
+                ("grid_candidates", C.c_double), ("grid_candidates_27cell", C.c_double)]
 
 
 class CProblem(C.Structure):
@@ -102,6 +102,8 @@ def load():
                                           C.POINTER(C.c_int), C.POINTER(CResult)]
     L.visma_icp_run_batch.argtypes = [C.c_void_p, C.POINTER(CProblem), C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.POINTER(CResult)]
+    L.visma_icp_voxel_down_sample.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _dp, C.c_double, _dp, _dp,
+                                              _dp, C.POINTER(C.c_int64)]
     L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -285,6 +287,19 @@ class Context:
         self._chk(self.L.visma_icp_run_batch(self._h, arr, n, int(max_iter), float(rel_fitness),
                                              float(rel_rmse), int(solver), out))
         return [Result(out[i]) for i in range(n)]
+
+    def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):
+        """open3d::VoxelDownSample on the GPU -> (points, normals, colors), voxels in ascending index order."""
+        p = _f64(xyz, (-1, 3)); n = len(p)
+        nn = None if normals is None else _f64(normals, (-1, 3))
+        cc = None if colors is None else _f64(colors, (-1, 3))
+        op = np.empty((max(n, 1), 3)); on = np.empty((max(n, 1), 3)); oc = np.empty((max(n, 1), 3))
+        m = C.c_int64(0)
+        self._chk(self.L.visma_icp_voxel_down_sample(
+            self._h, _p(p, _dp), n, None if nn is None else _p(nn, _dp), None if cc is None else _p(cc, _dp),
+            float(voxel_size), _p(op, _dp), _p(on, _dp), _p(oc, _dp), C.byref(m)))
+        m = m.value
+        return op[:m].copy(), (None if nn is None else on[:m].copy()), (None if cc is None else oc[:m].copy())
 
     # ---- options ----
     def set_nn_mode(self, mode):

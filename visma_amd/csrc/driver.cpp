@@ -186,11 +186,11 @@ public:
         HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * reduce_max_blocks()));
         partial_rows_ = (size_t)reduce_max_blocks();
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
-        HIP_TRY(hipMalloc(&d_cand_, sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d_cand_, 0, sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&d_cand_, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d_cand_, 0, 2 * sizeof(unsigned long long)));
         if (const char *e = std::getenv("VISMA_ICP_GRID_LANES")) {
             const int v = std::atoi(e);
-            if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32) grid_lanes_ = v;
+            if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
         }
         HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * (kNStats + 2),
                               hipHostMallocMapped | hipHostMallocCoherent));
@@ -695,16 +695,17 @@ public:
     void set_profiling(bool on) override { profiling_ = on; }
     void get_timing(visma_icp_timing *t, bool reset) override
     {
-        unsigned long long c = 0;
+        unsigned long long c[2] = {0, 0};
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(stream_);
         (void)collect_timing();
-        (void)hipMemcpy(&c, d_cand_, sizeof(c), hipMemcpyDeviceToHost);
-        timing_.grid_candidates = (double)c;
+        (void)hipMemcpy(c, d_cand_, sizeof(c), hipMemcpyDeviceToHost);
+        timing_.grid_candidates = (double)c[0];
+        timing_.grid_candidates_27cell = (double)c[1];
         *t = timing_;
         if (reset) {
             std::memset(&timing_, 0, sizeof(timing_));
-            (void)hipMemset(d_cand_, 0, sizeof(unsigned long long));
+            (void)hipMemset(d_cand_, 0, 2 * sizeof(unsigned long long));
         }
     }
     void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }
@@ -1633,6 +1634,24 @@ int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn, void 
     ctx->host_allreduce_user = user;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_voxel_down_sample(visma_icp_ctx *ctx, const double *xyz, int64_t n, const double *normals,
+                                const double *colors, double voxel_size, double *out_xyz,
+                                double *out_normals, double *out_colors, int64_t *n_out)
+{
+    CTX_CHECK();
+    if (!n_out || n < 0 || (n > 0 && (!xyz || !out_xyz)) || (normals && !out_normals) || (colors && !out_colors))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad voxel_down_sample arguments");
+    if (n > 0x7fffffff) return ctx->fail(VISMA_ICP_ERR_INVALID, "too many points for 32-bit indices");
+    if (!ctx->eng->supports_device_loop())   // only the HIP engine owns a GPU
+        return ctx->fail(VISMA_ICP_ERR_STATE, "voxel_down_sample needs the HIP engine");
+    int too_fine = 0;
+    hipError_t e = voxel_down_sample_device(xyz, normals, colors, n, voxel_size, out_xyz, out_normals,
+                                            out_colors, n_out, &too_fine, nullptr);
+    if (e != hipSuccess) return ctx->fail(VISMA_ICP_ERR_HIP, std::string("voxel_down_sample: ") + hipGetErrorString(e));
+    if (too_fine) return ctx->fail(VISMA_ICP_ERR_INVALID, "voxel grid too fine to key in 62 bits");
     return VISMA_ICP_OK;
 }
 

@@ -249,6 +249,19 @@ hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
     return hipGetLastError();
 }
 
+// generic exclusive scan of n u32 values (bsum: n/2048 + 2 entries of scratch); also
+// writes out[n] = total, so `out` needs n + 1 entries
+hipError_t launch_exclusive_scan_u32(const unsigned *in, long long n, unsigned *bsum, unsigned *out,
+                                     hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const int nb = (int)((n + kScanPerBlock - 1) / kScanPerBlock);
+    hipLaunchKernelGGL(scan_block_sum_kernel, dim3(nb), dim3(256), 0, stream, in, n, bsum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsum, nb);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(256), 0, stream, in, n, bsum, out);
+    return hipGetLastError();
+}
+
 int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) / kScanPerBlock); }
 
 // ------------------------------------------------------------------------
@@ -259,7 +272,7 @@ int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) /
 // G partial minima are merged with G-lane butterfly shuffles on the
 // (d2, original index) key, and lane 0 of the group accumulates the
 // correspondence's Jacobian/residual rows.
-template <bool PLANE, int G>
+template <bool PLANE, int G, int U>
 __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
-    unsigned ncand = 0;
+    unsigned ncand = 0, ncand_all = 0;
 
     const int sub = threadIdx.x % G;                       // lane within the query group
     const int groups_per_block = kBlock / G;
@@ -359,6 +372,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         for (int kk = 0; kk < 9; kk++) {
             const int k = order[kk];
             const unsigned b = rb[k], e = re[k];
+            if (sub == 0) ncand_all += e - b;
             if (kk > 0) {
                 const int dz = k / 3 - 1, dy = k % 3 - 1;
                 const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
@@ -370,16 +384,16 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 if ((ey * ey + ez * ez) * h2 > gbest) continue;
             }
             if (sub == 0) ncand += e - b;
-            // four candidates per lane in flight (the loads do not depend on each other)
-            for (unsigned j = b + sub; j < e; j += 4 * G) {
-                float4 q[4];
+            // U candidates per lane in flight (the loads do not depend on each other)
+            for (unsigned j = b + sub; j < e; j += U * G) {
+                float4 q[U];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     const unsigned ju = j + u * G;
                     q[u] = sorted[ju < e ? ju : j];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < U; u++) {
                     if (j + u * G < e) {
                         const float d = sqdist_f32(q[u], px, py, pz);
                         const unsigned id = __float_as_uint(q[u].w);
@@ -416,15 +430,21 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         }
     }
     block_reduce_store<NACC>(acc, partials);
-    if (cand_count) {
-        unsigned long long c = ncand;
+    if (cand_count) {   // [0] = candidates examined, [1] = candidates in the full 27-cell blocks
+        unsigned long long c = ncand, ca = ncand_all;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-        if ((threadIdx.x & 63) == 0 && c) atomicAdd(cand_count, c);
+        for (int o = 32; o > 0; o >>= 1) {
+            c += __shfl_down(c, o, 64);
+            ca += __shfl_down(ca, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0 && ca) {
+            atomicAdd(cand_count, c);
+            atomicAdd(cand_count + 1, ca);
+        }
     }
 }
 
-template <bool PLANE, int G>
+template <bool PLANE, int G, int U>
 static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, int ns,
                           const float4 *sorted, const unsigned *start, const GridParams &g,
                           const float4 *nrm, const Xform32 &T32, const Xform64 &T64,
@@ -432,7 +452,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           double *partials, unsigned long long *cand, const DevIcpState *st,
                           int nprob, long long out_stride)
 {
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G>), dim3(nblocks * nprob), dim3(kBlock), 0,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U>), dim3(nblocks * nprob), dim3(kBlock), 0,
                        stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
                        partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
 }
@@ -448,31 +468,29 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
-    const int G = lanes_per_query;
+    const int G = lanes_per_query % 100;
+    int U = lanes_per_query / 100;
+    if (U == 0) U = (G >= 8) ? 2 : 4;
     int64_t want = (ns * G + kBlock - 1) / kBlock;
     int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
     if (nblocks < 1) nblocks = 1;
-#define VISMA_GRID_CASE(GG)                                                                        \
-    case GG:                                                                                       \
+#define VISMA_GRID_CASE(GG, UU)                                                                    \
+    if (G == GG && U == UU) {                                                                      \
         if (point_to_plane)                                                                        \
-            launch_grid_t<true, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals,  \
-                                    T32, T64, off, r2f, idx_out, d2_out, partials, cand_count, \
-                                    st, nprob, (long long)out_stride);                     \
+            launch_grid_t<true, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,           \
+                                        tgt_normals, T32, T64, off, r2f, idx_out, d2_out,          \
+                                        partials, cand_count, st, nprob, (long long)out_stride);   \
         else                                                                                       \
-            launch_grid_t<false, GG>(nblocks, stream, src, (int)ns, sorted, start, g, tgt_normals, \
-                                     T32, T64, off, r2f, idx_out, d2_out, partials, cand_count, \
-                                     st, nprob, (long long)out_stride);                    \
-        break;
-    switch (G) {
-        VISMA_GRID_CASE(1)
-        VISMA_GRID_CASE(2)
-        VISMA_GRID_CASE(4)
-        VISMA_GRID_CASE(8)
-        VISMA_GRID_CASE(16)
-        VISMA_GRID_CASE(32)
-    default:
-        return hipErrorInvalidValue;
+            launch_grid_t<false, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,          \
+                                         tgt_normals, T32, T64, off, r2f, idx_out, d2_out,         \
+                                         partials, cand_count, st, nprob, (long long)out_stride);  \
+        launched = true;                                                                           \
     }
+    bool launched = false;
+    VISMA_GRID_CASE(1, 4) VISMA_GRID_CASE(2, 4) VISMA_GRID_CASE(4, 4) VISMA_GRID_CASE(4, 2)
+    VISMA_GRID_CASE(8, 4) VISMA_GRID_CASE(8, 2) VISMA_GRID_CASE(8, 1) VISMA_GRID_CASE(16, 2)
+    VISMA_GRID_CASE(16, 1) VISMA_GRID_CASE(32, 1) VISMA_GRID_CASE(2, 2)
+    if (!launched) return hipErrorInvalidValue;
 #undef VISMA_GRID_CASE
     if (nblocks_out) *nblocks_out = nblocks;
     return hipGetLastError();
@@ -488,7 +506,7 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
     const Xform64 T64{};
     const Offset64 off{};
     const GridParams g{};
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G>), dim3(total_blocks), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, 2>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
                        d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob);
 }

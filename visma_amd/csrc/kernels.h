@@ -108,6 +108,12 @@ hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipSt
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
 GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells);
 int grid_scan_blocks(int64_t ncell);
+
+// ---- voxel down-sampling (voxel.hip): host arrays in, host arrays out ---------
+hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, const double *h_col,
+                                    int64_t n, double voxel, double *h_out_xyz, double *h_out_nrm,
+                                    double *h_out_col, int64_t *n_out, int *too_fine,
+                                    hipStream_t stream);
 // counting sort of the target by cell: start[ncell+1], sorted[nt] = (x,y,z, bits(orig index))
 hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
                              unsigned *cell_of, unsigned *count, unsigned *bsum,
