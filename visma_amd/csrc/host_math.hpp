@@ -94,7 +94,10 @@ VISMA_HD Svd3 svd3(const double A[9])
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) G[i][j] = A[i * 3 + j];
     const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-    for (int sweep = 0; sweep < 64; sweep++) {
+    // Convergence: every column pair orthogonal to 2 ulp (|g| <= 4.4e-16 sqrt(ab)).
+    // A tighter bound only burns sweeps (each rotation is ~1.5 us of dependent f64
+    // div/sqrt when this runs in a one-thread GPU epilogue) without changing R.
+    for (int sweep = 0; sweep < 30; sweep++) {
         bool any = false;
         for (int pi = 0; pi < 3; pi++) {
             const int p = pairs[pi][0], q = pairs[pi][1];
@@ -104,11 +107,11 @@ VISMA_HD Svd3 svd3(const double A[9])
                 b += G[r][q] * G[r][q];
                 g += G[r][p] * G[r][q];
             }
-            if (g == 0.0 || fabs(g) <= 1e-17 * sqrt(a * b)) continue;
+            if (g == 0.0 || g * g <= 1.9e-31 * (a * b)) continue;
             any = true;
             const double zeta = (b - a) / (2.0 * g);
-            const double t = copysign(1.0, zeta) / (fabs(zeta) + hypot(1.0, zeta));
-            const double c = 1.0 / hypot(1.0, t), s = c * t;
+            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
             for (int r = 0; r < 3; r++) {
                 const double gp = G[r][p], gq = G[r][q];
                 G[r][p] = c * gp - s * gq;
