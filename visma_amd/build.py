@@ -33,7 +33,7 @@ def build_lib(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
-           "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH, "-ldl"]
+           "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH, "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_math.hpp"
@@ -1072,6 +1073,28 @@ void pack_f32(const float *xyz, int64_t n, int stride, std::vector<float> &out)
     }
 }
 
+// Run fn(i) for i in [0, n) on a few host threads (packing / ordering of clouds).
+template <typename F>
+void parallel_for(int64_t n, int64_t min_per_thread, F fn)
+{
+    int64_t nt = (int64_t)std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
+    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<int64_t> next(0);
+    for (int64_t t = 0; t < nt; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
 // Spatial (Morton / Z-order) permutation of packed xyzw points.  Neighbouring
 // lanes then query neighbouring grid cells, so a wave's candidate runs overlap
 // in L1/L2.  Returns order[pos] = original index and permutes `pts` in place.
@@ -1486,34 +1509,38 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
         // one NN launch + one fold/solve launch per pass for the whole batch
         std::vector<std::vector<float>> sbuf((size_t)n), tbuf((size_t)n);
         std::vector<Engine::BatchProblem> pb((size_t)n);
-        std::vector<int32_t> order;
         bool ok = true;
-        for (int i = 0; i < n && ok; i++) {
+        for (int i = 0; i < n; i++) {
             const visma_icp_problem &q = probs[i];
             if (q.ns < 0 || q.nt < 0 || (q.ns > 0 && !q.src_xyz) || (q.nt > 0 && !q.tgt_xyz))
                 return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch problem");
-            if (!(q.max_dist > 0.0)) { ok = false; break; }   // rare: handled by the sequential path
-            double c[3] = {0, 0, 0};
-            for (int64_t j = 0; j < q.nt; j++)
-                for (int a = 0; a < 3; a++) c[a] += q.tgt_xyz[(size_t)j * 3 + a];
-            if (q.nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)q.nt;
-            pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
-            pack_f64(q.src_xyz, q.ns, 3, c, sbuf[i]);
-            morton_order(sbuf[i], q.ns, order);
-            Engine::BatchProblem &b = pb[i];
-            b.src_xyzw = sbuf[i].data(); b.ns = q.ns;
-            b.tgt_xyzw = tbuf[i].data(); b.nt = q.nt;
-            b.Tc0 = to_centred(Mat4::from(q.init), c);
-            std::memcpy(b.centre, c, sizeof(c));
-            b.max_dist = q.max_dist;
-            for (int a = 0; a < 3; a++) { b.bb_min[a] = 0.f; b.bb_max[a] = 0.f; }
-            for (int64_t j = 0; j < q.nt; j++)
-                for (int a = 0; a < 3; a++) {
-                    const float v = tbuf[i][4 * j + a];
-                    if (j == 0 || v < b.bb_min[a]) b.bb_min[a] = v;
-                    if (j == 0 || v > b.bb_max[a]) b.bb_max[a] = v;
-                }
+            if (!(q.max_dist > 0.0)) ok = false;   // rare: handled by the sequential path
         }
+        if (ok)
+            parallel_for(n, 1, [&](int64_t i) {
+                const visma_icp_problem &q = probs[i];
+                double c[3] = {0, 0, 0};
+                for (int64_t j = 0; j < q.nt; j++)
+                    for (int a = 0; a < 3; a++) c[a] += q.tgt_xyz[(size_t)j * 3 + a];
+                if (q.nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)q.nt;
+                pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
+                pack_f64(q.src_xyz, q.ns, 3, c, sbuf[i]);
+                std::vector<int32_t> order;
+                morton_order(sbuf[i], q.ns, order);
+                Engine::BatchProblem &b = pb[i];
+                b.src_xyzw = sbuf[i].data(); b.ns = q.ns;
+                b.tgt_xyzw = tbuf[i].data(); b.nt = q.nt;
+                b.Tc0 = to_centred(Mat4::from(q.init), c);
+                std::memcpy(b.centre, c, sizeof(c));
+                b.max_dist = q.max_dist;
+                for (int a = 0; a < 3; a++) { b.bb_min[a] = 0.f; b.bb_max[a] = 0.f; }
+                for (int64_t j = 0; j < q.nt; j++)
+                    for (int a = 0; a < 3; a++) {
+                        const float v = tbuf[i][4 * j + a];
+                        if (j == 0 || v < b.bb_min[a]) b.bb_min[a] = v;
+                        if (j == 0 || v > b.bb_max[a]) b.bb_max[a] = v;
+                    }
+            });
         if (ok) {
             Engine::LoopParams lp;
             lp.Tc0 = Mat4::identity();
