@@ -187,8 +187,8 @@ public:
         HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * reduce_max_blocks()));
         partial_rows_ = (size_t)reduce_max_blocks();
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
-        HIP_TRY(hipMalloc(&d_cand_, 2 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d_cand_, 0, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&d_cand_, 2 * 4096 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long)));
         if (const char *e = std::getenv("VISMA_ICP_GRID_LANES")) {
             const int v = std::atoi(e);
             if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
@@ -696,17 +696,19 @@ public:
     void set_profiling(bool on) override { profiling_ = on; }
     void get_timing(visma_icp_timing *t, bool reset) override
     {
-        unsigned long long c[2] = {0, 0};
+        std::vector<unsigned long long> slots(2 * 4096, 0ull);
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(stream_);
         (void)collect_timing();
-        (void)hipMemcpy(c, d_cand_, sizeof(c), hipMemcpyDeviceToHost);
-        timing_.grid_candidates = (double)c[0];
-        timing_.grid_candidates_27cell = (double)c[1];
+        (void)hipMemcpy(slots.data(), d_cand_, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        double c[2] = {0.0, 0.0};
+        for (size_t i = 0; i < slots.size(); i += 2) { c[0] += (double)slots[i]; c[1] += (double)slots[i + 1]; }
+        timing_.grid_candidates = c[0];
+        timing_.grid_candidates_27cell = c[1];
         *t = timing_;
         if (reset) {
             std::memset(&timing_, 0, sizeof(timing_));
-            (void)hipMemset(d_cand_, 0, 2 * sizeof(unsigned long long));
+            (void)hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long));
         }
     }
     void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }

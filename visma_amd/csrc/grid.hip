@@ -430,7 +430,10 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         }
     }
     block_reduce_store<NACC>(acc, partials);
-    if (cand_count) {   // [0] = candidates examined, [1] = candidates in the full 27-cell blocks
+    if (cand_count) {
+        // profiling only: candidates examined / candidates in the full 27-cell blocks.
+        // One slot pair per workgroup (mod 4096) -- thousands of atomics on ONE address
+        // cost ~40 us per launch and used to distort the very time being measured.
         unsigned long long c = ncand, ca = ncand_all;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -438,8 +441,9 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             ca += __shfl_down(ca, o, 64);
         }
         if ((threadIdx.x & 63) == 0 && ca) {
-            atomicAdd(cand_count, c);
-            atomicAdd(cand_count + 1, ca);
+            unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
+            atomicAdd(slot, c);
+            atomicAdd(slot + 1, ca);
         }
     }
 }
