@@ -297,6 +297,9 @@ public:
         Xform64 T64;
         for (int i = 0; i < 12; i++) T64.m[i] = Tc.m[i];
         int e0 = -1;
+        // without RCCL the fold kernel publishes to mapped host memory itself
+        const unsigned long long seq = ++pub_seq_;
+        double *pub = comm_ ? nullptr : h_stats_dev_;
         if (use_grid_) {
             int nblocks = 1;
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -310,7 +313,7 @@ public:
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
             HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
-                                    (double *)d_stats_, stream_));
+                                    (double *)d_stats_, stream_, pub, seq));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             grid_pending_ = false;
         } else {
@@ -319,7 +322,7 @@ public:
                                   (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                   plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
                                   (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_));
+                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_, pub, seq));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             brute_reduced_ = true;
         }
@@ -333,8 +336,7 @@ public:
         }
         // publish to mapped host memory and spin on the sequence word (no DMA
         // packet, no interrupt wake-up: ~10 us less per iteration than memcpy+sync)
-        const unsigned long long seq = ++pub_seq_;
-        HIP_TRY(launch_publish_stats((const double *)d_stats_, h_stats_dev_, seq, stream_));
+        if (comm_) HIP_TRY(launch_publish_stats((const double *)d_stats_, h_stats_dev_, seq, stream_));
         volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(h_stats_ + kNStats);
         bool seen = false;
         for (long long spin = 0; spin < 400000000ll; ++spin) {
@@ -873,7 +875,8 @@ private:
     {
         if (grid_lanes_ > 0) return grid_lanes_;
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
-        return ns_ <= 16384 ? 8 : (ns_ <= 131072 ? 4 : 2);
+        // (lanes per query, loads in flight per lane), encoded G + 100*U
+        return ns_ <= 16384 ? 408 : (ns_ <= 131072 ? 404 : 402);
     }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
 };

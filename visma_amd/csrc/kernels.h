@@ -67,7 +67,8 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          int point_to_plane,
                          int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out, const DevIcpState *st,
-                         int *nblocks_out, hipStream_t stream);
+                         int *nblocks_out, hipStream_t stream, double *host_out = nullptr,
+                         unsigned long long seq = 0);
 
 int reduce_max_blocks();
 // stats (device) -> host_out[0..37] (mapped host memory), then host_out[38] = seq (u64 bits)
@@ -75,8 +76,11 @@ hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned 
                                 hipStream_t stream);
 
 // Fold `nblocks` partial rows into the 38 statistics (one workgroup, fixed order).
+// host_out (mapped host memory, may be NULL): also publish the 38 statistics there
+// and then raise host_out[38] = seq (u64 bits) -- see launch_publish_stats.
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
-                           double *stats_out, hipStream_t stream);
+                           double *stats_out, hipStream_t stream, double *host_out = nullptr,
+                           unsigned long long seq = 0);
 // On-device loop (icp_loop.hip): fold + solve + stop test, no host round trip.
 //  launch_finalize_solve : single GPU (fold partials, then advance the state)
 //  launch_finalize_state : fold partials into st->stats only (an all-reduce follows)

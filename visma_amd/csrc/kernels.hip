@@ -237,9 +237,17 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
 template <bool PLANE>
 __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ partials,
                                                         int nblocks,
-                                                        double *__restrict__ stats)
+                                                        double *__restrict__ stats,
+                                                        double *host_out, unsigned long long seq)
 {
     fold_partials<PLANE>(partials, nblocks, stats);
+    // optional: publish straight to mapped host memory (saves the publish launch);
+    // thread 0 wrote stats[] itself, so program order + a system fence suffice
+    if (host_out && threadIdx.x == 0) {
+        for (int i = 0; i < kNStats; i++) host_out[i] = stats[i];
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(host_out + kNStats) = seq;
+    }
 }
 
 // Copy the statistics into host-visible (mapped, coherent) memory and then raise
@@ -267,14 +275,15 @@ hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned 
 int reduce_max_blocks() { return 1024; }
 
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
-                           double *stats_out, hipStream_t stream)
+                           double *stats_out, hipStream_t stream, double *host_out,
+                           unsigned long long seq)
 {
     if (point_to_plane)
         hipLaunchKernelGGL(finalize_kernel<true>, dim3(1), dim3(1024), 0, stream, partials,
-                           nblocks, stats_out);
+                           nblocks, stats_out, host_out, seq);
     else
         hipLaunchKernelGGL(finalize_kernel<false>, dim3(1), dim3(1024), 0, stream, partials,
-                           nblocks, stats_out);
+                           nblocks, stats_out, host_out, seq);
     return hipGetLastError();
 }
 
@@ -284,7 +293,8 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const Xform64 &T64, const double frame_offset[3], float r2f,
                          int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out, const DevIcpState *st,
-                         int *nblocks_out, hipStream_t stream)
+                         int *nblocks_out, hipStream_t stream, double *host_out,
+                         unsigned long long seq)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
@@ -303,7 +313,7 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
     if (e != hipSuccess) return e;
     if (nblocks_out) *nblocks_out = nblocks;
     if (!stats_out) return hipSuccess;   // the caller folds the partial rows itself
-    return launch_finalize(partials, nblocks, point_to_plane, stats_out, stream);
+    return launch_finalize(partials, nblocks, point_to_plane, stats_out, stream, host_out, seq);
 }
 
 // ------------------------------------------------------------------------
