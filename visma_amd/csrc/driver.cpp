@@ -193,9 +193,9 @@ public:
             const int v = std::atoi(e);
             if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
         }
-        HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * (kNStats + 2),
+        HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * 2 * kNStats,     // {value, tag} granules
                               hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(h_stats_, 0, sizeof(double) * (kNStats + 2));
+        std::memset(h_stats_, 0, sizeof(double) * 2 * kNStats);
         HIP_TRY(hipHostGetDevicePointer((void **)&h_stats_dev_, h_stats_, 0));
         inited_ = true;
         return VISMA_ICP_OK;
@@ -337,21 +337,30 @@ public:
         // publish to mapped host memory and spin on the sequence word (no DMA
         // packet, no interrupt wake-up: ~10 us less per iteration than memcpy+sync)
         if (comm_) HIP_TRY(launch_publish_stats((const double *)d_stats_, h_stats_dev_, seq, stream_));
-        volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(h_stats_ + kNStats);
+        // every granule carries the sequence number it was written for
+        volatile unsigned long long *g = reinterpret_cast<volatile unsigned long long *>(h_stats_);
+        auto all_tagged = [&]() {
+            for (int i = kNStats - 1; i >= 0; --i)
+                if (g[2 * i + 1] != seq) return false;
+            return true;
+        };
         bool seen = false;
         for (long long spin = 0; spin < 400000000ll; ++spin) {
-            if (*flag == seq) { seen = true; break; }
+            if (all_tagged()) { seen = true; break; }
             if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(stream_) != hipErrorNotReady) {
-                seen = (*flag == seq);
+                seen = all_tagged();
                 break;
             }
         }
         if (!seen) {
             HIP_TRY(hipStreamSynchronize(stream_));   // surfaces a kernel fault, if any
-            if (*flag != seq) { err_ = "statistics were not published"; return VISMA_ICP_ERR_HIP; }
+            if (!all_tagged()) { err_ = "statistics were not published"; return VISMA_ICP_ERR_HIP; }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-        std::memcpy(stats, h_stats_, sizeof(double) * kNStats);
+        for (int i = 0; i < kNStats; i++) {
+            const unsigned long long v = g[2 * i];
+            std::memcpy(&stats[i], &v, sizeof(double));
+        }
         return maybe_collect_timing();
     }
 
