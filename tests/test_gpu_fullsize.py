@@ -1,0 +1,93 @@
+"""GPU: size-independent properties at BASELINE.json's full size (C4:
+262,144-point source -> 4,194,304-point target), where the CPU oracle is too
+slow to be the checker for every pass."""
+import time
+
+import numpy as np
+import pytest
+
+from visma_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+NS, NT = 262144, 4194304
+
+
+@pytest.fixture(scope="module")
+def c4():
+    return synth.make_pair(NS, NT, motion="radius")
+
+
+def test_c4_statistics_are_additive_over_source_shards(gpu_ctx_auto, c4):
+    """The reduction is a sum over correspondences: the statistics of the whole
+    source equal the sum over disjoint shards (this is what the multi-GPU
+    all-reduce relies on), and K never exceeds NS."""
+    ctx = gpu_ctx_auto
+    src, tgt, T_gt, r = c4
+    ctx.set_clouds_f64(src, tgt)
+    ctx.nn_pass(np.eye(4), r)
+    whole = ctx.reduce()
+    idx_whole = ctx.correspondence_index()
+    parts = np.zeros(38)
+    idx_parts = []
+    for lo, hi in ((0, 100000), (100000, 100001), (100001, NS)):
+        ctx.set_clouds_f64(src[lo:hi], tgt)
+        ctx.nn_pass(np.eye(4), r)
+        parts += ctx.reduce()
+        idx_parts.append(ctx.correspondence_index())
+    assert whole[0] == parts[0] <= NS
+    assert np.array_equal(idx_whole, np.concatenate(idx_parts))       # per-point results do not depend on the shard
+    assert np.max(np.abs(whole - parts) / np.maximum(np.abs(whole), 1.0)) < 1e-10
+
+
+def test_c4_known_answer_round_trip(gpu_ctx_auto, c4):
+    """source = T^-1 applied to a subset of the target: every correspondence must be
+    the point itself (d2 ~ 0) once T is applied, and ICP started nearby recovers T."""
+    ctx = gpu_ctx_auto
+    _, tgt, _, r = c4
+    rng = np.random.default_rng(12)
+    pick = np.sort(rng.choice(NT, NS, replace=False))
+    T = synth.T_gt_scaled(r)
+    Ti = np.linalg.inv(T)
+    src = tgt[pick] @ Ti[:3, :3].T + Ti[:3, 3]
+    ctx.set_clouds_f64(src, tgt)
+    ctx.nn_pass(T, r)
+    st = ctx.reduce()
+    si, ti, d2 = ctx.get_correspondences()
+    assert len(si) == NS == int(st[0])
+    assert np.mean(ti == pick) > 0.9999                                # its own image (up to exact duplicates)
+    assert np.sqrt(d2.max()) < 5e-6                                    # fp32 rounding of ~1 m coordinates
+    res = ctx.run(None, r, 30, 0.0, 0.0)
+    assert synth.rel_frobenius(res.transformation_, T) < 1e-6
+    assert res.fitness_ == 1.0 and res.inlier_rmse_ < 5e-6
+
+
+def test_c4_brute_force_and_grid_agree_bit_for_bit(lib, gpu_ctx_auto, c4):
+    ctx = gpu_ctx_auto
+    src, tgt, T_gt, r = c4
+    ctx.set_clouds_f64(src, tgt)
+    T0 = synth.make_T(synth.rot_y(0.3 * r), [0.2 * r, 0, -0.1 * r])
+    out = {}
+    for name, mode in (("grid", lib.NN_GRID), ("brute", lib.NN_BRUTE)):
+        ctx.set_nn_mode(mode)
+        t0 = time.time()
+        ctx.nn_pass(T0, r)
+        st = ctx.reduce()
+        out[name] = (ctx.correspondence_index(), ctx.get_correspondences()[2], st, time.time() - t0)
+    ctx.set_nn_mode(lib.NN_AUTO)
+    assert np.array_equal(out["grid"][0], out["brute"][0])
+    assert np.array_equal(out["grid"][1].view(np.uint32), out["brute"][1].view(np.uint32))
+    g, b = out["grid"][2], out["brute"][2]
+    assert np.max(np.abs(g - b) / np.maximum(np.abs(b), 1.0)) < 1e-10
+
+
+def test_c4_idempotent_at_the_fixed_point(gpu_ctx_auto, c4):
+    """Running ICP again from its own converged answer changes nothing measurable."""
+    ctx = gpu_ctx_auto
+    src, tgt, T_gt, r = c4
+    ctx.set_clouds_f64(src, tgt)
+    a = ctx.run(None, r, 60, 1e-9, 1e-9)
+    b = ctx.run(a.transformation_, r, 5, 0.0, 0.0)
+    assert synth.rel_frobenius(b.transformation_, a.transformation_) < 1e-6
+    assert abs(b.num_correspondences - a.num_correspondences) <= 0.0002 * NS
+    assert synth.rel_frobenius(a.transformation_, T_gt) < 2e-3          # noise-limited
