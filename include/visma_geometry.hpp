@@ -1,0 +1,127 @@
+// visma_geometry.hpp -- GPU versions of the mesh steps either side of ICP, with
+// the names and argument meaning of the reference's include/geometry.h:
+//
+//   feh::gpu::SamplePointCloudFromMesh   geometry.h:29-64
+//   feh::gpu::ComputeErrorMetric         geometry.h:85-101 (host)
+//   feh::gpu::MeasureSurfaceError        geometry.h:117-141
+//
+// Header-only over the C ABI in visma_icp.h; works with either Eigen storage
+// order (VISMA compiles with -DEIGEN_DEFAULT_TO_ROW_MAJOR, CMakeLists.txt:11-12).
+// They live in feh::gpu so that the reference's own geometry.h can stay on the
+// include path; `using namespace feh::gpu;` (or s/feh::/feh::gpu::/ at the three
+// call sites, src/evaluation.cpp:252,320 and src/annotation.cpp:126) switches over.
+//
+// Differences to know about:
+//  * the reference seeds std::knuth_b from the wall clock; here the stream is a
+//    counter-based Philox4x32-10 keyed by `seed` (reproducible);
+//  * SamplingMode::Reference reproduces the reference's mapping from uniforms to
+//    points (one face late, parallelogram instead of triangle -- about half of
+//    the points lie off the surface -- and no point when r < cdf[0]);
+//    SamplingMode::Surface (default) samples the surface itself, which is what
+//    the function's doc comment promises;
+//  * errors throw std::runtime_error; there is no CPU fallback.
+#pragma once
+#include <Eigen/Core>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "visma_icp.h"
+#include "visma_icp_open3d.hpp"
+
+namespace feh {
+namespace gpu {
+
+enum class SamplingMode { Surface = 0, Reference = 1 };
+
+template <typename T>
+struct GenericErrorMetric {
+    T mean_, std_, median_, min_, max_;
+};
+
+namespace detail {
+template <typename M>
+inline std::vector<double> rows3(const M &m)
+{
+    std::vector<double> o((size_t)m.rows() * 3);
+    for (Eigen::Index i = 0; i < m.rows(); ++i)
+        for (int c = 0; c < 3; ++c) o[(size_t)i * 3 + c] = (double)m(i, c);
+    return o;
+}
+template <typename M>
+inline std::vector<int32_t> faces3(const M &m)
+{
+    std::vector<int32_t> o((size_t)m.rows() * 3);
+    for (Eigen::Index i = 0; i < m.rows(); ++i)
+        for (int c = 0; c < 3; ++c) o[(size_t)i * 3 + c] = (int32_t)m(i, c);
+    return o;
+}
+inline visma_icp_ctx *ctx() { return open3d::cicp::detail::ThreadContext::instance().get(); }
+}  // namespace detail
+
+template <typename T>
+std::vector<Eigen::Matrix<T, 3, 1>> SamplePointCloudFromMesh(const Eigen::Matrix<T, Eigen::Dynamic, 3> &V,
+                                                             const Eigen::Matrix<int, Eigen::Dynamic, 3> &F,
+                                                             int max_num_pts = 1000,
+                                                             SamplingMode mode = SamplingMode::Surface,
+                                                             uint64_t seed = 0)
+{
+    std::vector<Eigen::Matrix<T, 3, 1>> out;
+    if (max_num_pts <= 0 || F.rows() == 0) return out;
+    const std::vector<double> v = detail::rows3(V);
+    const std::vector<int32_t> f = detail::faces3(F);
+    std::vector<double> p((size_t)max_num_pts * 3);
+    int64_t m = 0;
+    visma_icp_ctx *c = detail::ctx();
+    open3d::cicp::detail::check(c, visma_icp_sample_mesh(c, v.data(), V.rows(), f.data(), F.rows(), max_num_pts,
+                                                         mode == SamplingMode::Reference, seed, nullptr, p.data(), &m),
+                                "visma_icp_sample_mesh");
+    out.resize((size_t)m);
+    for (int64_t i = 0; i < m; ++i)
+        out[(size_t)i] = Eigen::Matrix<T, 3, 1>((T)p[3 * i], (T)p[3 * i + 1], (T)p[3 * i + 2]);
+    return out;
+}
+
+template <typename T>
+GenericErrorMetric<T> ComputeErrorMetric(std::vector<T> errors)
+{
+    std::vector<double> e(errors.begin(), errors.end());
+    double o[5];
+    if (visma_icp_error_metric(e.data(), (int64_t)e.size(), o) != VISMA_ICP_OK)
+        throw std::runtime_error("visma_icp_error_metric: invalid arguments");
+    return GenericErrorMetric<T>{(T)o[0], (T)o[1], (T)o[2], (T)o[3], (T)o[4]};
+}
+
+template <typename T>
+GenericErrorMetric<T> MeasureSurfaceError(const Eigen::Matrix<T, Eigen::Dynamic, 3> &Vs,
+                                          const Eigen::Matrix<int, Eigen::Dynamic, 3> &Fs,
+                                          const Eigen::Matrix<T, Eigen::Dynamic, 3> &Vt,
+                                          const Eigen::Matrix<int, Eigen::Dynamic, 3> &Ft, int num_samples,
+                                          SamplingMode mode = SamplingMode::Surface, uint64_t seed = 0)
+{
+    const std::vector<double> vs = detail::rows3(Vs), vt = detail::rows3(Vt);
+    const std::vector<int32_t> fs = detail::faces3(Fs), ft = detail::faces3(Ft);
+    double o[5];
+    visma_icp_ctx *c = detail::ctx();
+    open3d::cicp::detail::check(
+        c, visma_icp_measure_surface_error(c, vs.data(), Vs.rows(), fs.data(), Fs.rows(), vt.data(), Vt.rows(),
+                                           ft.data(), Ft.rows(), num_samples, mode == SamplingMode::Reference, seed, o),
+        "visma_icp_measure_surface_error");
+    return GenericErrorMetric<T>{(T)o[0], (T)o[1], (T)o[2], (T)o[3], (T)o[4]};
+}
+
+// The reference's own signature: any options object with options["num_samples"].asInt()
+// (Json::Value in the reference, geometry.h:122-124).
+template <typename T, typename Options>
+GenericErrorMetric<T> MeasureSurfaceError(const Eigen::Matrix<T, Eigen::Dynamic, 3> &Vs,
+                                          const Eigen::Matrix<int, Eigen::Dynamic, 3> &Fs,
+                                          const Eigen::Matrix<T, Eigen::Dynamic, 3> &Vt,
+                                          const Eigen::Matrix<int, Eigen::Dynamic, 3> &Ft, const Options &options)
+{
+    return MeasureSurfaceError<T>(Vs, Fs, Vt, Ft, (int)options["num_samples"].asInt());
+}
+
+}  // namespace gpu
+}  // namespace feh

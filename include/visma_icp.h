@@ -278,6 +278,40 @@ VISMA_ICP_API int visma_icp_voxel_down_sample(visma_icp_ctx *ctx, const double *
                                               double *out_normals, double *out_colors,
                                               int64_t *n_out);
 
+/* feh::SamplePointCloudFromMesh (include/geometry.h:29-64), the step that builds
+ * the ICP source from a CAD mesh (src/evaluation.cpp:252, src/annotation.cpp:126).
+ * V: nv x 3 f64, F: nf x 3 int32.  Sample i uses three uniforms (r, a, b): from
+ * `uniforms` (3n doubles) when given, else from a counter-based Philox4x32-10
+ * keyed by `seed` (the reference seeds std::knuth_b from the clock, so only its
+ * mapping uniforms -> points can be matched).  reference_quirks != 0 reproduces
+ * that mapping exactly: face k for r in [cdf[k], cdf[k+1]) (one face late, never
+ * the last face, NO point for r < cdf[0]) and v0 + a(v1-v0) + b(v2-v0) over the
+ * whole parallelogram -- about half of those points lie off the surface.
+ * reference_quirks == 0 samples the triangles themselves, area-uniformly.
+ * out_xyz holds n rows; *n_out <= n. */
+VISMA_ICP_API int visma_icp_sample_mesh(visma_icp_ctx *ctx, const double *V, int64_t nv,
+                                        const int32_t *F, int64_t nf, int64_t n,
+                                        int reference_quirks, uint64_t seed,
+                                        const double *uniforms, double *out_xyz, int64_t *n_out);
+/* Point -> triangle-mesh squared distance, face and closest point for np query
+ * points: what igl::AABB::squared_distance returns inside feh::MeasureSurfaceError
+ * (include/geometry.h:123-136).  face / closest may be NULL; exact ties go to the
+ * lowest face index. */
+VISMA_ICP_API int visma_icp_point_mesh_distance(visma_icp_ctx *ctx, const double *P, int64_t np,
+                                                const double *V, int64_t nv, const int32_t *F,
+                                                int64_t nf, double *d2, int32_t *face,
+                                                double *closest);
+/* feh::ComputeErrorMetric (include/geometry.h:85-101): out = mean, std, median
+ * (sorted[n >> 1]), min, max.  Host only. */
+VISMA_ICP_API int visma_icp_error_metric(const double *errors, int64_t n, double out[5]);
+/* feh::MeasureSurfaceError (include/geometry.h:117-141): sample the source mesh,
+ * distance of every sample to the target mesh, statistics of the distances. */
+VISMA_ICP_API int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const double *Vs, int64_t nvs,
+                                                  const int32_t *Fs, int64_t nfs, const double *Vt,
+                                                  int64_t nvt, const int32_t *Ft, int64_t nft,
+                                                  int64_t num_samples, int reference_quirks,
+                                                  uint64_t seed, double out[5]);
+
 /* Device self-test of the SO(3) math the kernels are built on (restatement of
  * core/rodrigues.h:143-226 in visma_amd/csrc/so3.h): for n axis-angle vectors
  * w (3n doubles) computes, ON THE GPU, R = rodrigues(w) (9n) and

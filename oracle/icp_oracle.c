@@ -763,6 +763,144 @@ int64_t vo_voxel_down_sample(const double *xyz, const double *normals, const dou
     return m;
 }
 
+/* ---- include/geometry.h ------------------------------------------------ */
+int64_t vo_sample_mesh(const double *V, const int32_t *F, int64_t nf, const double *u,
+                       int64_t n, int quirks, double *out_xyz)
+{
+    if (nf <= 0 || n <= 0) return 0;
+    double *cdf = (double *)malloc((size_t)nf * sizeof(double));
+    double total = 0.0;
+    for (int64_t i = 0; i < nf; i++) {                       /* geometry.h:33-39 */
+        const double *a = V + 3 * (int64_t)F[3 * i], *b = V + 3 * (int64_t)F[3 * i + 1],
+                     *c = V + 3 * (int64_t)F[3 * i + 2];
+        double e1[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+        double e2[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, cr[3];
+        cross3(e1, e2, cr);
+        cdf[i] = 0.5 * sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+        total += cdf[i];
+    }
+    cdf[0] /= total;                                         /* :40-43 */
+    for (int64_t i = 1; i < nf; i++) cdf[i] = cdf[i - 1] + cdf[i] / total;
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const double r = u[3 * i];
+        double a = u[3 * i + 1], b = u[3 * i + 2];
+        int64_t k = -1;
+        if (quirks) {                                        /* :52-54 */
+            for (int64_t j = 0; j + 1 < nf; j++)
+                if (cdf[j] <= r && r < cdf[j + 1]) { k = j; break; }
+        } else {
+            for (int64_t j = 0; j < nf; j++)
+                if (r < cdf[j]) { k = j; break; }
+            if (k < 0) k = nf - 1;
+            if (a + b > 1.0) { a = 1.0 - a; b = 1.0 - b; }
+        }
+        if (k < 0) continue;
+        const double *v0 = V + 3 * (int64_t)F[3 * k], *v1 = V + 3 * (int64_t)F[3 * k + 1],
+                     *v2 = V + 3 * (int64_t)F[3 * k + 2];
+        for (int d = 0; d < 3; d++)                          /* :57 */
+            out_xyz[3 * m + d] = v0[d] + a * (v1[d] - v0[d]) + b * (v2[d] - v0[d]);
+        m++;
+    }
+    free(cdf);
+    return m;
+}
+
+static inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+double vo_point_triangle_sqdist(const double p[3], const double a[3], const double b[3],
+                                const double c[3], double closest[3])
+{
+    double ab[3], ac[3], ap[3], bp[3], cp[3], q[3];
+    for (int i = 0; i < 3; i++) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; }
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    if (d1 <= 0.0 && d2 <= 0.0) { memcpy(q, a, sizeof(q)); goto done; }          /* vertex a */
+    for (int i = 0; i < 3; i++) bp[i] = p[i] - b[i];
+    {
+        const double d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+        if (d3 >= 0.0 && d4 <= d3) { memcpy(q, b, sizeof(q)); goto done; }       /* vertex b */
+        const double vc = d1 * d4 - d3 * d2;
+        if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {                               /* edge ab */
+            const double v = d1 / (d1 - d3);
+            for (int i = 0; i < 3; i++) q[i] = a[i] + v * ab[i];
+            goto done;
+        }
+        for (int i = 0; i < 3; i++) cp[i] = p[i] - c[i];
+        const double d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+        if (d6 >= 0.0 && d5 <= d6) { memcpy(q, c, sizeof(q)); goto done; }       /* vertex c */
+        const double vb = d5 * d2 - d1 * d6;
+        if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {                               /* edge ac */
+            const double w = d2 / (d2 - d6);
+            for (int i = 0; i < 3; i++) q[i] = a[i] + w * ac[i];
+            goto done;
+        }
+        const double va = d3 * d6 - d5 * d4;
+        if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {                 /* edge bc */
+            const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+            for (int i = 0; i < 3; i++) q[i] = b[i] + w * (c[i] - b[i]);
+            goto done;
+        }
+        const double denom = 1.0 / (va + vb + vc);                               /* interior */
+        const double v = vb * denom, w = vc * denom;
+        for (int i = 0; i < 3; i++) q[i] = a[i] + ab[i] * v + ac[i] * w;
+    }
+done:
+    if (closest) memcpy(closest, q, sizeof(q));
+    {
+        const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+        return dx * dx + dy * dy + dz * dz;
+    }
+}
+
+void vo_point_mesh_sqdist(const double *P, int64_t np, const double *V, const int32_t *F,
+                          int64_t nf, double *d2, int32_t *face, double *closest)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (int64_t i = 0; i < np; i++) {
+        double best = INFINITY, bq[3] = {0, 0, 0};
+        int32_t bf = -1;
+        for (int64_t f = 0; f < nf; f++) {
+            double q[3];
+            const double d = vo_point_triangle_sqdist(P + 3 * i, V + 3 * (int64_t)F[3 * f],
+                                                      V + 3 * (int64_t)F[3 * f + 1],
+                                                      V + 3 * (int64_t)F[3 * f + 2], q);
+            if (d < best) { best = d; bf = (int32_t)f; memcpy(bq, q, sizeof(q)); }
+        }
+        d2[i] = best;
+        if (face) face[i] = bf;
+        if (closest) memcpy(closest + 3 * i, bq, sizeof(bq));
+    }
+}
+
+static int cmp_double(const void *a, const void *b)
+{
+    const double x = *(const double *)a, y = *(const double *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+void vo_error_metric(const double *errors, int64_t n, double out[5])
+{
+    double mean = 0.0, sq = 0.0, mn = 1.79769313486231570815e308, mx = -1.79769313486231570815e308;
+    for (int64_t i = 0; i < n; i++) {                       /* geometry.h:90-95 */
+        mean += errors[i];
+        sq += errors[i] * errors[i];
+        if (errors[i] < mn) mn = errors[i];
+        if (errors[i] > mx) mx = errors[i];
+    }
+    mean /= (double)n;
+    double *s = (double *)malloc((size_t)(n > 0 ? n : 1) * sizeof(double));
+    memcpy(s, errors, (size_t)n * sizeof(double));
+    qsort(s, (size_t)n, sizeof(double), cmp_double);
+    out[0] = mean;
+    out[1] = sqrt(sq / (double)n - mean * mean);            /* :97 */
+    out[2] = n > 0 ? s[n >> 1] : 0.0;                       /* :99 */
+    out[3] = mn;
+    out[4] = mx;
+    free(s);
+}
+
 /* ---- core/rodrigues.h ------------------------------------------------ */
 void vo_hat(const double u[3], double M[9]) /* rodrigues.h:8-15 */
 {

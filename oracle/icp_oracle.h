@@ -143,6 +143,30 @@ int64_t vo_voxel_down_sample(const double *xyz, const double *normals, const dou
                              int64_t n, double voxel_size, double *out_xyz,
                              double *out_normals, double *out_colors);
 
+/* feh::SamplePointCloudFromMesh (include/geometry.h:29-64).  The reference draws
+ * from a TIME-seeded std::knuth_b, so only its mapping (uniforms -> points) can be
+ * restated: sample i uses (r, a, b) = u[3i..3i+2].  quirks != 0 reproduces the
+ * reference exactly -- face k is chosen for r in [cdf[k], cdf[k+1]) (geometry.h:53-54:
+ * one face late, the last face never, r < cdf[0] yields NO point) and the point is
+ * v0 + a(v1-v0) + b(v2-v0) with a,b in [0,1) (a parallelogram, :55-57).
+ * quirks == 0: face k for r in [cdf[k-1], cdf[k]) and (a,b) reflected into the
+ * triangle.  F = nf x 3 int32.  Returns the number of points written (<= n). */
+int64_t vo_sample_mesh(const double *V, const int32_t *F, int64_t nf, const double *u,
+                       int64_t n, int quirks, double *out_xyz);
+
+/* Closest point on a triangle (Ericson, Real-Time Collision Detection 5.1.5 -- the
+ * algorithm behind igl::point_simplex_squared_distance used by
+ * feh::MeasureSurfaceError, include/geometry.h:117-141). */
+double vo_point_triangle_sqdist(const double p[3], const double a[3], const double b[3],
+                                const double c[3], double closest[3]);
+/* For every query point the squared distance to the mesh, the face and the closest
+ * point (brute force over all faces; lowest face index on exact ties). */
+void vo_point_mesh_sqdist(const double *P, int64_t np, const double *V, const int32_t *F,
+                          int64_t nf, double *d2, int32_t *face, double *closest);
+/* feh::ComputeErrorMetric (include/geometry.h:85-101): out = mean, std, median
+ * (errors[n >> 1] of the sorted list), min, max. */
+void vo_error_metric(const double *errors, int64_t n, double out[5]);
+
 /* 3x3 SVD helper (one-sided Jacobi), exposed for tests. A = U diag(s) V^T,
  * s descending, row-major. */
 void vo_svd3(const double A[9], double U[9], double s[3], double V[9]);

@@ -246,6 +246,27 @@ class Oracle:
         """Returns (points, normals, colors) sorted by voxel index (ix, iy, iz)."""
         return _voxel(self.lib.vo_voxel_down_sample, xyz, voxel_size, normals, colors)
 
+    def sample_mesh(self, V, F, uniforms, quirks=True):
+        V = _f64(V, (-1, 3)); F = np.ascontiguousarray(F, np.int32).reshape(-1, 3)
+        u = _f64(uniforms, (-1, 3)); n = len(u)
+        out = np.empty((max(n, 1), 3))
+        self.lib.vo_sample_mesh.restype = C.c_int64
+        m = self.lib.vo_sample_mesh(_ptr(V, _dp), _ptr(F, _ip), C.c_int64(len(F)), _ptr(u, _dp),
+                                    C.c_int64(n), C.c_int(int(bool(quirks))), _ptr(out, _dp))
+        return out[:m].copy()
+
+    def point_mesh_sqdist(self, P, V, F):
+        P = _f64(P, (-1, 3)); V = _f64(V, (-1, 3)); F = np.ascontiguousarray(F, np.int32).reshape(-1, 3)
+        d2 = np.empty(len(P)); face = np.empty(len(P), np.int32); cl = np.empty((len(P), 3))
+        self.lib.vo_point_mesh_sqdist(_ptr(P, _dp), C.c_int64(len(P)), _ptr(V, _dp), _ptr(F, _ip),
+                                      C.c_int64(len(F)), _ptr(d2, _dp), _ptr(face, _ip), _ptr(cl, _dp))
+        return d2, face, cl
+
+    def error_metric(self, errors):
+        e = _f64(errors, (-1,)); out = np.empty(5)
+        self.lib.vo_error_metric(_ptr(e, _dp), C.c_int64(len(e)), _ptr(out, _dp))
+        return dict(zip(("mean", "std", "median", "min", "max"), out))
+
     def svd3(self, A):
         A = _f64(A, (9,)); U = np.empty(9); s = np.empty(3); V = np.empty(9)
         self.lib.vo_svd3(_ptr(A, _dp), _ptr(U, _dp), _ptr(s, _dp), _ptr(V, _dp))
@@ -366,6 +387,15 @@ class Ref:
     def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):
         """In the reference's own (hash-map) output order."""
         return _voxel(self.lib.ref_voxel_down_sample, xyz, voxel_size, normals, colors)
+
+    def point_mesh_sqdist(self, P, V, F):
+        """igl::AABB::squared_distance, as feh::MeasureSurfaceError calls it."""
+        P = _f64(P, (-1, 3)); V = _f64(V, (-1, 3)); F = np.ascontiguousarray(F, np.int32).reshape(-1, 3)
+        d2 = np.empty(len(P)); face = np.empty(len(P), np.int32); cl = np.empty((len(P), 3))
+        self.lib.ref_igl_point_mesh_sqdist(_ptr(P, _dp), C.c_int64(len(P)), _ptr(V, _dp), C.c_int64(len(V)),
+                                           _ptr(F, _ip), C.c_int64(len(F)), _ptr(d2, _dp), _ptr(face, _ip),
+                                           _ptr(cl, _dp))
+        return d2, face, cl
 
     def nn_distance(self, src, tgt):
         src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))

@@ -10,6 +10,7 @@
 #include <memory>
 
 #include "constrained_ICP.h"
+#include "visma_geometry.hpp"
 
 using namespace open3d;
 
@@ -91,6 +92,31 @@ int main(int argc, char **argv)
             extra = (double)open3d::VoxelDownSample(*scene, 0.05)->points_.size();
         } else if (mode == "evaluate") {
             result = open3d::EvaluateRegistration(*model, *scene, radius, init);
+        } else if (mode == "mesh") {        // src/evaluation.cpp:320 MeasureSurfaceError / :252 sampling
+            // "model" rows are the vertices, "scene" rows the faces (indices stored as doubles);
+            // the target mesh is the source moved by init; level = number of samples
+            Eigen::Matrix<double, Eigen::Dynamic, 3> V(ns, 3), Vt(ns, 3);
+            Eigen::Matrix<int, Eigen::Dynamic, 3> F(nt, 3);
+            for (int64_t i = 0; i < ns; i++) {
+                const Eigen::Vector3d q = init.block<3, 3>(0, 0) * model->points_[i] + init.block<3, 1>(0, 3);
+                for (int c = 0; c < 3; c++) { V(i, c) = model->points_[i](c); Vt(i, c) = q(c); }
+            }
+            for (int64_t i = 0; i < nt; i++)
+                for (int c = 0; c < 3; c++) F(i, c) = (int)scene->points_[i](c);
+            struct Opt { struct V { int v; int asInt() const { return v; } }; int n;
+                         V operator[](const char *) const { return V{n}; } } opt{level};
+            const auto m = feh::gpu::MeasureSurfaceError(V, F, Vt, F, opt);         // reference call shape
+            const auto m2 = feh::gpu::MeasureSurfaceError(V, F, Vt, F, level, feh::gpu::SamplingMode::Surface, 0);
+            if (m.mean_ != m2.mean_ || m.max_ != m2.max_) return 4;
+            result.transformation_.setZero();
+            result.transformation_(0, 0) = m.mean_; result.transformation_(0, 1) = m.std_;
+            result.transformation_(0, 2) = m.median_; result.transformation_(0, 3) = m.min_;
+            result.transformation_(1, 0) = m.max_;
+            const auto pts = feh::gpu::SamplePointCloudFromMesh(V, F, level, feh::gpu::SamplingMode::Reference, 3);
+            extra = (double)pts.size();
+            std::vector<double> d;
+            for (const auto &q : pts) d.push_back(q.norm());
+            result.transformation_(1, 1) = feh::gpu::ComputeErrorMetric(d).median_;
         } else if (mode == "estimator") {   // host-only: explicit correspondences, no GPU needed
             CorrespondenceSet cs;
             for (int64_t i = 0; i < ns; i++) cs.push_back(Eigen::Vector2i((int)i, (int)((i * 7919) % nt)));

@@ -136,11 +136,35 @@ def gen_voxel(ref):
     print("voxel fixture:", {k: v.shape for k, v in out.items() if k.endswith("_p")})
 
 
+def gen_mesh(ref):
+    """Point -> mesh distances of igl::AABB (thirdparty/libigl, as
+    include/geometry.h:123-136 calls it) on the reference's chair mesh."""
+    V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
+    F = F.astype(np.int32)
+    rng = np.random.Generator(np.random.Philox(71))
+    near = sample_mesh(V, F, 1500, 72) + rng.standard_normal((1500, 3)) * 0.01
+    on = sample_mesh(V, F, 300, 73)                      # on the surface (d ~ 0)
+    far = rng.uniform(-1.5, 1.5, (400, 3))
+    verts = V[rng.choice(len(V), 100, replace=False)]    # exact vertices: ties between faces
+    mids = 0.5 * (V[F[:100, 0]] + V[F[:100, 1]])         # on edges
+    P = np.concatenate([near, on, far, verts, mids])
+    d2, _, cl = ref.point_mesh_sqdist(P, V, F)
+    # MeasureSurfaceError inputs: the chair against a slightly moved copy of itself
+    T = make_T(rot_y(math.radians(2.0)), [0.004, -0.002, 0.003])
+    Vt = V @ T[:3, :3].T + T[:3, 3]
+    u = rng.random((2000, 3))
+    np.savez_compressed(os.path.join(HERE, "mesh.npz"), V=V, F=F, P=P, igl_d2=d2, igl_closest=cl,
+                        Vt=Vt, uniforms=u)
+    print("mesh fixture:", V.shape, F.shape, P.shape, "max d", math.sqrt(d2.max()))
+
+
 def main():
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Ref()
     if len(sys.argv) > 1 and sys.argv[1] == "voxel":
         return gen_voxel(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "mesh":
+        return gen_mesh(ref)
     V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
 
     # ---- C1/C2: chair CAD 5k samples -> 20k partial noisy scan ------------
@@ -336,6 +360,7 @@ def main():
                         dR_dw=np.array(dRs), w_back=np.array(w2), dw_dR=np.array(dws),
                         hat=np.array(hats))
     gen_voxel(ref)
+    gen_mesh(ref)
     print("golden fixtures written to", HERE)
 
 

@@ -134,3 +134,29 @@ def test_shim_icp_refinement_with_voxel_down_sample(bins, tmp_path):
     assert rc == 0, err
     assert int(r["extra"]) == len(down)
     assert synth.rel_frobenius(r["T"], want.T) < 1e-5 and abs(r["k"] - want.k) <= 2
+
+
+@pytest.mark.gpu
+def test_shim_mesh_steps(bins, tmp_path, lib):
+    """feh::gpu::{MeasureSurfaceError, SamplePointCloudFromMesh, ComputeErrorMetric} (include/geometry.h)."""
+    from oracle.oracle import Oracle
+    from visma_amd import _lib
+    o = Oracle()
+    m = np.load(os.path.join(G, "mesh.npz"))
+    V, F = m["V"], m["F"]
+    T = synth.make_T(synth.rot_y(0.03), [0.004, -0.002, 0.003])
+    n = 3000
+    ctx = _lib.Context(0)
+    pts = ctx.sample_mesh(V, F, n, quirks=False, seed=0)
+    Vt = V @ T[:3, :3].T + T[:3, 3]
+    want = o.error_metric(np.sqrt(o.point_mesh_sqdist(pts, Vt, F)[0]))
+    q = ctx.sample_mesh(V, F, n, quirks=True, seed=3)
+    for b in bins:                                   # both Eigen storage orders
+        rc, err, r = run(b, "mesh", tmp_path, V, F.astype(np.float64), 0.0, level=n, init=T)
+        assert rc == 0, err
+        got = r["T"]
+        # Vt is recomputed in C++ (Eigen product): values agree to rounding, not to the bit
+        assert abs(got[0, 0] - want["mean"]) < 1e-12 and abs(got[0, 1] - want["std"]) < 1e-10
+        assert abs(got[0, 2] - want["median"]) < 1e-12 and abs(got[1, 0] - want["max"]) < 1e-12
+        assert int(r["extra"]) == len(q)
+        assert abs(got[1, 1] - np.sort(np.linalg.norm(q, axis=1))[len(q) >> 1]) < 1e-14

@@ -104,6 +104,13 @@ def load():
                                       C.c_double, C.c_double, C.c_int, C.POINTER(CResult)]
     L.visma_icp_voxel_down_sample.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _dp, C.c_double, _dp, _dp,
                                               _dp, C.POINTER(C.c_int64)]
+    L.visma_icp_sample_mesh.argtypes = [C.c_void_p, _dp, C.c_int64, _ip, C.c_int64, C.c_int64, C.c_int,
+                                        C.c_uint64, _dp, _dp, C.POINTER(C.c_int64)]
+    L.visma_icp_point_mesh_distance.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, _ip, C.c_int64,
+                                                _dp, _ip, _dp]
+    L.visma_icp_error_metric.argtypes = [_dp, C.c_int64, _dp]
+    L.visma_icp_measure_surface_error.argtypes = [C.c_void_p, _dp, C.c_int64, _ip, C.c_int64, _dp, C.c_int64,
+                                                  _ip, C.c_int64, C.c_int64, C.c_int, C.c_uint64, _dp]
     L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -301,6 +308,35 @@ class Context:
         m = m.value
         return op[:m].copy(), (None if nn is None else on[:m].copy()), (None if cc is None else oc[:m].copy())
 
+    def sample_mesh(self, V, F, n, quirks=False, seed=0, uniforms=None):
+        """feh::SamplePointCloudFromMesh on the GPU -> (m, 3) points, m <= n."""
+        V = _f64(V, (-1, 3)); F = np.ascontiguousarray(F, np.int32).reshape(-1, 3)
+        u = None if uniforms is None else _f64(uniforms, (-1, 3))
+        if u is not None:
+            n = len(u)
+        out = np.empty((max(n, 1), 3)); m = C.c_int64(0)
+        self._chk(self.L.visma_icp_sample_mesh(self._h, _p(V, _dp), len(V), _p(F, _ip), len(F), int(n),
+                                               int(bool(quirks)), int(seed), None if u is None else _p(u, _dp),
+                                               _p(out, _dp), C.byref(m)))
+        return out[:m.value].copy()
+
+    def point_mesh_distance(self, P, V, F):
+        """-> (d2, face, closest) of every query point against the triangle mesh."""
+        P = _f64(P, (-1, 3)); V = _f64(V, (-1, 3)); F = np.ascontiguousarray(F, np.int32).reshape(-1, 3)
+        d2 = np.empty(max(len(P), 1)); face = np.empty(max(len(P), 1), np.int32); cl = np.empty((max(len(P), 1), 3))
+        self._chk(self.L.visma_icp_point_mesh_distance(self._h, _p(P, _dp), len(P), _p(V, _dp), len(V),
+                                                       _p(F, _ip), len(F), _p(d2, _dp), _p(face, _ip), _p(cl, _dp)))
+        return d2[:len(P)], face[:len(P)], cl[:len(P)]
+
+    def measure_surface_error(self, Vs, Fs, Vt, Ft, num_samples, quirks=False, seed=0):
+        Vs = _f64(Vs, (-1, 3)); Fs = np.ascontiguousarray(Fs, np.int32).reshape(-1, 3)
+        Vt = _f64(Vt, (-1, 3)); Ft = np.ascontiguousarray(Ft, np.int32).reshape(-1, 3)
+        out = np.empty(5)
+        self._chk(self.L.visma_icp_measure_surface_error(self._h, _p(Vs, _dp), len(Vs), _p(Fs, _ip), len(Fs),
+                                                         _p(Vt, _dp), len(Vt), _p(Ft, _ip), len(Ft),
+                                                         int(num_samples), int(bool(quirks)), int(seed), _p(out, _dp)))
+        return dict(zip(("mean", "std", "median", "min", "max"), out))
+
     # ---- options ----
     def set_nn_mode(self, mode):
         self._chk(self.L.visma_icp_set_nn_mode(self._h, int(mode)))
@@ -357,6 +393,15 @@ def comm_unique_id():
         msg = L.visma_icp_last_error(None)
         raise IcpError(rc, msg.decode() if msg else "")
     return bytes(buf.raw)
+
+
+def error_metric(errors):
+    L = load()
+    e = _f64(errors, (-1,)); out = np.empty(5)
+    rc = L.visma_icp_error_metric(_p(e, _dp), len(e), _p(out, _dp))
+    if rc != OK:
+        raise IcpError(rc, "error_metric")
+    return dict(zip(("mean", "std", "median", "min", "max"), out))
 
 
 def tile_config():

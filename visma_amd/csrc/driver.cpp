@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <memory>
 #include <string>
 #include <thread>
@@ -940,6 +941,7 @@ struct visma_icp_ctx {
     Mat4 last_Tc = Mat4::identity();
     bool last_plane = false;
     std::vector<int32_t> src_order;   // engine position -> caller's source index (Morton order)
+    double last_aux_kernel_ms = 0.0;  // kernel time of the last mesh-distance call
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
     int eng_fail(int code) { err = eng->error(); return code; }
@@ -1694,6 +1696,78 @@ int visma_icp_voxel_down_sample(visma_icp_ctx *ctx, const double *xyz, int64_t n
     if (e != hipSuccess) return ctx->fail(VISMA_ICP_ERR_HIP, std::string("voxel_down_sample: ") + hipGetErrorString(e));
     if (too_fine) return ctx->fail(VISMA_ICP_ERR_INVALID, "voxel grid too fine to key in 62 bits");
     return VISMA_ICP_OK;
+}
+
+int visma_icp_point_mesh_distance(visma_icp_ctx *ctx, const double *P, int64_t np, const double *V,
+                                  int64_t nv, const int32_t *F, int64_t nf, double *d2, int32_t *face,
+                                  double *closest)
+{
+    CTX_CHECK();
+    if (np < 0 || nv < 0 || nf < 0 || (np > 0 && (!P || !d2)) || (nf > 0 && (!V || !F)))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad point_mesh_distance arguments");
+    if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "needs the HIP engine");
+    float ms = 0.f;
+    hipError_t e = point_mesh_distance_device(P, np, V, nv, F, nf, d2, face, closest, &ms, nullptr);
+    if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
+                                          std::string("point_mesh_distance: ") + hipGetErrorString(e));
+    ctx->last_aux_kernel_ms = ms;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_sample_mesh(visma_icp_ctx *ctx, const double *V, int64_t nv, const int32_t *F, int64_t nf,
+                          int64_t n, int reference_quirks, uint64_t seed, const double *uniforms,
+                          double *out_xyz, int64_t *n_out)
+{
+    CTX_CHECK();
+    if (!n_out || n < 0 || nv < 0 || nf < 0 || (n > 0 && !out_xyz) || (nf > 0 && (!V || !F)))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad sample_mesh arguments");
+    if (n > 0x7fffffff) return ctx->fail(VISMA_ICP_ERR_INVALID, "too many samples for 32-bit indices");
+    if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "needs the HIP engine");
+    hipError_t e = sample_mesh_device(V, nv, F, nf, n, reference_quirks, (unsigned long long)seed, uniforms,
+                                      out_xyz, n_out, nullptr);
+    if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
+                                          std::string("sample_mesh: ") + hipGetErrorString(e));
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_error_metric(const double *errors, int64_t n, double out[5])
+{
+    if (!out || n < 0 || (n > 0 && !errors)) return VISMA_ICP_ERR_INVALID;
+    // feh::ComputeErrorMetric (include/geometry.h:85-101), same accumulation order
+    double mean = 0.0, sq = 0.0, mn = std::numeric_limits<double>::max(), mx = std::numeric_limits<double>::lowest();
+    for (int64_t i = 0; i < n; i++) {
+        mean += errors[i];
+        sq += errors[i] * errors[i];
+        mn = std::min(mn, errors[i]);
+        mx = std::max(mx, errors[i]);
+    }
+    mean /= (double)n;
+    std::vector<double> s(errors, errors + n);
+    std::sort(s.begin(), s.end());
+    out[0] = mean;
+    out[1] = std::sqrt(sq / (double)n - mean * mean);
+    out[2] = n > 0 ? s[(size_t)n >> 1] : 0.0;
+    out[3] = mn;
+    out[4] = mx;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const double *Vs, int64_t nvs, const int32_t *Fs,
+                                    int64_t nfs, const double *Vt, int64_t nvt, const int32_t *Ft,
+                                    int64_t nft, int64_t num_samples, int reference_quirks, uint64_t seed,
+                                    double out[5])
+{
+    CTX_CHECK();
+    if (!out || num_samples <= 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad measure_surface_error arguments");
+    std::vector<double> pts((size_t)num_samples * 3), d2((size_t)num_samples);
+    int64_t m = 0;
+    int rc = visma_icp_sample_mesh(ctx, Vs, nvs, Fs, nfs, num_samples, reference_quirks, seed, nullptr, pts.data(), &m);
+    if (rc) return rc;
+    if (m == 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "no sample could be drawn from the source mesh");
+    rc = visma_icp_point_mesh_distance(ctx, pts.data(), m, Vt, nvt, Ft, nft, d2.data(), nullptr, nullptr);
+    if (rc) return rc;
+    for (int64_t i = 0; i < m; i++) d2[i] = std::sqrt(d2[i]);       // geometry.h:137
+    return visma_icp_error_metric(d2.data(), m, out);
 }
 
 int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n)
