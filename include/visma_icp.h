@@ -301,6 +301,13 @@ VISMA_ICP_API int visma_icp_point_mesh_distance(visma_icp_ctx *ctx, const double
                                                 const double *V, int64_t nv, const int32_t *F,
                                                 int64_t nf, double *d2, int32_t *face,
                                                 double *closest);
+/* Device time (HIP events) of the distance kernel, and of building the search
+ * structure (Morton sort + BVH), of the last visma_icp_point_mesh_distance /
+ * visma_icp_measure_surface_error call.  Either pointer may be NULL. */
+VISMA_ICP_API int visma_icp_last_mesh_kernel_ms(visma_icp_ctx *ctx, double *query_ms, double *build_ms);
+/* 0 = choose (default: BVH from 64 faces up), 1 = brute force over all faces,
+ * 2 = BVH.  Both give the same minimum, face and closest point, bit for bit. */
+VISMA_ICP_API int visma_icp_set_mesh_search(visma_icp_ctx *ctx, int method);
 /* feh::ComputeErrorMetric (include/geometry.h:85-101): out = mean, std, median
  * (sorted[n >> 1]), min, max.  Host only. */
 VISMA_ICP_API int visma_icp_error_metric(const double *errors, int64_t n, double out[5]);

@@ -103,8 +103,16 @@ def test_error_metric_host(lib, oracle):
 # ---------------------------------------------------------------------------
 # GPU: product vs oracle / golden
 # ---------------------------------------------------------------------------
+@pytest.fixture(params=["brute", "bvh"])
+def mesh_ctx(request, gpu_ctx_auto):
+    gpu_ctx_auto.set_mesh_search(request.param)
+    yield gpu_ctx_auto
+    gpu_ctx_auto.set_mesh_search("auto")
+
+
 @pytest.mark.gpu
-def test_gpu_point_mesh_distance(gpu_ctx_auto, oracle, mesh):
+def test_gpu_point_mesh_distance(mesh_ctx, oracle, mesh):
+    gpu_ctx_auto = mesh_ctx
     d2, face, cl = gpu_ctx_auto.point_mesh_distance(mesh["P"], mesh["V"], mesh["F"])
     od2, oface, ocl = oracle.point_mesh_sqdist(mesh["P"], mesh["V"], mesh["F"])
     assert np.array_equal(d2, od2)                   # same arithmetic, no contraction: bit-exact
@@ -115,7 +123,30 @@ def test_gpu_point_mesh_distance(gpu_ctx_auto, oracle, mesh):
 
 
 @pytest.mark.gpu
-def test_gpu_point_mesh_edge_cases(gpu_ctx_auto, oracle, mesh):
+def test_gpu_bvh_equals_brute_force_on_a_scene(gpu_ctx_auto, mesh):
+    """10 chairs, queries near, on and far from the surface, duplicated faces (exact ties)."""
+    V, F = mesh["V"], mesh["F"]
+    rng = np.random.default_rng(9)
+    Vs, Fs = [], []
+    for i in range(10):
+        c, s_ = np.cos(0.7 * i), np.sin(0.7 * i)
+        R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+        Vs.append(V @ R.T + [2.0 * (i % 4), 0.0, 2.0 * (i // 4)]); Fs.append(F + i * len(V))
+    Vs = np.concatenate(Vs); Fs = np.concatenate(Fs + [Fs[3][:500]]).astype(np.int32)   # 500 duplicated faces
+    P = np.concatenate([gpu_ctx_auto.sample_mesh(Vs, Fs, 40000, seed=5) + rng.standard_normal((40000, 3)) * 0.02,
+                        gpu_ctx_auto.sample_mesh(Vs, Fs, 5000, seed=6),
+                        rng.uniform(-3, 9, (5000, 3)), Vs[::50]])
+    gpu_ctx_auto.set_mesh_search("brute")
+    a = gpu_ctx_auto.point_mesh_distance(P, Vs, Fs)
+    gpu_ctx_auto.set_mesh_search("bvh")
+    b = gpu_ctx_auto.point_mesh_distance(P, Vs, Fs)
+    gpu_ctx_auto.set_mesh_search("auto")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+def test_gpu_point_mesh_edge_cases(mesh_ctx, oracle, mesh):
+    gpu_ctx_auto = mesh_ctx
     V, F = mesh["V"], mesh["F"]
     # one triangle, one point per Voronoi region
     tv = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.0]]); tf = np.array([[0, 1, 2]], np.int32)

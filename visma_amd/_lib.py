@@ -108,6 +108,8 @@ def load():
                                         C.c_uint64, _dp, _dp, C.POINTER(C.c_int64)]
     L.visma_icp_point_mesh_distance.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int64, _ip, C.c_int64,
                                                 _dp, _ip, _dp]
+    L.visma_icp_last_mesh_kernel_ms.argtypes = [C.c_void_p, _dp, _dp]
+    L.visma_icp_set_mesh_search.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_error_metric.argtypes = [_dp, C.c_int64, _dp]
     L.visma_icp_measure_surface_error.argtypes = [C.c_void_p, _dp, C.c_int64, _ip, C.c_int64, _dp, C.c_int64,
                                                   _ip, C.c_int64, C.c_int64, C.c_int, C.c_uint64, _dp]
@@ -327,6 +329,16 @@ class Context:
         self._chk(self.L.visma_icp_point_mesh_distance(self._h, _p(P, _dp), len(P), _p(V, _dp), len(V),
                                                        _p(F, _ip), len(F), _p(d2, _dp), _p(face, _ip), _p(cl, _dp)))
         return d2[:len(P)], face[:len(P)], cl[:len(P)]
+
+    def last_mesh_kernel_ms(self):
+        """-> (query kernel ms, search-structure build ms) of the last mesh-distance call."""
+        ms, bms = C.c_double(0), C.c_double(0)
+        self._chk(self.L.visma_icp_last_mesh_kernel_ms(self._h, C.byref(ms), C.byref(bms)))
+        return ms.value, bms.value
+
+    def set_mesh_search(self, method):
+        """'auto' | 'brute' | 'bvh'"""
+        self._chk(self.L.visma_icp_set_mesh_search(self._h, {"auto": 0, "brute": 1, "bvh": 2}[method]))
 
     def measure_surface_error(self, Vs, Fs, Vt, Ft, num_samples, quirks=False, seed=0):
         Vs = _f64(Vs, (-1, 3)); Fs = np.ascontiguousarray(Fs, np.int32).reshape(-1, 3)

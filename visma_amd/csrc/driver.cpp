@@ -942,6 +942,8 @@ struct visma_icp_ctx {
     bool last_plane = false;
     std::vector<int32_t> src_order;   // engine position -> caller's source index (Morton order)
     double last_aux_kernel_ms = 0.0;  // kernel time of the last mesh-distance call
+    double last_aux_build_ms = 0.0;   // ... and of building its search structure
+    int mesh_method = 0;              // 0 choose, 1 brute force, 2 BVH
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
     int eng_fail(int code) { err = eng->error(); return code; }
@@ -1706,11 +1708,29 @@ int visma_icp_point_mesh_distance(visma_icp_ctx *ctx, const double *P, int64_t n
     if (np < 0 || nv < 0 || nf < 0 || (np > 0 && (!P || !d2)) || (nf > 0 && (!V || !F)))
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad point_mesh_distance arguments");
     if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "needs the HIP engine");
-    float ms = 0.f;
-    hipError_t e = point_mesh_distance_device(P, np, V, nv, F, nf, d2, face, closest, &ms, nullptr);
+    float ms = 0.f, bms = 0.f;
+    hipError_t e = point_mesh_distance_device(P, np, V, nv, F, nf, ctx->mesh_method, d2, face, closest, &ms, &bms,
+                                              nullptr);
     if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
                                           std::string("point_mesh_distance: ") + hipGetErrorString(e));
     ctx->last_aux_kernel_ms = ms;
+    ctx->last_aux_build_ms = bms;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_last_mesh_kernel_ms(visma_icp_ctx *ctx, double *query_ms, double *build_ms)
+{
+    CTX_CHECK();
+    if (query_ms) *query_ms = ctx->last_aux_kernel_ms;
+    if (build_ms) *build_ms = ctx->last_aux_build_ms;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_mesh_search(visma_icp_ctx *ctx, int method)
+{
+    CTX_CHECK();
+    if (method < 0 || method > 2) return ctx->fail(VISMA_ICP_ERR_INVALID, "mesh search method must be 0, 1 or 2");
+    ctx->mesh_method = method;
     return VISMA_ICP_OK;
 }
 
@@ -1742,8 +1762,9 @@ int visma_icp_error_metric(const double *errors, int64_t n, double out[5])
         mx = std::max(mx, errors[i]);
     }
     mean /= (double)n;
+    // sorted[n >> 1] (geometry.h:96-97) without the full sort
     std::vector<double> s(errors, errors + n);
-    std::sort(s.begin(), s.end());
+    if (n > 0) std::nth_element(s.begin(), s.begin() + (n >> 1), s.end());
     out[0] = mean;
     out[1] = std::sqrt(sq / (double)n - mean * mean);
     out[2] = n > 0 ? s[(size_t)n >> 1] : 0.0;
@@ -1759,15 +1780,21 @@ int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const double *Vs, int64_
 {
     CTX_CHECK();
     if (!out || num_samples <= 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad measure_surface_error arguments");
-    std::vector<double> pts((size_t)num_samples * 3), d2((size_t)num_samples);
+    if (nvs < 0 || nfs < 0 || nvt < 0 || nft < 0 || (nfs > 0 && (!Vs || !Fs)) || (nft > 0 && (!Vt || !Ft)))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad measure_surface_error arguments");
+    if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "needs the HIP engine");
+    std::vector<double> dist((size_t)num_samples);
     int64_t m = 0;
-    int rc = visma_icp_sample_mesh(ctx, Vs, nvs, Fs, nfs, num_samples, reference_quirks, seed, nullptr, pts.data(), &m);
-    if (rc) return rc;
+    float ms = 0.f, bms = 0.f;
+    hipError_t e = surface_distances_device(Vs, nvs, Fs, nfs, Vt, nvt, Ft, nft, num_samples, reference_quirks,
+                                            (unsigned long long)seed, ctx->mesh_method, dist.data(), &m, &ms, &bms,
+                                            nullptr);
+    if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
+                                          std::string("measure_surface_error: ") + hipGetErrorString(e));
+    ctx->last_aux_kernel_ms = ms;
+    ctx->last_aux_build_ms = bms;
     if (m == 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "no sample could be drawn from the source mesh");
-    rc = visma_icp_point_mesh_distance(ctx, pts.data(), m, Vt, nvt, Ft, nft, d2.data(), nullptr, nullptr);
-    if (rc) return rc;
-    for (int64_t i = 0; i < m; i++) d2[i] = std::sqrt(d2[i]);       // geometry.h:137
-    return visma_icp_error_metric(d2.data(), m, out);
+    return visma_icp_error_metric(dist.data(), m, out);
 }
 
 int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n)

@@ -114,12 +114,17 @@ GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int6
 int grid_scan_blocks(int64_t ncell);
 
 // ---- mesh steps (mesh.hip): host arrays in, host arrays out -------------------
+// method: 0 = choose, 1 = brute force (LDS-tiled scan of all faces), 2 = BVH
 hipError_t point_mesh_distance_device(const double *h_P, int64_t np, const double *h_V, int64_t nv,
-                                      const int32_t *h_F, int64_t nf, double *h_d2, int32_t *h_face,
-                                      double *h_closest, float *kernel_ms, hipStream_t stream);
+                                      const int32_t *h_F, int64_t nf, int method, double *h_d2, int32_t *h_face,
+                                      double *h_closest, float *kernel_ms, float *build_ms, hipStream_t stream);
 hipError_t sample_mesh_device(const double *h_V, int64_t nv, const int32_t *h_F, int64_t nf, int64_t n,
                               int quirks, unsigned long long seed, const double *h_uniforms,
                               double *h_out, int64_t *n_out, hipStream_t stream);
+hipError_t surface_distances_device(const double *h_Vs, int64_t nvs, const int32_t *h_Fs, int64_t nfs,
+                                    const double *h_Vt, int64_t nvt, const int32_t *h_Ft, int64_t nft, int64_t n,
+                                    int quirks, unsigned long long seed, int method, double *h_dist,
+                                    int64_t *n_out, float *kernel_ms, float *build_ms, hipStream_t stream);
 
 // ---- voxel down-sampling (voxel.hip): host arrays in, host arrays out ---------
 hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, const double *h_col,
