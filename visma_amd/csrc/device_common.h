@@ -118,17 +118,57 @@ __device__ __forceinline__ void accumulate_pair(double *acc, const float4 s4, co
     }
 }
 
+// Wave-wide sums of N values per lane with ~N shuffles instead of 6*N: at every
+// butterfly step a lane hands HALF of its values to its partner and keeps the other
+// half (the partner does the opposite), so the value count halves while the lane
+// distance halves.  After the six steps lane L holds the total of ONE value,
+// index multi_index<N>(L) (or -1: that lane ended up with padding).
+template <int N>
+__device__ __forceinline__ int multi_index(int lane)
+{
+    int n[7];
+    n[0] = N;
+#pragma unroll
+    for (int s = 0; s < 6; s++) n[s + 1] = (n[s] + 1) / 2;
+    int pos = 0;
+    bool ok = true;
+#pragma unroll
+    for (int s = 5; s >= 0; s--) {                       // undo the steps, last one first
+        if (lane & (32 >> s)) pos += n[s + 1];
+        ok = ok && pos < n[s];
+    }
+    return ok ? pos : -1;
+}
+
+template <int N>
+__device__ __forceinline__ double wave_sum_multi(double *v)
+{
+    const int lane = threadIdx.x & 63;
+    int n = N;
+#pragma unroll
+    for (int s = 0; s < 6; s++) {
+        const int m = 32 >> s, half = (n + 1) / 2;
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int i = 0; i < half; i++) {
+            const double lower = v[i], upper = (i + half < n) ? v[i + half] : 0.0;
+            const double send = up ? lower : upper, keep = up ? upper : lower;
+            v[i] = keep + __shfl_xor(send, m, 64);
+        }
+        n = half;
+    }
+    return v[0];
+}
+
 // wavefront shuffle reduction -> LDS across the 4 waves -> one partial row
 template <int NACC>
-__device__ __forceinline__ void block_reduce_store(const double *acc, double *partials)
+__device__ __forceinline__ void block_reduce_store(double *acc, double *partials)
 {
     __shared__ double wsum[kBlock / 64][NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int a = 0; a < NACC; a++) {
-        const double v = wave_sum(acc[a]);
-        if (lane == 0) wsum[wave][a] = v;
-    }
+    const double tot = wave_sum_multi<NACC>(acc);
+    const int slot = multi_index<NACC>(lane);
+    if (slot >= 0) wsum[wave][slot] = tot;
     __syncthreads();
     if (threadIdx.x < NACC) {
         double v = wsum[0][threadIdx.x];

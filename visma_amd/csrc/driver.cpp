@@ -185,8 +185,12 @@ public:
             return VISMA_ICP_ERR_NO_DEVICE;
         }
         HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * reduce_max_blocks()));
-        partial_rows_ = (size_t)reduce_max_blocks();
+        if (const char *e = std::getenv("VISMA_ICP_GRID_BLOCKS")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= kGridMaxBlocks) grid_blocks_ = v;
+        }
+        HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * kGridMaxBlocks));
+        partial_rows_ = (size_t)kGridMaxBlocks;
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
         HIP_TRY(hipMalloc(&d_cand_, 2 * 4096 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long)));
@@ -307,7 +311,7 @@ public:
             HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
-                                          (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
+                                          (float *)d_d2_, (double *)d_partials_, grid_blocks_,
                                           &nblocks, grid_lanes(),
                                           profiling_ ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_));
@@ -880,13 +884,15 @@ private:
     int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0;
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
+    static constexpr int kGridMaxBlocks = 8192;
+    int grid_blocks_ = 1024;   // workgroup cap of the single-problem grid launch (VISMA_ICP_GRID_BLOCKS)
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes() const
     {
         if (grid_lanes_ > 0) return grid_lanes_;
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
         // (lanes per query, loads in flight per lane), encoded G + 100*U
-        return ns_ <= 16384 ? 408 : (ns_ <= 131072 ? 404 : 402);
+        return ns_ <= 16384 ? 408 : (ns_ <= 131072 ? 404 : 1201);
     }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
 };

@@ -272,7 +272,11 @@ int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) /
 // G partial minima are merged with G-lane butterfly shuffles on the
 // (d2, original index) key, and lane 0 of the group accumulates the
 // correspondence's Jacobian/residual rows.
-template <bool PLANE, int G, int U>
+// ONE: every lane group has at most G queries (one per lane), so each lane keeps
+// ONE winner and builds its Jacobian/residual moments after the search -- the 29
+// f64 accumulators are then not live during the search (58 VGPRs less, one more
+// wave per SIMD) and no lane repeats another lane's accumulation.
+template <bool PLANE, int G, int U, bool ONE>
 __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
@@ -333,7 +337,21 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const int gid = vb * groups_per_block + threadIdx.x / G;
     const int i_begin = gid * per_group;
     const int i_end = min(i_begin + per_group, ns);
-    for (int i = i_begin; i < i_end; i++) {
+    __shared__ unsigned row_b[8][kBlock], row_e[8][kBlock];
+    __shared__ float row_bound[8][kBlock];
+    float4 keep_s = make_float4(0.f, 0.f, 0.f, 0.f);      // the query this lane accumulates
+    unsigned keep_pos = 0xFFFFFFFFu;                       // ... and its winner's slot in `sorted`
+    auto flush = [&]() {
+        if (keep_pos != 0xFFFFFFFFu) {
+            const float4 q4 = sorted[keep_pos];
+            float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PLANE) n4 = nrm[__float_as_uint(q4.w)];
+            accumulate_pair<PLANE>(acc, keep_s, q4, n4, T64, off);
+            keep_pos = 0xFFFFFFFFu;
+        }
+    };
+    int it = 0;
+    for (int i = i_begin; i < i_end; i++, it++) {
         const float4 s4 = src[i];
         float px, py, pz;
         xform_point_f32(T32, s4, px, py, pz);
@@ -341,18 +359,21 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         const int cy = cell_coord(py, g.mn[1], g.inv_h, g.dim[1]);
         const int cz = cell_coord(pz, g.mn[2], g.inv_h, g.dim[2]);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
-        float best = r2f;
-        unsigned bi = 0xFFFFFFFFu;
-        float4 qb = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (d2, original index) packed so that ONE 64-bit unsigned compare is the
+        // lexicographic test; d2 >= 0, so its IEEE bits are order preserving.  The
+        // start key (r2f, 0) makes the acceptance strict: d2 < r2f.
+        unsigned long long bkey = (unsigned long long)__float_as_uint(r2f) << 32;
+        unsigned bpos = 0xFFFFFFFFu;
         // The 3 x-adjacent cells of a (y,z) row are adjacent in memory: 9 runs.
         // Fetch all 9 (begin, end) pairs first -- 18 independent loads in flight
         // instead of 9 dependent round trips to the (sparse, L2-cold) cell table.
+        // (the cell count is capped at 2^26, so 32-bit cell arithmetic is exact)
         unsigned rb[9], re[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const int z = cz - 1 + k / 3, y = cy - 1 + k % 3;
             const bool ok = (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
-            const long long row = ((long long)(ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
+            const int row = ((ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
             rb[k] = ok ? start[row + x0] : 0u;
             re[k] = ok ? start[row + x1 + 1] : 0u;
         }
@@ -368,67 +389,81 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         const float lo_z = fmaxf(fz - 1e-3f, 0.f), hi_z = fmaxf(1.0f - fz - 1e-3f, 0.f);
         const float h2 = g.h * g.h * (1.0f - 1e-5f);
         constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+        // The row list goes to LDS in visiting order; every lane group then walks ITS
+        // OWN list with its own cursor, one batch of U*G candidates per trip of a single
+        // loop.  (A loop nest "for row: for batch" makes the wave run max-over-queries
+        // batches for EVERY row -- 4-5x more load instructions than a query needs.)
 #pragma unroll
-        for (int kk = 0; kk < 9; kk++) {
+        for (int kk = 1; kk < 9; kk++) {
             const int k = order[kk];
-            const unsigned b = rb[k], e = re[k];
-            if (sub == 0) ncand_all += e - b;
-            if (kk > 0) {
-                const int dz = k / 3 - 1, dy = k % 3 - 1;
-                const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
-                const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
+            const int dz = k / 3 - 1, dy = k % 3 - 1;
+            const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
+            const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
+            row_b[kk - 1][threadIdx.x] = rb[k];
+            row_e[kk - 1][threadIdx.x] = re[k];
+            row_bound[kk - 1][threadIdx.x] = (ey * ey + ez * ez) * h2;
+            if (cand_count && sub == 0) ncand_all += re[k] - rb[k];
+        }
+        unsigned base = rb[4], e = re[4];                       // centre row: never pruned
+        if (cand_count && sub == 0) { ncand_all += e - base; ncand += e - base; }
+        int kk = 0;                                             // next entry of the LDS list
+        for (;;) {
+            while (base >= e && kk < 8) {                       // group-uniform: advance to the next live row
+                const unsigned nb = row_b[kk][threadIdx.x], ne = row_e[kk][threadIdx.x];
+                const float bound = row_bound[kk][threadIdx.x];
+                ++kk;
                 // the group's current best bounds what any lane still needs
-                float gbest = best;
+                float gbest = __uint_as_float((unsigned)(bkey >> 32));
 #pragma unroll
                 for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
-                if ((ey * ey + ez * ez) * h2 > gbest) continue;
+                if (bound > gbest) continue;
+                base = nb;
+                e = ne;
+                if (cand_count && sub == 0) ncand += e - base;
             }
-            if (sub == 0) ncand += e - b;
-            // U candidates per lane in flight (the loads do not depend on each other)
-            for (unsigned j = b + sub; j < e; j += U * G) {
-                float4 q[U];
+            if (base >= e) break;
+            // U candidates per lane in flight (the loads do not depend on each other).  A slot
+            // past the end of the run re-reads the run's first point: evaluating a candidate
+            // twice cannot change the (d2, index) minimum, and it saves the per-slot guard.
+            unsigned jc[U];
+            float4 q[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned ju = j + u * G;
-                    q[u] = sorted[ju < e ? ju : j];
-                }
-#pragma unroll
-                for (int u = 0; u < U; u++) {
-                    if (j + u * G < e) {
-                        const float d = sqdist_f32(q[u], px, py, pz);
-                        const unsigned id = __float_as_uint(q[u].w);
-                        // (d2, index) lexicographic minimum; strict d2 < r2f
-                        if (d < best || (d == best && bi != 0xFFFFFFFFu && id < bi)) {
-                            best = d;
-                            bi = id;
-                            qb = q[u];
-                        }
-                    }
-                }
+            for (int u = 0; u < U; u++) {
+                const unsigned ju = base + sub + u * G;
+                jc[u] = ju < e ? ju : base;
+                q[u] = sorted[jc[u]];
             }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const float d = sqdist_f32(q[u], px, py, pz);
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q[u].w);
+                const bool lt = key < bkey;
+                bkey = lt ? key : bkey;
+                bpos = lt ? jc[u] : bpos;
+            }
+            base += U * G;
         }
         if (G > 1) {
             // butterfly merge over the G lanes: smallest (d2, index) wins everywhere
 #pragma unroll
             for (int m = G >> 1; m > 0; m >>= 1) {
-                const float ob = __shfl_xor(best, m, 64);
-                const unsigned oi = (unsigned)__shfl_xor((int)bi, m, 64);
-                const float ox = __shfl_xor(qb.x, m, 64), oy = __shfl_xor(qb.y, m, 64),
-                            oz = __shfl_xor(qb.z, m, 64);
-                const bool take = (ob < best) || (ob == best && oi < bi);
-                if (take) { best = ob; bi = oi; qb.x = ox; qb.y = oy; qb.z = oz; }
+                const unsigned ohi = (unsigned)__shfl_xor((int)(unsigned)(bkey >> 32), m, 64);
+                const unsigned olo = (unsigned)__shfl_xor((int)(unsigned)bkey, m, 64);
+                const unsigned op = (unsigned)__shfl_xor((int)bpos, m, 64);
+                const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
+                if (ok < bkey) { bkey = ok; bpos = op; }
             }
         }
         if (sub == 0) {
-            idx_out[i] = (bi == 0xFFFFFFFFu) ? -1 : (int)bi;
-            d2_out[i] = best;
-            if (bi != 0xFFFFFFFFu) {
-                float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (PLANE) n4 = nrm[bi];
-                accumulate_pair<PLANE>(acc, s4, qb, n4, T64, off);
-            }
+            idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)(unsigned)bkey;
+            d2_out[i] = __uint_as_float((unsigned)(bkey >> 32));
         }
+        // lane (it mod G) of the group keeps this query's winner
+        if ((it % G) == sub) { keep_s = s4; keep_pos = bpos; }
+        if (!ONE && (it % G) == G - 1) flush();
     }
+    flush();
     block_reduce_store<NACC>(acc, partials);
     if (cand_count) {
         // profiling only: candidates examined / candidates in the full 27-cell blocks.
@@ -456,9 +491,17 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           double *partials, unsigned long long *cand, const DevIcpState *st,
                           int nprob, long long out_stride)
 {
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U>), dim3(nblocks * nprob), dim3(kBlock), 0,
-                       stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
-                       partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
+    // one query per lane? (see ONE above)
+    const long long total_groups = (long long)nblocks * (kBlock / G);
+    const bool one = ((long long)ns + total_groups - 1) / total_groups <= G;
+    if (one)
+        hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, true>), dim3(nblocks * nprob), dim3(kBlock), 0,
+                           stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
+                           partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
+    else
+        hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, false>), dim3(nblocks * nprob), dim3(kBlock), 0,
+                           stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
+                           partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
 }
 
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -494,6 +537,9 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     VISMA_GRID_CASE(1, 4) VISMA_GRID_CASE(2, 4) VISMA_GRID_CASE(4, 4) VISMA_GRID_CASE(4, 2)
     VISMA_GRID_CASE(8, 4) VISMA_GRID_CASE(8, 2) VISMA_GRID_CASE(8, 1) VISMA_GRID_CASE(16, 2)
     VISMA_GRID_CASE(16, 1) VISMA_GRID_CASE(32, 1) VISMA_GRID_CASE(2, 2)
+    VISMA_GRID_CASE(1, 8) VISMA_GRID_CASE(2, 8) VISMA_GRID_CASE(1, 2) VISMA_GRID_CASE(1, 6) VISMA_GRID_CASE(2, 6)
+    VISMA_GRID_CASE(2, 3) VISMA_GRID_CASE(1, 3) VISMA_GRID_CASE(2, 1) VISMA_GRID_CASE(4, 1)
+    VISMA_GRID_CASE(1, 12) VISMA_GRID_CASE(2, 12) VISMA_GRID_CASE(1, 16) VISMA_GRID_CASE(2, 16) VISMA_GRID_CASE(1, 10) VISMA_GRID_CASE(4, 8)
     if (!launched) return hipErrorInvalidValue;
 #undef VISMA_GRID_CASE
     if (nblocks_out) *nblocks_out = nblocks;
@@ -510,7 +556,7 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
     const Xform64 T64{};
     const Offset64 off{};
     const GridParams g{};
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, 2>), dim3(total_blocks), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, 2, false>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
                        d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob);
 }
