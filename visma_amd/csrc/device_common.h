@@ -191,17 +191,15 @@ __device__ __forceinline__ void fold_partials(const double *__restrict__ partial
     const int a = threadIdx.x & 31, g = threadIdx.x >> 5;
     double v = 0.0;
     if (a < NACC) {
-        // rows g, g+32, g+64, ...: four independent load/add chains in flight
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        // rows g, g+32, g+64, ...: eight independent load/add chains in flight
+        double c[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         int b = g;
-        for (; b + 3 * NG < nblocks; b += 4 * NG) {
-            v0 += partials[(long long)b * kReduceAcc + a];
-            v1 += partials[(long long)(b + NG) * kReduceAcc + a];
-            v2 += partials[(long long)(b + 2 * NG) * kReduceAcc + a];
-            v3 += partials[(long long)(b + 3 * NG) * kReduceAcc + a];
+        for (; b + 7 * NG < nblocks; b += 8 * NG) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) c[u] += partials[(long long)(b + u * NG) * kReduceAcc + a];
         }
-        for (; b < nblocks; b += NG) v0 += partials[(long long)b * kReduceAcc + a];
-        v = (v0 + v1) + (v2 + v3);
+        for (; b < nblocks; b += NG) c[0] += partials[(long long)b * kReduceAcc + a];
+        v = ((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]));
     }
     part[g][a] = v;
     __syncthreads();

@@ -185,9 +185,13 @@ public:
             return VISMA_ICP_ERR_NO_DEVICE;
         }
         HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        if (const char *e = std::getenv("VISMA_ICP_GRID_SUB")) {
+            const int v = std::atoi(e);
+            if (v == 1 || v == 2) grid_sub_ = v;
+        }
         if (const char *e = std::getenv("VISMA_ICP_GRID_BLOCKS")) {
             const int v = std::atoi(e);
-            if (v >= 1 && v <= kGridMaxBlocks) grid_blocks_ = v;
+            if (v >= 1 && v <= kGridMaxBlocks) grid_blocks_env_ = v;
         }
         HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * kGridMaxBlocks));
         partial_rows_ = (size_t)kGridMaxBlocks;
@@ -311,7 +315,7 @@ public:
             HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
-                                          (float *)d_d2_, (double *)d_partials_, grid_blocks_,
+                                          (float *)d_d2_, (double *)d_partials_, grid_blocks(),
                                           &nblocks, grid_lanes(),
                                           profiling_ ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_));
@@ -793,7 +797,7 @@ private:
         HIP_TRY(hipStreamSynchronize(stream_));
         float mn[3], mx[3];
         grid_decode_bbox(box, mn, mx);
-        grid_ = grid_plan(mn, mx, max_dist, kGridMaxCells);
+        grid_ = grid_plan(mn, mx, max_dist, kGridMaxCells, grid_sub_);
         if ((int64_t)nt_ > sorted_cap_) {
             free_dev(d_sorted_); free_dev(d_cell_of_);
             HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * nt_));
@@ -885,14 +889,26 @@ private:
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
     static constexpr int kGridMaxBlocks = 8192;
-    int grid_blocks_ = 1024;   // workgroup cap of the single-problem grid launch (VISMA_ICP_GRID_BLOCKS)
+    int grid_sub_ = 1;         // row refinement the planner may use (VISMA_ICP_GRID_SUB=2: 25 half-pitch rows --
+                               // 42 % fewer candidates at C4 but slower, 59 vs 51 us: more rows, 4x the table)
+    int grid_blocks_env_ = 0;  // VISMA_ICP_GRID_BLOCKS override of the workgroup cap below
+    int grid_blocks() const
+    {
+        // workgroup cap of the single-problem grid launch.  Up to 262,144 sources 1024
+        // workgroups give one query per lane group (the kernel's ONE variant); beyond that
+        // more workgroups keep it that way -- the fold of their partial rows costs less
+        // than running the multi-round variant (1M sources: 0.12 vs 0.17 ms per iteration)
+        if (grid_blocks_env_ > 0) return grid_blocks_env_;
+        if (ns_ <= 262144) return 1024;
+        return (int)std::min<int64_t>(kGridMaxBlocks, (ns_ + kBlock - 1) / kBlock);
+    }
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes() const
     {
         if (grid_lanes_ > 0) return grid_lanes_;
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
         // (lanes per query, loads in flight per lane), encoded G + 100*U
-        return ns_ <= 16384 ? 408 : (ns_ <= 131072 ? 404 : 1201);
+        return ns_ <= 32768 ? 804 : (ns_ <= 98304 ? 802 : 1201);
     }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
 };

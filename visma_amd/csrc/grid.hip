@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void cell_count_kernel(const float4 *__restric
     if (i >= n) return;
     const float4 q = pts[i];
     int cx = cell_coord(q.x, g.mn[0], g.inv_h, g.dim[0]);
-    int cy = cell_coord(q.y, g.mn[1], g.inv_h, g.dim[1]);
-    int cz = cell_coord(q.z, g.mn[2], g.inv_h, g.dim[2]);
+    int cy = cell_coord(q.y, g.mn[1], g.inv_hs, g.dim[1]);
+    int cz = cell_coord(q.z, g.mn[2], g.inv_hs, g.dim[2]);
     cx = min(max(cx, 0), g.dim[0] - 1);
     cy = min(max(cy, 0), g.dim[1] - 1);
     cz = min(max(cz, 0), g.dim[2] - 1);
@@ -200,27 +200,46 @@ void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3])
     }
 }
 
-GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells)
+GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells, int max_sub)
 {
     GridParams g;
     float h = (float)(max_dist * 1.001);
     if (!(h > 0.f) || !isfinite(h)) h = 1.0f;
+    double ext[3];
+    for (int a = 0; a < 3; a++) {
+        ext[a] = (double)mx[a] - (double)mn[a];
+        if (!(ext[a] >= 0.0) || !isfinite(ext[a])) ext[a] = 0.0;
+    }
     for (;;) {
         double n = 1.0;
+        bool too_long = false;
         for (int a = 0; a < 3; a++) {
-            double ext = (double)mx[a] - (double)mn[a];
-            if (!(ext >= 0.0) || !isfinite(ext)) ext = 0.0;
-            double d = floor(ext / h) + 1.0;
+            double d = floor(ext[a] / h) + 1.0;
             if (d > 2.0e9) d = 2.0e9;
+            // the cell coordinate is computed in fp32: its error grows with the coordinate,
+            // and the 0.1 % slack between h and max_dist must stay above it
+            if (d > (double)kGridMaxDim) too_long = true;
             g.dim[a] = (int)d;
             n *= d;
         }
-        if (n <= (double)max_cells) break;
+        if (n <= (double)max_cells && !too_long) break;
         h *= 1.26f;
+    }
+    g.sub = 1;
+    if (max_sub >= 2) {
+        // rows at half pitch: thinner rows, far fewer candidates per query; 4x the table
+        const double dy = floor(ext[1] / (0.5 * h)) + 1.0, dz = floor(ext[2] / (0.5 * h)) + 1.0;
+        if ((double)g.dim[0] * dy * dz <= (double)kGridMaxCellsFine) {
+            g.sub = 2;
+            g.dim[1] = (int)dy;
+            g.dim[2] = (int)dz;
+        }
     }
     for (int a = 0; a < 3; a++) g.mn[a] = mn[a];
     g.h = h;
     g.inv_h = 1.0f / h;
+    g.hs = g.sub == 2 ? 0.5f * h : h;
+    g.inv_hs = 1.0f / g.hs;
     g.ncell = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
     return g;
 }
@@ -356,75 +375,45 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         float px, py, pz;
         xform_point_f32(T32, s4, px, py, pz);
         const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
-        const int cy = cell_coord(py, g.mn[1], g.inv_h, g.dim[1]);
-        const int cz = cell_coord(pz, g.mn[2], g.inv_h, g.dim[2]);
+        const int cy = cell_coord(py, g.mn[1], g.inv_hs, g.dim[1]);
+        const int cz = cell_coord(pz, g.mn[2], g.inv_hs, g.dim[2]);
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
         // (d2, original index) packed so that ONE 64-bit unsigned compare is the
         // lexicographic test; d2 >= 0, so its IEEE bits are order preserving.  The
         // start key (r2f, 0) makes the acceptance strict: d2 < r2f.
         unsigned long long bkey = (unsigned long long)__float_as_uint(r2f) << 32;
         unsigned bpos = 0xFFFFFFFFu;
-        // The 3 x-adjacent cells of a (y,z) row are adjacent in memory: 9 runs.
-        // Fetch all 9 (begin, end) pairs first -- 18 independent loads in flight
-        // instead of 9 dependent round trips to the (sparse, L2-cold) cell table.
-        // (the cell count is capped at 2^26, so 32-bit cell arithmetic is exact)
-        unsigned rb[9], re[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const int z = cz - 1 + k / 3, y = cy - 1 + k % 3;
-            const bool ok = (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
-            const int row = ((ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
-            rb[k] = ok ? start[row + x0] : 0u;
-            re[k] = ok ? start[row + x1 + 1] : 0u;
-        }
-        // Visit the centre row first, then the 4 edge rows, then the 4 corner rows,
-        // and SKIP a row whose slab cannot contain a better candidate: every point
-        // of row (dy,dz) is at least delta = |(dist to the slab in y, in z)| away.
-        // Margins: 1e-3 cell on each slab distance (fp32 binning of query and
-        // candidates) and 1e-5 relative on the squared bound (fp32 d2 rounding), so
-        // a skipped candidate has d2 > best strictly -- it could neither win nor tie.
-        const float fy = (py - g.mn[1]) * g.inv_h - (float)cy;     // position inside the cell, [0,1)
-        const float fz = (pz - g.mn[2]) * g.inv_h - (float)cz;
+        // Rows (y,z) are visited nearest first and a row is SKIPPED when its slab cannot
+        // hold a better candidate: every point of row (dy,dz) is at least
+        // |(dist to the slab in y, in z)| away.  Margins: 1e-3 cell on each slab distance
+        // (fp32 binning of query and candidates, see kGridMaxDim) and 1e-5 relative on the
+        // squared bound (fp32 d2 rounding), so a skipped candidate has d2 > best strictly
+        // -- it could neither win nor tie.
+        const float fy = (py - g.mn[1]) * g.inv_hs - (float)cy;     // position inside the cell, [0,1)
+        const float fz = (pz - g.mn[2]) * g.inv_hs - (float)cz;
         const float lo_y = fmaxf(fy - 1e-3f, 0.f), hi_y = fmaxf(1.0f - fy - 1e-3f, 0.f);
         const float lo_z = fmaxf(fz - 1e-3f, 0.f), hi_z = fmaxf(1.0f - fz - 1e-3f, 0.f);
-        const float h2 = g.h * g.h * (1.0f - 1e-5f);
-        constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
-        // The row list goes to LDS in visiting order; every lane group then walks ITS
-        // OWN list with its own cursor, one batch of U*G candidates per trip of a single
-        // loop.  (A loop nest "for row: for batch" makes the wave run max-over-queries
-        // batches for EVERY row -- 4-5x more load instructions than a query needs.)
-#pragma unroll
-        for (int kk = 1; kk < 9; kk++) {
-            const int k = order[kk];
-            const int dz = k / 3 - 1, dy = k % 3 - 1;
-            const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
-            const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
-            row_b[kk - 1][threadIdx.x] = rb[k];
-            row_e[kk - 1][threadIdx.x] = re[k];
-            row_bound[kk - 1][threadIdx.x] = (ey * ey + ez * ez) * h2;
-            if (cand_count && sub == 0) ncand_all += re[k] - rb[k];
-        }
-        unsigned base = rb[4], e = re[4];                       // centre row: never pruned
-        if (cand_count && sub == 0) { ncand_all += e - base; ncand += e - base; }
-        int kk = 0;                                             // next entry of the LDS list
-        for (;;) {
-            while (base >= e && kk < 8) {                       // group-uniform: advance to the next live row
-                const unsigned nb = row_b[kk][threadIdx.x], ne = row_e[kk][threadIdx.x];
-                const float bound = row_bound[kk][threadIdx.x];
-                ++kk;
-                // the group's current best bounds what any lane still needs
-                float gbest = __uint_as_float((unsigned)(bkey >> 32));
-#pragma unroll
-                for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
-                if (bound > gbest) continue;
-                base = nb;
-                e = ne;
-                if (cand_count && sub == 0) ncand += e - base;
-            }
-            if (base >= e) break;
-            // U candidates per lane in flight (the loads do not depend on each other).  A slot
-            // past the end of the run re-reads the run's first point: evaluating a candidate
-            // twice cannot change the (d2, index) minimum, and it saves the per-slot guard.
+        const float h2 = g.hs * g.hs * (1.0f - 1e-5f);
+        // squared lower bound of row offset (dy, dz), compile-time offsets
+        auto row_bound_of = [&](int dy, int dz) {
+            const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y + (float)(-dy - 1) : hi_y + (float)(dy - 1));
+            const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z + (float)(-dz - 1) : hi_z + (float)(dz - 1));
+            return (ey * ey + ez * ez) * h2;
+        };
+        // (begin, end) of the run of the 3 x-adjacent cells of row (dy, dz); they are
+        // adjacent in memory.  (32-bit cell arithmetic: the cell count is below 2^31)
+        auto row_range = [&](int dy, int dz, bool want, unsigned &rb, unsigned &re) {
+            const int z = cz + dz, y = cy + dy;
+            const bool ok = want && (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+            const int row = ((ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
+            rb = ok ? start[row + x0] : 0u;
+            re = ok ? start[row + x1 + 1] : 0u;
+        };
+        unsigned base = 0, e = 0;
+        // One batch of U*G candidates of the current run.  A slot past the end of the run
+        // re-reads the run's first point: evaluating a candidate twice cannot change the
+        // (d2, index) minimum, and it saves the per-slot guard.
+        auto batch = [&]() {
             unsigned jc[U];
             float4 q[U];
 #pragma unroll
@@ -443,6 +432,82 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 bpos = lt ? jc[u] : bpos;
             }
             base += U * G;
+        };
+        // Every lane group walks ITS OWN row list (LDS, visiting order) with its own
+        // cursor, one batch per trip of a single loop.  (A loop nest "for row: for batch"
+        // makes the wave run max-over-queries batches for EVERY row -- 4-5x more load
+        // instructions than a query needs.)
+        auto walk = [&]() {
+            int kk = 0;
+            for (;;) {
+                while (base >= e && kk < 8) {                   // group-uniform: next live row
+                    const unsigned nb = row_b[kk][threadIdx.x], ne = row_e[kk][threadIdx.x];
+                    const float bound = row_bound[kk][threadIdx.x];
+                    ++kk;
+                    // the group's current best bounds what any lane still needs
+                    float gbest = __uint_as_float((unsigned)(bkey >> 32));
+#pragma unroll
+                    for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
+                    if (bound > gbest) continue;
+                    base = nb;
+                    e = ne;
+                    if (cand_count && sub == 0) ncand += e - base;
+                }
+                if (base >= e) break;
+                batch();
+            }
+        };
+        {
+            // centre row + the 8 rows around it: all 18 (begin, end) loads in flight at once
+            constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+            unsigned rb[9], re[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) row_range(k % 3 - 1, k / 3 - 1, true, rb[k], re[k]);
+#pragma unroll
+            for (int kk = 1; kk < 9; kk++) {
+                const int k = order[kk];
+                row_b[kk - 1][threadIdx.x] = rb[k];
+                row_e[kk - 1][threadIdx.x] = re[k];
+                row_bound[kk - 1][threadIdx.x] = row_bound_of(k % 3 - 1, k / 3 - 1);
+                if (cand_count && sub == 0) ncand_all += re[k] - rb[k];
+            }
+            base = rb[4];
+            e = re[4];                                           // centre row: never pruned
+            if (cand_count && sub == 0) { ncand_all += e - base; ncand += e - base; }
+            walk();
+        }
+        if (g.sub == 2) {
+            // half-pitch rows: the 16 rows of the second ring, nearest first, in two passes
+            // of 8.  They matter only while the best so far is farther than half a cell
+            // (sparse places, queries without a neighbour): most lanes skip both passes.
+            constexpr int r2y[16] = {0, -2, 2, 0, -1, 1, -2, 2, -2, 2, -1, 1, -2, 2, -2, 2};
+            constexpr int r2z[16] = {-2, 0, 0, 2, -2, -2, -1, -1, 1, 1, 2, 2, -2, -2, 2, 2};
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                float gbest = __uint_as_float((unsigned)(bkey >> 32));
+#pragma unroll
+                for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
+                bool any = false;
+                unsigned rb[8], re[8];
+                float bd[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    bd[k] = row_bound_of(r2y[pass * 8 + k], r2z[pass * 8 + k]);
+                    const bool want = !(bd[k] > gbest);
+                    any = any || want;
+                    row_range(r2y[pass * 8 + k], r2z[pass * 8 + k], want, rb[k], re[k]);
+                }
+                if (!any) continue;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    row_b[k][threadIdx.x] = rb[k];
+                    row_e[k][threadIdx.x] = re[k];
+                    row_bound[k][threadIdx.x] = bd[k];
+                    if (cand_count && sub == 0) ncand_all += re[k] - rb[k];
+                }
+                base = e = 0;
+                walk();
+            }
         }
         if (G > 1) {
             // butterfly merge over the G lanes: smallest (d2, index) wins everywhere

@@ -95,11 +95,15 @@ hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream);
 // ---- radius-cell uniform grid (grid.hip) -------------------------------------
 struct GridParams {
     float mn[3];      // lower corner of the target's bounding box
-    float h, inv_h;   // cell edge (>= 1.001 * max_dist) and its reciprocal
-    int dim[3];       // cells per axis
+    float h, inv_h;   // cell edge along x (>= 1.001 * max_dist) and its reciprocal
+    int dim[3];       // cells per axis (y and z counted in cells of edge h / sub)
+    int sub;          // 1, or 2: rows (y,z) at half pitch -- 25 thinner rows instead of 9
+    float hs, inv_hs; // h / sub and its reciprocal
     int64_t ncell;
 };
-constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;
+constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;        // at sub = 1
+constexpr int64_t kGridMaxCellsFine = 256ll * 1024 * 1024;   // at sub = 2 (1 GiB table)
+constexpr int kGridMaxDim = 2048;   // per axis at sub = 1: keeps the fp32 binning error < 1e-3 cell
 
 // One problem of a batch with its OWN clouds (offsets into concatenated arrays).
 struct ProbDesc {
@@ -110,7 +114,7 @@ struct ProbDesc {
 
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
-GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells);
+GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells, int max_sub = 1);
 int grid_scan_blocks(int64_t ncell);
 
 // ---- mesh steps (mesh.hip): host arrays in, host arrays out -------------------
