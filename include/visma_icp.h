@@ -235,6 +235,10 @@ VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
  * `level` problems then advance together with one set of launches per
  * iteration.  Results agree to rounding. */
 VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
+/* Kernel timing with HIP events on the context's stream (read with
+ * visma_icp_get_timing).  0 = off, 1 = every launch, n > 1 = every n-th ICP pass
+ * (the event records themselves cost ~3 us each; sampling keeps a timed run close
+ * to an untimed one).  Candidate counting of the grid kernel follows the same switch. */
 VISMA_ICP_API int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out,
                                        int reset);

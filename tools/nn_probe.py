@@ -34,9 +34,11 @@ def main():
             rd = tm["reduce_ms"] / tm["reduce_launches"]
             pairs = ns * nt
             ctx.set_device_loop(False)
+            ctx.set_profiling(False)                 # wall time without the event records
             t0 = time.time()
             ctx.run(None, r, iters, 0, 0)
             wall_host = time.time() - t0
+            ctx.set_profiling(True)
             ctx.set_device_loop(None)
             ctx.get_timing(reset=True)
             rec = dict(mode=name, ns=ns, nt=nt, radius=r, nn_ms=nn, reduce_ms=rd,

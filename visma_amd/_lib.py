@@ -363,7 +363,8 @@ class Context:
         self._chk(self.L.visma_icp_set_device_loop(self._h, -1 if on is None else int(bool(on))))
 
     def set_profiling(self, on=True):
-        self._chk(self.L.visma_icp_set_profiling(self._h, int(bool(on))))
+        """False/0 off, True/1 every launch, n > 1 every n-th ICP pass."""
+        self._chk(self.L.visma_icp_set_profiling(self._h, int(on)))
 
     def get_timing(self, reset=False):
         t = CTiming()
