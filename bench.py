@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--ns", type=int, default=NS_DEFAULT)
     ap.add_argument("--nt", type=int, default=NT_DEFAULT)
     ap.add_argument("--nn", choices=["auto", "grid", "brute"], default="auto")
+    ap.add_argument("--shard", choices=["source", "target"], default="source",
+                    help="multi-GPU decomposition: source points (one all-reduce of 38 f64 per iteration; "
+                         "default) or target points (north_star's wording: MIN all-reduce of NS keys + the "
+                         "same sum; for targets that exceed one GPU)")
     ap.add_argument("--brute-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -181,15 +185,23 @@ def main():
     ns, nt = args.ns, args.nt
     src, tgt, T_gt, radius = synth.make_pair(ns, nt, motion="radius")
 
-    # source shard of this rank (contiguous slice; full target everywhere)
-    lo = (ns * rank) // world
-    hi = (ns * (rank + 1)) // world
-    ns_local = hi - lo
     ctx = _lib.Context(local_rank)
-    # every rank must centre on the SAME point: set_clouds_f64 centres on the
-    # (full) target centroid, which all ranks share.
-    ctx.set_clouds_f64(src[lo:hi], tgt)
-    ctx.set_global_source_count(ns)
+    if args.shard == "source" or (world == 1 and not force_comm):
+        # source shard of this rank (contiguous slice; full target everywhere)
+        lo = (ns * rank) // world
+        hi = (ns * (rank + 1)) // world
+        ns_local, nt_local = hi - lo, nt
+        # every rank must centre on the SAME point: set_clouds_f64 centres on the
+        # (full) target centroid, which all ranks share.
+        ctx.set_clouds_f64(src[lo:hi], tgt)
+        ctx.set_global_source_count(ns)
+    else:
+        # target shard of this rank (contiguous slice of the global index space; all sources)
+        lo = (nt * rank) // world
+        hi = (nt * (rank + 1)) // world
+        ns_local, nt_local = ns, hi - lo
+        ctx.set_target_shard(lo, nt, tgt.mean(0))
+        ctx.set_clouds_f64(src, tgt[lo:hi])
     if dist is not None:
         import torch
         if rank == 0:
@@ -255,9 +267,9 @@ def main():
     if rank == 0:
         tile = _lib.tile_config()
         if mode == "grid":
-            roofline = grid_roofline(ns_local, nt, nn_ms, cand, cand27, load_traffic("grid", ns_local, nt))
+            roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, cand27, load_traffic("grid", ns_local, nt_local))
         else:
-            roofline = brute_roofline(ns_local, nt, nn_ms, tile, load_traffic("brute", ns_local, nt))
+            roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
         roofline["launches_timed"] = tm["nn_launches"]
         roofline["timed_every_nth_pass"] = prof_every
         roofline["reduce_finalize_avg_ms"] = tm["reduce_ms"] / max(tm["reduce_launches"], 1)
@@ -270,7 +282,9 @@ def main():
             "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, "
                                    "nn=%s" % (ns, nt, args.steps, mode),
                        "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode,
-                       "parallelism": "source-sharded x%d, 1 ncclAllReduce(38 f64)/iter" % world},
+                       "parallelism": ("source-sharded x%d, 1 ncclAllReduce(38 f64)/iter" % world)
+                       if args.shard == "source" else
+                       ("target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter" % (world, ns))},
             "mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
             "matched_corr_per_sec": last.num_correspondences * args.steps / elapsed,
             "fitness": last.fitness_, "inlier_rmse": last.inlier_rmse_,
@@ -279,7 +293,7 @@ def main():
             "roofline": roofline,
         }
         if brute is not None:
-            b = brute_roofline(ns_local, nt, brute["nn_ms"], tile, load_traffic("brute", ns_local, nt))
+            b = brute_roofline(ns_local, nt_local, brute["nn_ms"], tile, load_traffic("brute", ns_local, nt_local))
             b.update(steps=brute["steps"], ms_per_step=brute["ms_per_step"],
                      iterations_per_sec=1e3 / brute["ms_per_step"],
                      mpairs_per_sec=float(ns) * nt / brute["ms_per_step"] / 1e3,

@@ -265,6 +265,24 @@ VISMA_ICP_API int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks,
 typedef int (*visma_icp_allreduce_fn)(void *user, double *inout, int n);
 VISMA_ICP_API int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn,
                                           void *user, int rank, int nranks);
+/* TARGET-sharded ranks (the literal reading of "the target cloud is sharded
+ * across the GPUs"; for targets that exceed one GPU).  Every rank holds ALL source
+ * points and target points [global_offset, global_offset + nt) of a target of
+ * global_nt points (< 2^31).  Summing per-shard accumulators directly would count a
+ * source point once per shard that has a neighbour of it, which is not the reference
+ * algorithm (Registration.cpp:53-85 keeps ONE nearest neighbour); the exact scheme is
+ * two collectives per iteration: a MIN all-reduce of NS packed keys
+ * (fp32 d2 bits << 32 | global index: smallest distance, lowest index on ties), then
+ * the owner of each winner accumulates it and the 38 statistics are summed as in the
+ * source-sharded mode.  Correspondence indices are global.  `centre` must be the SAME
+ * point on every rank (e.g. the centroid of the whole target); call this BEFORE
+ * visma_icp_set_clouds_f64.  global_nt = 0 switches the mode off.  Needs
+ * visma_icp_comm_init (RCCL) or both host callbacks below; the host loop only. */
+VISMA_ICP_API int visma_icp_set_target_shard(visma_icp_ctx *ctx, int64_t global_offset,
+                                             int64_t global_nt, const double centre[3]);
+/* Host-supplied MIN all-reduce of n uint64 keys, in place (tests / other transports). */
+typedef int (*visma_icp_minreduce_fn)(void *user, uint64_t *inout, int64_t n);
+VISMA_ICP_API int visma_icp_set_minreduce(visma_icp_ctx *ctx, visma_icp_minreduce_fn fn, void *user);
 /* Total source points over all ranks (fitness denominator); 0 = local ns. */
 VISMA_ICP_API int visma_icp_set_global_source_count(visma_icp_ctx *ctx, int64_t ns_total);
 

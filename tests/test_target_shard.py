@@ -1,0 +1,126 @@
+"""Target-sharded ranks (include/visma_icp.h: visma_icp_set_target_shard).
+
+Two contexts on ONE GPU, each holding half of the target and all of the source, driven by
+two host threads whose exchange callbacks meet at a barrier -- the same two collectives per
+iteration (MIN of the packed keys, SUM of the 38 statistics) that RCCL performs between
+GPUs.  The result must be the single-context result: identical correspondences (global
+indices, lowest index on ties), transform to summation order.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from visma_amd import _lib, synth
+
+
+class Exchange:
+    """In-process stand-in for the two all-reduces of a 2-rank communicator."""
+
+    def __init__(self, n):
+        self.n = n
+        self.barrier = threading.Barrier(n)
+        self.slots = [None] * n
+        self.calls = {"min": 0, "sum": 0}
+
+    def _reduce(self, rank, a, op, kind):
+        self.slots[rank] = a.copy()
+        self.barrier.wait()
+        out = self.slots[0].copy()
+        for r in range(1, self.n):          # rank order: every rank gets bit-identical sums
+            out = op(out, self.slots[r])
+        self.barrier.wait()
+        a[:] = out
+        if rank == 0:
+            self.calls[kind] += 1
+
+    def minreduce(self, rank):
+        return lambda a: self._reduce(rank, a, np.minimum, "min")
+
+    def allreduce(self, rank):
+        return lambda a: self._reduce(rank, a, np.add, "sum")
+
+
+def run_sharded(src, tgt, radius, iters, nn_mode, cuts, normals=None, plane=False):
+    n = len(cuts) - 1
+    ex = Exchange(n)
+    centre = tgt.mean(0)
+    out = [None] * n
+    err = []
+
+    def worker(rank):
+        try:
+            ctx = _lib.Context(0)
+            ctx.set_nn_mode(nn_mode)
+            lo, hi = cuts[rank], cuts[rank + 1]
+            ctx.set_target_shard(lo, len(tgt), centre)
+            ctx.set_clouds_f64(src, tgt[lo:hi])
+            if normals is not None:
+                ctx.set_target_normals_f64(normals[lo:hi])
+            ctx.set_minreduce(ex.minreduce(rank))
+            ctx.set_allreduce(ex.allreduce(rank), rank, n)
+            if plane:
+                res = ctx.run_point_to_plane(None, radius, iters, 0, 0)
+            else:
+                res = ctx.run(None, radius, iters, 0, 0)
+            out[rank] = (res, ctx.correspondence_index())
+        except Exception as e:                  # pragma: no cover
+            err.append(e)
+            ex.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if err:
+        raise err[0]
+    return out, ex
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nn_mode", [_lib.NN_BRUTE, _lib.NN_GRID])
+def test_target_sharded_equals_single_context(lib, nn_mode):
+    src, tgt, T_gt, radius = synth.make_pair(20000, 60000, motion="radius")
+    tgt = np.concatenate([tgt, tgt[:500]])                 # exact duplicates across the shards: ties
+    ref = _lib.Context(0)
+    ref.set_nn_mode(nn_mode)
+    ref.set_clouds_f64(src, tgt)
+    want = ref.run(None, radius, 12, 0, 0)
+    want_idx = ref.correspondence_index()
+    cuts = [0, 23456, len(tgt)]                             # ragged shards
+    out, ex = run_sharded(src, tgt, radius, 12, nn_mode, cuts)
+    assert ex.calls["min"] == 13 and ex.calls["sum"] == 13   # one of each per NN pass
+    for res, idx in out:
+        assert np.array_equal(idx, want_idx)                # global indices, lowest on ties
+        assert res.num_correspondences == want.num_correspondences
+        assert synth.rel_frobenius(res.transformation_, want.transformation_) < 1e-12
+        assert abs(res.inlier_rmse_ - want.inlier_rmse_) < 1e-12
+    assert np.array_equal(out[0][0].transformation_, out[1][0].transformation_)   # ranks agree to the bit
+
+
+@pytest.mark.gpu
+def test_target_sharded_three_ranks_point_to_plane_and_empty_shard(lib):
+    src, tgt, T_gt, radius = synth.make_pair(6000, 30000, motion="radius")
+    nrm = tgt / np.linalg.norm(tgt, axis=1, keepdims=True)
+    ref = _lib.Context(0)
+    ref.set_clouds_f64(src, tgt)
+    ref.set_target_normals_f64(nrm)
+    want = ref.run_point_to_plane(None, radius, 8, 0, 0)
+    want_idx = ref.correspondence_index()
+    cuts = [0, 11111, 11111, len(tgt)]                      # the middle rank owns nothing
+    out, _ = run_sharded(src, tgt, radius, 8, _lib.NN_AUTO, cuts, normals=nrm, plane=True)
+    for res, idx in out:
+        assert np.array_equal(idx, want_idx)
+        # Gauss-Newton with made-up normals is ill-conditioned: f64 summation order shows at 1e-10
+        assert synth.rel_frobenius(res.transformation_, want.transformation_) < 1e-7
+
+
+@pytest.mark.gpu
+def test_target_shard_needs_an_exchange(lib):
+    src, tgt, _, radius = synth.make_pair(2000, 8000, motion="radius")
+    ctx = _lib.Context(0)
+    ctx.set_target_shard(0, 16000, tgt.mean(0))
+    ctx.set_clouds_f64(src, tgt)
+    with pytest.raises(_lib.IcpError):
+        ctx.run(None, radius, 2, 0, 0)                      # no RCCL communicator, no callbacks
+    with pytest.raises(_lib.IcpError):
+        ctx.set_target_shard(0, 2 ** 31 + 5, None)          # global indices must fit 31 bits

@@ -50,6 +50,7 @@ class CProblem(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int)
+MINREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint64), C.c_int64)
 ENG_SET = C.CFUNCTYPE(C.c_int, C.c_void_p, _fp, C.c_int64)
 ENG_NN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_double)
 ENG_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, _dp, C.c_int, _dp)
@@ -113,6 +114,8 @@ def load():
     L.visma_icp_error_metric.argtypes = [_dp, C.c_int64, _dp]
     L.visma_icp_measure_surface_error.argtypes = [C.c_void_p, _dp, C.c_int64, _ip, C.c_int64, _dp, C.c_int64,
                                                   _ip, C.c_int64, C.c_int64, C.c_int, C.c_uint64, _dp]
+    L.visma_icp_set_target_shard.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp]
+    L.visma_icp_set_minreduce.argtypes = [C.c_void_p, MINREDUCE_FN, C.c_void_p]
     L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -393,6 +396,25 @@ class Context:
         cb = ALLREDUCE_FN(tramp)
         self._keep.append(cb)
         self._chk(self.L.visma_icp_set_allreduce(self._h, cb, None, int(rank), int(nranks)))
+
+    def set_target_shard(self, global_offset, global_nt, centre=None):
+        """Target-sharded rank: this context holds targets [offset, offset + nt) of `global_nt`.
+        Call before set_clouds_f64; `centre` must be the same on every rank."""
+        c = None if centre is None else _f64(centre, (3,))
+        self._chk(self.L.visma_icp_set_target_shard(self._h, int(global_offset), int(global_nt),
+                                                    None if c is None else _p(c, _dp)))
+
+    def set_minreduce(self, fn):
+        """fn(np.ndarray[uint64, n]) must take the element-wise minimum across ranks in place."""
+        def tramp(_user, ptr, n):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(n,)))
+                return 0
+            except Exception:
+                return 1
+        cb = MINREDUCE_FN(tramp)
+        self._keep.append(cb)
+        self._chk(self.L.visma_icp_set_minreduce(self._h, cb, None))
 
     def set_global_source_count(self, n):
         self._chk(self.L.visma_icp_set_global_source_count(self._h, int(n)))

@@ -78,6 +78,8 @@ struct Rccl {
 Rccl g_rccl;
 constexpr int kNcclFloat64 = 8;  // ncclFloat64 / ncclDouble (rccl.h)
 constexpr int kNcclSum = 0;      // ncclSum
+constexpr int kNcclMin = 3;      // ncclMin
+constexpr int kNcclUint64 = 5;   // ncclUint64
 
 // ---- engines --------------------------------------------------------------------
 class Engine {
@@ -135,6 +137,9 @@ public:
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
     virtual bool has_device_allreduce() const { return false; }
+    // target-sharded ranks: this engine holds targets [offset, offset + nt) of the global cloud
+    virtual int set_target_shard(int64_t, int64_t) { err_ = "target sharding needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    virtual void set_minreduce(visma_icp_minreduce_fn, void *) {}
     const std::string &error() const { return err_; }
     int64_t ns() const { return ns_; }
     int64_t nt() const { return nt_; }
@@ -155,7 +160,7 @@ public:
         (void)hipSetDevice(device_);
         if (comm_) g_rccl.CommDestroy(comm_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
-        free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_);
+        free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
@@ -323,10 +328,12 @@ public:
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
-            if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-            HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
-                                    (double *)d_stats_, stream_, pub, seq));
-            if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            if (!tshard_) {
+                if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
+                                        (double *)d_stats_, stream_, pub, seq));
+                if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            }
             grid_pending_ = false;
         } else {
             if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -334,9 +341,17 @@ public:
                                   (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                   plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
                                   (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_, pub, seq));
+                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_,
+                                  tshard_ ? nullptr : pub, seq));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             brute_reduced_ = true;
+        }
+        if (tshard_) {
+            // The local pass above found this shard's winner of every source point.  The
+            // global winner is the smallest (d2, global index) key over the ranks; its owner
+            // accumulates the pair, so each correspondence is counted exactly once.
+            int rc = shard_exchange(T64, plane, offset, pub, seq);
+            if (rc) return rc;
         }
         if (comm_) {
             // ONE all-reduce of the 38 f64 accumulators per ICP iteration
@@ -700,6 +715,56 @@ public:
     }
     int nn_mode_used() const override { return use_grid_ ? VISMA_ICP_NN_GRID : VISMA_ICP_NN_BRUTE; }
 
+    int set_target_shard(int64_t offset, int64_t global_nt) override
+    {
+        if (offset < 0 || global_nt < 0 || global_nt > 0x7fffffffll) {
+            err_ = "bad target shard (global indices must fit 31 bits)";
+            return VISMA_ICP_ERR_INVALID;
+        }
+        tshard_ = global_nt > 0;
+        tgt_offset_ = offset;
+        tgt_global_ = global_nt;
+        return VISMA_ICP_OK;
+    }
+    void set_minreduce(visma_icp_minreduce_fn fn, void *user) override { minreduce_ = fn; minreduce_user_ = user; }
+
+    int shard_exchange(const Xform64 &T64, bool plane, const double offset[3], double *pub, unsigned long long seq)
+    {
+        if (tgt_offset_ + nt_ > tgt_global_) { err_ = "target shard exceeds the global target"; return VISMA_ICP_ERR_INVALID; }
+        if (!comm_ && !minreduce_) { err_ = "target-sharded mode needs visma_icp_comm_init or visma_icp_set_minreduce"; return VISMA_ICP_ERR_STATE; }
+        if (ns_ > gkeys_cap_) {
+            free_dev(d_gkeys_);
+            HIP_TRY(hipMalloc(&d_gkeys_, sizeof(unsigned long long) * std::max<int64_t>(ns_, 1)));
+            gkeys_cap_ = ns_;
+        }
+        HIP_TRY(launch_shard_keys((const int32_t *)d_idx_, (const float *)d_d2_, ns_, (unsigned)tgt_offset_,
+                                  (unsigned long long *)d_gkeys_, stream_));
+        if (comm_) {
+            int rc = g_rccl.AllReduce(d_gkeys_, d_gkeys_, (size_t)ns_, kNcclUint64, kNcclMin, comm_, stream_);
+            if (rc != 0) {
+                err_ = std::string("ncclAllReduce(min): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+                return VISMA_ICP_ERR_RCCL;
+            }
+        } else {
+            // host-supplied exchange (tests, other transports): through host memory
+            h_gkeys_.resize((size_t)ns_);
+            HIP_TRY(hipMemcpyAsync(h_gkeys_.data(), d_gkeys_, sizeof(unsigned long long) * ns_, hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            if (ns_ > 0 && minreduce_(minreduce_user_, (uint64_t *)h_gkeys_.data(), ns_) != 0) {
+                err_ = "min-reduce callback failed";
+                return VISMA_ICP_ERR_ENGINE;
+            }
+            HIP_TRY(hipMemcpyAsync(d_gkeys_, h_gkeys_.data(), sizeof(unsigned long long) * ns_, hipMemcpyHostToDevice, stream_));
+        }
+        int nblocks = 1;
+        HIP_TRY(launch_shard_accumulate((const float4 *)d_src_, ns_, (const unsigned long long *)d_gkeys_,
+                                        (const float4 *)d_tgt_, nt_, (unsigned)tgt_offset_, (const float4 *)d_nrm_,
+                                        T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_, (float *)d_d2_,
+                                        (double *)d_partials_, reduce_max_blocks(), &nblocks, stream_));
+        HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0, (double *)d_stats_, stream_, pub, seq));
+        return VISMA_ICP_OK;
+    }
+
     int comm_init(int rank, int nranks, const void *id) override
     {
         HIP_TRY(hipSetDevice(device_));
@@ -876,6 +941,12 @@ private:
     std::vector<std::pair<int, int>> pending_;
     visma_icp_timing timing_{};
     NcclComm comm_ = nullptr;
+    bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
+    int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
+    void *d_gkeys_ = nullptr;
+    std::vector<unsigned long long> h_gkeys_;
+    visma_icp_minreduce_fn minreduce_ = nullptr;
+    void *minreduce_user_ = nullptr;
     // radius-cell grid (valid for one target + one radius)
     int nn_mode_ = VISMA_ICP_NN_AUTO;
     bool use_grid_ = false, grid_valid_ = false, grid_pending_ = false, brute_reduced_ = false;
@@ -960,6 +1031,8 @@ struct visma_icp_ctx {
     std::unique_ptr<Engine> eng;
     std::string err;
     double centre[3] = {0, 0, 0};
+    bool fixed_centre = false;        // centre given by the caller (target-sharded ranks share one)
+    bool target_sharded = false;
     bool have_src = false, have_tgt = false;
     visma_icp_allreduce_fn host_allreduce = nullptr;
     void *host_allreduce_user = nullptr;
@@ -1011,7 +1084,7 @@ struct visma_icp_ctx {
     // measured 46 vs 68 us per iteration at 5k x 20k), device loop for sweeps of
     // many transforms (their solves run in parallel and nothing syncs per pass)
     int loop_mode = 2;
-    bool device_loop_possible() const { return eng->supports_device_loop() && !host_allreduce; }
+    bool device_loop_possible() const { return eng->supports_device_loop() && !host_allreduce && !target_sharded; }
     bool use_device_loop() const { return loop_mode == 1 && device_loop_possible(); }
     bool use_device_loop_batched() const { return loop_mode != 0 && device_loop_possible(); }
     static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }
@@ -1242,9 +1315,13 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad cloud arguments");
     // centre on the target centroid: sequential f64 sum in index order
     double c[3] = {0, 0, 0};
-    for (int64_t j = 0; j < nt; j++)
-        for (int a = 0; a < 3; a++) c[a] += tgt[(size_t)j * tstride + a];
-    if (nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)nt;
+    if (ctx->fixed_centre) {
+        std::memcpy(c, ctx->centre, sizeof(c));
+    } else {
+        for (int64_t j = 0; j < nt; j++)
+            for (int a = 0; a < 3; a++) c[a] += tgt[(size_t)j * tstride + a];
+        if (nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)nt;
+    }
     std::vector<float> buf;
     pack_f64(tgt, nt, tstride, c, buf);
     int rc = ctx->eng->set_target(buf.data(), nt);
@@ -1706,6 +1783,24 @@ int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn, void 
     ctx->host_allreduce_user = user;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_target_shard(visma_icp_ctx *ctx, int64_t global_offset, int64_t global_nt, const double centre[3])
+{
+    CTX_CHECK();
+    int rc = ctx->eng->set_target_shard(global_offset, global_nt);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->target_sharded = global_nt > 0;
+    ctx->fixed_centre = centre != nullptr && global_nt > 0;
+    if (ctx->fixed_centre) std::memcpy(ctx->centre, centre, 3 * sizeof(double));
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_minreduce(visma_icp_ctx *ctx, visma_icp_minreduce_fn fn, void *user)
+{
+    CTX_CHECK();
+    ctx->eng->set_minreduce(fn, user);
     return VISMA_ICP_OK;
 }
 

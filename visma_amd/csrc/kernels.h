@@ -71,6 +71,15 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          unsigned long long seq = 0);
 
 int reduce_max_blocks();
+// target-sharded ranks: keys of the local winners / moments of the global winners owned here
+hipError_t launch_shard_keys(const int32_t *idx, const float *d2, int64_t ns, unsigned offset,
+                             unsigned long long *keys, hipStream_t stream);
+hipError_t launch_shard_accumulate(const float4 *src, int64_t ns, const unsigned long long *keys,
+                                   const float4 *tgt, int64_t nt_local, unsigned offset,
+                                   const float4 *tgt_normals, const Xform64 &T64,
+                                   const double frame_offset[3], float r2f, int point_to_plane,
+                                   int32_t *idx_out, float *d2_out, double *partials,
+                                   int max_partial_blocks, int *nblocks_out, hipStream_t stream);
 // stats (device) -> host_out[0..37] (mapped host memory), then host_out[38] = seq (u64 bits)
 hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned long long seq,
                                 hipStream_t stream);

@@ -234,6 +234,85 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(
     block_reduce_store<NACC>(acc, partials);
 }
 
+// ------------------------------------------------------------------------
+// Target-sharded ranks: global winners by a min-reduce of keys
+// ------------------------------------------------------------------------
+// key = (fp32 d2 bits << 32) | GLOBAL target index; all ones = no neighbour.  The
+// smallest key over the ranks is the (d2, lowest index) winner of the whole target.
+__global__ __launch_bounds__(256) void shard_keys_kernel(const int *__restrict__ idx,
+                                                         const float *__restrict__ d2, int ns,
+                                                         unsigned offset,
+                                                         unsigned long long *__restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const int j = idx[i];
+    keys[i] = j < 0 ? ~0ull
+                    : (((unsigned long long)__float_as_uint(d2[i]) << 32) | ((unsigned)j + offset));
+}
+
+// After the min-reduce: every rank writes the global (index, d2) of every source
+// point, and accumulates the Jacobian/residual moments of the winners IT owns.
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void shard_accumulate_kernel(
+    const float4 *__restrict__ src, int ns, const unsigned long long *__restrict__ keys,
+    const float4 *__restrict__ tgt, long long nt_local, unsigned offset,
+    const float4 *__restrict__ nrm, Xform64 T64, Offset64 off, float r2f,
+    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        const unsigned long long key = keys[i];
+        const bool hit = key != ~0ull;
+        const unsigned gj = (unsigned)key;
+        idx_out[i] = hit ? (int)gj : -1;
+        d2_out[i] = hit ? __uint_as_float((unsigned)(key >> 32)) : r2f;
+        const long long lj = (long long)gj - (long long)offset;
+        if (hit && lj >= 0 && lj < nt_local) {
+            float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (PLANE) n4 = nrm[lj];
+            accumulate_pair<PLANE>(acc, src[i], tgt[lj], n4, T64, off);
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
+hipError_t launch_shard_keys(const int32_t *idx, const float *d2, int64_t ns, unsigned offset,
+                             unsigned long long *keys, hipStream_t stream)
+{
+    if (ns > 0)
+        hipLaunchKernelGGL(shard_keys_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, idx, d2,
+                           (int)ns, offset, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_accumulate(const float4 *src, int64_t ns, const unsigned long long *keys,
+                                   const float4 *tgt, int64_t nt_local, unsigned offset,
+                                   const float4 *tgt_normals, const Xform64 &T64,
+                                   const double frame_offset[3], float r2f, int point_to_plane,
+                                   int32_t *idx_out, float *d2_out, double *partials,
+                                   int max_partial_blocks, int *nblocks_out, hipStream_t stream)
+{
+    Offset64 off;
+    for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
+    int64_t want = (ns + kBlock - 1) / kBlock;
+    int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
+    if (nblocks < 1) nblocks = 1;
+    if (point_to_plane)
+        hipLaunchKernelGGL(shard_accumulate_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src, (int)ns,
+                           keys, tgt, (long long)nt_local, offset, tgt_normals, T64, off, r2f, idx_out, d2_out,
+                           partials);
+    else
+        hipLaunchKernelGGL(shard_accumulate_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src, (int)ns,
+                           keys, tgt, (long long)nt_local, offset, tgt_normals, T64, off, r2f, idx_out, d2_out,
+                           partials);
+    if (nblocks_out) *nblocks_out = nblocks;
+    return hipGetLastError();
+}
+
 // Publish the 38 statistics to mapped (fine-grained, uncached) host memory as
 // self-validating 16-byte granules {value, sequence tag}: each granule is ONE
 // global_store_dwordx4, so the host can accept a value as soon as its tag shows
