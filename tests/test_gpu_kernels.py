@@ -230,3 +230,26 @@ def test_batch_of_different_clouds_in_flight(gpu_ctx_auto, oracle):
     o = oracle.registration_icp(s0, t0, r0, init=i0, max_iter=25)
     assert synth.rel_frobenius(batched[3].transformation_, o.T) < TOL_T
     assert batched[3].num_correspondences == o.k
+
+
+@pytest.mark.gpu
+def test_batch_shares_uploads_and_grids_between_problems_with_the_same_clouds(gpu_ctx_auto):
+    """24 yaw starts of 3 models against ONE scene (the shape of src/annotation.cpp:35-61,103-168):
+    problems that pass the same arrays share one packed copy / upload / grid.  Same answers,
+    bit for bit, as the batch given private copies of every cloud."""
+    ctx = gpu_ctx_auto
+    scene = synth.surface_points(30000, 77)
+    models = [synth.surface_points(n, 80 + i)[:n] * 0.999 for i, n in enumerate((3000, 5000, 800))]
+    shared, private = [], []
+    for m in models:
+        for k in range(8):
+            init = synth.make_T(synth.rot_y(2 * np.pi * k / 8), [0.001 * k, 0, 0])
+            r = 0.05 if k % 2 else 0.03                       # two radii -> two grids over one scene
+            shared.append((m, scene, init, r))
+            private.append((m.copy(), scene.copy(), init, r))
+    a = ctx.run_batch(shared, max_iter=20)
+    b = ctx.run_batch(private, max_iter=20)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.transformation_, y.transformation_)
+        assert x.num_correspondences == y.num_correspondences and x.iterations == y.iterations
+        assert x.inlier_rmse_ == y.inlier_rmse_

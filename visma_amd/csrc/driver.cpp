@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -125,6 +126,9 @@ public:
         double centre[3];
         double max_dist;
         float bb_min[3], bb_max[3];   // bounding box of the (centred) target
+        // problems that share clouds (24 yaw starts of one model, every model against the
+        // same scene): index of an EARLIER problem whose uploaded source / built grid is reused
+        int src_share = -1, grid_share = -1;
     };
     virtual int run_loop_batch(const LoopParams &, const std::vector<BatchProblem> &, LoopResult *)
     {
@@ -570,9 +574,18 @@ public:
         if (comm_) { err_ = "batched loop is single-GPU"; return VISMA_ICP_ERR_STATE; }
         // ---- layout of the concatenated arrays
         std::vector<ProbDesc> descs((size_t)B);
-        int64_t src_tot = 0, tgt_tot = 0, cell_tot = 0, max_ncell = 0;
+        int64_t src_tot = 0, tgt_tot = 0, cell_tot = 0, max_ncell = 0, out_tot = 0;
         int total_blocks = 0;
-        const int G = 4;
+        // lanes per query / loads in flight (G + 100 U); VISMA_ICP_BATCH_LANES overrides
+        // (measured on config 3, 288 problems / 5.2 M queries per pass: G=1,U=8 21.6 ms, G=4,U=8 34 ms;
+        // few small problems need the lanes of G=4 to fill the chip)
+        int64_t queries = 0;
+        for (int b = 0; b < B; b++) queries += pb[b].ns;
+        int lanes = queries >= 200000 ? 801 : 804;
+        if (const char *e = std::getenv("VISMA_ICP_BATCH_LANES")) { const int v = std::atoi(e); if (v > 0) lanes = v; }
+        const int G = lanes % 100;
+        if (G < 1 || G > 64 || (G & (G - 1))) { err_ = "bad VISMA_ICP_BATCH_LANES"; return VISMA_ICP_ERR_INVALID; }
+        bool one_per_lane = true;
         for (int b = 0; b < B; b++) {
             const BatchProblem &q = pb[b];
             if (q.ns < 0 || q.nt < 0 || !(q.max_dist > 0.0)) { err_ = "bad batch problem"; return VISMA_ICP_ERR_INVALID; }
@@ -582,25 +595,51 @@ public:
             const int64_t cap = std::min<int64_t>(kGridMaxCells, std::max<int64_t>(4096, 8 * q.nt));
             float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
             if (q.nt > 0) for (int a = 0; a < 3; a++) { mn[a] = q.bb_min[a]; mx[a] = q.bb_max[a]; }
-            d.g = grid_plan(mn, mx, q.max_dist, cap);
-            d.src_off = src_tot; d.sorted_off = tgt_tot; d.start_off = cell_tot; d.out_off = src_tot;
+            if ((q.src_share >= 0 && (q.src_share >= b || pb[q.src_share].ns != q.ns || pb[q.src_share].src_share >= 0)) ||
+                (q.grid_share >= 0 && (q.grid_share >= b || pb[q.grid_share].nt != q.nt || pb[q.grid_share].grid_share >= 0))) {
+                err_ = "bad cloud sharing in the batch";
+                return VISMA_ICP_ERR_INVALID;
+            }
+            if (q.grid_share >= 0) {
+                d.g = descs[q.grid_share].g;
+                d.sorted_off = descs[q.grid_share].sorted_off;
+                d.start_off = descs[q.grid_share].start_off;
+            } else {
+                d.g = grid_plan(mn, mx, q.max_dist, cap);
+                d.sorted_off = tgt_tot;
+                d.start_off = cell_tot;
+                tgt_tot += q.nt;
+                cell_tot += d.g.ncell + 1;
+                max_ncell = std::max(max_ncell, d.g.ncell);
+            }
+            if (q.src_share >= 0) {
+                d.src_off = descs[q.src_share].src_off;
+            } else {
+                d.src_off = src_tot;
+                src_tot += q.ns;
+            }
+            d.out_off = out_tot;
+            out_tot += q.ns;
             d.ns = (int)q.ns;
             d.first_block = total_blocks;
-            int64_t nb = (q.ns * G + kBlock - 1) / kBlock;
+            // one query per lane (the kernel's ONE variant) up to 262,144 source points per problem
+            int64_t nb = (q.ns + kBlock - 1) / kBlock;
             if (nb < 1) nb = 1;
-            if (nb > 256) nb = 256;
+            if (nb > 1024) { nb = 1024; one_per_lane = false; }
             d.nblocks = (int)nb;
             total_blocks += d.nblocks;
-            src_tot += q.ns; tgt_tot += q.nt; cell_tot += d.g.ncell + 1;
-            max_ncell = std::max(max_ncell, d.g.ncell);
         }
         // ---- device buffers
         if (src_tot > bt_src_cap_) {
-            free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_);
+            free_dev(bt_src_);
             HIP_TRY(hipMalloc(&bt_src_, sizeof(float4) * std::max<int64_t>(src_tot, 1)));
-            HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(src_tot, 1)));
-            HIP_TRY(hipMalloc(&bt_d2_, sizeof(float) * std::max<int64_t>(src_tot, 1)));
             bt_src_cap_ = src_tot;
+        }
+        if (out_tot > bt_out_cap_) {
+            free_dev(bt_idx_); free_dev(bt_d2_);
+            HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(out_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_d2_, sizeof(float) * std::max<int64_t>(out_tot, 1)));
+            bt_out_cap_ = out_tot;
         }
         if (tgt_tot > bt_tgt_cap_) {
             free_dev(bt_tgt_); free_dev(bt_sorted_); free_dev(bt_cell_of_);
@@ -643,7 +682,8 @@ public:
         for (int b = 0; b < B; b++) {
             const BatchProblem &q = pb[b];
             const ProbDesc &d = descs[b];
-            if (q.ns > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_src_ + d.src_off, q.src_xyzw, sizeof(float4) * q.ns, hipMemcpyHostToDevice, stream_));
+            if (q.ns > 0 && q.src_share < 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_src_ + d.src_off, q.src_xyzw, sizeof(float4) * q.ns, hipMemcpyHostToDevice, stream_));
+            if (q.grid_share >= 0) continue;
             if (q.nt > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_tgt_ + d.sorted_off, q.tgt_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
             HIP_TRY(launch_grid_build((const float4 *)bt_tgt_ + d.sorted_off, q.nt, d.g,
                                       (unsigned *)bt_cell_of_ + d.sorted_off, (unsigned *)bt_count_ + d.start_off,
@@ -678,7 +718,7 @@ public:
                 HIP_TRY(launch_nn_grid_reduce_batch((const float4 *)bt_src_, (const float4 *)bt_sorted_,
                                                     (const unsigned *)bt_start_, (const ProbDesc *)bt_descs_, B,
                                                     total_blocks, (int32_t *)bt_idx_, (float *)bt_d2_,
-                                                    (double *)d_partials_, G, st, stream_));
+                                                    (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
                 HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_));
@@ -961,7 +1001,7 @@ private:
     // batch of problems with their own clouds (concatenated arrays)
     void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
     void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
-    int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0;
+    int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0, bt_out_cap_ = 0;
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
     static constexpr int kGridMaxBlocks = 8192;
@@ -1638,27 +1678,60 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
                 return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch problem");
             if (!(q.max_dist > 0.0)) ok = false;   // rare: handled by the sequential path
         }
+        // Problems often share clouds: the 24 yaw starts of one model (src/annotation.cpp:35-61),
+        // every model against the same scene.  Equal (pointer, count) pairs are packed, uploaded
+        // and gridded ONCE.
+        std::vector<int> tshare((size_t)n, -1), sshare((size_t)n, -1), gshare((size_t)n, -1);
+        for (int i = 0; ok && i < n; i++)
+            for (int j = 0; j < i; j++) {
+                if (tshare[j] >= 0) continue;                      // only first occurrences are referenced
+                if (probs[j].tgt_xyz == probs[i].tgt_xyz && probs[j].nt == probs[i].nt) { tshare[i] = j; break; }
+            }
+        for (int i = 0; ok && i < n; i++) {
+            const int t = tshare[i] >= 0 ? tshare[i] : i;
+            for (int j = 0; j < i; j++) {
+                const int tj = tshare[j] >= 0 ? tshare[j] : j;
+                if (tj != t) continue;
+                if (gshare[i] < 0 && gshare[j] < 0 && probs[j].max_dist == probs[i].max_dist) gshare[i] = j;
+                if (sshare[i] < 0 && sshare[j] < 0 && probs[j].src_xyz == probs[i].src_xyz && probs[j].ns == probs[i].ns)
+                    sshare[i] = j;
+            }
+        }
+        std::vector<std::array<double, 3>> cen((size_t)n);
         if (ok)
-            parallel_for(n, 1, [&](int64_t i) {
+            parallel_for(n, 1, [&](int64_t i) {                    // targets: first occurrences only
+                if (tshare[i] >= 0) return;
                 const visma_icp_problem &q = probs[i];
                 double c[3] = {0, 0, 0};
                 for (int64_t j = 0; j < q.nt; j++)
                     for (int a = 0; a < 3; a++) c[a] += q.tgt_xyz[(size_t)j * 3 + a];
                 if (q.nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)q.nt;
+                for (int a = 0; a < 3; a++) cen[i][a] = c[a];
                 pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
-                pack_f64(q.src_xyz, q.ns, 3, c, sbuf[i]);
-                std::vector<int32_t> order;
-                morton_order(sbuf[i], q.ns, order);
+            });
+        if (ok)
+            parallel_for(n, 1, [&](int64_t i) {
+                const visma_icp_problem &q = probs[i];
+                const int t = tshare[i] >= 0 ? tshare[i] : (int)i;
+                const double *c = cen[t].data();
+                if (sshare[i] < 0) {
+                    pack_f64(q.src_xyz, q.ns, 3, c, sbuf[i]);
+                    std::vector<int32_t> order;
+                    morton_order(sbuf[i], q.ns, order);
+                }
                 Engine::BatchProblem &b = pb[i];
-                b.src_xyzw = sbuf[i].data(); b.ns = q.ns;
-                b.tgt_xyzw = tbuf[i].data(); b.nt = q.nt;
+                b.src_xyzw = sshare[i] < 0 ? sbuf[i].data() : nullptr; b.ns = q.ns;
+                b.tgt_xyzw = tbuf[t].data(); b.nt = q.nt;
+                b.src_share = sshare[i];
+                b.grid_share = gshare[i];
                 b.Tc0 = to_centred(Mat4::from(q.init), c);
-                std::memcpy(b.centre, c, sizeof(c));
+                std::memcpy(b.centre, c, 3 * sizeof(double));
                 b.max_dist = q.max_dist;
                 for (int a = 0; a < 3; a++) { b.bb_min[a] = 0.f; b.bb_max[a] = 0.f; }
+                if (gshare[i] >= 0) return;                        // the grid (and its box) is reused
                 for (int64_t j = 0; j < q.nt; j++)
                     for (int a = 0; a < 3; a++) {
-                        const float v = tbuf[i][4 * j + a];
+                        const float v = tbuf[t][4 * j + a];
                         if (j == 0 || v < b.bb_min[a]) b.bb_min[a] = v;
                         if (j == 0 || v > b.bb_max[a]) b.bb_max[a] = v;
                     }

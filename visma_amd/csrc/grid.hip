@@ -611,7 +611,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     return hipGetLastError();
 }
 
-template <int G>
+template <int G, int U, bool ONE>
 static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const float4 *src,
                                 const float4 *sorted, const unsigned *start, const ProbDesc *descs,
                                 int nprob, int *idx_out, float *d2_out, double *partials,
@@ -621,23 +621,35 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
     const Xform64 T64{};
     const Offset64 off{};
     const GridParams g{};
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, 2, false>), dim3(total_blocks), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
                        d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob);
 }
 
+// lanes_per_query = G + 100 * U; one_per_lane: every problem has at most G queries per lane group
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
                                        const ProbDesc *descs, int nprob, int total_blocks,
                                        int32_t *idx_out, float *d2_out, double *partials,
-                                       int lanes_per_query, const DevIcpState *st, hipStream_t stream)
+                                       int lanes_per_query, int one_per_lane, const DevIcpState *st,
+                                       hipStream_t stream)
 {
     if (!st || !descs) return hipErrorInvalidValue;
-    switch (lanes_per_query) {
-    case 2: launch_grid_batch_t<2>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st); break;
-    case 4: launch_grid_batch_t<4>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st); break;
-    case 8: launch_grid_batch_t<8>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st); break;
-    default: return hipErrorInvalidValue;
+    const int G = lanes_per_query % 100, U = lanes_per_query / 100;
+    bool launched = false;
+#define VISMA_BATCH_CASE(GG, UU)                                                                              \
+    if (G == GG && U == UU) {                                                                                 \
+        if (one_per_lane)                                                                                     \
+            launch_grid_batch_t<GG, UU, true>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out,  \
+                                              d2_out, partials, st);                                          \
+        else                                                                                                  \
+            launch_grid_batch_t<GG, UU, false>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
+                                               d2_out, partials, st);                                         \
+        launched = true;                                                                                      \
     }
+    VISMA_BATCH_CASE(4, 2) VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
+    VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4)
+#undef VISMA_BATCH_CASE
+    if (!launched) return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -163,7 +163,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
                                        const ProbDesc *descs, int nprob, int total_blocks,
                                        int32_t *idx_out, float *d2_out, double *partials,
-                                       int lanes_per_query, const DevIcpState *st,
+                                       int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream);
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
                                        int nprob, hipStream_t stream);
