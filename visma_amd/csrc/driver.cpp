@@ -141,6 +141,15 @@ public:
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
     virtual bool has_device_allreduce() const { return false; }
+    // Host staging for the packed (x,y,z,0) fp32 clouds handed to set_source / set_target.
+    // The HIP engine returns pinned memory (grow-only), so the upload runs at link speed.
+    virtual float *staging(int slot, size_t nfloats)
+    {
+        std::vector<float> &v = stage_[slot & 1];
+        if (v.size() < nfloats) v.resize(nfloats);
+        return v.data();
+    }
+    std::vector<float> stage_[2];
     // target-sharded ranks: this engine holds targets [offset, offset + nt) of the global cloud
     virtual int set_target_shard(int64_t, int64_t) { err_ = "target sharding needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     virtual void set_minreduce(visma_icp_minreduce_fn, void *) {}
@@ -165,6 +174,7 @@ public:
         if (comm_) g_rccl.CommDestroy(comm_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
+        for (int i = 0; i < 2; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
@@ -219,6 +229,24 @@ public:
         return VISMA_ICP_OK;
     }
 
+    float *staging(int slot, size_t nfloats) override
+    {
+        slot &= 1;
+        if (pin_cap_[slot] < nfloats) {
+            if (pin_[slot]) (void)hipHostFree(pin_[slot]);
+            pin_[slot] = nullptr;
+            pin_cap_[slot] = 0;
+            const size_t want = nfloats + nfloats / 4 + 1024;
+            if (hipSetDevice(device_) != hipSuccess ||
+                hipHostMalloc((void **)&pin_[slot], want * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                pin_[slot] = nullptr;
+                return Engine::staging(slot, nfloats);     // pageable memory still works, only slower
+            }
+            pin_cap_[slot] = want;
+        }
+        return pin_[slot];
+    }
     int set_source(const float *xyzw, int64_t ns) override
     {
         HIP_TRY(hipSetDevice(device_));
@@ -980,6 +1008,8 @@ private:
     int ev_used_ = 0;
     std::vector<std::pair<int, int>> pending_;
     visma_icp_timing timing_{};
+    float *pin_[2] = {nullptr, nullptr};   // pinned staging (see staging())
+    size_t pin_cap_[2] = {0, 0};
     NcclComm comm_ = nullptr;
     bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
     int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
@@ -1206,31 +1236,6 @@ struct visma_icp_ctx {
 
 namespace {
 
-int pack_f64(const double *xyz, int64_t n, int stride, const double c[3], std::vector<float> &out)
-{
-    out.resize((size_t)(n > 0 ? n : 1) * 4);
-    for (int64_t i = 0; i < n; i++) {
-        const double *p = xyz + (size_t)i * stride;
-        out[4 * i + 0] = (float)(p[0] - c[0]);
-        out[4 * i + 1] = (float)(p[1] - c[1]);
-        out[4 * i + 2] = (float)(p[2] - c[2]);
-        out[4 * i + 3] = 0.f;
-    }
-    return 0;
-}
-
-void pack_f32(const float *xyz, int64_t n, int stride, std::vector<float> &out)
-{
-    out.resize((size_t)(n > 0 ? n : 1) * 4);
-    for (int64_t i = 0; i < n; i++) {
-        const float *p = xyz + (size_t)i * stride;
-        out[4 * i + 0] = p[0];
-        out[4 * i + 1] = p[1];
-        out[4 * i + 2] = p[2];
-        out[4 * i + 3] = 0.f;
-    }
-}
-
 // Run fn(i) for i in [0, n) on a few host threads (packing / ordering of clouds).
 template <typename F>
 void parallel_for(int64_t n, int64_t min_per_thread, F fn)
@@ -1253,6 +1258,69 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
     for (auto &t : th) t.join();
 }
 
+constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
+
+// (x - c) as fp32 (x,y,z,0) rows; `par`: spread over host threads
+void pack_f64_to(const double *xyz, int64_t n, int stride, const double c[3], float *out, bool par)
+{
+    auto body = [&](int64_t ch) {
+        const int64_t lo = ch * kHostChunk, hi = std::min(n, lo + kHostChunk);
+        for (int64_t i = lo; i < hi; i++) {
+            const double *p = xyz + (size_t)i * stride;
+            out[4 * i + 0] = (float)(p[0] - c[0]);
+            out[4 * i + 1] = (float)(p[1] - c[1]);
+            out[4 * i + 2] = (float)(p[2] - c[2]);
+            out[4 * i + 3] = 0.f;
+        }
+    };
+    const int64_t nch = (n + kHostChunk - 1) / kHostChunk;
+    if (par) parallel_for(nch, 1, body);
+    else for (int64_t ch = 0; ch < nch; ch++) body(ch);
+}
+
+int pack_f64(const double *xyz, int64_t n, int stride, const double c[3], std::vector<float> &out)
+{
+    out.resize((size_t)(n > 0 ? n : 1) * 4);
+    pack_f64_to(xyz, n, stride, c, out.data(), false);
+    return 0;
+}
+
+void pack_f32_to(const float *xyz, int64_t n, int stride, float *out)
+{
+    for (int64_t i = 0; i < n; i++) {
+        const float *p = xyz + (size_t)i * stride;
+        out[4 * i + 0] = p[0];
+        out[4 * i + 1] = p[1];
+        out[4 * i + 2] = p[2];
+        out[4 * i + 3] = 0.f;
+    }
+}
+
+// Centroid in f64.  Fixed chunks summed in index order and combined in chunk order: the
+// value does not depend on the number of threads (every rank of a multi-GPU run, and every
+// repeat, gets the same centre).
+void centroid_f64(const double *xyz, int64_t n, int stride, double c[3], bool par)
+{
+    c[0] = c[1] = c[2] = 0.0;
+    if (n <= 0) return;
+    const int64_t nch = (n + kHostChunk - 1) / kHostChunk;
+    std::vector<double> part((size_t)nch * 3, 0.0);
+    auto body = [&](int64_t ch) {
+        const int64_t lo = ch * kHostChunk, hi = std::min(n, lo + kHostChunk);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int64_t i = lo; i < hi; i++) {
+            const double *p = xyz + (size_t)i * stride;
+            s0 += p[0]; s1 += p[1]; s2 += p[2];
+        }
+        part[3 * ch] = s0; part[3 * ch + 1] = s1; part[3 * ch + 2] = s2;
+    };
+    if (par) parallel_for(nch, 1, body);
+    else for (int64_t ch = 0; ch < nch; ch++) body(ch);
+    for (int64_t ch = 0; ch < nch; ch++)
+        for (int a = 0; a < 3; a++) c[a] += part[3 * ch + a];
+    for (int a = 0; a < 3; a++) c[a] /= (double)n;
+}
+
 // Spatial (Morton / Z-order) permutation of packed xyzw points.  Neighbouring
 // lanes then query neighbouring grid cells, so a wave's candidate runs overlap
 // in L1/L2.  Returns order[pos] = original index and permutes `pts` in place.
@@ -1266,7 +1334,7 @@ inline uint32_t spread10(uint32_t v)
     return v;
 }
 
-void morton_order(std::vector<float> &pts, int64_t n, std::vector<int32_t> &order)
+void morton_order_ptr(float *pts, int64_t n, std::vector<int32_t> &order, bool par)
 {
     order.resize((size_t)n);
     if (n <= 0) return;
@@ -1280,25 +1348,58 @@ void morton_order(std::vector<float> &pts, int64_t n, std::vector<int32_t> &orde
     float ext = 0.f;
     for (int a = 0; a < 3; a++) ext = std::max(ext, mx[a] - mn[a]);
     const float scale = (ext > 0.f && std::isfinite(ext)) ? 1023.0f / ext : 0.f;
-    std::vector<std::pair<uint32_t, int32_t>> keys((size_t)n);
-    for (int64_t i = 0; i < n; i++) {
-        uint32_t q[3];
-        for (int a = 0; a < 3; a++) {
-            float u = (pts[4 * i + a] - mn[a]) * scale;
-            if (!(u >= 0.f)) u = 0.f;
-            if (u > 1023.f) u = 1023.f;
-            q[a] = (uint32_t)u;
+    std::vector<uint32_t> key((size_t)n), key2((size_t)n);
+    std::vector<int32_t> idx2((size_t)n);
+    const int64_t nch = (n + kHostChunk - 1) / kHostChunk;
+    auto keys_body = [&](int64_t ch) {
+        const int64_t lo = ch * kHostChunk, hi = std::min(n, lo + kHostChunk);
+        for (int64_t i = lo; i < hi; i++) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; a++) {
+                float u = (pts[4 * i + a] - mn[a]) * scale;
+                if (!(u >= 0.f)) u = 0.f;
+                if (u > 1023.f) u = 1023.f;
+                q[a] = (uint32_t)u;
+            }
+            key[i] = spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2);
+            order[i] = (int32_t)i;
         }
-        keys[i] = {spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2), (int32_t)i};
+    };
+    if (par) parallel_for(nch, 1, keys_body);
+    else for (int64_t ch = 0; ch < nch; ch++) keys_body(ch);
+    // stable LSD radix sort, 3 passes of 10 bits: ties keep the original index order
+    uint32_t *ka = key.data(), *kb = key2.data();
+    int32_t *ia = order.data(), *ib = idx2.data();
+    for (int pass = 0; pass < 3; pass++) {
+        const int sh = 10 * pass;
+        uint32_t hist[1025];
+        std::memset(hist, 0, sizeof(hist));
+        for (int64_t i = 0; i < n; i++) hist[((ka[i] >> sh) & 1023u) + 1]++;
+        for (int b = 0; b < 1024; b++) hist[b + 1] += hist[b];
+        for (int64_t i = 0; i < n; i++) {
+            const uint32_t d = (ka[i] >> sh) & 1023u;
+            const uint32_t pos = hist[d]++;
+            kb[pos] = ka[i];
+            ib[pos] = ia[i];
+        }
+        std::swap(ka, kb);
+        std::swap(ia, ib);
     }
-    std::sort(keys.begin(), keys.end());   // ties broken by original index: deterministic
+    if (ia != order.data()) std::memcpy(order.data(), ia, (size_t)n * sizeof(int32_t));
     std::vector<float> out((size_t)n * 4);
-    for (int64_t pos = 0; pos < n; pos++) {
-        const int32_t o = keys[pos].second;
-        order[pos] = o;
-        std::memcpy(&out[4 * pos], &pts[4 * (size_t)o], 4 * sizeof(float));
-    }
-    std::memcpy(pts.data(), out.data(), out.size() * sizeof(float));
+    auto gather = [&](int64_t ch) {
+        const int64_t lo = ch * kHostChunk, hi = std::min(n, lo + kHostChunk);
+        for (int64_t pos = lo; pos < hi; pos++)
+            std::memcpy(&out[4 * pos], &pts[4 * (size_t)order[pos]], 4 * sizeof(float));
+    };
+    if (par) parallel_for(nch, 1, gather);
+    else for (int64_t ch = 0; ch < nch; ch++) gather(ch);
+    std::memcpy(pts, out.data(), out.size() * sizeof(float));
+}
+
+void morton_order(std::vector<float> &pts, int64_t n, std::vector<int32_t> &order)
+{
+    morton_order_ptr(pts.data(), n, order, false);
 }
 
 }  // namespace
@@ -1354,21 +1455,19 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     if (ns < 0 || nt < 0 || sstride < 3 || tstride < 3 || (ns > 0 && !src) || (nt > 0 && !tgt))
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad cloud arguments");
     // centre on the target centroid: sequential f64 sum in index order
+    // centre on the target centroid (fixed chunked f64 sum: thread-count independent)
     double c[3] = {0, 0, 0};
-    if (ctx->fixed_centre) {
-        std::memcpy(c, ctx->centre, sizeof(c));
-    } else {
-        for (int64_t j = 0; j < nt; j++)
-            for (int a = 0; a < 3; a++) c[a] += tgt[(size_t)j * tstride + a];
-        if (nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)nt;
-    }
-    std::vector<float> buf;
-    pack_f64(tgt, nt, tstride, c, buf);
-    int rc = ctx->eng->set_target(buf.data(), nt);
+    if (ctx->fixed_centre) std::memcpy(c, ctx->centre, sizeof(c));
+    else centroid_f64(tgt, nt, tstride, c, true);
+    // pack on a few host threads straight into the engine's (pinned) staging memory
+    float *tb = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
+    pack_f64_to(tgt, nt, tstride, c, tb, true);
+    int rc = ctx->eng->set_target(tb, nt);
     if (rc) return ctx->eng_fail(rc);
-    pack_f64(src, ns, sstride, c, buf);
-    morton_order(buf, ns, ctx->src_order);
-    rc = ctx->eng->set_source(buf.data(), ns);
+    float *sb = ctx->eng->staging(1, (size_t)std::max<int64_t>(ns, 1) * 4);
+    pack_f64_to(src, ns, sstride, c, sb, true);
+    morton_order_ptr(sb, ns, ctx->src_order, true);
+    rc = ctx->eng->set_source(sb, ns);
     if (rc) return ctx->eng_fail(rc);
     std::memcpy(ctx->centre, c, sizeof(c));
     ctx->have_src = ctx->have_tgt = true;
@@ -1379,9 +1478,9 @@ int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt, int s
 {
     CTX_CHECK();
     if (nt < 0 || stride < 3 || (nt > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad target arguments");
-    std::vector<float> buf;
-    pack_f32(xyz, nt, stride, buf);
-    int rc = ctx->eng->set_target(buf.data(), nt);
+    float *buf = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
+    pack_f32_to(xyz, nt, stride, buf);
+    int rc = ctx->eng->set_target(buf, nt);
     if (rc) return ctx->eng_fail(rc);
     ctx->centre[0] = ctx->centre[1] = ctx->centre[2] = 0.0;
     ctx->have_tgt = true;
@@ -1392,10 +1491,10 @@ int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns, int s
 {
     CTX_CHECK();
     if (ns < 0 || stride < 3 || (ns > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
-    std::vector<float> buf;
-    pack_f32(xyz, ns, stride, buf);
-    morton_order(buf, ns, ctx->src_order);
-    int rc = ctx->eng->set_source(buf.data(), ns);
+    float *buf = ctx->eng->staging(1, (size_t)std::max<int64_t>(ns, 1) * 4);
+    pack_f32_to(xyz, ns, stride, buf);
+    morton_order_ptr(buf, ns, ctx->src_order, true);
+    int rc = ctx->eng->set_source(buf, ns);
     if (rc) return ctx->eng_fail(rc);
     ctx->have_src = true;
     return VISMA_ICP_OK;
@@ -1429,10 +1528,10 @@ int visma_icp_set_target_normals_f64(visma_icp_ctx *ctx, const double *n, int64_
     if (!ctx->have_tgt) return ctx->fail(VISMA_ICP_ERR_STATE, "set the target first");
     if (nt != ctx->eng->nt() || stride < 3 || (nt > 0 && !n))
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad normals arguments");
-    std::vector<float> buf;
     const double zero[3] = {0, 0, 0};
-    pack_f64(n, nt, stride, zero, buf);
-    int rc = ctx->eng->set_target_normals(buf.data(), nt);
+    float *buf = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
+    pack_f64_to(n, nt, stride, zero, buf, true);
+    int rc = ctx->eng->set_target_normals(buf, nt);
     if (rc) return ctx->eng_fail(rc);
     return VISMA_ICP_OK;
 }
@@ -1702,10 +1801,8 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
             parallel_for(n, 1, [&](int64_t i) {                    // targets: first occurrences only
                 if (tshare[i] >= 0) return;
                 const visma_icp_problem &q = probs[i];
-                double c[3] = {0, 0, 0};
-                for (int64_t j = 0; j < q.nt; j++)
-                    for (int a = 0; a < 3; a++) c[a] += q.tgt_xyz[(size_t)j * 3 + a];
-                if (q.nt > 0) for (int a = 0; a < 3; a++) c[a] /= (double)q.nt;
+                double c[3];
+                centroid_f64(q.tgt_xyz, q.nt, 3, c, false);       // the same value as set_clouds_f64 computes
                 for (int a = 0; a < 3; a++) cen[i][a] = c[a];
                 pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
             });
