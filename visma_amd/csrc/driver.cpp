@@ -470,6 +470,10 @@ public:
         if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
         int rc = choose_mode(lp.max_dist);
         if (rc) return rc;
+        // Many problems advancing together fill the chip whatever the cloud size: AUTO then
+        // takes the grid even for a target too small to pay off for ONE problem (a sweep over
+        // a 3 k-point target fell back to 24 sequential brute-force loops: 25 ms instead of 2).
+        if (nprob > 1 && !use_grid_ && nn_mode_ == VISMA_ICP_NN_AUTO && grid_valid_ && nt_ > 0) use_grid_ = true;
         r2f_ = (float)(lp.max_dist * lp.max_dist);
         for (int i = 0; i < 12; i++) T32_.m[i] = (float)lp.Tc0.m[i];
         if (nprob > 1 && (!use_grid_ || comm_)) {
