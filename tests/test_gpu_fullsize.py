@@ -91,3 +91,26 @@ def test_c4_idempotent_at_the_fixed_point(gpu_ctx_auto, c4):
     assert synth.rel_frobenius(b.transformation_, a.transformation_) < 2e-6
     assert abs(b.num_correspondences - a.num_correspondences) <= 0.0002 * NS
     assert synth.rel_frobenius(a.transformation_, T_gt) < 2e-3          # noise-limited
+
+
+def test_beyond_c4_one_million_sources_sixteen_million_targets(lib, gpu_ctx_auto):
+    """4x the size BASELINE names on both sides (1,048,576 -> 16,777,216): the multi-workgroup
+    ONE-variant launch (4096 workgroups), a 256 MiB target, brute force == grid bit for bit."""
+    ctx = gpu_ctx_auto
+    ns, nt = 1 << 20, 1 << 24
+    src, tgt, T_gt, r = synth.make_pair(ns, nt, motion="radius")
+    ctx.set_clouds_f64(src, tgt)
+    res = ctx.run(None, r, 30, 0.0, 0.0)
+    assert res.num_correspondences == ns and res.fitness_ == 1.0
+    assert synth.rel_frobenius(res.transformation_, T_gt) < 2e-3          # noise-limited
+    T0 = synth.make_T(synth.rot_y(0.3 * r), [0.2 * r, 0, -0.1 * r])
+    out = {}
+    for name, mode in (("grid", lib.NN_GRID), ("brute", lib.NN_BRUTE)):
+        ctx.set_nn_mode(mode)
+        ctx.nn_pass(T0, r)
+        st = ctx.reduce()
+        out[name] = (ctx.correspondence_index(), ctx.get_correspondences()[2], st)
+    ctx.set_nn_mode(lib.NN_AUTO)
+    assert np.array_equal(out["grid"][0], out["brute"][0])
+    assert np.array_equal(out["grid"][1].view(np.uint32), out["brute"][1].view(np.uint32))
+    assert np.max(np.abs(out["grid"][2] - out["brute"][2]) / np.maximum(np.abs(out["brute"][2]), 1.0)) < 1e-10
