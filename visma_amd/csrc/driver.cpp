@@ -2050,7 +2050,7 @@ int visma_icp_sample_mesh(visma_icp_ctx *ctx, const double *V, int64_t nv, const
 
 int visma_icp_error_metric(const double *errors, int64_t n, double out[5])
 {
-    if (!out || n < 0 || (n > 0 && !errors)) return VISMA_ICP_ERR_INVALID;
+    if (!out || n <= 0 || !errors) return VISMA_ICP_ERR_INVALID;   // the reference indexes errors[n >> 1]
     // feh::ComputeErrorMetric (include/geometry.h:85-101), same accumulation order
     double mean = 0.0, sq = 0.0, mn = std::numeric_limits<double>::max(), mx = std::numeric_limits<double>::lowest();
     for (int64_t i = 0; i < n; i++) {
