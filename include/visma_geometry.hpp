@@ -29,12 +29,41 @@
 #include <vector>
 
 #include "visma_icp.h"
+#include "visma_io.h"
 #include "visma_icp_open3d.hpp"
 
 namespace feh {
 namespace gpu {
 
 enum class SamplingMode { Surface = 0, Reference = 1 };
+
+// feh::LoadMesh for .obj / .ply (core/utils.cpp:125-135: igl::readOBJ / igl::readPLY, first
+// three columns kept).  Host code.  Returns false on failure like the reference.
+template <typename DerivedV, typename DerivedF>
+inline bool LoadMesh(const std::string &file, Eigen::PlainObjectBase<DerivedV> &V, Eigen::PlainObjectBase<DerivedF> &F)
+{
+    if (file.find(".obj") != std::string::npos) {
+        double *v = nullptr; int32_t *f = nullptr; int64_t nv = 0, nf = 0; int fs = 0;
+        if (visma_io_read_obj(file.c_str(), &v, &nv, &f, &nf, &fs) != VISMA_IO_OK) return false;
+        V.resize(nv, 3);
+        F.resize(nf, fs < 3 ? fs : 3);
+        for (int64_t i = 0; i < nv; i++) for (int a = 0; a < 3; a++) V(i, a) = (typename DerivedV::Scalar)v[3 * i + a];
+        for (int64_t i = 0; i < nf; i++) for (int a = 0; a < F.cols(); a++) F(i, a) = (typename DerivedF::Scalar)f[(size_t)i * fs + a];
+        visma_io_free(v); visma_io_free(f);
+        return true;
+    }
+    if (file.find(".ply") != std::string::npos) {
+        visma_io_cloud c;
+        if (visma_io_read_ply(file.c_str(), &c) != VISMA_IO_OK) return false;
+        V.resize(c.n, 3);
+        F.resize(c.n_faces, 3);
+        for (int64_t i = 0; i < c.n; i++) for (int a = 0; a < 3; a++) V(i, a) = (typename DerivedV::Scalar)c.xyz[3 * i + a];
+        for (int64_t i = 0; i < c.n_faces; i++) for (int a = 0; a < 3; a++) F(i, a) = (typename DerivedF::Scalar)c.faces[3 * i + a];
+        visma_io_free_cloud(&c);
+        return true;
+    }
+    return false;
+}
 
 template <typename T>
 struct GenericErrorMetric {

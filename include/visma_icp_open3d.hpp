@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "visma_icp.h"
+#include "visma_io.h"
 
 namespace open3d {
 namespace cicp {
@@ -371,6 +372,29 @@ inline std::shared_ptr<PointCloud> VoxelDownSample(const PointCloud &input, doub
     return output;
 }
 
+// open3d::ReadPointCloudFromPLY (O3D/IO/FileFormat/FilePLY.cpp:206-264): the scene and scan
+// clouds of both callers (src/evaluation.cpp:124,211; src/annotation.cpp:76-157).  Same
+// points / normals / colours as the rply-based reader; false (and a message on stderr) on
+// failure, like the reference.
+inline bool ReadPointCloudFromPLY(const std::string &filename, PointCloud &pointcloud)
+{
+    visma_io_cloud c;
+    if (visma_io_read_ply(filename.c_str(), &c) != VISMA_IO_OK) {
+        std::fprintf(stderr, "Read PLY failed: %s\n", visma_io_last_error());
+        return false;
+    }
+    pointcloud.points_.resize((size_t)c.n);
+    pointcloud.normals_.resize((size_t)c.n_normals);
+    pointcloud.colors_.resize((size_t)c.n_colors);
+    for (int64_t i = 0; i < c.n; i++) pointcloud.points_[(size_t)i] = Eigen::Vector3d(c.xyz[3 * i], c.xyz[3 * i + 1], c.xyz[3 * i + 2]);
+    for (int64_t i = 0; i < c.n_normals; i++)
+        pointcloud.normals_[(size_t)i] = Eigen::Vector3d(c.normals[3 * i], c.normals[3 * i + 1], c.normals[3 * i + 2]);
+    for (int64_t i = 0; i < c.n_colors; i++)
+        pointcloud.colors_[(size_t)i] = Eigen::Vector3d(c.colors[3 * i], c.colors[3 * i + 1], c.colors[3 * i + 2]);
+    visma_io_free_cloud(&c);
+    return true;
+}
+
 // feh::ICPRefinement (src/evaluation.cpp:258-271) from the down-sampling on:
 // scene = VoxelDownSample(scene, voxel_size); RegistrationICP(scene_est, scene, ...).
 inline RegistrationResult ICPRefinement(const PointCloud &scene_raw, const PointCloud &scene_est,
@@ -448,6 +472,10 @@ inline RegistrationResult EvaluateRegistration(const PointCloud &source, const P
                                                const Eigen::Matrix4d &transformation)
 {
     return cicp::EvaluateRegistration(source, target, max_correspondence_distance, transformation);
+}
+inline bool ReadPointCloudFromPLY(const std::string &filename, PointCloud &pointcloud)
+{
+    return cicp::ReadPointCloudFromPLY(filename, pointcloud);
 }
 inline RegistrationResult RegistrationICP(const PointCloud &source, const PointCloud &target,
                                           double max_correspondence_distance,

@@ -397,6 +397,45 @@ class Ref:
                                            _ptr(cl, _dp))
         return d2, face, cl
 
+    # ---- file readers (open3d::ReadPointCloudFromPLY / ReadTriangleMeshFromPLY, igl::readOBJ) ----
+    def _take(self, ptr, n, dtype):
+        a = np.ctypeslib.as_array(ptr, shape=(max(n, 1),)).astype(dtype)[:n].copy()
+        self.lib.ref_io_free(ptr)
+        return a
+
+    def read_ply_cloud(self, path):
+        """-> dict(xyz, normals, colors) or None when the reference reader fails."""
+        xyz, nrm, col = _dp(), _dp(), _dp()
+        n, nn, nc = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.lib.ref_io_free.argtypes = [C.c_void_p]
+        if not self.lib.ref_read_ply_cloud(str(path).encode(), C.byref(xyz), C.byref(n), C.byref(nrm), C.byref(nn),
+                                           C.byref(col), C.byref(nc)):
+            return None
+        return dict(xyz=self._take(xyz, 3 * n.value, np.float64).reshape(-1, 3),
+                    normals=self._take(nrm, 3 * nn.value, np.float64).reshape(-1, 3),
+                    colors=self._take(col, 3 * nc.value, np.float64).reshape(-1, 3))
+
+    def read_ply_mesh(self, path):
+        xyz, tri = _dp(), _ip()
+        n, nt = C.c_int64(0), C.c_int64(0)
+        self.lib.ref_io_free.argtypes = [C.c_void_p]
+        if not self.lib.ref_read_ply_mesh(str(path).encode(), C.byref(xyz), C.byref(n), C.byref(tri), C.byref(nt)):
+            return None
+        return dict(xyz=self._take(xyz, 3 * n.value, np.float64).reshape(-1, 3),
+                    faces=self._take(tri, 3 * nt.value, np.int32).reshape(-1, 3))
+
+    def read_obj(self, path):
+        """igl::readOBJ(path, V, F) -> (V [nv x vcols], F [nf x fcols]) or None."""
+        V, F = _dp(), _ip()
+        nv, nf, vc, fc = C.c_int64(0), C.c_int64(0), C.c_int(0), C.c_int(0)
+        if not self.lib.ref_igl_read_obj(str(path).encode(), C.byref(V), C.byref(nv), C.byref(vc), C.byref(F),
+                                         C.byref(nf), C.byref(fc)):
+            return None
+        self.lib.ref_io_free.argtypes = [C.c_void_p]
+        v = self._take(V, nv.value * vc.value, np.float64).reshape(nv.value, max(vc.value, 0))
+        f = self._take(F, nf.value * fc.value, np.int32).reshape(nf.value, max(fc.value, 0))
+        return v, f
+
     def nn_distance(self, src, tgt):
         src = _f64(src, (-1, 3)); tgt = _f64(tgt, (-1, 3))
         d = np.empty(len(src))

@@ -6,6 +6,9 @@
 // itself is not compiled: it pulls in utils.h (OpenCV, jsoncpp, abseil, glog),
 // none of which exist in this image.
 #include <igl/AABB.h>
+#include <igl/readOBJ.h>
+
+#include <cstdlib>
 
 #include <cstdint>
 
@@ -29,4 +32,20 @@ extern "C" void ref_igl_point_mesh_sqdist(const double *P, int64_t np, const dou
         if (face) face[i] = I(i);
         if (closest) for (int a = 0; a < 3; a++) closest[3 * i + a] = C(i, a);
     }
+}
+
+// igl::readOBJ(path, V, F) as src/evaluation.cpp:140 / src/annotation.cpp:125 call it.
+// Returns 1 on success; *V is nv x vcols (row-major), *F nf x fcols; free with std::free.
+extern "C" int ref_igl_read_obj(const char *path, double **V, int64_t *nv, int *vcols, int32_t **F, int64_t *nf,
+                                int *fcols)
+{
+    Eigen::MatrixXd Vm;
+    Eigen::MatrixXi Fm;
+    if (!igl::readOBJ(path, Vm, Fm)) return 0;
+    *nv = Vm.rows(); *vcols = (int)Vm.cols(); *nf = Fm.rows(); *fcols = (int)Fm.cols();
+    *V = (double *)std::malloc(sizeof(double) * (size_t)(Vm.size() ? Vm.size() : 1));
+    *F = (int32_t *)std::malloc(sizeof(int32_t) * (size_t)(Fm.size() ? Fm.size() : 1));
+    for (int64_t i = 0; i < Vm.rows(); i++) for (int a = 0; a < Vm.cols(); a++) (*V)[i * Vm.cols() + a] = Vm(i, a);
+    for (int64_t i = 0; i < Fm.rows(); i++) for (int a = 0; a < Fm.cols(); a++) (*F)[i * Fm.cols() + a] = Fm(i, a);
+    return 1;
 }

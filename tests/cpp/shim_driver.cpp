@@ -117,6 +117,26 @@ int main(int argc, char **argv)
             std::vector<double> d;
             for (const auto &q : pts) d.push_back(q.norm());
             result.transformation_(1, 1) = feh::gpu::ComputeErrorMetric(d).median_;
+        } else if (mode == "io") {          // host-only: src/evaluation.cpp:124 / core/utils.cpp:125 loaders
+            // argv[2] still holds the (unused) clouds; the files come from the environment
+            const char *ply = std::getenv("SHIM_PLY"), *objf = std::getenv("SHIM_OBJ");
+            PointCloud pc;
+            if (!ply || !objf || !open3d::ReadPointCloudFromPLY(ply, pc)) return 4;
+            Eigen::Matrix<double, Eigen::Dynamic, 3> V;
+            Eigen::Matrix<int, Eigen::Dynamic, 3> F;
+            if (!feh::gpu::LoadMesh(objf, V, F)) return 5;
+            if (open3d::ReadPointCloudFromPLY("/nonexistent.ply", pc)) return 6;    // false, message on stderr
+            open3d::ReadPointCloudFromPLY(ply, pc);
+            result.transformation_.setZero();
+            result.transformation_(0, 0) = (double)pc.points_.size();
+            result.transformation_(0, 1) = (double)pc.normals_.size();
+            result.transformation_(0, 2) = (double)pc.colors_.size();
+            result.transformation_(0, 3) = pc.points_.empty() ? 0.0 : pc.points_.back()(2);
+            result.transformation_(1, 0) = (double)V.rows();
+            result.transformation_(1, 1) = (double)F.rows();
+            result.transformation_(1, 2) = V.rows() ? V(V.rows() - 1, 1) : 0.0;
+            result.transformation_(1, 3) = F.rows() ? (double)F(F.rows() - 1, 2) : 0.0;
+            result.transformation_(2, 0) = pc.colors_.empty() ? 0.0 : pc.colors_[0](1);
         } else if (mode == "estimator") {   // host-only: explicit correspondences, no GPU needed
             CorrespondenceSet cs;
             for (int64_t i = 0; i < ns; i++) cs.push_back(Eigen::Vector2i((int)i, (int)((i * 7919) % nt)));

@@ -158,6 +158,111 @@ def gen_mesh(ref):
     print("mesh fixture:", V.shape, F.shape, P.shape, "max d", math.sqrt(d2.max()))
 
 
+def _ply_header(fmt, elems):
+    lines = ["ply", "format %s 1.0" % fmt, "comment written by tests/golden/gen_golden.py", "obj_info a b c"]
+    for name, count, props in elems:
+        lines.append("element %s %d" % (name, count))
+        lines += ["property " + p for p in props]
+    lines.append("end_header")
+    return ("\n".join(lines) + "\n").encode()
+
+
+def gen_io(ref):
+    """On-disk formats: small files in the layouts VISMA's callers read, and what
+    the reference's readers (rply-based ReadPointCloudFromPLY / ReadTriangleMeshFromPLY,
+    igl::readOBJ) return for them.  The files are written by THIS script (our own writer)
+    except cube.ply, a 640-byte data file of the reference (misc/cube.ply)."""
+    import shutil, struct
+    d = os.path.join(HERE, "io")
+    os.makedirs(d, exist_ok=True)
+    shutil.copyfile(REF + "/misc/cube.ply", os.path.join(d, "cube.ply"))
+    rng = np.random.default_rng(91)
+    n = 300
+    xyz = rng.standard_normal((n, 3))
+    nrm = rng.standard_normal((n, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    col = rng.integers(0, 256, (n, 3))
+    qual = rng.random(n); lab = rng.integers(-5, 5, n)
+    faces = [list(rng.integers(0, n, 3)) for _ in range(120)] + [list(rng.integers(0, n, 4)) for _ in range(5)] \
+        + [list(rng.integers(0, n, 2))]                       # triangles, quads, one 2-gon
+    # (1) binary little endian: float xyz + extra properties in between + normals + uchar colours; faces uchar/int
+    b = _ply_header("binary_little_endian", [
+        ("vertex", n, ["float x", "float y", "float quality", "float z", "float nx", "float ny", "float nz",
+                       "int label", "uchar red", "uchar green", "uchar blue"]),
+        ("face", len(faces), ["list uchar int vertex_indices"])])
+    for i in range(n):
+        b += struct.pack("<fffffffiBBB", xyz[i, 0], xyz[i, 1], qual[i], xyz[i, 2], *nrm[i], lab[i], *col[i])
+    for f in faces:
+        b += struct.pack("<B%di" % len(f), len(f), *f)
+    open(os.path.join(d, "gen_le.ply"), "wb").write(b)
+    # (2) binary big endian: double xyz, ushort colours, short normals-like ints; faces "vertex_index" uint8/uint
+    b = _ply_header("binary_big_endian", [
+        ("vertex", n, ["double x", "double y", "double z", "ushort red", "ushort green", "ushort blue",
+                       "short nx", "short ny", "short nz"]),
+        ("face", 100, ["list uint8 uint32 vertex_index"])])
+    for i in range(n):
+        b += struct.pack(">dddHHHhhh", *xyz[i], *(col[i] * 200), *(nrm[i] * 1000).astype(int))
+    for f in faces[:100]:
+        b += struct.pack(">B%dI" % len(f), len(f), *f)
+    open(os.path.join(d, "gen_be.ply"), "wb").write(b)
+    # (3) ASCII: full-precision text in "float" properties, face element BEFORE the vertex element
+    t = _ply_header("ascii", [("face", 60, ["list uchar int vertex_indices"]),
+                              ("vertex", n, ["float x", "float y", "float z", "float nx", "float ny", "float nz",
+                                             "uchar red", "uchar green", "uchar blue"])]).decode()
+    for f in faces[:60]:
+        t += " ".join(str(v) for v in [len(f)] + list(f)) + "\n"
+    for i in range(n):
+        t += "%.17g %.9g %r %.6f %.6f %.6f %d %d %d\n" % (xyz[i, 0], xyz[i, 1], float(xyz[i, 2]), *nrm[i], *col[i])
+    open(os.path.join(d, "gen_ascii.ply"), "w").write(t)
+    # (4) vertices only, no normals / colours
+    b = _ply_header("binary_little_endian", [("vertex", 17, ["float x", "float y", "float z"])])
+    b += xyz[:17].astype("<f4").tobytes()
+    open(os.path.join(d, "gen_points.ply"), "wb").write(b)
+    # (5) broken: truncated body / no vertex element
+    open(os.path.join(d, "bad_truncated.ply"), "wb").write(b[:-20])
+    open(os.path.join(d, "bad_novertex.ply"), "wb").write(_ply_header("ascii", [("face", 0, ["list uchar int vertex_indices"])]))
+    # ---- OBJ
+    V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
+    V, F = V[:400], F[(F < 400).all(1)][:500]
+    def obj(name, body):
+        open(os.path.join(d, name), "w").write(body)
+    obj("tri.obj", "# comment\no thing\n" + "".join("v %.9g %.9g %.9g\n" % tuple(v) for v in V)
+        + "".join("vn 0 0 1\nvt 0.5 0.5\n" for _ in range(3)) + "g grp\ns off\n"
+        + "".join("f %d/1/1 %d/2/2 %d/3/3\n" % tuple(f + 1) for f in F))
+    obj("mixed_syntax.obj", "".join("v %r %r %r\n" % tuple(float(x) for x in v) for v in V) + "vn 0 0 1\n"
+        + "".join(("f %d %d %d\n", "f %d//1 %d//1 %d//1\n", "f %d/1 %d/1 %d/1\n")[i % 3] % tuple(f + 1)
+                  for i, f in enumerate(F)) + "vt 0 0\n")
+    body = ""
+    for i, f in enumerate(F[:200]):                      # negative (relative) indices, vertices interleaved
+        body += "".join("v %.9g %.9g %.9g\n" % tuple(V[j]) for j in f) + "f -3 -2 -1\n"
+    obj("negative.obj", body)
+    quads = np.concatenate([F[:50], F[50:100, :1]], axis=1)
+    obj("quads.obj", "".join("v %.9g %.9g %.9g 1.0\n" % tuple(v) for v in V) + "".join("f %d %d %d %d\n" % tuple(q + 1) for q in quads))
+    obj("colors.obj", "".join("v %.9g %.9g %.9g 0.1 0.2 0.3\n" % tuple(v) for v in V) + "".join("f %d %d %d\n" % tuple(f + 1) for f in F[:20]))
+    obj("bad_mixed_faces.obj", "".join("v %.9g %.9g %.9g\n" % tuple(v) for v in V[:10]) + "f 1 2 3\nf 1 2 3 4\n")
+    obj("bad_short_vertex.obj", "v 1 2\nv 1 2 3\nf 1 2 2\n")
+    obj("bad_face_token.obj", "v 1 2 3\nv 1 2 3\nv 0 0 0\nf 1 x 3\n")
+    out = {}
+    for name in sorted(os.listdir(d)):
+        path = os.path.join(d, name)
+        key = name.replace(".", "_")
+        if name.endswith(".ply"):
+            c = ref.read_ply_cloud(path)
+            m = ref.read_ply_mesh(path)
+            out[key + "_ok"] = np.array([c is not None, m is not None])
+            if c is not None:
+                for k in ("xyz", "normals", "colors"):
+                    out[key + "_" + k] = c[k]
+            if m is not None:
+                out[key + "_faces"] = m["faces"]
+        else:
+            r = ref.read_obj(path)
+            out[key + "_ok"] = np.array([r is not None])
+            if r is not None:
+                out[key + "_V"], out[key + "_F"] = r
+    np.savez_compressed(os.path.join(HERE, "io.npz"), **out)
+    print("io fixture:", {k: v.tolist() for k, v in out.items() if k.endswith("_ok")})
+
+
 def main():
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Ref()
@@ -165,6 +270,8 @@ def main():
         return gen_voxel(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "mesh":
         return gen_mesh(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "io":
+        return gen_io(ref)
     V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
 
     # ---- C1/C2: chair CAD 5k samples -> 20k partial noisy scan ------------
@@ -361,6 +468,7 @@ def main():
                         hat=np.array(hats))
     gen_voxel(ref)
     gen_mesh(ref)
+    gen_io(ref)
     print("golden fixtures written to", HERE)
 
 

@@ -1,0 +1,103 @@
+"""On-disk formats either side of the ICP path (include/visma_io.h).
+
+Host code: runs without a GPU.  Every expected array in golden/io.npz is an OUTPUT of the
+reference's own readers (open3d::ReadPointCloudFromPLY / ReadTriangleMeshFromPLY on rply,
+igl::readOBJ) for the files under golden/io/ -- written by tests/golden/gen_golden.py, except
+cube.ply, a data file of the reference.  The bar is bit-exact: reading is integer / byte work
+plus exact widening to double.
+"""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+D = os.path.join(HERE, "golden", "io")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return dict(np.load(os.path.join(HERE, "golden", "io.npz")))
+
+
+@pytest.fixture(scope="module")
+def io(lib):
+    from visma_amd import _lib
+    return _lib
+
+
+PLY_OK = ["cube.ply", "gen_le.ply", "gen_be.ply", "gen_ascii.ply", "gen_points.ply"]
+
+
+@pytest.mark.parametrize("name", PLY_OK)
+def test_ply_matches_the_reference_readers(io, gold, name):
+    key = name.replace(".", "_")
+    assert gold[key + "_ok"].all()
+    got = io.read_ply(os.path.join(D, name))
+    for k in ("xyz", "normals", "colors"):
+        want = gold[key + "_" + k]
+        assert got[k].shape == want.shape, k
+        assert np.array_equal(got[k], want), k           # bit-exact (NaN-free by construction)
+    assert np.array_equal(got["faces"], gold[key + "_faces"])
+
+
+def test_ply_semantics_spelled_out(io):
+    c = io.read_ply(os.path.join(D, "gen_le.ply"))
+    assert c["xyz"].shape == (300, 3) and c["normals"].shape == (300, 3) and c["colors"].shape == (300, 3)
+    assert c["colors"].min() >= 0 and c["colors"].max() <= 1.0                 # value / 255.0
+    assert np.array_equal(c["xyz"], c["xyz"].astype(np.float32).astype(np.float64))   # float widened exactly
+    assert c["faces"].shape == (126, 3)                  # quads give their first 3 corners; the 2-gon keeps a 0
+    a = io.read_ply(os.path.join(D, "gen_ascii.ply"))
+    b = io.read_ply(os.path.join(D, "gen_be.ply"))
+    assert np.array_equal(a["xyz"][:, 0], b["xyz"][:, 0])    # %.17g text of a "float" property keeps the double
+    assert b["colors"].max() > 1.0                         # ushort colours: still value / 255.0, as the reference
+    p = io.read_ply(os.path.join(D, "gen_points.ply"))
+    assert p["normals"].shape == (0, 3) and p["colors"].shape == (0, 3) and p["faces"].shape == (0, 3)
+
+
+@pytest.mark.parametrize("name", ["bad_truncated.ply", "bad_novertex.ply", "does_not_exist.ply", "tri.obj"])
+def test_ply_failures_are_reported(io, gold, name):
+    key = name.replace(".", "_") + "_ok"
+    if key in gold and name.endswith(".ply"):
+        assert not gold[key].any()                       # the reference fails on it too
+    with pytest.raises(io.IoError):
+        io.read_ply(os.path.join(D, name))               # (an OBJ file is "not a PLY file")
+
+
+OBJ_OK = ["tri.obj", "mixed_syntax.obj", "negative.obj", "quads.obj", "colors.obj"]
+
+
+@pytest.mark.parametrize("name", OBJ_OK)
+def test_obj_matches_igl(io, gold, name):
+    key = name.replace(".", "_")
+    V, F = io.read_obj(os.path.join(D, name))
+    assert np.array_equal(V, gold[key + "_V"][:, :3])    # LoadMesh keeps leftCols(3) (core/utils.cpp:132)
+    assert np.array_equal(F, gold[key + "_F"])
+    if name == "quads.obj":
+        assert F.shape[1] == 4 and gold[key + "_V"].shape[1] == 4
+    if name == "colors.obj":
+        assert gold[key + "_V"].shape[1] == 6
+
+
+@pytest.mark.parametrize("name", ["bad_mixed_faces.obj", "bad_short_vertex.obj", "bad_face_token.obj", "nope.obj"])
+def test_obj_failures_are_reported(io, gold, name):
+    key = name.replace(".", "_") + "_ok"
+    if key in gold:
+        assert not gold[key].any()
+    with pytest.raises(io.IoError):
+        io.read_obj(os.path.join(D, name))
+
+
+def test_obj_feeds_the_mesh_fixture(io):
+    """The chair of golden/mesh.npz written as OBJ and read back: same arrays."""
+    m = np.load(os.path.join(HERE, "golden", "mesh.npz"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as t:
+        path = os.path.join(t, "chair.obj")
+        with open(path, "w") as f:
+            for v in m["V"]:
+                f.write("v %r %r %r\n" % tuple(float(x) for x in v))
+            for tri in m["F"]:
+                f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in tri))
+        V, F = io.read_obj(path)
+    assert np.array_equal(V, m["V"]) and np.array_equal(F, m["F"])

@@ -70,6 +70,25 @@ def test_estimator_entry_points_host_only(bins, tmp_path):
             assert abs(r["rmse"] - o.compute_rmse(src, tgt, corr)) < 1e-12
 
 
+def test_shim_file_readers_host_only(bins, tmp_path):
+    """open3d::ReadPointCloudFromPLY and feh::gpu::LoadMesh through the shim need no GPU."""
+    from visma_amd import _lib
+    ply = os.path.join(G, "io", "gen_le.ply"); objf = os.path.join(G, "io", "tri.obj")
+    c = _lib.read_ply(ply); V, F = _lib.read_obj(objf)
+    os.environ["SHIM_PLY"], os.environ["SHIM_OBJ"] = ply, objf
+    try:
+        for b in bins:
+            rc, err, r = run(b, "io", tmp_path, np.zeros((1, 3)), np.zeros((1, 3)), 0.1)
+            assert rc == 0, err
+            t = r["T"]
+            assert (t[0, 0], t[0, 1], t[0, 2]) == (len(c["xyz"]), len(c["normals"]), len(c["colors"]))
+            assert t[0, 3] == c["xyz"][-1, 2] and t[2, 0] == c["colors"][0, 1]
+            assert (t[1, 0], t[1, 1]) == (len(V), len(F)) and t[1, 2] == V[-1, 1] and t[1, 3] == F[-1, 2]
+            assert "Read PLY failed" in err
+    finally:
+        del os.environ["SHIM_PLY"], os.environ["SHIM_OBJ"]
+
+
 def test_shim_without_gpu_fails_loudly(bins, tmp_path):
     if os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")

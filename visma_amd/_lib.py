@@ -439,6 +439,49 @@ def error_metric(errors):
     return dict(zip(("mean", "std", "median", "min", "max"), out))
 
 
+class CIoCloud(C.Structure):
+    _fields_ = [("n", C.c_int64), ("xyz", _dp), ("n_normals", C.c_int64), ("normals", _dp),
+                ("n_colors", C.c_int64), ("colors", _dp), ("n_faces", C.c_int64), ("faces", _ip)]
+
+
+class IoError(RuntimeError):
+    pass
+
+
+def read_ply(path):
+    """open3d::ReadPointCloudFromPLY / ReadTriangleMeshFromPLY -> dict(xyz, normals, colors, faces)."""
+    L = load()
+    L.visma_io_last_error.restype = C.c_char_p
+    c = CIoCloud()
+    rc = L.visma_io_read_ply(str(path).encode(), C.byref(c))
+    if rc != OK:
+        raise IoError("visma_io_read_ply: %s" % L.visma_io_last_error().decode())
+    def take(ptr, n, cols, dt):
+        if n == 0:
+            return np.zeros((0, cols), dt)
+        return np.ctypeslib.as_array(ptr, shape=(n * cols,)).astype(dt).reshape(n, cols).copy()
+    out = dict(xyz=take(c.xyz, c.n, 3, np.float64), normals=take(c.normals, c.n_normals, 3, np.float64),
+               colors=take(c.colors, c.n_colors, 3, np.float64), faces=take(c.faces, c.n_faces, 3, np.int32))
+    L.visma_io_free_cloud(C.byref(c))
+    return out
+
+
+def read_obj(path):
+    """igl::readOBJ(path, V, F) -> (V [nv x 3], F [nf x face_size])."""
+    L = load()
+    L.visma_io_last_error.restype = C.c_char_p
+    L.visma_io_free.argtypes = [C.c_void_p]
+    V, F = _dp(), _ip()
+    nv, nf, fs = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    rc = L.visma_io_read_obj(str(path).encode(), C.byref(V), C.byref(nv), C.byref(F), C.byref(nf), C.byref(fs))
+    if rc != OK:
+        raise IoError("visma_io_read_obj: %s" % L.visma_io_last_error().decode())
+    v = np.ctypeslib.as_array(V, shape=(max(3 * nv.value, 1),))[:3 * nv.value].reshape(-1, 3).copy()
+    f = np.ctypeslib.as_array(F, shape=(max(nf.value * fs.value, 1),))[:nf.value * fs.value].reshape(nf.value, max(fs.value, 0)).copy()
+    L.visma_io_free(V); L.visma_io_free(F)
+    return v, f
+
+
 def tile_config():
     L = load()
     a = C.c_int(); b = C.c_int(); c = C.c_int()
