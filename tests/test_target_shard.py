@@ -124,3 +124,38 @@ def test_target_shard_needs_an_exchange(lib):
         ctx.run(None, radius, 2, 0, 0)                      # no RCCL communicator, no callbacks
     with pytest.raises(_lib.IcpError):
         ctx.set_target_shard(0, 2 ** 31 + 5, None)          # global indices must fit 31 bits
+
+
+@pytest.mark.gpu
+def test_source_sharded_equals_single_context(lib):
+    """The default decomposition of bench.py --gpus N (each rank: a slice of the source, the whole
+    target, ONE sum of the 38 statistics per pass), on the real HIP engine with threads as ranks."""
+    src, tgt, T_gt, radius = synth.make_pair(30000, 100000, motion="radius")
+    ref = _lib.Context(0)
+    ref.set_clouds_f64(src, tgt)
+    want = ref.run(None, radius, 15, 0, 0)
+    n = 3
+    ex = Exchange(n)
+    cuts = [0, 7001, 19000, len(src)]
+    out, err = [None] * n, []
+
+    def worker(rank):
+        try:
+            ctx = _lib.Context(0)
+            ctx.set_clouds_f64(src[cuts[rank]:cuts[rank + 1]], tgt)
+            ctx.set_global_source_count(len(src))
+            ctx.set_allreduce(ex.allreduce(rank), rank, n)
+            out[rank] = ctx.run(None, radius, 15, 0, 0)
+        except Exception as e:                  # pragma: no cover
+            err.append(e)
+            ex.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err
+    assert ex.calls["sum"] == 16 and ex.calls["min"] == 0
+    for res in out:
+        assert res.num_correspondences == want.num_correspondences and res.fitness_ == want.fitness_
+        assert synth.rel_frobenius(res.transformation_, want.transformation_) < 1e-12
+        assert np.array_equal(res.transformation_, out[0].transformation_)      # ranks agree to the bit
