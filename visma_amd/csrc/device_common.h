@@ -180,12 +180,13 @@ __device__ __forceinline__ void block_reduce_store(double *acc, double *partials
 
 // One workgroup; folds `nblocks` partial rows in a fixed order and expands the
 // compact point-to-point moments into the 6x6 / 6x1 normal equations.
-template <bool PLANE>
+// NT = threads of the workgroup (a multiple of 32, at most 1024): 32 statistics x NT/32 row groups.
+template <bool PLANE, int NT = 1024>
 __device__ __forceinline__ void fold_partials(const double *__restrict__ partials, int nblocks,
                                               double *__restrict__ stats)
 {
     constexpr int NACC = Acc<PLANE>::N;
-    constexpr int NG = 32;                 // row groups (1024 threads = 32 stats x 32 groups)
+    constexpr int NG = NT / 32;            // row groups (1024 threads = 32 stats x 32 groups)
     __shared__ double part[NG][33];
     __shared__ double tot[32];
     const int a = threadIdx.x & 31, g = threadIdx.x >> 5;

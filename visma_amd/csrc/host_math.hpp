@@ -88,76 +88,107 @@ struct Svd3 {
     double U[9], s[3], V[9];
 };
 
+// Written so that every array index is a compile-time constant after unrolling: on the GPU
+// (one-thread epilogue of the batched device loop) the first version indexed G / W / the sort
+// permutation dynamically, which put them in scratch memory -- 720 B of private segment and
+// most of the 8 us the solve took.  Same operations in the same order as before.
 VISMA_HD Svd3 svd3(const double A[9])
 {
     double G[3][3], W[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+#pragma unroll
     for (int i = 0; i < 3; i++)
+#pragma unroll
         for (int j = 0; j < 3; j++) G[i][j] = A[i * 3 + j];
-    const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
     // Convergence: every column pair orthogonal to 2 ulp (|g| <= 4.4e-16 sqrt(ab)).
-    // A tighter bound only burns sweeps (each rotation is ~1.5 us of dependent f64
-    // div/sqrt when this runs in a one-thread GPU epilogue) without changing R.
-    for (int sweep = 0; sweep < 30; sweep++) {
-        bool any = false;
-        for (int pi = 0; pi < 3; pi++) {
-            const int p = pairs[pi][0], q = pairs[pi][1];
-            double a = 0, b = 0, g = 0;
-            for (int r = 0; r < 3; r++) {
-                a += G[r][p] * G[r][p];
-                b += G[r][q] * G[r][q];
-                g += G[r][p] * G[r][q];
-            }
-            if (g == 0.0 || g * g <= 1.9e-31 * (a * b)) continue;
-            any = true;
-            const double zeta = (b - a) / (2.0 * g);
-            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-            const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
-            for (int r = 0; r < 3; r++) {
-                const double gp = G[r][p], gq = G[r][q];
-                G[r][p] = c * gp - s * gq;
-                G[r][q] = s * gp + c * gq;
-                const double wp = W[r][p], wq = W[r][q];
-                W[r][p] = c * wp - s * wq;
-                W[r][q] = s * wp + c * wq;
-            }
+    // A tighter bound only burns sweeps (each rotation is a chain of dependent f64
+    // div/sqrt) without changing R.
+    bool any = false;
+    auto rotate = [&](const int p, const int q) {
+        double a = 0, b = 0, g = 0;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            a += G[r][p] * G[r][p];
+            b += G[r][q] * G[r][q];
+            g += G[r][p] * G[r][q];
         }
+        if (g == 0.0 || g * g <= 1.9e-31 * (a * b)) return;
+        any = true;
+        const double zeta = (b - a) / (2.0 * g);
+        const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const double gp = G[r][p], gq = G[r][q];
+            G[r][p] = c * gp - s * gq;
+            G[r][q] = s * gp + c * gq;
+            const double wp = W[r][p], wq = W[r][q];
+            W[r][p] = c * wp - s * wq;
+            W[r][q] = s * wp + c * wq;
+        }
+    };
+    for (int sweep = 0; sweep < 30; sweep++) {
+        any = false;
+        rotate(0, 1);
+        rotate(0, 2);
+        rotate(1, 2);
         if (!any) break;
     }
     double n[3];
-    int o[3] = {0, 1, 2};
+#pragma unroll
     for (int j = 0; j < 3; j++) n[j] = sqrt(G[0][j] * G[0][j] + G[1][j] * G[1][j] + G[2][j] * G[2][j]);
-    for (int a = 0; a < 2; a++)   // sort the three indices by descending norm
-        for (int b = a + 1; b < 3; b++)
-            if (n[o[b]] > n[o[a]]) { const int t = o[a]; o[a] = o[b]; o[b] = t; }
+    // columns by descending norm: the same three comparisons as a sort of an index permutation
+    // (a, b) = (0,1), (0,2), (1,2), carried out on the columns themselves
+    auto order = [&](const int a, const int b) {
+        if (n[b] > n[a]) {
+            const double t = n[a]; n[a] = n[b]; n[b] = t;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double tg = G[r][a]; G[r][a] = G[r][b]; G[r][b] = tg;
+                const double tw = W[r][a]; W[r][a] = W[r][b]; W[r][b] = tw;
+            }
+        }
+    };
+    order(0, 1);
+    order(0, 2);
+    order(1, 2);
     Svd3 out;
-    double u[3][3];
+    double u[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
     int rank = 0;
+#pragma unroll
     for (int j = 0; j < 3; j++) {
-        out.s[j] = n[o[j]];
-        for (int r = 0; r < 3; r++) out.V[r * 3 + j] = W[r][o[j]];
-        if (n[o[j]] > 1e-300 && n[o[j]] > 1e-15 * n[o[0]]) {
-            for (int r = 0; r < 3; r++) u[j][r] = G[r][o[j]] / n[o[j]];
+        out.s[j] = n[j];
+#pragma unroll
+        for (int r = 0; r < 3; r++) out.V[r * 3 + j] = W[r][j];
+        if (n[j] > 1e-300 && n[j] > 1e-15 * n[0]) {
+#pragma unroll
+            for (int r = 0; r < 3; r++) u[j][r] = G[r][j] / n[j];
             rank = j + 1;
         }
     }
     if (rank == 0) {
         // zero matrix: no rotation is needed; U = V = I, which is also what the
         // reference's JacobiSVD returns (so the update is a pure translation)
+#pragma unroll
         for (int i = 0; i < 9; i++) out.U[i] = out.V[i] = (i % 4 == 0) ? 1.0 : 0.0;
         return out;
     }
     if (rank == 1) {
+        // the axis along which u0 is smallest (first one on ties), crossed with u0
         int m = 0;
-        for (int r = 1; r < 3; r++) if (fabs(u[0][r]) < fabs(u[0][m])) m = r;
-        double e[3] = {0, 0, 0};
-        e[m] = 1.0;
+        double mv = fabs(u[0][0]);
+        if (fabs(u[0][1]) < mv) { m = 1; mv = fabs(u[0][1]); }
+        if (fabs(u[0][2]) < mv) { m = 2; }
+        const double e[3] = {m == 0 ? 1.0 : 0.0, m == 1 ? 1.0 : 0.0, m == 2 ? 1.0 : 0.0};
         cross3(u[0], e, u[1]);
         const double l = sqrt(u[1][0] * u[1][0] + u[1][1] * u[1][1] + u[1][2] * u[1][2]);
+#pragma unroll
         for (int r = 0; r < 3; r++) u[1][r] /= l;
         rank = 2;
     }
     if (rank == 2) cross3(u[0], u[1], u[2]);
+#pragma unroll
     for (int j = 0; j < 3; j++)
+#pragma unroll
         for (int r = 0; r < 3; r++) out.U[r * 3 + j] = u[j][r];
     return out;
 }

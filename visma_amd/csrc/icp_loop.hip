@@ -16,7 +16,7 @@
 
 namespace visma {
 
-__device__ void advance_state(DevIcpState *st)
+__device__ __forceinline__ void advance_state(DevIcpState *st)
 {
     const double *stats = st->stats;
     const double K = stats[0];
@@ -62,15 +62,20 @@ __device__ void advance_state(DevIcpState *st)
     st->rmse_prev = rmse;
 }
 
+// 256 threads, not the 1024 of the plain fold kernel: the one-thread solve below needs more
+// than the 128 VGPRs a 1024-thread workgroup leaves per lane (it spilled ~1500 scratch
+// accesses per solve), and a device loop folds few partial rows per problem anyway.
+constexpr int kSolveThreads = 256;
+
 template <bool PLANE>
-__global__ __launch_bounds__(1024) void finalize_solve_kernel(const double *__restrict__ partials,
+__global__ __launch_bounds__(kSolveThreads) void finalize_solve_kernel(const double *__restrict__ partials,
                                                               int nblocks, DevIcpState *st,
                                                               int do_solve)
 {
     st += blockIdx.x;                                        // one workgroup per problem
     partials += (long long)blockIdx.x * nblocks * kReduceAcc;
     if (!st->active) return;
-    fold_partials<PLANE>(partials, nblocks, st->stats);
+    fold_partials<PLANE, kSolveThreads>(partials, nblocks, st->stats);
     if (do_solve && threadIdx.x == 0) advance_state(st);   // same thread wrote the stats
 }
 
@@ -84,10 +89,10 @@ static hipError_t launch_fs(const double *partials, int nblocks, DevIcpState *st
                             int do_solve, int nprob, hipStream_t stream)
 {
     if (plane)
-        hipLaunchKernelGGL(finalize_solve_kernel<true>, dim3(nprob), dim3(1024), 0, stream, partials,
+        hipLaunchKernelGGL(finalize_solve_kernel<true>, dim3(nprob), dim3(kSolveThreads), 0, stream, partials,
                            nblocks, st, do_solve);
     else
-        hipLaunchKernelGGL(finalize_solve_kernel<false>, dim3(nprob), dim3(1024), 0, stream, partials,
+        hipLaunchKernelGGL(finalize_solve_kernel<false>, dim3(nprob), dim3(kSolveThreads), 0, stream, partials,
                            nblocks, st, do_solve);
     return hipGetLastError();
 }
@@ -104,21 +109,21 @@ hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpStat
     return launch_fs(partials, nblocks, st, plane, 0, 1, stream);
 }
 
-__global__ __launch_bounds__(1024) void finalize_solve_batch_kernel(const double *__restrict__ partials,
+__global__ __launch_bounds__(kSolveThreads) void finalize_solve_batch_kernel(const double *__restrict__ partials,
                                                                    const ProbDesc *__restrict__ descs,
                                                                    DevIcpState *st)
 {
     const ProbDesc d = descs[blockIdx.x];                    // one workgroup per problem
     st += blockIdx.x;
     if (!st->active) return;
-    fold_partials<false>(partials + (long long)d.first_block * kReduceAcc, d.nblocks, st->stats);
+    fold_partials<false, kSolveThreads>(partials + (long long)d.first_block * kReduceAcc, d.nblocks, st->stats);
     if (threadIdx.x == 0) advance_state(st);
 }
 
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
                                        int nprob, hipStream_t stream)
 {
-    hipLaunchKernelGGL(finalize_solve_batch_kernel, dim3(nprob), dim3(1024), 0, stream, partials, descs,
+    hipLaunchKernelGGL(finalize_solve_batch_kernel, dim3(nprob), dim3(kSolveThreads), 0, stream, partials, descs,
                        st);
     return hipGetLastError();
 }
