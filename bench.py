@@ -59,7 +59,7 @@ def parse():
                          "same sum; for targets that exceed one GPU)")
     ap.add_argument("--brute-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=20)
     return ap.parse_args()
 
 
