@@ -49,6 +49,25 @@ def test_abi_exports_every_declared_symbol(lib):
     assert b"gfx950" in L.visma_icp_version()
 
 
+def test_abi_exports_the_io_symbols_and_headers_are_plain_c(lib, tmp_path):
+    """include/visma_io.h is exported too, and both ABI headers compile as C99 and as C++11."""
+    import shutil, subprocess
+    hdr = open(os.path.join(ROOT, "include", "visma_io.h")).read()
+    names = sorted(set(re.findall(r"VISMA_IO_API\s+[\w\s\*]+?\b(visma_io_\w+)\s*\(", hdr)))
+    assert len(names) == 5, names
+    L = ctypes.CDLL(lib.LIB_PATH)
+    assert not [n for n in names if not hasattr(L, n)]
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler here")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "visma_icp.h"\n#include "visma_io.h"\n'
+                   "int main(void) { visma_icp_ctx *c = 0; visma_icp_result r; visma_io_cloud p; (void)r; (void)p;\n"
+                   "  return visma_icp_create(&c, 0) ? 1 : (visma_icp_destroy(c), 0); }\n")
+    inc = "-I" + os.path.join(ROOT, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", inc, "-fsyntax-only", str(src)], check=True)
+    subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
+
+
 def test_no_cpu_fallback(lib):
     """Without a GPU the product refuses to create a context (no silent fallback)."""
     if os.path.exists("/dev/kfd"):
