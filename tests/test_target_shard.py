@@ -13,6 +13,9 @@ import pytest
 
 from visma_amd import _lib, synth
 
+# threads meeting at a barrier: never hang a test run
+pytestmark = pytest.mark.timeout(300)
+
 
 class Exchange:
     """In-process stand-in for the two all-reduces of a 2-rank communicator."""
