@@ -5,6 +5,7 @@ distances must match its kernel specification BIT FOR BIT; the f64 statistics
 to summation-order accuracy; the final SE(3) within 1e-5 relative Frobenius
 of the f64 reference algorithm (north_star tolerance).
 """
+import os
 import numpy as np
 import pytest
 
@@ -253,3 +254,31 @@ def test_batch_shares_uploads_and_grids_between_problems_with_the_same_clouds(gp
         assert np.array_equal(x.transformation_, y.transformation_)
         assert x.num_correspondences == y.num_correspondences and x.iterations == y.iterations
         assert x.inlier_rmse_ == y.inlier_rmse_
+
+
+@pytest.mark.gpu
+def test_half_pitch_rows_option_is_exact(lib, oracle):
+    """VISMA_ICP_GRID_SUB=2 (25 half-pitch rows, second ring visited lazily; off by default because it
+    measured slower) must return the brute-force answer too -- including queries without any
+    neighbour, which walk all 25 rows."""
+    os.environ["VISMA_ICP_GRID_SUB"] = "2"
+    try:
+        ctx = lib.Context(0)
+    finally:
+        del os.environ["VISMA_ICP_GRID_SUB"]
+    src, tgt, T_gt, r = synth.make_pair(20000, 120000, motion="radius")
+    src = np.concatenate([src, src[:500] + [0.0, 3.0 * r, 0.0], src[:50] + 5.0])     # near misses, far outliers
+    ctx.set_clouds_f64(src, tgt)
+    out = {}
+    for name, mode in (("grid", lib.NN_GRID), ("brute", lib.NN_BRUTE)):
+        ctx.set_nn_mode(mode)
+        ctx.nn_pass(np.eye(4), r)
+        st = ctx.reduce()
+        out[name] = (ctx.correspondence_index(), ctx.get_correspondences()[2], st)
+    assert np.array_equal(out["grid"][0], out["brute"][0])
+    assert np.array_equal(out["grid"][1].view(np.uint32), out["brute"][1].view(np.uint32))
+    assert (out["grid"][0] < 0).sum() >= 50
+    a = ctx.run(None, r, 10, 0, 0)
+    ctx.set_nn_mode(lib.NN_BRUTE)
+    b = ctx.run(None, r, 10, 0, 0)
+    assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
