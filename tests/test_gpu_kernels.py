@@ -282,3 +282,15 @@ def test_half_pitch_rows_option_is_exact(lib, oracle):
     ctx.set_nn_mode(lib.NN_BRUTE)
     b = ctx.run(None, r, 10, 0, 0)
     assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
+
+
+@pytest.mark.gpu
+def test_randomised_grid_equals_brute_force(lib):
+    """tools/fuzz_grid_vs_brute.py: 300 random configurations (lattices on cell faces, duplicates,
+    planes, elongated boxes, far-off origins, extreme radii) -- the two searches must agree bit for bit."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_grid_vs_brute.py"), "300", "7"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "300 configurations, 0 mismatches" in p.stdout
