@@ -225,6 +225,25 @@ VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_proble
  * worthwhile and the LDS-tiled brute-force kernel otherwise; BRUTE / GRID force
  * one.  The grid is (re)built on the GPU when the target or the radius changes. */
 VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
+/* Arithmetic of the nearest-neighbour search.
+ *   0            fp32 distances on the fp32-rounded, centred clouds (the kernel
+ *                specification; what runs above 131,072 source points, e.g. in bench.py, and
+ *                in the brute-force / batched / target-sharded paths).  Near-ties between two candidates,
+ *                and candidates within ~1e-6 of the radius, can be decided differently
+ *                from the reference's f64 KD-tree; one flipped pair among K moves the
+ *                update by ~(pair spacing)/K -- negligible for large clouds, but above
+ *                1e-5 in about 2 % of random registrations with a few thousand points.
+ *   1 (default)  f64 search whenever the clouds are given in f64 (visma_icp_set_clouds_f64),
+ *                the grid search is in use and the source has at most 131,072 points:
+ *                the caller's f64 coordinates, the reference's f64 sum of squares and its
+ *                strict d2 < (double)(float)(r*r) test, i.e. the reference's correspondences;
+ *                statistics from the f64 coordinates too.  fp32 search otherwise.
+ *   2            f64 search for any size (same conditions otherwise).
+ * Takes effect at the next visma_icp_set_clouds_f64.  Cost of the f64 search: +6 % per
+ * iteration at 5k -> 20k points, +30 % at 64k -> 256k (measured on MI355X). */
+VISMA_ICP_API int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode);
+/* 1 when the last pass ran the f64 search. */
+VISMA_ICP_API int visma_icp_get_search_precision_used(visma_icp_ctx *ctx, int *is_f64);
 /* Which search the last nn_pass used (VISMA_ICP_NN_BRUTE or VISMA_ICP_NN_GRID). */
 VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
 /* Where the ICP loop runs.  1: ON THE DEVICE (per-iteration solve, compose and

@@ -87,6 +87,11 @@ public:
             if (rc != VISMA_ICP_OK)
                 throw std::runtime_error(std::string("visma_icp_create failed: ") +
                                          visma_icp_last_error(nullptr));
+            // drop-in callers want the reference's correspondences: f64 search for the cloud
+            // sizes where one flipped near-tie would show (VISMA_ICP_SEARCH_PRECISION=0/1/2 overrides)
+            int prec = 1;
+            if (const char *e = std::getenv("VISMA_ICP_SEARCH_PRECISION")) prec = std::atoi(e);
+            visma_icp_set_search_precision(ctx_, prec);
         }
         return ctx_;
     }

@@ -44,8 +44,13 @@ def _gpu_present():
 
 @pytest.fixture(scope="session")
 def _gpu_ctx_session(lib):
-    """A HIP context on device 0.  On a GPU box a failure here is a FAILURE, not a skip."""
-    return lib.Context(0)
+    """A HIP context on device 0.  On a GPU box a failure here is a FAILURE, not a skip.
+    Pinned to the fp32 search: these tests check the kernels against their fp32 specification
+    (oracle group B) bit for bit, and the brute-force kernel against the grid.  The default
+    ("auto": f64 search for small clouds) is covered by tests/test_search_precision.py."""
+    ctx = lib.Context(0)
+    ctx.set_search_precision("f32")
+    return ctx
 
 
 @pytest.fixture(params=["brute", "grid"])

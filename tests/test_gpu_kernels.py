@@ -264,6 +264,7 @@ def test_half_pitch_rows_option_is_exact(lib, oracle):
     os.environ["VISMA_ICP_GRID_SUB"] = "2"
     try:
         ctx = lib.Context(0)
+        ctx.set_search_precision("f32")                       # compared with the (fp32) brute-force kernel
     finally:
         del os.environ["VISMA_ICP_GRID_SUB"]
     src, tgt, T_gt, r = synth.make_pair(20000, 120000, motion="radius")

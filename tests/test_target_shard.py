@@ -85,6 +85,7 @@ def test_target_sharded_equals_single_context(lib, nn_mode):
     src, tgt, T_gt, radius = synth.make_pair(20000, 60000, motion="radius")
     tgt = np.concatenate([tgt, tgt[:500]])                 # exact duplicates across the shards: ties
     ref = _lib.Context(0)
+    ref.set_search_precision("f32")          # sharded ranks exchange fp32 keys
     ref.set_nn_mode(nn_mode)
     ref.set_clouds_f64(src, tgt)
     want = ref.run(None, radius, 12, 0, 0)
@@ -105,6 +106,7 @@ def test_target_sharded_three_ranks_point_to_plane_and_empty_shard(lib):
     src, tgt, T_gt, radius = synth.make_pair(6000, 30000, motion="radius")
     nrm = tgt / np.linalg.norm(tgt, axis=1, keepdims=True)
     ref = _lib.Context(0)
+    ref.set_search_precision("f32")          # sharded ranks exchange fp32 keys
     ref.set_clouds_f64(src, tgt)
     ref.set_target_normals_f64(nrm)
     want = ref.run_point_to_plane(None, radius, 8, 0, 0)
@@ -134,7 +136,7 @@ def test_source_sharded_equals_single_context(lib):
     """The default decomposition of bench.py --gpus N (each rank: a slice of the source, the whole
     target, ONE sum of the 38 statistics per pass), on the real HIP engine with threads as ranks."""
     src, tgt, T_gt, radius = synth.make_pair(30000, 100000, motion="radius")
-    ref = _lib.Context(0)
+    ref = _lib.Context(0)                     # default search precision on both sides (f64 here)
     ref.set_clouds_f64(src, tgt)
     want = ref.run(None, radius, 15, 0, 0)
     n = 3

@@ -9,6 +9,7 @@ from visma_amd import _lib, synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 ctx = _lib.Context(0)
+ctx.set_search_precision("f32")          # the brute-force kernel is fp32: compare like with like
 bad = 0
 for it in range(N):
     kind = rng.integers(0, 7)

@@ -1,5 +1,5 @@
 """Distribution of the final-transform error of the GPU path against the f64 oracle (the CPU
-restatement of the reference algorithm) over random registrations.  usage: fuzz_icp_vs_oracle.py [N] [seed]
+restatement of the reference algorithm) over random registrations.  usage: fuzz_icp_vs_oracle.py [N] [seed] [f32|auto|f64]
 Test infrastructure: imports oracle/."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,7 @@ from oracle.oracle import Oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 o = Oracle(); ctx = _lib.Context(0)
+ctx.set_search_precision(sys.argv[3] if len(sys.argv) > 3 else "f32")      # f32 | auto | f64
 errs = []
 for it in range(N):
     ns = int(rng.integers(500, 8000)); nt = int(rng.integers(2000, 40000))

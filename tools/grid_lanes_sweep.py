@@ -14,6 +14,7 @@ for code in sys.argv[2:]:
     os.environ["VISMA_ICP_GRID_LANES"] = code
     ctx = _lib.Context(0)
     ctx.set_profiling(True)
+    ctx.set_search_precision(os.environ.get("SEARCH_PRECISION", "f32"))
     ctx.set_clouds_f64(src, tgt)
     ctx.set_nn_mode(_lib.NN_GRID)
     ctx.run(None, r, 1, 0, 0)

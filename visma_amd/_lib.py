@@ -116,6 +116,8 @@ def load():
                                                   _ip, C.c_int64, C.c_int64, C.c_int, C.c_uint64, _dp]
     L.visma_icp_set_target_shard.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _dp]
     L.visma_icp_set_minreduce.argtypes = [C.c_void_p, MINREDUCE_FN, C.c_void_p]
+    L.visma_icp_set_search_precision.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_get_search_precision_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_nn_mode.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
@@ -338,6 +340,15 @@ class Context:
         ms, bms = C.c_double(0), C.c_double(0)
         self._chk(self.L.visma_icp_last_mesh_kernel_ms(self._h, C.byref(ms), C.byref(bms)))
         return ms.value, bms.value
+
+    def set_search_precision(self, mode):
+        """'f32' (default) | 'auto' (f64 search for small f64 clouds) | 'f64'; before set_clouds_f64."""
+        self._chk(self.L.visma_icp_set_search_precision(self._h, {"f32": 0, "auto": 1, "f64": 2}[mode]))
+
+    def search_is_f64(self):
+        v = C.c_int(0)
+        self._chk(self.L.visma_icp_get_search_precision_used(self._h, C.byref(v)))
+        return bool(v.value)
 
     def set_mesh_search(self, method):
         """'auto' | 'brute' | 'bvh'"""

@@ -73,16 +73,16 @@ struct Acc {
 
 // Jacobian / residual rows of ONE correspondence, in f64 (design rules R1/R2):
 // p = T64 * s (+ frame offset), q = target point (+ frame offset).
+// (sx,sy,sz) = source point, (qx,qy,qz) = its target point, both in the centred frame
 template <bool PLANE>
-__device__ __forceinline__ void accumulate_pair(double *acc, const float4 s4, const float4 q4,
-                                                const float4 n4, const Xform64 &T64,
-                                                const Offset64 &off)
+__device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, const double sy, const double sz,
+                                                  const double qx, const double qy, const double qz,
+                                                  const float4 n4, const Xform64 &T64, const Offset64 &off)
 {
-    const double sx = s4.x, sy = s4.y, sz = s4.z;
     const double p[3] = {T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3] + off.v[0],
                          T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7] + off.v[1],
                          T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11] + off.v[2]};
-    const double q[3] = {(double)q4.x + off.v[0], (double)q4.y + off.v[1], (double)q4.z + off.v[2]};
+    const double q[3] = {qx + off.v[0], qy + off.v[1], qz + off.v[2]};
     const double r[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
     acc[0] += 1.0;
     if (!PLANE) {
@@ -116,6 +116,15 @@ __device__ __forceinline__ void accumulate_pair(double *acc, const float4 s4, co
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[23 + a] += J[a] * rr;
     }
+}
+
+template <bool PLANE>
+__device__ __forceinline__ void accumulate_pair(double *acc, const float4 s4, const float4 q4,
+                                                const float4 n4, const Xform64 &T64,
+                                                const Offset64 &off)
+{
+    accumulate_pair_d<PLANE>(acc, (double)s4.x, (double)s4.y, (double)s4.z, (double)q4.x, (double)q4.y,
+                             (double)q4.z, n4, T64, off);
 }
 
 // Wave-wide sums of N values per lane with ~N shuffles instead of 6*N: at every

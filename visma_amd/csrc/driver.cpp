@@ -141,6 +141,10 @@ public:
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
     virtual bool has_device_allreduce() const { return false; }
+    // f64 copies of the clouds for the double-precision search (after set_source / set_target;
+    // same order as those: source in Morton order).  nullptr pair = drop them.
+    virtual int set_clouds64(const Pt64 *, const Pt64 *) { err_ = "double-precision search needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    virtual bool search_is_f64() const { return false; }
     // Host staging for the packed (x,y,z,0) fp32 clouds handed to set_source / set_target.
     // The HIP engine returns pinned memory (grow-only), so the upload runs at link speed.
     virtual float *staging(int slot, size_t nfloats)
@@ -174,6 +178,7 @@ public:
         if (comm_) g_rccl.CommDestroy(comm_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
+        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_);
         for (int i = 0; i < 2; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
@@ -228,6 +233,21 @@ public:
         inited_ = true;
         return VISMA_ICP_OK;
     }
+
+    int set_clouds64(const Pt64 *src, const Pt64 *tgt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_);
+        grid_valid_ = false;                                     // the sorted f64 copy is built with the grid
+        if (!src || !tgt) return VISMA_ICP_OK;
+        HIP_TRY(hipMalloc(&d_src64_, sizeof(Pt64) * std::max<int64_t>(ns_, 1)));
+        HIP_TRY(hipMalloc(&d_tgt64_, sizeof(Pt64) * std::max<int64_t>(nt_, 1)));
+        if (ns_ > 0) HIP_TRY(hipMemcpyAsync(d_src64_, src, sizeof(Pt64) * ns_, hipMemcpyHostToDevice, stream_));
+        if (nt_ > 0) HIP_TRY(hipMemcpyAsync(d_tgt64_, tgt, sizeof(Pt64) * nt_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    bool search_is_f64() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr; }
 
     float *staging(int slot, size_t nfloats) override
     {
@@ -301,6 +321,7 @@ public:
         const int64_t ns_min_pad = ((ns_ + kBlock - 1) / kBlock) * kBlock;
         for (int i = 0; i < 12; i++) T32_.m[i] = (float)Tc.m[i];
         r2f_ = (float)(max_dist * max_dist);
+        r2d_ = (double)r2f_;                                     // (double)(float)(r*r): KDTreeFlann.cpp:184-185
         int rc = choose_mode(max_dist);
         if (rc) return rc;
         view_offset_ = 0;
@@ -358,7 +379,7 @@ public:
                                           (float *)d_d2_, (double *)d_partials_, grid_blocks(),
                                           &nblocks, grid_lanes(),
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
-                                          1, 0, stream_));
+                                          1, 0, stream_, f64_src(), f64_sorted(), r2d_));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (!tshard_) {
                 if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -436,7 +457,8 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, grid_lanes(), nullptr, nullptr, 1, 0, stream_));
+                                          &nblocks, grid_lanes(), nullptr, nullptr, 1, 0, stream_,
+                                          f64_src(), f64_sorted(), r2d_));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -475,6 +497,7 @@ public:
         // a 3 k-point target fell back to 24 sequential brute-force loops: 25 ms instead of 2).
         if (nprob > 1 && !use_grid_ && nn_mode_ == VISMA_ICP_NN_AUTO && grid_valid_ && nt_ > 0) use_grid_ = true;
         r2f_ = (float)(lp.max_dist * lp.max_dist);
+        r2d_ = (double)r2f_;
         for (int i = 0; i < 12; i++) T32_.m[i] = (float)lp.Tc0.m[i];
         if (nprob > 1 && (!use_grid_ || comm_)) {
             err_ = "batched loop needs the grid search on a single GPU";
@@ -545,7 +568,7 @@ public:
                                                   (float *)d_d2_, (double *)d_partials_,
                                                   reduce_max_blocks(), &nblocks, grid_lanes(),
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
-                                                  nprob, loop_out_stride_, stream_));
+                                                  nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_));
                 } else {
                     HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
                                             T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
@@ -883,13 +906,14 @@ private:
         HIP_TRY(hipMalloc(&d_src_, sizeof(float4) * (ns > 0 ? ns : 1)));
         ns_ = ns;
         have_pass_ = false;
+        free_dev(d_src64_);                                      // belongs to the previous source
         return VISMA_ICP_OK;
     }
     int ensure_target(int64_t nt)
     {
         if (nt < 0) { err_ = "negative point count"; return VISMA_ICP_ERR_INVALID; }
         if (nt > 0x7fffffff - 4096) { err_ = "target too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
-        free_dev(d_tgt_); free_dev(d_nrm_);
+        free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_tgt64_); free_dev(d_sorted64_);
         has_normals_ = false;
         // pad to a whole number of LDS chunks with +inf points (never accepted)
         nt_pad_ = ((nt + kTChunk - 1) / kTChunk) * kTChunk;
@@ -953,9 +977,12 @@ private:
             HIP_TRY(hipMalloc(&d_bsum_, sizeof(unsigned) * (grid_scan_blocks(grid_.ncell) + 1)));
             cell_cap_ = grid_.ncell + 1;
         }
+        free_dev(d_sorted64_);
+        if (d_tgt64_ && d_src64_) HIP_TRY(hipMalloc(&d_sorted64_, sizeof(Pt64) * std::max<int64_t>(nt_, 1)));
         HIP_TRY(launch_grid_build((const float4 *)d_tgt_, nt_, grid_, (unsigned *)d_cell_of_,
                                   (unsigned *)d_count_, (unsigned *)d_bsum_, (unsigned *)d_start_,
-                                  (float4 *)d_sorted_, stream_));
+                                  (float4 *)d_sorted_, stream_, d_sorted64_ ? (const Pt64 *)d_tgt64_ : nullptr,
+                                  (Pt64 *)d_sorted64_));
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
         grid_valid_ = true;
         grid_radius_ = max_dist;
@@ -1014,6 +1041,7 @@ private:
     int ev_used_ = 0;
     std::vector<std::pair<int, int>> pending_;
     visma_icp_timing timing_{};
+    void *d_src64_ = nullptr, *d_tgt64_ = nullptr, *d_sorted64_ = nullptr;   // double-precision search
     float *pin_[2] = {nullptr, nullptr};   // pinned staging (see staging())
     size_t pin_cap_[2] = {0, 0};
     NcclComm comm_ = nullptr;
@@ -1041,6 +1069,9 @@ private:
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
     static constexpr int kGridMaxBlocks = 8192;
+    double r2d_ = 0.0;
+    const Pt64 *f64_src() const { return d_sorted64_ ? (const Pt64 *)d_src64_ : nullptr; }
+    const Pt64 *f64_sorted() const { return d_src64_ ? (const Pt64 *)d_sorted64_ : nullptr; }
     int grid_sub_ = 1;         // row refinement the planner may use (VISMA_ICP_GRID_SUB=2: 25 half-pitch rows --
                                // 42 % fewer candidates at C4 but slower, 59 vs 51 us: more rows, 4x the table)
     int grid_blocks_env_ = 0;  // VISMA_ICP_GRID_BLOCKS override of the workgroup cap below
@@ -1060,6 +1091,8 @@ private:
         if (grid_lanes_ > 0) return grid_lanes_;
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
         // (lanes per query, loads in flight per lane), encoded G + 100*U
+        if (f64_src())   // 32-byte candidates: fewer in flight per lane (measured 5k: 408 15.8 us vs 804 18.1)
+            return ns_ <= 32768 ? 408 : (ns_ <= 131072 ? 802 : 801);
         return ns_ <= 32768 ? 804 : (ns_ <= 98304 ? 802 : 1201);
     }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
@@ -1107,6 +1140,7 @@ struct visma_icp_ctx {
     std::unique_ptr<Engine> eng;
     std::string err;
     double centre[3] = {0, 0, 0};
+    int search_precision = 1;         // 0 fp32 search, 1 f64 for small clouds (auto, default), 2 f64 always
     bool fixed_centre = false;        // centre given by the caller (target-sharded ranks share one)
     bool target_sharded = false;
     bool have_src = false, have_tgt = false;
@@ -1265,6 +1299,7 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
 }
 
 constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
+constexpr int64_t kF64AutoMaxSources = 131072;   // search precision "auto": f64 up to this many source points
 
 // (x - c) as fp32 (x,y,z,0) rows; `par`: spread over host threads
 void pack_f64_to(const double *xyz, int64_t n, int stride, const double c[3], float *out, bool par)
@@ -1475,6 +1510,31 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     morton_order_ptr(sb, ns, ctx->src_order, true);
     rc = ctx->eng->set_source(sb, ns);
     if (rc) return ctx->eng_fail(rc);
+    // double-precision search: the caller's own f64 coordinates (centred in f64) go along
+    const bool want64 = !ctx->target_sharded &&        // (sharded ranks exchange fp32 keys)
+                        (ctx->search_precision == 2 || (ctx->search_precision == 1 && ns <= kF64AutoMaxSources));
+    if (want64 && ctx->eng->supports_device_loop()) {
+        std::vector<Pt64> t8((size_t)std::max<int64_t>(nt, 1)), s8((size_t)std::max<int64_t>(ns, 1));
+        parallel_for((nt + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
+            const int64_t lo = ch * kHostChunk, hi = std::min(nt, lo + kHostChunk);
+            for (int64_t j = lo; j < hi; j++) {
+                const double *q = tgt + (size_t)j * tstride;
+                t8[(size_t)j] = Pt64{q[0] - c[0], q[1] - c[1], q[2] - c[2], (unsigned long long)j};
+            }
+        });
+        parallel_for((ns + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
+            const int64_t lo = ch * kHostChunk, hi = std::min(ns, lo + kHostChunk);
+            for (int64_t pos = lo; pos < hi; pos++) {
+                const double *q = src + (size_t)ctx->src_order[(size_t)pos] * sstride;    // Morton order, like sb
+                s8[(size_t)pos] = Pt64{q[0] - c[0], q[1] - c[1], q[2] - c[2], (unsigned long long)ctx->src_order[(size_t)pos]};
+            }
+        });
+        rc = ctx->eng->set_clouds64(s8.data(), t8.data());
+        if (rc) return ctx->eng_fail(rc);
+    } else if (ctx->eng->supports_device_loop()) {
+        rc = ctx->eng->set_clouds64(nullptr, nullptr);
+        if (rc) return ctx->eng_fail(rc);
+    }
     std::memcpy(ctx->centre, c, sizeof(c));
     ctx->have_src = ctx->have_tgt = true;
     return VISMA_ICP_OK;
@@ -1959,6 +2019,22 @@ int visma_icp_set_allreduce(visma_icp_ctx *ctx, visma_icp_allreduce_fn fn, void 
     ctx->host_allreduce_user = user;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode)
+{
+    CTX_CHECK();
+    if (mode < 0 || mode > 2) return ctx->fail(VISMA_ICP_ERR_INVALID, "search precision must be 0, 1 or 2");
+    ctx->search_precision = mode;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_search_precision_used(visma_icp_ctx *ctx, int *is_f64)
+{
+    CTX_CHECK();
+    if (!is_f64) return ctx->fail(VISMA_ICP_ERR_INVALID, "null output");
+    *is_f64 = ctx->eng->search_is_f64() ? 1 : 0;
     return VISMA_ICP_OK;
 }
 

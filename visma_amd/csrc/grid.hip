@@ -168,7 +168,9 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float4 *__restr
                                                            const unsigned *__restrict__ cell_of,
                                                            const unsigned *__restrict__ start,
                                                            unsigned *__restrict__ cursor,
-                                                           float4 *__restrict__ sorted)
+                                                           float4 *__restrict__ sorted,
+                                                           const Pt64 *__restrict__ pts64,
+                                                           Pt64 *__restrict__ sorted64)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -176,6 +178,11 @@ __global__ __launch_bounds__(256) void cell_scatter_kernel(const float4 *__restr
     const unsigned pos = start[c] + atomicAdd(&cursor[c], 1u);
     const float4 q = pts[i];
     sorted[pos] = make_float4(q.x, q.y, q.z, __uint_as_float((unsigned)i));
+    if (pts64) {                                   // the f64 copy goes to the same slot
+        Pt64 q8 = pts64[i];
+        q8.w = (unsigned long long)(unsigned)i;
+        sorted64[pos] = q8;
+    }
 }
 
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream)
@@ -246,7 +253,8 @@ GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int6
 
 hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
                              unsigned *cell_of, unsigned *count, unsigned *bsum,
-                             unsigned *start, float4 *sorted, hipStream_t stream)
+                             unsigned *start, float4 *sorted, hipStream_t stream,
+                             const Pt64 *tgt64, Pt64 *sorted64)
 {
     hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned) * (size_t)g.ncell, stream);
     if (e != hipSuccess) return e;
@@ -264,7 +272,7 @@ hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
     if (e != hipSuccess) return e;
     if (nt > 0)
         hipLaunchKernelGGL(cell_scatter_kernel, dim3(pblocks), dim3(256), 0, stream, tgt, (int)nt,
-                           cell_of, start, count, sorted);
+                           cell_of, start, count, sorted, tgt64, sorted64);
     return hipGetLastError();
 }
 
@@ -295,14 +303,25 @@ int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) /
 // ONE winner and builds its Jacobian/residual moments after the search -- the 29
 // f64 accumulators are then not live during the search (58 VGPRs less, one more
 // wave per SIMD) and no lane repeats another lane's accumulation.
-template <bool PLANE, int G, int U, bool ONE>
+//
+// F64: the DOUBLE-PRECISION search (visma_icp_set_search_precision).  fp32 distances on fp32
+// coordinates decide near-ties differently from the reference's f64 KD-tree about once in
+// 10^5 queries; with K matched pairs one flipped pair moves the update by ~(pair spacing)/K,
+// i.e. above the 1e-5 parity tolerance for clouds of a few thousand points (measured: 5 of 300
+// random small registrations, tools/fuzz_icp_vs_oracle.py).  Here candidates are the caller's
+// f64 points (32 B each), the source is transformed in f64, d2 is the reference's f64
+// sum-of-squares (x, y, z order) and acceptance is d2 < (double)(float)(r*r)
+// (KDTreeFlann.cpp:184-185): the correspondences ARE the reference's.  Cells and row pruning
+// still use the fp32 view of the same points (margins cover the difference).
+template <bool PLANE, int G, int U, bool ONE, bool F64 = false>
 __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
     Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out, float *__restrict__ d2_out,
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
     const DevIcpState *__restrict__ st, int bpp, long long out_stride,
-    const ProbDesc *__restrict__ descs, int nprob)
+    const ProbDesc *__restrict__ descs, int nprob, const Pt64 *__restrict__ src64 = nullptr,
+    const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0)
 {
     constexpr int NACC = Acc<PLANE>::N;
     int prob, lb;
@@ -359,21 +378,39 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     __shared__ unsigned row_b[8][kBlock], row_e[8][kBlock];
     __shared__ float row_bound[8][kBlock];
     float4 keep_s = make_float4(0.f, 0.f, 0.f, 0.f);      // the query this lane accumulates
+    int keep_i = 0;                                        // (F64: its index instead)
     unsigned keep_pos = 0xFFFFFFFFu;                       // ... and its winner's slot in `sorted`
     auto flush = [&]() {
         if (keep_pos != 0xFFFFFFFFu) {
-            const float4 q4 = sorted[keep_pos];
             float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (PLANE) n4 = nrm[__float_as_uint(q4.w)];
-            accumulate_pair<PLANE>(acc, keep_s, q4, n4, T64, off);
+            if constexpr (F64) {
+                const Pt64 s8 = src64[keep_i], q8 = sorted64[keep_pos];
+                if (PLANE) n4 = nrm[(unsigned)q8.w];
+                accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, n4, T64, off);
+            } else {
+                const float4 q4 = sorted[keep_pos];
+                if (PLANE) n4 = nrm[__float_as_uint(q4.w)];
+                accumulate_pair<PLANE>(acc, keep_s, q4, n4, T64, off);
+            }
             keep_pos = 0xFFFFFFFFu;
         }
     };
     int it = 0;
     for (int i = i_begin; i < i_end; i++, it++) {
-        const float4 s4 = src[i];
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float px, py, pz;
-        xform_point_f32(T32, s4, px, py, pz);
+        double pxd = 0.0, pyd = 0.0, pzd = 0.0;
+        if constexpr (F64) {
+            // the reference's transform of a source point (PointCloud.cpp:75-80), in f64
+            const Pt64 s8 = src64[i];
+            pxd = T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0;
+            pyd = T64.m[4] * s8.x + T64.m[5] * s8.y + T64.m[6] * s8.z + T64.m[7] * 1.0;
+            pzd = T64.m[8] * s8.x + T64.m[9] * s8.y + T64.m[10] * s8.z + T64.m[11] * 1.0;
+            px = (float)pxd; py = (float)pyd; pz = (float)pzd;
+        } else {
+            s4 = src[i];
+            xform_point_f32(T32, s4, px, py, pz);
+        }
         const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(py, g.mn[1], g.inv_hs, g.dim[1]);
         const int cz = cell_coord(pz, g.mn[2], g.inv_hs, g.dim[2]);
@@ -383,6 +420,13 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // start key (r2f, 0) makes the acceptance strict: d2 < r2f.
         unsigned long long bkey = (unsigned long long)__float_as_uint(r2f) << 32;
         unsigned bpos = 0xFFFFFFFFu;
+        double bd = r2d;                                   // F64: best d2 so far (strictly below r2d once set)
+        unsigned bidx = 0xFFFFFFFFu;                       // F64: ... and its original index
+        // what a row bound is compared with: the best squared distance so far, as fp32
+        auto best_f32 = [&]() {
+            if constexpr (F64) { const float f = (float)bd; return f + f * 1e-6f; }   // rounded UP a little
+            else return __uint_as_float((unsigned)(bkey >> 32));
+        };
         // Rows (y,z) are visited nearest first and a row is SKIPPED when its slab cannot
         // hold a better candidate: every point of row (dy,dz) is at least
         // |(dist to the slab in y, in z)| away.  Margins: 1e-3 cell on each slab distance
@@ -415,21 +459,45 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // (d2, index) minimum, and it saves the per-slot guard.
         auto batch = [&]() {
             unsigned jc[U];
-            float4 q[U];
+            if constexpr (F64) {
+                Pt64 q[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const unsigned ju = base + sub + u * G;
-                jc[u] = ju < e ? ju : base;
-                q[u] = sorted[jc[u]];
-            }
+                for (int u = 0; u < U; u++) {
+                    const unsigned ju = base + sub + u * G;
+                    jc[u] = ju < e ? ju : base;
+                    q[u] = sorted64[jc[u]];
+                }
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const float d = sqdist_f32(q[u], px, py, pz);
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q[u].w);
-                const bool lt = key < bkey;
-                bkey = lt ? key : bkey;
-                bpos = lt ? jc[u] : bpos;
+                for (int u = 0; u < U; u++) {
+                    // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
+                    const double dx = q[u].x - pxd, dy = q[u].y - pyd, dz = q[u].z - pzd;
+                    double d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    const unsigned id = (unsigned)q[u].w;
+                    // strictly nearer, or as near with a lower index (a re-read of the winner is neither)
+                    const bool lt = d < bd || (d == bd && id < bidx && bidx != 0xFFFFFFFFu);
+                    bd = lt ? d : bd;
+                    bidx = lt ? id : bidx;
+                    bpos = lt ? jc[u] : bpos;
+                }
+            } else {
+                float4 q[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned ju = base + sub + u * G;
+                    jc[u] = ju < e ? ju : base;
+                    q[u] = sorted[jc[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float d = sqdist_f32(q[u], px, py, pz);
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(d) << 32) | __float_as_uint(q[u].w);
+                    const bool lt = key < bkey;
+                    bkey = lt ? key : bkey;
+                    bpos = lt ? jc[u] : bpos;
+                }
             }
             base += U * G;
         };
@@ -445,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     const float bound = row_bound[kk][threadIdx.x];
                     ++kk;
                     // the group's current best bounds what any lane still needs
-                    float gbest = __uint_as_float((unsigned)(bkey >> 32));
+                    float gbest = best_f32();
 #pragma unroll
                     for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
                     if (bound > gbest) continue;
@@ -484,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             constexpr int r2z[16] = {-2, 0, 0, 2, -2, -2, -1, -1, 1, 1, 2, 2, -2, -2, 2, 2};
 #pragma unroll
             for (int pass = 0; pass < 2; pass++) {
-                float gbest = __uint_as_float((unsigned)(bkey >> 32));
+                float gbest = best_f32();
 #pragma unroll
                 for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
                 bool any = false;
@@ -513,19 +581,32 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             // butterfly merge over the G lanes: smallest (d2, index) wins everywhere
 #pragma unroll
             for (int m = G >> 1; m > 0; m >>= 1) {
-                const unsigned ohi = (unsigned)__shfl_xor((int)(unsigned)(bkey >> 32), m, 64);
-                const unsigned olo = (unsigned)__shfl_xor((int)(unsigned)bkey, m, 64);
-                const unsigned op = (unsigned)__shfl_xor((int)bpos, m, 64);
-                const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
-                if (ok < bkey) { bkey = ok; bpos = op; }
+                if constexpr (F64) {
+                    const double od = __shfl_xor(bd, m, 64);
+                    const unsigned oi = (unsigned)__shfl_xor((int)bidx, m, 64);
+                    const unsigned op = (unsigned)__shfl_xor((int)bpos, m, 64);
+                    // 0xFFFFFFFF ("none") is the largest index, so it loses every tie at r2d
+                    if (od < bd || (od == bd && oi < bidx)) { bd = od; bidx = oi; bpos = op; }
+                } else {
+                    const unsigned ohi = (unsigned)__shfl_xor((int)(unsigned)(bkey >> 32), m, 64);
+                    const unsigned olo = (unsigned)__shfl_xor((int)(unsigned)bkey, m, 64);
+                    const unsigned op = (unsigned)__shfl_xor((int)bpos, m, 64);
+                    const unsigned long long ok = ((unsigned long long)ohi << 32) | olo;
+                    if (ok < bkey) { bkey = ok; bpos = op; }
+                }
             }
         }
         if (sub == 0) {
-            idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)(unsigned)bkey;
-            d2_out[i] = __uint_as_float((unsigned)(bkey >> 32));
+            if constexpr (F64) {
+                idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
+                d2_out[i] = (float)bd;
+            } else {
+                idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)(unsigned)bkey;
+                d2_out[i] = __uint_as_float((unsigned)(bkey >> 32));
+            }
         }
         // lane (it mod G) of the group keeps this query's winner
-        if ((it % G) == sub) { keep_s = s4; keep_pos = bpos; }
+        if ((it % G) == sub) { keep_s = s4; keep_i = i; keep_pos = bpos; }
         if (!ONE && (it % G) == G - 1) flush();
     }
     flush();
@@ -554,11 +635,24 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const float4 *nrm, const Xform32 &T32, const Xform64 &T64,
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
                           double *partials, unsigned long long *cand, const DevIcpState *st,
-                          int nprob, long long out_stride)
+                          int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d)
 {
     // one query per lane? (see ONE above)
     const long long total_groups = (long long)nblocks * (kBlock / G);
     const bool one = ((long long)ns + total_groups - 1) / total_groups <= G;
+    if (src64) {
+        if (one)
+            hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, true, true>), dim3(nblocks * nprob), dim3(kBlock),
+                               0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
+                               partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,
+                               sorted64, r2d);
+        else
+            hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, false, true>), dim3(nblocks * nprob), dim3(kBlock),
+                               0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
+                               partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,
+                               sorted64, r2d);
+        return;
+    }
     if (one)
         hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, true>), dim3(nblocks * nprob), dim3(kBlock), 0,
                            stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
@@ -576,8 +670,10 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int32_t *idx_out, float *d2_out, double *partials,
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
-                                 int nprob, int64_t out_stride, hipStream_t stream)
+                                 int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
+                                 const Pt64 *sorted64, double r2d)
 {
+    if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
     const int G = lanes_per_query % 100;
@@ -591,11 +687,11 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,           \
                                         tgt_normals, T32, T64, off, r2f, idx_out, d2_out,          \
-                                        partials, cand_count, st, nprob, (long long)out_stride);   \
+                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d);   \
         else                                                                                       \
             launch_grid_t<false, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,          \
                                          tgt_normals, T32, T64, off, r2f, idx_out, d2_out,         \
-                                         partials, cand_count, st, nprob, (long long)out_stride);  \
+                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d);  \
         launched = true;                                                                           \
     }
     bool launched = false;

@@ -102,6 +102,12 @@ hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpStat
 hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream);
 
 // ---- radius-cell uniform grid (grid.hip) -------------------------------------
+// A point in f64 for the double-precision search (32 B: x, y, z, original index).
+struct Pt64 {
+    double x, y, z;
+    unsigned long long w;
+};
+
 struct GridParams {
     float mn[3];      // lower corner of the target's bounding box
     float h, inv_h;   // cell edge along x (>= 1.001 * max_dist) and its reciprocal
@@ -145,9 +151,11 @@ hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, co
                                     double *h_out_col, int64_t *n_out, int *too_fine,
                                     hipStream_t stream);
 // counting sort of the target by cell: start[ncell+1], sorted[nt] = (x,y,z, bits(orig index))
+// tgt64 / sorted64 (both or neither): the f64 copy of the target is scattered in the same order
 hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
                              unsigned *cell_of, unsigned *count, unsigned *bsum,
-                             unsigned *start, float4 *sorted, hipStream_t stream);
+                             unsigned *start, float4 *sorted, hipStream_t stream,
+                             const Pt64 *tgt64 = nullptr, Pt64 *sorted64 = nullptr);
 // fused transform + grid NN + Jacobian/residual + reduction to partial rows
 // (launch_finalize folds them); also writes idx_out / d2_out.
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -157,7 +165,9 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int32_t *idx_out, float *d2_out, double *partials,
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
-                                 int nprob, int64_t out_stride, hipStream_t stream);
+                                 int nprob, int64_t out_stride, hipStream_t stream,
+                                 const Pt64 *src64 = nullptr, const Pt64 *sorted64 = nullptr,
+                                 double r2d = 0.0);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
 // offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
