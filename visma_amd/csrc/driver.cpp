@@ -566,7 +566,7 @@ public:
                                                   (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                                   T32_, T64, nullptr, r2f_, plane, (int32_t *)d_idx_,
                                                   (float *)d_d2_, (double *)d_partials_,
-                                                  reduce_max_blocks(), &nblocks, grid_lanes(),
+                                                  reduce_max_blocks(), &nblocks, grid_lanes(nprob),
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
                                                   nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_));
                 } else {
@@ -1086,13 +1086,15 @@ private:
         return (int)std::min<int64_t>(kGridMaxBlocks, (ns_ + kBlock - 1) / kBlock);
     }
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
-    int grid_lanes() const
+    int grid_lanes(int nprob = 1) const
     {
         if (grid_lanes_ > 0) return grid_lanes_;
+        const int64_t q = ns_ * (int64_t)nprob;                  // queries of one launch
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
         // (lanes per query, loads in flight per lane), encoded G + 100*U
         if (f64_src())   // 32-byte candidates: fewer in flight per lane (measured 5k: 408 15.8 us vs 804 18.1)
-            return ns_ <= 32768 ? 408 : (ns_ <= 131072 ? 802 : 801);
+            return q <= 32768 ? 408 : (q <= 131072 && nprob == 1 ? 802 : 402);
+        if (nprob > 1) return q <= 32768 ? 804 : 402;          // sweeps: many queries per launch
         return ns_ <= 32768 ? 804 : (ns_ <= 98304 ? 802 : 1201);
     }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
@@ -1458,6 +1460,10 @@ int visma_icp_create(visma_icp_ctx **out, int device)
     if (rc) { g_create_error = e->error(); return rc; }
     visma_icp_ctx *c = new visma_icp_ctx();
     c->eng = std::move(e);
+    if (const char *p = std::getenv("VISMA_ICP_SEARCH_PRECISION")) {     // initial value of the option
+        const int v = std::atoi(p);
+        if (v >= 0 && v <= 2) c->search_precision = v;
+    }
     *out = c;
     return VISMA_ICP_OK;
 }
