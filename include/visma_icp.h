@@ -228,7 +228,7 @@ VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
 /* Arithmetic of the nearest-neighbour search.
  *   0            fp32 distances on the fp32-rounded, centred clouds (the kernel
  *                specification; what runs above 131,072 source points, e.g. in bench.py, and
- *                in the brute-force / batched / target-sharded paths).  Near-ties between two candidates,
+ *                in the brute-force and target-sharded paths).  Near-ties between two candidates,
  *                and candidates within ~1e-6 of the radius, can be decided differently
  *                from the reference's f64 KD-tree; one flipped pair among K moves the
  *                update by ~(pair spacing)/K -- negligible for large clouds, but above

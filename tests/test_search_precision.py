@@ -109,3 +109,18 @@ def test_auto_precision_policy_and_sweep(lib, oracle):
     ctx.set_clouds_f64(src, tgt)
     ctx.run(None, r, 2, 0, 0)
     assert not ctx.search_is_f64()
+
+
+def test_batched_problems_use_the_f64_search_too(lib, oracle):
+    """Config 3 (many small ICPs in flight) is exactly where one flipped pair shows."""
+    probs, want = [], []
+    for seed in (11, 12, 13):
+        src, tgt, init, r = hard_case(seed)
+        src, tgt = src[:2500], tgt[:12000]
+        probs.append((src, tgt, init, r))
+        want.append(oracle.registration_icp(src, tgt, r, init=init, max_iter=15))
+    ctx = _lib.Context(0)
+    got = ctx.run_batch(probs, max_iter=15)
+    for g, w in zip(got, want):
+        assert g.num_correspondences == w.k
+        assert synth.rel_frobenius(g.transformation_, w.T) < 1e-10

@@ -129,6 +129,8 @@ public:
         // problems that share clouds (24 yaw starts of one model, every model against the
         // same scene): index of an EARLIER problem whose uploaded source / built grid is reused
         int src_share = -1, grid_share = -1;
+        // f64 copies for the double-precision search (all problems of a batch or none)
+        const Pt64 *src64 = nullptr, *tgt64 = nullptr;
     };
     virtual int run_loop_batch(const LoopParams &, const std::vector<BatchProblem> &, LoopResult *)
     {
@@ -184,6 +186,7 @@ public:
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
+        free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
         if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
@@ -637,6 +640,11 @@ public:
         int64_t queries = 0;
         for (int b = 0; b < B; b++) queries += pb[b].ns;
         int lanes = queries >= 200000 ? 801 : 804;
+        {
+            bool all64 = B > 0;
+            for (int b = 0; b < B; b++) all64 = all64 && (pb[b].src64 || pb[b].src_share >= 0 || pb[b].ns == 0);
+            if (all64) lanes = queries >= 200000 ? 402 : 804;     // 32-byte candidates (measured on the yaw sweeps)
+        }
         if (const char *e = std::getenv("VISMA_ICP_BATCH_LANES")) { const int v = std::atoi(e); if (v > 0) lanes = v; }
         const int G = lanes % 100;
         if (G < 1 || G > 64 || (G & (G - 1))) { err_ = "bad VISMA_ICP_BATCH_LANES"; return VISMA_ICP_ERR_INVALID; }
@@ -690,6 +698,19 @@ public:
             HIP_TRY(hipMalloc(&bt_src_, sizeof(float4) * std::max<int64_t>(src_tot, 1)));
             bt_src_cap_ = src_tot;
         }
+        bool f64 = B > 0;
+        for (int b = 0; b < B; b++) {
+            const BatchProblem &q = pb[b];
+            const BatchProblem &sq = q.src_share >= 0 ? pb[q.src_share] : q, &tq = q.grid_share >= 0 ? pb[q.grid_share] : q;
+            f64 = f64 && (q.ns == 0 || sq.src64) && (q.nt == 0 || tq.tgt64);
+        }
+        if (f64 && (src_tot > bt_src64_cap_ || tgt_tot > bt_tgt64_cap_)) {
+            free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
+            HIP_TRY(hipMalloc(&bt_src64_, sizeof(Pt64) * std::max<int64_t>(src_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_tgt64_, sizeof(Pt64) * std::max<int64_t>(tgt_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_sorted64_, sizeof(Pt64) * std::max<int64_t>(tgt_tot, 1)));
+            bt_src64_cap_ = src_tot; bt_tgt64_cap_ = tgt_tot;
+        }
         if (out_tot > bt_out_cap_) {
             free_dev(bt_idx_); free_dev(bt_d2_);
             HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(out_tot, 1)));
@@ -738,12 +759,18 @@ public:
             const BatchProblem &q = pb[b];
             const ProbDesc &d = descs[b];
             if (q.ns > 0 && q.src_share < 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_src_ + d.src_off, q.src_xyzw, sizeof(float4) * q.ns, hipMemcpyHostToDevice, stream_));
+            if (f64 && q.ns > 0 && q.src_share < 0)
+                HIP_TRY(hipMemcpyAsync((Pt64 *)bt_src64_ + d.src_off, q.src64, sizeof(Pt64) * q.ns, hipMemcpyHostToDevice, stream_));
             if (q.grid_share >= 0) continue;
             if (q.nt > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_tgt_ + d.sorted_off, q.tgt_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
+            if (f64 && q.nt > 0)
+                HIP_TRY(hipMemcpyAsync((Pt64 *)bt_tgt64_ + d.sorted_off, q.tgt64, sizeof(Pt64) * q.nt, hipMemcpyHostToDevice, stream_));
             HIP_TRY(launch_grid_build((const float4 *)bt_tgt_ + d.sorted_off, q.nt, d.g,
                                       (unsigned *)bt_cell_of_ + d.sorted_off, (unsigned *)bt_count_ + d.start_off,
                                       (unsigned *)bt_bsum_, (unsigned *)bt_start_ + d.start_off,
-                                      (float4 *)bt_sorted_ + d.sorted_off, stream_));
+                                      (float4 *)bt_sorted_ + d.sorted_off, stream_,
+                                      f64 ? (const Pt64 *)bt_tgt64_ + d.sorted_off : nullptr,
+                                      f64 ? (Pt64 *)bt_sorted64_ + d.sorted_off : nullptr));
         }
         HIP_TRY(hipMemcpyAsync(bt_descs_, descs.data(), sizeof(ProbDesc) * B, hipMemcpyHostToDevice, stream_));
         for (int b = 0; b < B; b++) {
@@ -773,7 +800,9 @@ public:
                 HIP_TRY(launch_nn_grid_reduce_batch((const float4 *)bt_src_, (const float4 *)bt_sorted_,
                                                     (const unsigned *)bt_start_, (const ProbDesc *)bt_descs_, B,
                                                     total_blocks, (int32_t *)bt_idx_, (float *)bt_d2_,
-                                                    (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_));
+                                                    (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_,
+                                                    f64 ? (const Pt64 *)bt_src64_ : nullptr,
+                                                    f64 ? (const Pt64 *)bt_sorted64_ : nullptr));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
                 HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_));
@@ -1064,6 +1093,8 @@ private:
     size_t partial_rows_ = 0;
     // batch of problems with their own clouds (concatenated arrays)
     void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
+    void *bt_src64_ = nullptr, *bt_tgt64_ = nullptr, *bt_sorted64_ = nullptr;
+    int64_t bt_src64_cap_ = 0, bt_tgt64_cap_ = 0;
     void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
     int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0, bt_out_cap_ = 0;
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
@@ -1869,6 +1900,11 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
             }
         }
         std::vector<std::array<double, 3>> cen((size_t)n);
+        // double-precision search for the whole batch when every problem qualifies
+        bool want64 = ctx->search_precision != 0;
+        for (int i = 0; want64 && i < n; i++)
+            if (ctx->search_precision == 1 && probs[i].ns > kF64AutoMaxSources) want64 = false;
+        std::vector<std::vector<Pt64>> s8((size_t)n), t8((size_t)n);
         if (ok)
             parallel_for(n, 1, [&](int64_t i) {                    // targets: first occurrences only
                 if (tshare[i] >= 0) return;
@@ -1877,6 +1913,12 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
                 centroid_f64(q.tgt_xyz, q.nt, 3, c, false);       // the same value as set_clouds_f64 computes
                 for (int a = 0; a < 3; a++) cen[i][a] = c[a];
                 pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
+                if (want64) {
+                    t8[i].resize((size_t)std::max<int64_t>(q.nt, 1));
+                    for (int64_t j = 0; j < q.nt; j++)
+                        t8[i][(size_t)j] = Pt64{q.tgt_xyz[3 * j] - c[0], q.tgt_xyz[3 * j + 1] - c[1],
+                                               q.tgt_xyz[3 * j + 2] - c[2], (unsigned long long)j};
+                }
             });
         if (ok)
             parallel_for(n, 1, [&](int64_t i) {
@@ -1887,8 +1929,17 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
                     pack_f64(q.src_xyz, q.ns, 3, c, sbuf[i]);
                     std::vector<int32_t> order;
                     morton_order(sbuf[i], q.ns, order);
+                    if (want64) {
+                        s8[i].resize((size_t)std::max<int64_t>(q.ns, 1));
+                        for (int64_t pos = 0; pos < q.ns; pos++) {
+                            const double *sp = q.src_xyz + 3 * (size_t)order[(size_t)pos];
+                            s8[i][(size_t)pos] = Pt64{sp[0] - c[0], sp[1] - c[1], sp[2] - c[2], (unsigned long long)order[(size_t)pos]};
+                        }
+                    }
                 }
                 Engine::BatchProblem &b = pb[i];
+                b.src64 = (want64 && sshare[i] < 0) ? s8[i].data() : nullptr;
+                b.tgt64 = want64 ? t8[t].data() : nullptr;
                 b.src_xyzw = sshare[i] < 0 ? sbuf[i].data() : nullptr; b.ns = q.ns;
                 b.tgt_xyzw = tbuf[t].data(); b.nt = q.nt;
                 b.src_share = sshare[i];

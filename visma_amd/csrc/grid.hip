@@ -340,6 +340,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         src += d.src_off;
         ns = d.ns;
         sorted += d.sorted_off;
+        if constexpr (F64) { src64 += d.src_off; sorted64 += d.sorted_off; }
         start += d.start_off;
         g = d.g;
         out_stride = 0;
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     }
     if (st) st += prob;
     if (!load_loop_state(st, T32, T64, off, r2f)) return;
+    if constexpr (F64) r2d = (double)r2f;                  // (double)(float)(r*r), also when the radius comes from the state
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
     double acc[NACC];
@@ -707,43 +709,50 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     return hipGetLastError();
 }
 
-template <int G, int U, bool ONE>
+template <int G, int U, bool ONE, bool F64>
 static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const float4 *src,
                                 const float4 *sorted, const unsigned *start, const ProbDesc *descs,
                                 int nprob, int *idx_out, float *d2_out, double *partials,
-                                const DevIcpState *st)
+                                const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64)
 {
     const Xform32 T32{};
     const Xform64 T64{};
     const Offset64 off{};
     const GridParams g{};
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE>), dim3(total_blocks), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE, F64>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
-                       d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob);
+                       d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0);
 }
 
-// lanes_per_query = G + 100 * U; one_per_lane: every problem has at most G queries per lane group
+// lanes_per_query = G + 100 * U; one_per_lane: every problem has at most G queries per lane group;
+// src64 / sorted64 (both or neither): the f64 search, arrays concatenated like src / sorted
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
                                        const ProbDesc *descs, int nprob, int total_blocks,
                                        int32_t *idx_out, float *d2_out, double *partials,
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
-                                       hipStream_t stream)
+                                       hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64)
 {
-    if (!st || !descs) return hipErrorInvalidValue;
+    if (!st || !descs || (src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     const int G = lanes_per_query % 100, U = lanes_per_query / 100;
     bool launched = false;
 #define VISMA_BATCH_CASE(GG, UU)                                                                              \
     if (G == GG && U == UU) {                                                                                 \
-        if (one_per_lane)                                                                                     \
-            launch_grid_batch_t<GG, UU, true>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out,  \
-                                              d2_out, partials, st);                                          \
+        if (src64 && one_per_lane)                                                                            \
+            launch_grid_batch_t<GG, UU, true, true>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out,  \
+                                                    d2_out, partials, st, src64, sorted64);                   \
+        else if (src64)                                                                                       \
+            launch_grid_batch_t<GG, UU, false, true>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
+                                                     d2_out, partials, st, src64, sorted64);                  \
+        else if (one_per_lane)                                                                                \
+            launch_grid_batch_t<GG, UU, true, false>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
+                                                     d2_out, partials, st, nullptr, nullptr);                 \
         else                                                                                                  \
-            launch_grid_batch_t<GG, UU, false>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
-                                               d2_out, partials, st);                                         \
+            launch_grid_batch_t<GG, UU, false, false>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
+                                                      d2_out, partials, st, nullptr, nullptr);                \
         launched = true;                                                                                      \
     }
     VISMA_BATCH_CASE(4, 2) VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
-    VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4)
+    VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4) VISMA_BATCH_CASE(8, 4)
 #undef VISMA_BATCH_CASE
     if (!launched) return hipErrorInvalidValue;
     return hipGetLastError();

@@ -174,7 +174,8 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        const ProbDesc *descs, int nprob, int total_blocks,
                                        int32_t *idx_out, float *d2_out, double *partials,
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
-                                       hipStream_t stream);
+                                       hipStream_t stream, const Pt64 *src64 = nullptr,
+                                       const Pt64 *sorted64 = nullptr);
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
                                        int nprob, hipStream_t stream);
 
