@@ -124,3 +124,21 @@ def test_batched_problems_use_the_f64_search_too(lib, oracle):
     for g, w in zip(got, want):
         assert g.num_correspondences == w.k
         assert synth.rel_frobenius(g.transformation_, w.T) < 1e-10
+
+
+def test_small_cloud_with_a_huge_radius_stays_in_f64(lib, oracle):
+    """A radius comparable to the cloud gives a degenerate grid (a few cells); for small f64 clouds the
+    f64 grid search is kept anyway (the fp32 brute-force kernel would be the AUTO choice otherwise)."""
+    src, tgt, T_gt, r = synth.make_pair(1500, 4000, motion="radius")
+    r = 0.6                                               # the surface is about 1 m across
+    ctx = _lib.Context(0)
+    ctx.set_clouds_f64(src, tgt)
+    init = synth.make_T(synth.rot_y(0.05), [0.01, 0.0, -0.02])
+    ctx.nn_pass(init, r)
+    st = ctx.reduce()
+    assert ctx.search_is_f64() and ctx.nn_mode_used() == _lib.NN_GRID
+    k, idx, d2, e2 = oracle.nn_pass(oracle.transform_points(src, init), tgt, r)
+    assert np.array_equal(ctx.correspondence_index(), idx) and int(st[0]) == k
+    got = ctx.run(init, r, 10, 0, 0)
+    want = oracle.registration_icp(src, tgt, r, init=init, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
+    assert synth.rel_frobenius(got.transformation_, want.T) < 1e-10

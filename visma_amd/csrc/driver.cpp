@@ -979,6 +979,10 @@ private:
         // proper grid the fused kernel wins at every size measured: 20-22 us per
         // iteration against 33-37 for 500 ... 4000 target points.)
         use_grid_ = grid_.ncell >= 512;
+        // Small f64 clouds keep the (f64) grid search even on a degenerate grid -- a radius that is
+        // large against the cloud's extent -- so that their correspondences stay the reference's;
+        // scanning most of a few-thousand-point target per query is cheap.
+        if (!use_grid_ && d_src64_ && d_tgt64_ && (double)ns_ * (double)nt_ <= 2.0e8) use_grid_ = true;
         return VISMA_ICP_OK;
     }
     int build_grid(double max_dist)
