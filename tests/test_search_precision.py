@@ -142,3 +142,35 @@ def test_small_cloud_with_a_huge_radius_stays_in_f64(lib, oracle):
     got = ctx.run(init, r, 10, 0, 0)
     want = oracle.registration_icp(src, tgt, r, init=init, max_iter=10, rel_fitness=0.0, rel_rmse=0.0)
     assert synth.rel_frobenius(got.transformation_, want.T) < 1e-10
+
+
+def test_reference_fixtures_under_the_default_precision(lib):
+    """The committed outputs of the compiled reference (tests/golden/*.npz), with a default context:
+    small f64 clouds -> f64 search -> the reference's correspondences and iteration counts, every
+    yaw of the orientation sweep included (the fp32 search is allowed a few pairs of slack there)."""
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ctx = _lib.Context(0)
+    g = np.load(os.path.join(G, "chair_5k_20k.npz"))
+    ctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    for it in (0, 1, 5, 20):
+        r = ctx.run(g["init"], float(g["radius"]), it, 0.0, 0.0)
+        row = g["trace"][it]
+        assert ctx.search_is_f64()
+        assert synth.rel_frobenius(r.transformation_, row[:16].reshape(4, 4)) < 1e-12
+        assert r.num_correspondences == row[18] and abs(r.inlier_rmse_ - row[17]) < 1e-13
+    assert np.array_equal(ctx.correspondence_index(), g["final_idx"])
+    g = np.load(os.path.join(G, "chair_offset3m.npz"))
+    ctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    for row, it in zip(g["trace"], g["trace_iters"]):
+        r = ctx.run(g["init"], float(g["radius"]), int(it), 0.0, 0.0)
+        assert synth.rel_frobenius(r.transformation_, row[:16].reshape(4, 4)) < 1e-11      # 3 m from the origin
+        assert r.num_correspondences == row[18]
+    g = np.load(os.path.join(G, "yaw_sweep.npz"))
+    ctx.set_clouds_f64(g["model"].astype(np.float64), g["scene"].astype(np.float64))
+    best, level, per = ctx.run_yaw_sweep(int(g["level"]), float(g["radius"]))
+    assert level == int(g["best"])
+    for p, T, k in zip(per, g["T"], g["k"]):
+        assert p.num_correspondences == k
+        if k > 50:                                        # (a yaw that matched almost nothing has no defined rotation)
+            assert synth.rel_frobenius(p.transformation_, T) < 1e-9
