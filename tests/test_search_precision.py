@@ -174,3 +174,22 @@ def test_reference_fixtures_under_the_default_precision(lib):
         assert p.num_correspondences == k
         if k > 50:                                        # (a yaw that matched almost nothing has no defined rotation)
             assert synth.rel_frobenius(p.transformation_, T) < 1e-9
+
+
+def test_point_to_plane_under_the_default_precision(lib):
+    """O3D's point-to-plane estimator on the reference's fragment pair: f64 search + f64 coordinates in
+    the statistics (the normals travel as fp32), against the compiled reference's trace."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fragments.npz"))
+    ctx = _lib.Context(0)
+    ctx.set_clouds_f64(g["src"].astype(np.float64), g["tgt"].astype(np.float64))
+    r = ctx.run(g["init"], float(g["radius"]), 10, 0.0, 0.0)
+    assert ctx.search_is_f64()
+    assert synth.rel_frobenius(r.transformation_, g["trace_p2p"][10][:16].reshape(4, 4)) < 1e-11
+    assert r.num_correspondences == g["trace_p2p"][10][18]
+    ctx.set_target_normals_f64(g["tgt_normals"].astype(np.float64))
+    for it in (1, 10):
+        r = ctx.run_point_to_plane(g["init"], float(g["radius"]), it, 0.0, 0.0)
+        row = g["trace_p2plane"][it]
+        assert r.num_correspondences == row[18]
+        assert synth.rel_frobenius(r.transformation_, row[:16].reshape(4, 4)) < 1e-6     # fp32 normals
