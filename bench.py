@@ -58,6 +58,7 @@ def parse():
                          "default) or target points (north_star's wording: MIN all-reduce of NS keys + the "
                          "same sum; for targets that exceed one GPU)")
     ap.add_argument("--brute-steps", type=int, default=3)
+    ap.add_argument("--f64-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
     return ap.parse_args()
@@ -267,6 +268,27 @@ def main():
                  "rel_frobenius_vs_grid": synth.rel_frobenius(Tb, Tg)}
         ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID}[args.nn])
 
+    # the same workload with the double-precision search (outside the timed region; 1 GPU only):
+    # what exact tie-breaking would cost at this size
+    f64_extra = None
+    if world == 1 and mode == "grid" and not ctx.search_is_f64() and args.f64_steps > 0:
+        c64 = _lib.Context(local_rank)
+        c64.set_search_precision("f64")
+        c64.set_clouds_f64(src, tgt)
+        c64.set_nn_mode(_lib.NN_GRID)
+        c64.set_profiling(1)
+        T64w, _ = c64.iterate(np.eye(4), radius, 2)
+        c64.get_timing(reset=True)
+        t0f = time.perf_counter()
+        T64, _ = c64.iterate(np.eye(4), radius, args.f64_steps)
+        tf = time.perf_counter() - t0f
+        tm64 = c64.get_timing(reset=True)
+        Tf32, _ = ctx.iterate(np.eye(4), radius, args.f64_steps)
+        f64_extra = {"steps": args.f64_steps, "iterations_per_sec": args.f64_steps / tf,
+                     "nn_ms": tm64["nn_ms"] / max(tm64["nn_launches"], 1),
+                     "rel_frobenius_vs_f32_search": synth.rel_frobenius(T64, Tf32)}
+        del c64
+
     if rank == 0:
         tile = _lib.tile_config()
         if mode == "grid":
@@ -302,6 +324,8 @@ def main():
                      mpairs_per_sec=float(ns) * nt / brute["ms_per_step"] / 1e3,
                      rel_frobenius_vs_grid=brute["rel_frobenius_vs_grid"])
             out["brute_force"] = b
+        if f64_extra is not None:
+            out["f64_search"] = f64_extra
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(src, tgt, radius, args.cpu_iters)
             # parity of the two paths on this workload, same iteration count
