@@ -1128,7 +1128,7 @@ private:
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
         // (lanes per query, loads in flight per lane), encoded G + 100*U
         if (f64_src())   // 32-byte candidates: fewer in flight per lane (measured 5k: 408 15.8 us vs 804 18.1)
-            return q <= 32768 ? 408 : (q <= 131072 && nprob == 1 ? 802 : 402);
+            return q <= 32768 ? 408 : (nprob > 1 ? 402 : (q <= 131072 ? 802 : 801));
         if (nprob > 1) return q <= 32768 ? 804 : 402;          // sweeps: many queries per launch
         return ns_ <= 32768 ? 804 : (ns_ <= 98304 ? 802 : 1201);
     }
