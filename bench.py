@@ -206,14 +206,51 @@ def main():
         ns_local, nt_local = ns, hi - lo
         ctx.set_target_shard(lo, nt, tgt.mean(0))
         ctx.set_clouds_f64(src, tgt[lo:hi])
+    comm_kind = "none"
     if dist is not None:
         import torch
-        if rank == 0:
-            uid = torch.tensor(list(_lib.comm_unique_id()), dtype=torch.uint8, device="cuda")
-        else:
-            uid = torch.zeros(_lib.UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+        # the library's own RCCL communicator (dlopen'ed librccl): one ncclAllReduce of 38 f64 per
+        # iteration on the context's stream.  Should it fail to come up on this node, every rank falls
+        # back TOGETHER to the same exchange through torch.distributed (RCCL as well, but via a host
+        # callback: slower) rather than leaving the job without a number.
+        ok = 0 if os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" else 1     # (to exercise the fallback)
+        uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
+        if rank == 0 and ok:
+            try:
+                uid_bytes = _lib.comm_unique_id()
+            except Exception as e:      # noqa: BLE001
+                print("bench: ncclGetUniqueId failed (%s)" % e, file=sys.stderr)
+                ok = 0
+        uid = torch.tensor(list(uid_bytes), dtype=torch.uint8, device="cuda")
         dist.broadcast(uid, 0)
-        ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.broadcast(flag, 0)
+        ok = int(flag.item())
+        if ok:
+            try:
+                ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
+            except Exception as e:      # noqa: BLE001
+                print("bench: rank %d: ncclCommInitRank failed (%s)" % (rank, e), file=sys.stderr)
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            comm_kind = "rccl"
+        else:
+            comm_kind = "torch.distributed callback"
+            if args.shard == "target" and not (world == 1 and not force_comm):
+                raise SystemExit("bench: the target-sharded mode needs the library's own RCCL communicator")
+            ctx2 = _lib.Context(local_rank)                   # a context without the half-made communicator
+            ctx2.set_search_precision("auto" if ns <= 131072 else "f32")
+            ctx2.set_clouds_f64(src[(ns * rank) // world:(ns * (rank + 1)) // world], tgt)
+            ctx2.set_global_source_count(ns)
+            ctx = ctx2
+
+            def torch_allreduce(a):
+                t = torch.from_numpy(a.copy()).cuda()
+                dist.all_reduce(t)
+                a[:] = t.cpu().numpy()
+            ctx.set_allreduce(torch_allreduce, rank, world)
 
     def sync_all():
         if dist is not None:
@@ -307,7 +344,8 @@ def main():
             "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, "
                                    "nn=%s" % (ns, nt, args.steps, mode),
                        "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode,
-                       "parallelism": ("source-sharded x%d, 1 ncclAllReduce(38 f64)/iter" % world)
+                       "parallelism": ("source-sharded x%d, 1 ncclAllReduce(38 f64)/iter%s" % (
+                           world, "" if comm_kind in ("rccl", "none") else " [" + comm_kind + "]"))
                        if args.shard == "source" else
                        ("target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter" % (world, ns))},
             "mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
