@@ -77,7 +77,8 @@ struct Acc {
 template <bool PLANE>
 __device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, const double sy, const double sz,
                                                   const double qx, const double qy, const double qz,
-                                                  const float4 n4, const Xform64 &T64, const Offset64 &off)
+                                                  const double nx, const double ny, const double nz,
+                                                  const Xform64 &T64, const Offset64 &off)
 {
     const double p[3] = {T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3] + off.v[0],
                          T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7] + off.v[1],
@@ -98,7 +99,7 @@ __device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, 
 #pragma unroll
             for (int b = 0; b < 3; b++) acc[14 + a * 3 + b] += q[a] * p[b];
     } else {
-        const double n[3] = {(double)n4.x, (double)n4.y, (double)n4.z};
+        const double n[3] = {nx, ny, nz};
         const double rr = r[0] * n[0] + r[1] * n[1] + r[2] * n[2];
         // J = [p x n | n]  (TransformationEstimation.cpp:87-89); p x n = hat(p) n
         double J[6], H[9];
@@ -124,7 +125,7 @@ __device__ __forceinline__ void accumulate_pair(double *acc, const float4 s4, co
                                                 const Offset64 &off)
 {
     accumulate_pair_d<PLANE>(acc, (double)s4.x, (double)s4.y, (double)s4.z, (double)q4.x, (double)q4.y,
-                             (double)q4.z, n4, T64, off);
+                             (double)q4.z, (double)n4.x, (double)n4.y, (double)n4.z, T64, off);
 }
 
 // Wave-wide sums of N values per lane with ~N shuffles instead of 6*N: at every

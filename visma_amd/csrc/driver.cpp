@@ -147,6 +147,7 @@ public:
     // same order as those: source in Morton order).  nullptr pair = drop them.
     virtual int set_clouds64(const Pt64 *, const Pt64 *) { err_ = "double-precision search needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     virtual bool search_is_f64() const { return false; }
+    virtual int set_target_normals64(const Pt64 *) { return VISMA_ICP_OK; }     // f64 normals for the f64 search
     // Host staging for the packed (x,y,z,0) fp32 clouds handed to set_source / set_target.
     // The HIP engine returns pinned memory (grow-only), so the upload runs at link speed.
     virtual float *staging(int slot, size_t nfloats)
@@ -180,7 +181,7 @@ public:
         if (comm_) g_rccl.CommDestroy(comm_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
-        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_);
+        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         for (int i = 0; i < 2; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
@@ -240,7 +241,7 @@ public:
     int set_clouds64(const Pt64 *src, const Pt64 *tgt) override
     {
         HIP_TRY(hipSetDevice(device_));
-        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_);
+        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         grid_valid_ = false;                                     // the sorted f64 copy is built with the grid
         if (!src || !tgt) return VISMA_ICP_OK;
         HIP_TRY(hipMalloc(&d_src64_, sizeof(Pt64) * std::max<int64_t>(ns_, 1)));
@@ -251,6 +252,15 @@ public:
         return VISMA_ICP_OK;
     }
     bool search_is_f64() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr; }
+    int set_target_normals64(const Pt64 *n) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        free_dev(d_nrm64_);
+        if (!n || !d_tgt64_) return VISMA_ICP_OK;
+        HIP_TRY(hipMalloc(&d_nrm64_, sizeof(Pt64) * std::max<int64_t>(nt_, 1)));
+        if (nt_ > 0) HIP_TRY(hipMemcpy(d_nrm64_, n, sizeof(Pt64) * nt_, hipMemcpyHostToDevice));
+        return VISMA_ICP_OK;
+    }
 
     float *staging(int slot, size_t nfloats) override
     {
@@ -382,7 +392,7 @@ public:
                                           (float *)d_d2_, (double *)d_partials_, grid_blocks(),
                                           &nblocks, grid_lanes(),
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
-                                          1, 0, stream_, f64_src(), f64_sorted(), r2d_));
+                                          1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (!tshard_) {
                 if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -461,7 +471,7 @@ public:
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                           &nblocks, grid_lanes(), nullptr, nullptr, 1, 0, stream_,
-                                          f64_src(), f64_sorted(), r2d_));
+                                          f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -571,7 +581,7 @@ public:
                                                   (float *)d_d2_, (double *)d_partials_,
                                                   reduce_max_blocks(), &nblocks, grid_lanes(nprob),
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
-                                                  nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_));
+                                                  nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_));
                 } else {
                     HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
                                             T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
@@ -942,7 +952,7 @@ private:
     {
         if (nt < 0) { err_ = "negative point count"; return VISMA_ICP_ERR_INVALID; }
         if (nt > 0x7fffffff - 4096) { err_ = "target too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
-        free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_tgt64_); free_dev(d_sorted64_);
+        free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         has_normals_ = false;
         // pad to a whole number of LDS chunks with +inf points (never accepted)
         nt_pad_ = ((nt + kTChunk - 1) / kTChunk) * kTChunk;
@@ -1075,6 +1085,7 @@ private:
     std::vector<std::pair<int, int>> pending_;
     visma_icp_timing timing_{};
     void *d_src64_ = nullptr, *d_tgt64_ = nullptr, *d_sorted64_ = nullptr;   // double-precision search
+    void *d_nrm64_ = nullptr;
     float *pin_[2] = {nullptr, nullptr};   // pinned staging (see staging())
     size_t pin_cap_[2] = {0, 0};
     NcclComm comm_ = nullptr;
@@ -1640,6 +1651,13 @@ int visma_icp_set_target_normals_f64(visma_icp_ctx *ctx, const double *n, int64_
     pack_f64_to(n, nt, stride, zero, buf, true);
     int rc = ctx->eng->set_target_normals(buf, nt);
     if (rc) return ctx->eng_fail(rc);
+    if (ctx->eng->supports_device_loop()) {                 // the f64 search takes the normals in f64 as well
+        std::vector<Pt64> n8((size_t)std::max<int64_t>(nt, 1));
+        for (int64_t j = 0; j < nt; j++)
+            n8[(size_t)j] = Pt64{n[(size_t)j * stride], n[(size_t)j * stride + 1], n[(size_t)j * stride + 2], 0ull};
+        rc = ctx->eng->set_target_normals64(n8.data());
+        if (rc) return ctx->eng_fail(rc);
+    }
     return VISMA_ICP_OK;
 }
 

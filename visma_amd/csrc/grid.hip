@@ -321,7 +321,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
     const DevIcpState *__restrict__ st, int bpp, long long out_stride,
     const ProbDesc *__restrict__ descs, int nprob, const Pt64 *__restrict__ src64 = nullptr,
-    const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0)
+    const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0, const Pt64 *__restrict__ nrm64 = nullptr)
 {
     constexpr int NACC = Acc<PLANE>::N;
     int prob, lb;
@@ -387,8 +387,12 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (F64) {
                 const Pt64 s8 = src64[keep_i], q8 = sorted64[keep_pos];
-                if (PLANE) n4 = nrm[(unsigned)q8.w];
-                accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, n4, T64, off);
+                double nx = 0.0, ny = 0.0, nz = 0.0;
+                if (PLANE) {
+                    if (nrm64) { const Pt64 n8 = nrm64[(unsigned)q8.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                    else { n4 = nrm[(unsigned)q8.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
+                }
+                accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
             } else {
                 const float4 q4 = sorted[keep_pos];
                 if (PLANE) n4 = nrm[__float_as_uint(q4.w)];
@@ -637,7 +641,8 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const float4 *nrm, const Xform32 &T32, const Xform64 &T64,
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
                           double *partials, unsigned long long *cand, const DevIcpState *st,
-                          int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d)
+                          int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d,
+                          const Pt64 *nrm64)
 {
     // one query per lane? (see ONE above)
     const long long total_groups = (long long)nblocks * (kBlock / G);
@@ -647,12 +652,12 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
             hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, true, true>), dim3(nblocks * nprob), dim3(kBlock),
                                0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
                                partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,
-                               sorted64, r2d);
+                               sorted64, r2d, nrm64);
         else
             hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, false, true>), dim3(nblocks * nprob), dim3(kBlock),
                                0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
                                partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,
-                               sorted64, r2d);
+                               sorted64, r2d, nrm64);
         return;
     }
     if (one)
@@ -673,7 +678,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
-                                 const Pt64 *sorted64, double r2d)
+                                 const Pt64 *sorted64, double r2d, const Pt64 *nrm64)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     Offset64 off;
@@ -689,11 +694,11 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,           \
                                         tgt_normals, T32, T64, off, r2f, idx_out, d2_out,          \
-                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d);   \
+                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64);   \
         else                                                                                       \
             launch_grid_t<false, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,          \
                                          tgt_normals, T32, T64, off, r2f, idx_out, d2_out,         \
-                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d);  \
+                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64);  \
         launched = true;                                                                           \
     }
     bool launched = false;

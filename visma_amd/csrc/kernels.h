@@ -167,7 +167,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream,
                                  const Pt64 *src64 = nullptr, const Pt64 *sorted64 = nullptr,
-                                 double r2d = 0.0);
+                                 double r2d = 0.0, const Pt64 *nrm64 = nullptr);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
 // offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
