@@ -174,8 +174,16 @@ def main():
     if world > 1 or force_comm:
         import torch
         import torch.distributed as dist
+        # VISMA_BENCH_BACKEND=gloo: a dry run of the multi-rank logic on a box with fewer GPUs than ranks
+        # (ranks share devices, torch tensors stay on the CPU, the exchange is the torch callback)
+        backend = os.environ.get("VISMA_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+        tdev = "cuda" if backend == "nccl" else "cpu"
 
     from visma_amd import _lib, build, synth
     if rank == 0:
@@ -213,7 +221,7 @@ def main():
         # iteration on the context's stream.  Should it fail to come up on this node, every rank falls
         # back TOGETHER to the same exchange through torch.distributed (RCCL as well, but via a host
         # callback: slower) rather than leaving the job without a number.
-        ok = 0 if os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" else 1     # (to exercise the fallback)
+        ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or backend != "nccl") else 1
         uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
         if rank == 0 and ok:
             try:
@@ -221,9 +229,9 @@ def main():
             except Exception as e:      # noqa: BLE001
                 print("bench: ncclGetUniqueId failed (%s)" % e, file=sys.stderr)
                 ok = 0
-        uid = torch.tensor(list(uid_bytes), dtype=torch.uint8, device="cuda")
+        uid = torch.tensor(list(uid_bytes), dtype=torch.uint8, device=tdev)
         dist.broadcast(uid, 0)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
         dist.broadcast(flag, 0)
         ok = int(flag.item())
         if ok:
@@ -232,7 +240,7 @@ def main():
             except Exception as e:      # noqa: BLE001
                 print("bench: rank %d: ncclCommInitRank failed (%s)" % (rank, e), file=sys.stderr)
                 ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()):
             comm_kind = "rccl"
@@ -247,7 +255,7 @@ def main():
             ctx = ctx2
 
             def torch_allreduce(a):
-                t = torch.from_numpy(a.copy()).cuda()
+                t = torch.from_numpy(a.copy()).to(tdev)
                 dist.all_reduce(t)
                 a[:] = t.cpu().numpy()
             ctx.set_allreduce(torch_allreduce, rank, world)
@@ -262,7 +270,7 @@ def main():
         if dist is None:
             return x
         import torch
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
