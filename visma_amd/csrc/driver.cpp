@@ -152,11 +152,11 @@ public:
     // The HIP engine returns pinned memory (grow-only), so the upload runs at link speed.
     virtual float *staging(int slot, size_t nfloats)
     {
-        std::vector<float> &v = stage_[slot & 1];
+        std::vector<float> &v = stage_[slot & 3];
         if (v.size() < nfloats) v.resize(nfloats);
         return v.data();
     }
-    std::vector<float> stage_[2];
+    std::vector<float> stage_[4];     // slots 0/1: fp32 target / source; 2/3: their f64 copies
     // target-sharded ranks: this engine holds targets [offset, offset + nt) of the global cloud
     virtual int set_target_shard(int64_t, int64_t) { err_ = "target sharding needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     virtual void set_minreduce(visma_icp_minreduce_fn, void *) {}
@@ -182,7 +182,7 @@ public:
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
-        for (int i = 0; i < 2; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
+        for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
@@ -264,7 +264,7 @@ public:
 
     float *staging(int slot, size_t nfloats) override
     {
-        slot &= 1;
+        slot &= 3;
         if (pin_cap_[slot] < nfloats) {
             if (pin_[slot]) (void)hipHostFree(pin_[slot]);
             pin_[slot] = nullptr;
@@ -1086,8 +1086,8 @@ private:
     visma_icp_timing timing_{};
     void *d_src64_ = nullptr, *d_tgt64_ = nullptr, *d_sorted64_ = nullptr;   // double-precision search
     void *d_nrm64_ = nullptr;
-    float *pin_[2] = {nullptr, nullptr};   // pinned staging (see staging())
-    size_t pin_cap_[2] = {0, 0};
+    float *pin_[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging (see staging())
+    size_t pin_cap_[4] = {0, 0, 0, 0};
     NcclComm comm_ = nullptr;
     bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
     int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
@@ -1566,7 +1566,9 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     const bool want64 = !ctx->target_sharded &&        // (sharded ranks exchange fp32 keys)
                         (ctx->search_precision == 2 || (ctx->search_precision == 1 && ns <= kF64AutoMaxSources));
     if (want64 && ctx->eng->supports_device_loop()) {
-        std::vector<Pt64> t8((size_t)std::max<int64_t>(nt, 1)), s8((size_t)std::max<int64_t>(ns, 1));
+        // (Pt64 = 8 floats of staging; pinned on the HIP engine)
+        Pt64 *t8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(2, (size_t)std::max<int64_t>(nt, 1) * 8));
+        Pt64 *s8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(3, (size_t)std::max<int64_t>(ns, 1) * 8));
         parallel_for((nt + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
             const int64_t lo = ch * kHostChunk, hi = std::min(nt, lo + kHostChunk);
             for (int64_t j = lo; j < hi; j++) {
@@ -1581,7 +1583,7 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
                 s8[(size_t)pos] = Pt64{q[0] - c[0], q[1] - c[1], q[2] - c[2], (unsigned long long)ctx->src_order[(size_t)pos]};
             }
         });
-        rc = ctx->eng->set_clouds64(s8.data(), t8.data());
+        rc = ctx->eng->set_clouds64(s8, t8);
         if (rc) return ctx->eng_fail(rc);
     } else if (ctx->eng->supports_device_loop()) {
         rc = ctx->eng->set_clouds64(nullptr, nullptr);
