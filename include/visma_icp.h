@@ -51,7 +51,9 @@ typedef enum {
     VISMA_ICP_SOLVER_GN_EXPMAP = 2
 } visma_icp_solver;
 
-/* Nearest-neighbour search implementation (results are identical). */
+/* Nearest-neighbour search implementation (identical results at equal search
+ * precision; the brute-force kernel is always fp32, see
+ * visma_icp_set_search_precision). */
 typedef enum {
     VISMA_ICP_NN_AUTO = 0,
     VISMA_ICP_NN_BRUTE = 1, /* brute force over the whole target           */

@@ -27,16 +27,30 @@ def is_stale():
 
 
 def build_lib(force=False, verbose=False):
-    """Compile visma_amd/lib/libvisma_icp.so for gfx950 (cross-compiles without a GPU)."""
+    """Compile visma_amd/lib/libvisma_icp.so for gfx950 (cross-compiles without a GPU).
+    One hipcc process per source file, run side by side, then one link."""
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
-           "-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB_PATH, "-ldl", "-lpthread"]
+    obj_dir = os.path.join(LIB_DIR, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        cmd = [hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH, "-ldl", "-lpthread"]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
+    shutil.rmtree(obj_dir, ignore_errors=True)
     return LIB_PATH
 
 

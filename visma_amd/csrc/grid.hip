@@ -702,12 +702,10 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         launched = true;                                                                           \
     }
     bool launched = false;
-    VISMA_GRID_CASE(1, 4) VISMA_GRID_CASE(2, 4) VISMA_GRID_CASE(4, 4) VISMA_GRID_CASE(4, 2)
-    VISMA_GRID_CASE(8, 4) VISMA_GRID_CASE(8, 2) VISMA_GRID_CASE(8, 1) VISMA_GRID_CASE(16, 2)
-    VISMA_GRID_CASE(16, 1) VISMA_GRID_CASE(32, 1) VISMA_GRID_CASE(2, 2)
-    VISMA_GRID_CASE(1, 8) VISMA_GRID_CASE(2, 8) VISMA_GRID_CASE(1, 2) VISMA_GRID_CASE(1, 6) VISMA_GRID_CASE(2, 6)
-    VISMA_GRID_CASE(2, 3) VISMA_GRID_CASE(1, 3) VISMA_GRID_CASE(2, 1) VISMA_GRID_CASE(4, 1)
-    VISMA_GRID_CASE(1, 12) VISMA_GRID_CASE(2, 12) VISMA_GRID_CASE(1, 16) VISMA_GRID_CASE(2, 16) VISMA_GRID_CASE(1, 10) VISMA_GRID_CASE(4, 8)
+    // the (G, U) pairs the driver's policies use, plus a few neighbours for VISMA_ICP_GRID_LANES
+    // experiments (every pair is 8 kernel instantiations: PLANE x ONE x F64)
+    VISMA_GRID_CASE(1, 8) VISMA_GRID_CASE(1, 12) VISMA_GRID_CASE(2, 4) VISMA_GRID_CASE(2, 8)
+    VISMA_GRID_CASE(4, 4) VISMA_GRID_CASE(4, 8) VISMA_GRID_CASE(8, 4) VISMA_GRID_CASE(1, 4)
     if (!launched) return hipErrorInvalidValue;
 #undef VISMA_GRID_CASE
     if (nblocks_out) *nblocks_out = nblocks;
@@ -756,8 +754,8 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                                       d2_out, partials, st, nullptr, nullptr);                \
         launched = true;                                                                                      \
     }
-    VISMA_BATCH_CASE(4, 2) VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
-    VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4) VISMA_BATCH_CASE(8, 4)
+    VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
+    VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4)
 #undef VISMA_BATCH_CASE
     if (!launched) return hipErrorInvalidValue;
     return hipGetLastError();
