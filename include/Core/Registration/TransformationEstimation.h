@@ -1,8 +1,9 @@
-// Core/Registration/TransformationEstimation.h -- the estimator plugin
-// interface of the path (shape of O3D/Core/Registration/
-// TransformationEstimation.h:38-111).  The two stock estimators are declared
-// here and implemented in visma_icp_open3d.hpp on top of the C ABI's
-// statistics / solve functions.
+// Core/Registration/TransformationEstimation.h (stand-alone header set of the MI355X ICP shim)
+//
+// The estimator plugin interface that open3d::RegistrationICP accepts, with the names and call
+// signatures of Open3D 0.3.0 so that VISMA's call sites and user plugins compile unchanged.
+// Nothing here computes: the two stock estimators get their bodies in visma_icp_open3d.hpp, on
+// top of the C ABI (statistics from the GPU, closed-form / Gauss-Newton solve on the host).
 #pragma once
 #include <Eigen/Core>
 #include <vector>
@@ -10,55 +11,43 @@
 namespace open3d {
 
 class PointCloud;
+using CorrespondenceSet = std::vector<Eigen::Vector2i>;   // (source index, target index) pairs
 
-typedef std::vector<Eigen::Vector2i> CorrespondenceSet;
+enum class TransformationEstimationType { Unspecified = 0, PointToPoint = 1, PointToPlane = 2, ColoredICP = 3 };
 
-enum class TransformationEstimationType {
-    Unspecified = 0,
-    PointToPoint = 1,
-    PointToPlane = 2,
-    ColoredICP = 3,
-};
+// The two operations an estimator provides, as seen by the registration loop.  QUAL closes the
+// declaration: "= 0" in the interface, "override" in the estimators.
+#define VISMA_ICP_ESTIMATOR_OPS(QUAL)                                                               \
+    virtual double ComputeRMSE(const PointCloud &src, const PointCloud &dst,                        \
+                               const CorrespondenceSet &pairs) const QUAL;                          \
+    virtual Eigen::Matrix4d ComputeTransformation(const PointCloud &src, const PointCloud &dst,     \
+                                                  const CorrespondenceSet &pairs) const QUAL;
 
 class TransformationEstimation {
 public:
-    TransformationEstimation() {}
-    virtual ~TransformationEstimation() {}
+    virtual ~TransformationEstimation() = default;
     virtual TransformationEstimationType GetTransformationEstimationType() const = 0;
-    virtual double ComputeRMSE(const PointCloud &source, const PointCloud &target,
-                               const CorrespondenceSet &corres) const = 0;
-    virtual Eigen::Matrix4d ComputeTransformation(const PointCloud &source,
-                                                  const PointCloud &target,
-                                                  const CorrespondenceSet &corres) const = 0;
+    VISMA_ICP_ESTIMATOR_OPS(= 0)
 };
 
+// p' = c R p + t minimising sum |q - p'|^2 over the pairs (Umeyama); c = 1 unless with_scaling_.
 class TransformationEstimationPointToPoint : public TransformationEstimation {
 public:
-    TransformationEstimationPointToPoint(bool with_scaling = false) : with_scaling_(with_scaling) {}
-    ~TransformationEstimationPointToPoint() override {}
-    TransformationEstimationType GetTransformationEstimationType() const override
-    {
-        return TransformationEstimationType::PointToPoint;
-    }
-    inline double ComputeRMSE(const PointCloud &source, const PointCloud &target,
-                              const CorrespondenceSet &corres) const override;
-    inline Eigen::Matrix4d ComputeTransformation(const PointCloud &source, const PointCloud &target,
-                                                 const CorrespondenceSet &corres) const override;
-    bool with_scaling_ = false;
+    explicit TransformationEstimationPointToPoint(bool with_scaling = false) : with_scaling_(with_scaling) {}
+    TransformationEstimationType GetTransformationEstimationType() const override { return kind; }
+    VISMA_ICP_ESTIMATOR_OPS(override)
+    bool with_scaling_;
+    static constexpr TransformationEstimationType kind = TransformationEstimationType::PointToPoint;
 };
 
+// One Gauss-Newton step on sum ((q - p') . n_q)^2; needs normals on the target cloud.
 class TransformationEstimationPointToPlane : public TransformationEstimation {
 public:
-    TransformationEstimationPointToPlane() {}
-    ~TransformationEstimationPointToPlane() override {}
-    TransformationEstimationType GetTransformationEstimationType() const override
-    {
-        return TransformationEstimationType::PointToPlane;
-    }
-    inline double ComputeRMSE(const PointCloud &source, const PointCloud &target,
-                              const CorrespondenceSet &corres) const override;
-    inline Eigen::Matrix4d ComputeTransformation(const PointCloud &source, const PointCloud &target,
-                                                 const CorrespondenceSet &corres) const override;
+    TransformationEstimationType GetTransformationEstimationType() const override { return kind; }
+    VISMA_ICP_ESTIMATOR_OPS(override)
+    static constexpr TransformationEstimationType kind = TransformationEstimationType::PointToPlane;
 };
+
+#undef VISMA_ICP_ESTIMATOR_OPS
 
 }  // namespace open3d
