@@ -236,7 +236,8 @@ VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
  *                update by ~(pair spacing)/K -- negligible for large clouds, but above
  *                1e-5 in about 2 % of random registrations with a few thousand points.
  *   1 (default)  f64 search whenever the clouds are given in f64 (visma_icp_set_clouds_f64),
- *                the grid search is in use and the source has at most 131,072 points:
+ *                the grid search is in use, the source has at most 131,072 points and the
+ *                target at most 8,388,608:
  *                the caller's f64 coordinates, the reference's f64 sum of squares and its
  *                strict d2 < (double)(float)(r*r) test, i.e. the reference's correspondences;
  *                statistics from the f64 coordinates too.  fp32 search otherwise.

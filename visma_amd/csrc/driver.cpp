@@ -1348,6 +1348,7 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
 
 constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
 constexpr int64_t kF64AutoMaxSources = 131072;   // search precision "auto": f64 up to this many source points
+constexpr int64_t kF64AutoMaxTargets = 8388608;  // ... and target points (the f64 copies cost 64 B per target point)
 
 // (x - c) as fp32 (x,y,z,0) rows; `par`: spread over host threads
 void pack_f64_to(const double *xyz, int64_t n, int stride, const double c[3], float *out, bool par)
@@ -1564,7 +1565,8 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     if (rc) return ctx->eng_fail(rc);
     // double-precision search: the caller's own f64 coordinates (centred in f64) go along
     const bool want64 = !ctx->target_sharded &&        // (sharded ranks exchange fp32 keys)
-                        (ctx->search_precision == 2 || (ctx->search_precision == 1 && ns <= kF64AutoMaxSources));
+                        (ctx->search_precision == 2 ||
+                         (ctx->search_precision == 1 && ns <= kF64AutoMaxSources && nt <= kF64AutoMaxTargets));
     if (want64 && ctx->eng->supports_device_loop()) {
         // (Pt64 = 8 floats of staging; pinned on the HIP engine)
         Pt64 *t8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(2, (size_t)std::max<int64_t>(nt, 1) * 8));
