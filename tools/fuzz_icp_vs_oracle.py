@@ -5,11 +5,15 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from visma_amd import _lib, synth
-from oracle.oracle import Oracle
+from oracle.oracle import Oracle, Ref
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-o = Oracle(); ctx = _lib.Context(0)
+# the checker: the compiled reference itself (oracle/_ref, Open3D's RegistrationICP on its KD-tree)
+# when it is there -- much faster than the brute-force restatement -- else the restatement
+o = Ref() if (Ref.available() and os.environ.get("FUZZ_CHECKER", "ref") == "ref") else Oracle()
+print("checker:", type(o).__name__)
+ctx = _lib.Context(0)
 ctx.set_search_precision(sys.argv[3] if len(sys.argv) > 3 else "f32")      # f32 | auto | f64
 errs = []
 for it in range(N):
