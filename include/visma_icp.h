@@ -241,7 +241,9 @@ VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
  *                the caller's f64 coordinates, the reference's f64 sum of squares and its
  *                strict d2 < (double)(float)(r*r) test, i.e. the reference's correspondences;
  *                statistics from the f64 coordinates too.  fp32 search otherwise.
- *   2            f64 search for any size (same conditions otherwise).
+ *   2            f64 search for any size (same conditions otherwise).  Choose it when a large
+ *                source has only a few thousand matches (what matters is the number of matched
+ *                pairs K, which the automatic choice can only guess from the source size).
  * Takes effect at the next visma_icp_set_clouds_f64.  Cost of the f64 search: +6 % per
  * iteration at 5k -> 20k points, +30 % at 64k -> 256k (measured on MI355X). */
 VISMA_ICP_API int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode);
