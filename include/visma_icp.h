@@ -94,6 +94,16 @@ typedef struct {
     int64_t aux_launches;
     double grid_candidates; /* target points examined by the grid search (sum) */
     double grid_candidates_27cell; /* ... points in the full 3x3x3 cell blocks (before row pruning) */
+    /* streamed (LDS-tile) search, profiled launches only: */
+    double tile_workgroups;          /* workgroups of the streamed search */
+    double tile_fallback_workgroups; /* parts (see tile_parts) searched from global memory: footprint larger than the tile */
+    double tile_parts;               /* parts the chunks were searched in (1 per workgroup unless a footprint had to be split) */
+    double tile_points;              /* target points streamed into LDS (sum over workgroups) */
+    double tile_rows;                /* (y,z) rows of the footprints (sum over workgroups) */
+    double f64_reranks;              /* queries re-ranked in f64 (runner-up or radius inside the rounding band) */
+    double tile_phase_cycles[7];     /* shader cycles per workgroup phase, summed over workgroups: source + transform,
+                                        run bounds + footprint rows + scan, tile streaming, search + re-rank,
+                                        winner fetch, moments + row; [6] unused */
 } visma_icp_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */

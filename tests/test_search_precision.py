@@ -85,30 +85,37 @@ def test_f64_search_closes_the_parity_gap_of_small_clouds(lib, oracle):
         assert errs[(it, "f64")] < 1e-10, errs
 
 
-def test_auto_precision_policy_and_sweep(lib, oracle):
+def test_exact_search_is_the_default_at_every_size_and_in_sweeps(lib, oracle):
+    """No size-keyed policy any more: the default search is the exact one (fp32 ranking, f64
+    re-rank of the candidates inside the rounding band) and returns what the f64 search returns."""
     src, tgt, T_gt, r = synth.make_pair(3000, 9000, motion="radius")
     ctx = _lib.Context(0)
-    ctx.set_search_precision("auto")
     ctx.set_clouds_f64(src, tgt)
-    best, lvl, per = ctx.run_yaw_sweep(8, r * 2)           # the batched device loop runs the f64 kernel too
-    assert ctx.search_is_f64()
+    best, lvl, per = ctx.run_yaw_sweep(8, r * 2)           # the batched device loop runs it too
+    assert ctx.search_mode_used() == "exact"
     ref = _lib.Context(0)
     ref.set_search_precision("f64")
     ref.set_clouds_f64(src, tgt)
     ref.set_device_loop(False)
     b2, l2, p2 = ref.run_yaw_sweep(8, r * 2)
+    assert ref.search_mode_used() == "f64"
     assert lvl == l2
     for a, b in zip(per, p2):
         assert a.num_correspondences == b.num_correspondences and a.iterations == b.iterations
-        assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-9
+        assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
     big_s, big_t, _, rr = synth.make_pair(140000, 200000, motion="radius")
-    ctx.set_clouds_f64(big_s, big_t)                       # above the auto limit: fp32 search
-    ctx.run(None, rr, 2, 0, 0)
-    assert not ctx.search_is_f64()
-    ctx.set_nn_mode(_lib.NN_BRUTE)                         # brute force is always the fp32 kernel
+    ctx.set_clouds_f64(big_s, big_t)                       # round 1 switched to fp32 above 131,072 sources
+    a = ctx.run(None, rr, 3, 0, 0)
+    assert ctx.search_mode_used() == "exact"
+    ref.set_clouds_f64(big_s, big_t)
+    b = ref.run(None, rr, 3, 0, 0)
+    assert a.num_correspondences == b.num_correspondences
+    assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
+    assert np.array_equal(ctx.correspondence_index(), ref.correspondence_index())
+    ctx.set_nn_mode(_lib.NN_BRUTE)                         # brute force is the fp32 kernel
     ctx.set_clouds_f64(src, tgt)
     ctx.run(None, r, 2, 0, 0)
-    assert not ctx.search_is_f64()
+    assert ctx.search_mode_used() == "f32"
 
 
 def test_batched_problems_use_the_f64_search_too(lib, oracle):

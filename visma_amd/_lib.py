@@ -41,7 +41,10 @@ class CTiming(C.Structure):
     _fields_ = [("nn_ms", C.c_double), ("nn_launches", C.c_int64),
                 ("reduce_ms", C.c_double), ("reduce_launches", C.c_int64),
                 ("aux_ms", C.c_double), ("aux_launches", C.c_int64),
-                ("grid_candidates", C.c_double), ("grid_candidates_27cell", C.c_double)]
+                ("grid_candidates", C.c_double), ("grid_candidates_27cell", C.c_double),
+                ("tile_workgroups", C.c_double), ("tile_fallback_workgroups", C.c_double), ("tile_parts", C.c_double),
+                ("tile_points", C.c_double), ("tile_rows", C.c_double), ("f64_reranks", C.c_double),
+                ("tile_phase_cycles", C.c_double * 7)]
 
 
 class CProblem(C.Structure):
@@ -342,13 +345,19 @@ class Context:
         return ms.value, bms.value
 
     def set_search_precision(self, mode):
-        """'f32' (default) | 'auto' (f64 search for small f64 clouds) | 'f64'; before set_clouds_f64."""
-        self._chk(self.L.visma_icp_set_search_precision(self._h, {"f32": 0, "auto": 1, "f64": 2}[mode]))
+        """'exact' (default; alias 'auto': fp32 ranking, near-ties re-ranked in f64) | 'f32' | 'f64';
+        before set_clouds_f64."""
+        self._chk(self.L.visma_icp_set_search_precision(self._h, {"f32": 0, "auto": 1, "exact": 1, "f64": 2}[mode]))
 
-    def search_is_f64(self):
+    def search_mode_used(self):
+        """'f32' | 'exact' | 'f64': the arithmetic of the last pass."""
         v = C.c_int(0)
         self._chk(self.L.visma_icp_get_search_precision_used(self._h, C.byref(v)))
-        return bool(v.value)
+        return {0: "f32", 1: "exact", 2: "f64"}[v.value]
+
+    def search_is_f64(self):
+        """True when the last pass returned the reference's own (f64) correspondences."""
+        return self.search_mode_used() != "f32"
 
     def set_mesh_search(self, method):
         """'auto' | 'brute' | 'bvh'"""
@@ -383,7 +392,9 @@ class Context:
     def get_timing(self, reset=False):
         t = CTiming()
         self._chk(self.L.visma_icp_get_timing(self._h, C.byref(t), int(bool(reset))))
-        return {k: getattr(t, k) for k, _ in CTiming._fields_}
+        d = {k: getattr(t, k) for k, _ in CTiming._fields_}
+        d["tile_phase_cycles"] = [float(x) for x in d["tile_phase_cycles"]]
+        return d
 
     def launch_config(self):
         a = C.c_int(); b = C.c_int()

@@ -41,6 +41,15 @@ __device__ __forceinline__ bool load_loop_state(const DevIcpState *st, Xform32 &
     return true;
 }
 
+// The cell coordinate of the radius-cell grid; build and every query kernel MUST use this
+// same expression.
+__device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int dim)
+{
+    float u = floorf((v - mn) * inv_h);
+    u = fminf(fmaxf(u, -2.0f), (float)dim + 1.0f);   // also tames inf / huge values
+    return (int)u;
+}
+
 __device__ __forceinline__ float sqdist_f32(const float4 q, float px, float py, float pz)
 {
     const float dx = q.x - px, dy = q.y - py, dz = q.z - pz;
@@ -53,6 +62,20 @@ __device__ __forceinline__ float min3_f32(float a, float b, float c)
     float r;
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
+}
+
+// ---- agent-scope accesses for data handed between workgroups inside one launch ------------
+__device__ __forceinline__ void store_agent_f64(double *p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p),
+                       (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent_f64(const double *p)
+{
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __longlong_as_double((long long)v);
 }
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -171,8 +194,9 @@ __device__ __forceinline__ double wave_sum_multi(double *v)
 }
 
 // wavefront shuffle reduction -> LDS across the 4 waves -> one partial row
+// (row = nullptr: partials + blockIdx.x * kReduceAcc; agent: write-through stores for the fused fold)
 template <int NACC>
-__device__ __forceinline__ void block_reduce_store(double *acc, double *partials)
+__device__ __forceinline__ void block_reduce_store(double *acc, double *partials, bool agent = false)
 {
     __shared__ double wsum[kBlock / 64][NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -184,7 +208,45 @@ __device__ __forceinline__ void block_reduce_store(double *acc, double *partials
         double v = wsum[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < kBlock / 64; w++) v += wsum[w][threadIdx.x];
-        partials[(long long)blockIdx.x * kReduceAcc + threadIdx.x] = v;
+        double *dst = partials + (long long)blockIdx.x * kReduceAcc + threadIdx.x;
+        if (agent) store_agent_f64(dst, v);
+        else *dst = v;
+    }
+}
+
+// The 38 statistics from the folded accumulator totals: point-to-plane totals are the
+// statistics; the compact point-to-point moments are expanded into the literal 6x6 / 6x1
+// normal equations (J^T J = [[sum(|p|^2 I - p p^T), hat(sum p)], [., K I]],
+// J^T r = [-vee(sum q p^T); sum p - sum q]).
+template <bool PLANE>
+__device__ __forceinline__ void expand_moments(const double *tot, double *stats)
+{
+    if (PLANE) {
+        for (int i = 0; i < 29; i++) stats[i] = tot[i];
+        for (int i = 29; i < kNStats; i++) stats[i] = 0.0;
+    } else {
+        const double K = tot[0];
+        const double Px = tot[2], Py = tot[3], Pz = tot[4];
+        const double Qx = tot[5], Qy = tot[6], Qz = tot[7];
+        const double Sxx = tot[8], Sxy = tot[9], Sxz = tot[10];
+        const double Syy = tot[11], Syz = tot[12], Szz = tot[13];
+        const double *M = &tot[14];
+        stats[0] = K;
+        stats[1] = tot[1];
+        double *J = stats + 2;  // upper triangle, row by row
+        // row 0: sum(|p|^2 I - p p^T) | hat(sum p)
+        J[0] = Syy + Szz; J[1] = -Sxy; J[2] = -Sxz; J[3] = 0.0; J[4] = -Pz; J[5] = Py;
+        J[6] = Sxx + Szz; J[7] = -Syz; J[8] = Pz; J[9] = 0.0; J[10] = -Px;
+        J[11] = Sxx + Syy; J[12] = -Py; J[13] = Px; J[14] = 0.0;
+        J[15] = K; J[16] = 0.0; J[17] = 0.0;
+        J[18] = K; J[19] = 0.0;
+        J[20] = K;
+        double *r = stats + 23;  // J^T r = [ -vee(sum q p^T) ; sum p - sum q ]
+        double v3[3];
+        vee(M, v3);
+        r[0] = -v3[0]; r[1] = -v3[1]; r[2] = -v3[2];
+        r[3] = Px - Qx; r[4] = Py - Qy; r[5] = Pz - Qz;
+        for (int i = 0; i < 9; i++) stats[29 + i] = M[i];
     }
 }
 
@@ -221,36 +283,111 @@ __device__ __forceinline__ void fold_partials(const double *__restrict__ partial
         tot[threadIdx.x] = t;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (PLANE) {
-            for (int i = 0; i < 29; i++) stats[i] = tot[i];
-            for (int i = 29; i < kNStats; i++) stats[i] = 0.0;
-        } else {
-            const double K = tot[0];
-            const double Px = tot[2], Py = tot[3], Pz = tot[4];
-            const double Qx = tot[5], Qy = tot[6], Qz = tot[7];
-            const double Sxx = tot[8], Sxy = tot[9], Sxz = tot[10];
-            const double Syy = tot[11], Syz = tot[12], Szz = tot[13];
-            const double *M = &tot[14];
-            stats[0] = K;
-            stats[1] = tot[1];
-            double *J = stats + 2;  // upper triangle, row by row
-            // row 0: sum(|p|^2 I - p p^T) | hat(sum p)
-            J[0] = Syy + Szz; J[1] = -Sxy; J[2] = -Sxz; J[3] = 0.0; J[4] = -Pz; J[5] = Py;
-            J[6] = Sxx + Szz; J[7] = -Syz; J[8] = Pz; J[9] = 0.0; J[10] = -Px;
-            J[11] = Sxx + Syy; J[12] = -Py; J[13] = Px; J[14] = 0.0;
-            J[15] = K; J[16] = 0.0; J[17] = 0.0;
-            J[18] = K; J[19] = 0.0;
-            J[20] = K;
-            double *r = stats + 23;  // J^T r = [ -vee(sum q p^T) ; sum p - sum q ]
-            double v3[3];
-            vee(M, v3);
-            r[0] = -v3[0]; r[1] = -v3[1]; r[2] = -v3[2];
-            r[3] = Px - Qx; r[4] = Py - Qy; r[5] = Pz - Qz;
-            for (int i = 0; i < 9; i++) stats[29 + i] = M[i];
-        }
+    if (threadIdx.x == 0) expand_moments<PLANE>(tot, stats);
+}
+
+
+// Publish the 38 statistics to mapped (fine-grained, uncached) host memory as
+// self-validating 16-byte granules {value, sequence tag}: each granule is ONE
+// global_store_dwordx4, so the host can accept a value as soon as its tag shows
+// the expected sequence number -- no system-scope fence (whose L2 write-back of
+// the launch's ~2 MB of dirty index output cost ~10 us per iteration).
+__device__ __forceinline__ void publish_tagged_stats(const double *stats, double *host_out,
+                                                     unsigned long long seq)
+{
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    __syncthreads();                                   // stats[] was written by thread 0
+    if (threadIdx.x < kNStats) {
+        const unsigned long long v = (unsigned long long)__double_as_longlong(stats[threadIdx.x]);
+        u4 g;
+        g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
+        g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
+        __builtin_nontemporal_store(g, reinterpret_cast<u4 *>(host_out) + threadIdx.x);
     }
 }
 
+// Fused fold.  Every workgroup of a problem has written its partial row (kReduceAcc doubles,
+// agent-scope stores) at partials[(row0 + lb) * kReduceAcc]; this folds them to the 38
+// statistics INSIDE the launch: the last workgroup to arrive in each group of kFoldGroup rows
+// sums that group (fixed order) into a level-2 row, the last group folder sums the level-2
+// rows (fixed order), expands the moments and publishes.  Sums do not depend on arrival order:
+// repeat runs are bit-identical.  Hand-off per the agent-scope recipe: write-through stores,
+// every storing wave drains, one relaxed agent atomic as the ticket, one acquire by the reader.
+// tickets: ticket_stride words per problem, zero before the first launch (the last arrivers
+// re-arm them); [0] = level 2, [1 + g] = level 1 of group g.
+constexpr int kFoldGroup = 32;
+template <bool PLANE, int NTH>
+__device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *partials, long long row0, int lb,
+                                           int bpp, int prob)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    constexpr int NG = NTH / 32;
+    __shared__ double f_part[NG][33];
+    __shared__ double f_tot[32];
+    __shared__ int f_flag[2];
+    const int tid = threadIdx.x;
+    const int ngroups = (bpp + kFoldGroup - 1) / kFoldGroup;
+    unsigned *tk = f.tickets + (long long)prob * f.ticket_stride;
+    const int grp = lb / kFoldGroup;
+    const int gsize = min(kFoldGroup, bpp - grp * kFoldGroup);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tk + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f_flag[0] = (t == (unsigned)(gsize - 1)) ? 1 : 0;
+        if (f_flag[0]) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tk + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!f_flag[0]) return;
+    const int sa = tid & 31, sg = tid >> 5;
+    {
+        const double *grows = partials + (row0 + (long long)grp * kFoldGroup) * kReduceAcc;
+        double v = 0.0;
+        if (sa < NACC)
+            for (int r = sg; r < gsize; r += NG) v += load_agent_f64(grows + (long long)r * kReduceAcc + sa);
+        f_part[sg][sa] = v;
+    }
+    __syncthreads();
+    double *rows2 = f.partials2 + ((long long)prob * f.ticket_stride + grp) * kReduceAcc;
+    if (tid < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) t += f_part[gg][tid];
+        if (tid < NACC) store_agent_f64(rows2 + tid, t);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f_flag[1] = (t == (unsigned)(ngroups - 1)) ? 1 : 0;
+        if (f_flag[1]) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!f_flag[1]) return;
+    {
+        const double *g2 = f.partials2 + (long long)prob * f.ticket_stride * kReduceAcc;
+        double v = 0.0;
+        if (sa < NACC)
+            for (int r = sg; r < ngroups; r += NG) v += load_agent_f64(g2 + (long long)r * kReduceAcc + sa);
+        f_part[sg][sa] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) t += f_part[gg][tid];
+        f_tot[tid] = t;
+    }
+    __syncthreads();
+    double *stats = f.stats_out + (long long)prob * f.stats_stride;
+    if (tid == 0) expand_moments<PLANE>(f_tot, stats);
+    if (f.host_out) publish_tagged_stats(stats, f.host_out, f.seq);
+}
 
 }  // namespace visma

@@ -147,6 +147,8 @@ public:
     // same order as those: source in Morton order).  nullptr pair = drop them.
     virtual int set_clouds64(const Pt64 *, const Pt64 *) { err_ = "double-precision search needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     virtual bool search_is_f64() const { return false; }
+    virtual bool search_is_exact() const { return false; }
+    virtual void set_exact(bool) {}
     virtual int set_target_normals64(const Pt64 *) { return VISMA_ICP_OK; }     // f64 normals for the f64 search
     // Host staging for the packed (x,y,z,0) fp32 clouds handed to set_source / set_target.
     // The HIP engine returns pinned memory (grow-only), so the upload runs at link speed.
@@ -186,6 +188,7 @@ public:
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
+        free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
@@ -230,6 +233,11 @@ public:
             const int v = std::atoi(e);
             if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
         }
+        if (const char *e = std::getenv("VISMA_ICP_TILE")) tile_enabled_ = std::atoi(e) != 0;
+        if (const char *e = std::getenv("VISMA_ICP_TILE_CONFIG")) { const int v = std::atoi(e); if (v >= 0 && v <= 11) tile_config_ = v; }
+        if (const char *e = std::getenv("VISMA_ICP_TILE_FALLBACK")) tile_fallback_ = std::atoi(e) != 0;
+        if (const char *e = std::getenv("VISMA_ICP_TILE_FOLD")) tile_fused_fold_ = std::atoi(e) != 0;
+        if (const char *e = std::getenv("VISMA_ICP_FUSED_FOLD")) fused_fold_ = std::atoi(e) != 0;
         HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * 2 * kNStats,     // {value, tag} granules
                               hipHostMallocMapped | hipHostMallocCoherent));
         std::memset(h_stats_, 0, sizeof(double) * 2 * kNStats);
@@ -251,7 +259,9 @@ public:
         HIP_TRY(hipStreamSynchronize(stream_));
         return VISMA_ICP_OK;
     }
-    bool search_is_f64() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr; }
+    bool search_is_f64() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr && !exact_; }
+    bool search_is_exact() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr; }
+    void set_exact(bool on) override { exact_ = on; }
     int set_target_normals64(const Pt64 *n) override
     {
         HIP_TRY(hipSetDevice(device_));
@@ -332,7 +342,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
         const int64_t ns_min_pad = ((ns_ + kBlock - 1) / kBlock) * kBlock;
-        for (int i = 0; i < 12; i++) T32_.m[i] = (float)Tc.m[i];
+        for (int i = 0; i < 12; i++) { T32_.m[i] = (float)Tc.m[i]; T64_last_.m[i] = Tc.m[i]; }
         r2f_ = (float)(max_dist * max_dist);
         r2d_ = (double)r2f_;                                     // (double)(float)(r*r): KDTreeFlann.cpp:184-185
         int rc = choose_mode(max_dist);
@@ -383,8 +393,40 @@ public:
         // without RCCL the fold kernel publishes to mapped host memory itself
         const unsigned long long seq = ++pub_seq_;
         double *pub = comm_ ? nullptr : h_stats_dev_;
-        if (use_grid_) {
+        if (use_tile()) {
+            // ONE launch: streamed search + exact re-rank + moments + fused fold + publication
+            const int cfg = tile_config(ns_);
+            const int nblocks = tile_blocks(ns_, cfg);
+            const size_t tstride = 1 + (size_t)(nblocks + 31) / 32;
+            int rc = ensure_tile_buffers((size_t)nblocks, tstride);
+            if (rc) return rc;
+            TileArgs ta = tile_args(T64, offset, prof);
+            ta.bpp = nblocks;
+            ta.tickets = tile_fused_fold_ ? (unsigned *)d_tickets_ : nullptr;
+            ta.ticket_stride = (int)tstride;
+            ta.stats_out = (double *)d_stats_;
+            ta.stats_stride = 0;
+            ta.host_out = pub;
+            ta.seq = seq;
+            if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+            HIP_TRY(launch_nn_tile_reduce(ta, plane ? 1 : 0, cfg, nblocks, stream_));
+            if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+            if (!tile_fused_fold_) {
+                if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
+                                        (double *)d_stats_, stream_, pub, seq));
+                if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+            }
+            grid_pending_ = false;
+        } else if (use_grid_) {
             int nblocks = 1;
+            // the fold of the partial rows runs inside the search launch (no second kernel)
+            const bool fused = fused_fold_ && !tshard_;
+            FoldArgs fa{};
+            if (fused) {
+                int rc = make_fold(grid_launch_blocks(ns_, grid_lanes(), grid_blocks()), 1, (double *)d_stats_, 0, pub, seq, &fa);
+                if (rc) return rc;
+            }
             if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
             HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
@@ -392,9 +434,10 @@ public:
                                           (float *)d_d2_, (double *)d_partials_, grid_blocks(),
                                           &nblocks, grid_lanes(),
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
-                                          1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_));
+                                          1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
+                                          exact_ ? 1 : 0, fused ? &fa : nullptr));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
-            if (!tshard_) {
+            if (!tshard_ && !fused) {
                 if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
                 HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
                                         (double *)d_stats_, stream_, pub, seq));
@@ -461,23 +504,31 @@ public:
     {
         HIP_TRY(hipSetDevice(device_));
         if (!have_pass_) { err_ = "no nn_pass yet"; return VISMA_ICP_ERR_STATE; }
-        if (use_grid_ && grid_pending_) {
+        if (use_grid_ && grid_pending_ && use_tile()) {
             // nn_pass without a reduction: run the fused kernel for its index output
-            Xform64 T64;
-            for (int i = 0; i < 12; i++) T64.m[i] = (double)T32_.m[i];
+            const int cfg = tile_config(ns_);
+            const int nblocks = tile_blocks(ns_, cfg);
+            int rc = ensure_tile_buffers((size_t)nblocks, 1);
+            if (rc) return rc;
+            TileArgs ta = tile_args(T64_last_, nullptr, false);
+            ta.bpp = nblocks;
+            HIP_TRY(launch_nn_tile_reduce(ta, 0, cfg, nblocks, stream_));
+            grid_pending_ = false;
+        } else if (use_grid_ && grid_pending_) {
+            // nn_pass without a reduction: run the fused kernel for its index output
+            const Xform64 T64 = T64_last_;
             int nblocks = 1;
             HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                           &nblocks, grid_lanes(), nullptr, nullptr, 1, 0, stream_,
-                                          f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_));
+                                          f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0));
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
             // the reduction kernel, run it for its index output
-            Xform64 T64;
-            for (int i = 0; i < 12; i++) T64.m[i] = (double)T32_.m[i];
+            const Xform64 T64 = T64_last_;
             HIP_TRY(launch_reduce((const float4 *)d_src_, ns_, (const float4 *)d_tgt_,
                                   (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                   plan_.tgt_splits, ns_pad_, T32_, T64, nullptr, r2f_, 0,
@@ -574,14 +625,24 @@ public:
             for (int j = 0; j < n; j++) {
                 int nblocks = 1, e0 = -1;
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                bool fused = false;
                 if (use_grid_) {
+                    // fold inside the search launch: the statistics land in the problems' device state
+                    FoldArgs fa{};
+                    fused = fused_fold_ != 0;
+                    if (fused) {
+                        rc = make_fold(grid_launch_blocks(ns_, grid_lanes(nprob), reduce_max_blocks()), nprob,
+                                       st->stats, (long long)(sizeof(DevIcpState) / sizeof(double)), nullptr, 0, &fa);
+                        if (rc) return rc;
+                    }
                     HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
                                                   (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                                   T32_, T64, nullptr, r2f_, plane, (int32_t *)d_idx_,
                                                   (float *)d_d2_, (double *)d_partials_,
                                                   reduce_max_blocks(), &nblocks, grid_lanes(nprob),
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
-                                                  nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_));
+                                                  nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
+                                                  exact_ ? 1 : 0, fused ? &fa : nullptr));
                 } else {
                     HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
                                             T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
@@ -597,14 +658,16 @@ public:
                                           reduce_max_blocks(), nullptr, st, &nblocks, stream_));
                 }
                 if (comm_) {
-                    HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
+                    if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
                     // ONE all-reduce of the 38 f64 accumulators per ICP iteration
                     int nrc = g_rccl.AllReduce(st->stats, st->stats, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
                     if (nrc != 0) {
                         err_ = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nrc) : "error");
                         return VISMA_ICP_ERR_RCCL;
                     }
-                    HIP_TRY(launch_solve_state(st, stream_));
+                    HIP_TRY(launch_solve_state(st, 1, stream_));
+                } else if (fused) {
+                    HIP_TRY(launch_solve_state(st, nprob, stream_));
                 } else {
                     HIP_TRY(launch_finalize_solve((const double *)d_partials_, nblocks, st, plane, nprob, stream_));
                 }
@@ -799,8 +862,21 @@ public:
         // the staging memory of the caller must stay valid until the copies are done
         HIP_TRY(hipStreamSynchronize(stream_));
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
-        // ---- the loop: one NN launch + one fold/solve launch per pass for ALL problems
+        // ---- the loop: one NN launch (search + fold) + one solve launch per pass for ALL problems
         DevIcpState *st = (DevIcpState *)d_state_;
+        FoldArgs bfa{};
+        if (fused_fold_) {
+            int max_nb = 1;
+            for (int b = 0; b < B; b++) max_nb = std::max(max_nb, descs[b].nblocks);
+            const size_t tstride = 1 + (size_t)(max_nb + 31) / 32;
+            int rc2 = ensure_tile_buffers((size_t)total_blocks, tstride * B);
+            if (rc2) return rc2;
+            bfa.tickets = (unsigned *)d_tickets_;
+            bfa.partials2 = (double *)d_partials2_;
+            bfa.ticket_stride = (int)tstride;
+            bfa.stats_out = st->stats;
+            bfa.stats_stride = (long long)(sizeof(DevIcpState) / sizeof(double));
+        }
         const int chunk = lp.check_stop ? 8 : lp.passes;
         int done = 0;
         while (done < lp.passes) {
@@ -812,10 +888,12 @@ public:
                                                     total_blocks, (int32_t *)bt_idx_, (float *)bt_d2_,
                                                     (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_,
                                                     f64 ? (const Pt64 *)bt_src64_ : nullptr,
-                                                    f64 ? (const Pt64 *)bt_sorted64_ : nullptr));
+                                                    f64 ? (const Pt64 *)bt_sorted64_ : nullptr, exact_ ? 1 : 0,
+                                                    fused_fold_ ? &bfa : nullptr));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-                HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_));
+                if (fused_fold_) HIP_TRY(launch_solve_state(st, B, stream_));
+                else HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             }
             done += n;
@@ -927,10 +1005,28 @@ public:
         for (size_t i = 0; i < slots.size(); i += 2) { c[0] += (double)slots[i]; c[1] += (double)slots[i + 1]; }
         timing_.grid_candidates = c[0];
         timing_.grid_candidates_27cell = c[1];
+        if (d_tstats_) {
+            std::vector<unsigned long long> ts(24 * 512, 0ull);
+            (void)hipMemcpy(ts.data(), d_tstats_, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            double v[24];
+            for (int k = 0; k < 24; k++) v[k] = 0.0;
+            for (size_t i = 0; i < ts.size(); i++) v[i % 24] += (double)ts[i];
+            for (int k = 0; k < 6; k++) timing_.tile_phase_cycles[k] = v[8 + k];
+            timing_.tile_phase_cycles[6] = 0.0;
+            timing_.tile_parts = v[7];
+            timing_.tile_workgroups = v[0];
+            timing_.tile_fallback_workgroups = v[1];
+            timing_.tile_points = v[2];
+            timing_.f64_reranks = v[3];
+            timing_.tile_rows = v[4];
+            timing_.grid_candidates += v[5];
+            timing_.grid_candidates_27cell += v[6];
+        }
         *t = timing_;
         if (reset) {
             std::memset(&timing_, 0, sizeof(timing_));
             (void)hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long));
+            if (d_tstats_) (void)hipMemset(d_tstats_, 0, 24 * 512 * sizeof(unsigned long long));
         }
     }
     void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }
@@ -978,6 +1074,10 @@ private:
     int choose_mode(double max_dist)
     {
         if (nn_mode_ == VISMA_ICP_NN_BRUTE || nt_ == 0) { use_grid_ = false; return VISMA_ICP_OK; }
+        {
+            int rc = ensure_f64_views();
+            if (rc) return rc;
+        }
         if (!(grid_valid_ && grid_radius_ == max_dist)) {
             int rc = build_grid(max_dist);
             if (rc) return rc;
@@ -1144,6 +1244,120 @@ private:
         return ns_ <= 32768 ? 804 : (ns_ <= 98304 ? 802 : 1201);
     }
     int64_t sorted_cap_ = 0, cell_cap_ = 0;
+
+    // ---- streamed search with exact tie-breaks + fused fold (tile.hip) --------------------
+    bool exact_ = true;          // search precision "exact" (default): fp32 ranking, f64 re-rank of near-ties
+    int tile_enabled_ = 0;       // VISMA_ICP_TILE=1: the LDS-streamed kernel (tile.hip, experimental)
+    int fused_fold_ = 1;         // VISMA_ICP_FUSED_FOLD=0: fold the partial rows in a second launch
+    int tile_config_ = -1;       // VISMA_ICP_TILE_CONFIG: LDS tile geometry (see launch_nn_tile_reduce)
+    int tile_fallback_ = 0;      // VISMA_ICP_TILE_FALLBACK=1: every workgroup searches from global memory (tests)
+    int tile_fused_fold_ = 1;    // VISMA_ICP_TILE_FOLD=0: fold the partial rows in a second launch (experiments)
+    void *d_partials2_ = nullptr, *d_tickets_ = nullptr, *d_tstats_ = nullptr;
+    size_t tickets_cap_ = 0;     // words in d_tickets_ (= rows in d_partials2_)
+    Xform64 T64_last_{};         // transform of the last nn_pass, f64
+    bool use_tile() const
+    {
+        return tile_enabled_ && use_grid_ && exact_ && d_src64_ && d_sorted64_ && grid_.sub == 1 && !tshard_;
+    }
+    int tile_config(int64_t queries) const
+    {
+        if (tile_config_ >= 0) return tile_config_;
+        (void)queries;
+        return 0;
+    }
+    // workgroups of ONE problem with ns queries
+    static int tile_blocks(int64_t ns, int config)
+    {
+        const int nth = tile_threads(config);
+        const int64_t nb = (ns + nth - 1) / nth;
+        return (int)(nb < 1 ? 1 : nb);
+    }
+    int ensure_tile_buffers(size_t rows, size_t ticket_words)
+    {
+        if (rows > partial_rows_) {
+            free_dev(d_partials_);
+            HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * rows));
+            partial_rows_ = rows;
+        }
+        if (ticket_words > tickets_cap_) {
+            free_dev(d_partials2_); free_dev(d_tickets_);
+            HIP_TRY(hipMalloc(&d_partials2_, sizeof(double) * kReduceAcc * ticket_words));
+            HIP_TRY(hipMalloc(&d_tickets_, sizeof(unsigned) * ticket_words));
+            HIP_TRY(hipMemsetAsync(d_tickets_, 0, sizeof(unsigned) * ticket_words, stream_));
+            tickets_cap_ = ticket_words;
+        }
+        if (!d_tstats_) {
+            HIP_TRY(hipMalloc(&d_tstats_, sizeof(unsigned long long) * 24 * 512));
+            HIP_TRY(hipMemsetAsync(d_tstats_, 0, sizeof(unsigned long long) * 24 * 512, stream_));
+        }
+        return VISMA_ICP_OK;
+    }
+    // the arguments every tile launch of the resident clouds shares
+    TileArgs tile_args(const Xform64 &T64, const double offset[3], bool prof) const
+    {
+        TileArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.src64 = (const Pt64 *)d_src64_;
+        a.ns = (int)ns_;
+        a.sorted = (const float4 *)d_sorted_;
+        a.sorted64 = (const Pt64 *)d_sorted64_;
+        a.start = (const unsigned *)d_start_;
+        a.g = grid_;
+        a.nrm = (const float4 *)d_nrm_;
+        a.nrm64 = (const Pt64 *)d_nrm64_;
+        a.T64 = T64;
+        for (int k = 0; k < 3; k++) a.off.v[k] = offset ? offset[k] : 0.0;
+        a.r2f = r2f_;
+        a.idx_out = (int *)d_idx_;
+        a.d2_out = (float *)d_d2_;
+        a.partials = (double *)d_partials_;
+        a.partials2 = (double *)d_partials2_;
+        a.stats = prof ? (unsigned long long *)d_tstats_ : nullptr;
+        a.nprob = 1;
+        a.force_fallback = tile_fallback_;
+        return a;
+    }
+    // workgroups per problem of launch_nn_grid_reduce (same arithmetic as the launcher)
+    static int grid_launch_blocks(int64_t ns, int lanes, int max_blocks)
+    {
+        const int G = lanes % 100;
+        int64_t want = (ns * G + kBlock - 1) / kBlock;
+        int nb = (int)(want > max_blocks ? max_blocks : want);
+        return nb < 1 ? 1 : nb;
+    }
+    // fold arguments for `nprob` problems of `bpp` workgroups each (buffers grown as needed)
+    int make_fold(int bpp, int nprob, double *stats_out, long long stats_stride, double *host_out,
+                  unsigned long long seq, FoldArgs *out)
+    {
+        const size_t tstride = 1 + (size_t)(bpp + 31) / 32;
+        int rc = ensure_tile_buffers((size_t)bpp * nprob, tstride * nprob);
+        if (rc) return rc;
+        out->tickets = (unsigned *)d_tickets_;
+        out->partials2 = (double *)d_partials2_;
+        out->ticket_stride = (int)tstride;
+        out->stats_out = stats_out;
+        out->stats_stride = stats_stride;
+        out->host_out = host_out;
+        out->seq = seq;
+        return VISMA_ICP_OK;
+    }
+    // f64 views of clouds that were uploaded as fp32 (the exact search needs them)
+    int ensure_f64_views()
+    {
+        if (!exact_ || tshard_) return VISMA_ICP_OK;
+        if (!d_src64_ && d_src_) {
+            HIP_TRY(hipMalloc(&d_src64_, sizeof(Pt64) * std::max<int64_t>(ns_, 1)));
+            HIP_TRY(launch_promote_pt64((const float4 *)d_src_, (Pt64 *)d_src64_, ns_, stream_));
+        }
+        if (!d_tgt64_ && d_tgt_) {
+            HIP_TRY(hipMalloc(&d_tgt64_, sizeof(Pt64) * std::max<int64_t>(nt_, 1)));
+            HIP_TRY(launch_promote_pt64((const float4 *)d_tgt_, (Pt64 *)d_tgt64_, nt_, stream_));
+            free_dev(d_sorted64_);
+            grid_valid_ = false;
+        }
+        if (!d_sorted64_) grid_valid_ = false;
+        return VISMA_ICP_OK;
+    }
 };
 
 class HookEngine : public Engine {
@@ -1347,8 +1561,6 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
 }
 
 constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
-constexpr int64_t kF64AutoMaxSources = 131072;   // search precision "auto": f64 up to this many source points
-constexpr int64_t kF64AutoMaxTargets = 8388608;  // ... and target points (the f64 copies cost 64 B per target point)
 
 // (x - c) as fp32 (x,y,z,0) rows; `par`: spread over host threads
 void pack_f64_to(const double *xyz, int64_t n, int stride, const double c[3], float *out, bool par)
@@ -1511,6 +1723,7 @@ int visma_icp_create(visma_icp_ctx **out, int device)
         const int v = std::atoi(p);
         if (v >= 0 && v <= 2) c->search_precision = v;
     }
+    c->eng->set_exact(c->search_precision == 1);
     *out = c;
     return VISMA_ICP_OK;
 }
@@ -1564,9 +1777,10 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     rc = ctx->eng->set_source(sb, ns);
     if (rc) return ctx->eng_fail(rc);
     // double-precision search: the caller's own f64 coordinates (centred in f64) go along
+    // (the size-keyed policy of round 1 is gone: the exact search costs the same as the fp32 one)
     const bool want64 = !ctx->target_sharded &&        // (sharded ranks exchange fp32 keys)
-                        (ctx->search_precision == 2 ||
-                         (ctx->search_precision == 1 && ns <= kF64AutoMaxSources && nt <= kF64AutoMaxTargets));
+                        ctx->search_precision != 0;
+    ctx->eng->set_exact(ctx->search_precision == 1);
     if (want64 && ctx->eng->supports_device_loop()) {
         // (Pt64 = 8 floats of staging; pinned on the HIP engine)
         Pt64 *t8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(2, (size_t)std::max<int64_t>(nt, 1) * 8));
@@ -1927,9 +2141,7 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
         }
         std::vector<std::array<double, 3>> cen((size_t)n);
         // double-precision search for the whole batch when every problem qualifies
-        bool want64 = ctx->search_precision != 0;
-        for (int i = 0; want64 && i < n; i++)
-            if (ctx->search_precision == 1 && probs[i].ns > kF64AutoMaxSources) want64 = false;
+        const bool want64 = ctx->search_precision != 0;
         std::vector<std::vector<Pt64>> s8((size_t)n), t8((size_t)n);
         if (ok)
             parallel_for(n, 1, [&](int64_t i) {                    // targets: first occurrences only
@@ -2110,6 +2322,7 @@ int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode)
     CTX_CHECK();
     if (mode < 0 || mode > 2) return ctx->fail(VISMA_ICP_ERR_INVALID, "search precision must be 0, 1 or 2");
     ctx->search_precision = mode;
+    ctx->eng->set_exact(mode == 1);
     return VISMA_ICP_OK;
 }
 
@@ -2117,7 +2330,7 @@ int visma_icp_get_search_precision_used(visma_icp_ctx *ctx, int *is_f64)
 {
     CTX_CHECK();
     if (!is_f64) return ctx->fail(VISMA_ICP_ERR_INVALID, "null output");
-    *is_f64 = ctx->eng->search_is_f64() ? 1 : 0;
+    *is_f64 = ctx->eng->search_is_f64() ? 2 : (ctx->eng->search_is_exact() ? 1 : 0);
     return VISMA_ICP_OK;
 }
 

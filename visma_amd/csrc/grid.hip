@@ -62,14 +62,6 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4 *__restrict__ pt
     }
 }
 
-// The cell coordinate; build and query MUST use this same expression.
-__device__ __forceinline__ int cell_coord(float v, float mn, float inv_h, int dim)
-{
-    float u = floorf((v - mn) * inv_h);
-    u = fminf(fmaxf(u, -2.0f), (float)dim + 1.0f);   // also tames inf / huge values
-    return (int)u;
-}
-
 __global__ __launch_bounds__(256) void cell_count_kernel(const float4 *__restrict__ pts, int n,
                                                          GridParams g,
                                                          unsigned *__restrict__ cell_of,
@@ -313,7 +305,47 @@ int grid_scan_blocks(int64_t ncell) { return (int)((ncell + kScanPerBlock - 1) /
 // sum-of-squares (x, y, z order) and acceptance is d2 < (double)(float)(r*r)
 // (KDTreeFlann.cpp:184-185): the correspondences ARE the reference's.  Cells and row pruning
 // still use the fp32 view of the same points (margins cover the difference).
-template <bool PLANE, int G, int U, bool ONE, bool F64 = false>
+//
+// HYB: the EXACT search at fp32 cost (the default, visma_icp_set_search_precision 1).  Candidates
+// are ranked with fp32 arithmetic on the fp32 view of the target, but the three best squared
+// distances are kept with their positions, plus the value of the fourth.  A query is decisive
+// when its runner-up lies outside the rounding band of the best (2E, E bounding
+// |d64 - sqrt(d2_32)|); otherwise the two or three candidates inside the band are fetched in
+// f64 and ranked with the reference's arithmetic (flann dist.h:159-176), lowest original index
+// on exact ties; acceptance is always decided in f64: d2 < (double)(float)(r*r)
+// (KDTreeFlann.cpp:184-185).  Four candidates inside one band (about once in 1e9 queries;
+// clouds with duplicated points) re-scan the neighbourhood in f64.  Source transform and
+// statistics are the F64 ones, so the results equal the F64 kernel's bit for bit.
+__device__ __forceinline__ float med3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// sorted insertion of (d, pos) into the three best of a query; h4 = value of the fourth
+struct Top3 {
+    float h1, h2, h3, h4;
+    unsigned p1, p2, p3;
+    __device__ __forceinline__ void init(float lim)
+    {
+        h1 = h2 = h3 = h4 = lim;
+        p1 = p2 = p3 = 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ void insert(float d, unsigned pos)
+    {
+        const bool lt1 = d < h1, lt2 = d < h2, lt3 = d < h3;
+        h4 = med3_f32(h3, h4, d);
+        h3 = med3_f32(h2, h3, d);
+        h2 = med3_f32(h1, h2, d);
+        h1 = fminf(h1, d);
+        p3 = lt2 ? p2 : (lt3 ? pos : p3);
+        p2 = lt1 ? p1 : (lt2 ? pos : p2);
+        p1 = lt1 ? pos : p1;
+    }
+};
+
+template <bool PLANE, int G, int U, bool ONE, bool F64 = false, bool HYB = false>
 __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ sorted,
     const unsigned *__restrict__ start, GridParams g, const float4 *__restrict__ nrm, Xform32 T32,
@@ -321,10 +353,14 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
     const DevIcpState *__restrict__ st, int bpp, long long out_stride,
     const ProbDesc *__restrict__ descs, int nprob, const Pt64 *__restrict__ src64 = nullptr,
-    const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0, const Pt64 *__restrict__ nrm64 = nullptr)
+    const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0, const Pt64 *__restrict__ nrm64 = nullptr,
+    const FoldArgs fold = FoldArgs{})
 {
+    static_assert(!(F64 && HYB), "F64 and HYB are different searches");
+    constexpr bool S64 = F64 || HYB;                       // f64 source, transform and statistics
     constexpr int NACC = Acc<PLANE>::N;
     int prob, lb;
+    long long row0;
     if (descs) {
         // batch of problems with their own clouds: find the problem this workgroup
         // belongs to (largest p with first_block <= blockIdx.x; wave-uniform)
@@ -340,7 +376,8 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         src += d.src_off;
         ns = d.ns;
         sorted += d.sorted_off;
-        if constexpr (F64) { src64 += d.src_off; sorted64 += d.sorted_off; }
+        if constexpr (S64) { src64 += d.src_off; sorted64 += d.sorted_off; }
+        row0 = d.first_block;
         start += d.start_off;
         g = d.g;
         out_stride = 0;
@@ -352,10 +389,11 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // (the yaw sweep of src/annotation.cpp:35-61 is 24 such problems).
         prob = blockIdx.x / bpp;
         lb = blockIdx.x - prob * bpp;
+        row0 = (long long)prob * bpp;
     }
     if (st) st += prob;
     if (!load_loop_state(st, T32, T64, off, r2f)) return;
-    if constexpr (F64) r2d = (double)r2f;                  // (double)(float)(r*r), also when the radius comes from the state
+    if constexpr (S64) r2d = (double)r2f;                  // (double)(float)(r*r), also when the radius comes from the state
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
     double acc[NACC];
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     auto flush = [&]() {
         if (keep_pos != 0xFFFFFFFFu) {
             float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (F64) {
+            if constexpr (S64) {
                 const Pt64 s8 = src64[keep_i], q8 = sorted64[keep_pos];
                 double nx = 0.0, ny = 0.0, nz = 0.0;
                 if (PLANE) {
@@ -406,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
         float px, py, pz;
         double pxd = 0.0, pyd = 0.0, pzd = 0.0;
-        if constexpr (F64) {
+        if constexpr (S64) {
             // the reference's transform of a source point (PointCloud.cpp:75-80), in f64
             const Pt64 s8 = src64[i];
             pxd = T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0;
@@ -428,9 +466,22 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         unsigned bpos = 0xFFFFFFFFu;
         double bd = r2d;                                   // F64: best d2 so far (strictly below r2d once set)
         unsigned bidx = 0xFFFFFFFFu;                       // F64: ... and its original index
+        // HYB: rounding band.  p32 = fl(p64), q32 = fl(q64): the difference vector is off by at most
+        // u (|p|+|q|) per component, u = 2^-24, and the fp32 evaluation of d2 adds 3u relative, so
+        // |d64 - sqrt(d2_32)| <= u (2 |p| + 2.5 r).  E is more than twice that.
+        float hyb_E = 0.f, hyb_rup = 0.f;
+        Top3 top;
+        if constexpr (HYB) {
+            const float r_f = sqrtf(r2f);
+            hyb_rup = r_f * (1.0f + 2.4e-7f);
+            hyb_E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + hyb_rup) + 4.8e-7f * hyb_rup;
+            const float t = hyb_rup + 2.0f * hyb_E;
+            top.init(t * t * (1.0f + 6e-7f));              // candidates at or beyond it never matter
+        }
         // what a row bound is compared with: the best squared distance so far, as fp32
         auto best_f32 = [&]() {
             if constexpr (F64) { const float f = (float)bd; return f + f * 1e-6f; }   // rounded UP a little
+            else if constexpr (HYB) return top.h1;
             else return __uint_as_float((unsigned)(bkey >> 32));
         };
         // Rows (y,z) are visited nearest first and a row is SKIPPED when its slab cannot
@@ -441,8 +492,9 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // -- it could neither win nor tie.
         const float fy = (py - g.mn[1]) * g.inv_hs - (float)cy;     // position inside the cell, [0,1)
         const float fz = (pz - g.mn[2]) * g.inv_hs - (float)cz;
-        const float lo_y = fmaxf(fy - 1e-3f, 0.f), hi_y = fmaxf(1.0f - fy - 1e-3f, 0.f);
-        const float lo_z = fmaxf(fz - 1e-3f, 0.f), hi_z = fmaxf(1.0f - fz - 1e-3f, 0.f);
+        const float mgn = HYB ? 1e-3f + 4.0f * hyb_E * g.inv_hs : 1e-3f;    // HYB: plus the rounding band
+        const float lo_y = fmaxf(fy - mgn, 0.f), hi_y = fmaxf(1.0f - fy - mgn, 0.f);
+        const float lo_z = fmaxf(fz - mgn, 0.f), hi_z = fmaxf(1.0f - fz - mgn, 0.f);
         const float h2 = g.hs * g.hs * (1.0f - 1e-5f);
         // squared lower bound of row offset (dy, dz), compile-time offsets
         auto row_bound_of = [&](int dy, int dz) {
@@ -486,6 +538,20 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     bd = lt ? d : bd;
                     bidx = lt ? id : bidx;
                     bpos = lt ? jc[u] : bpos;
+                }
+            } else if constexpr (HYB) {
+                float4 q[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const unsigned ju = base + sub + u * G;
+                    jc[u] = ju < e ? ju : base;
+                    q[u] = sorted[jc[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    float d = sqdist_f32(q[u], px, py, pz);
+                    d = (base + sub + u * G < e) ? d : INFINITY;   // a padding slot is not another candidate
+                    top.insert(d, jc[u]);
                 }
             } else {
                 float4 q[U];
@@ -583,7 +649,74 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 walk();
             }
         }
-        if (G > 1) {
+        if constexpr (HYB) {
+            if (G > 1) {
+                // butterfly merge over the G lanes: the three best of the union, and the fourth value
+#pragma unroll
+                for (int m = G >> 1; m > 0; m >>= 1) {
+                    const float o1 = __shfl_xor(top.h1, m, 64), o2 = __shfl_xor(top.h2, m, 64);
+                    const float o3 = __shfl_xor(top.h3, m, 64), o4 = __shfl_xor(top.h4, m, 64);
+                    const unsigned q1 = (unsigned)__shfl_xor((int)top.p1, m, 64);
+                    const unsigned q2 = (unsigned)__shfl_xor((int)top.p2, m, 64);
+                    const unsigned q3 = (unsigned)__shfl_xor((int)top.p3, m, 64);
+                    // (the lanes of a pair must end up with the SAME triple: insert in a fixed order)
+                    Top3 t2;
+                    const bool mine_first = (threadIdx.x & m) == 0;
+                    t2 = top;
+                    if (!mine_first) { t2.h1 = o1; t2.h2 = o2; t2.h3 = o3; t2.h4 = o4; t2.p1 = q1; t2.p2 = q2; t2.p3 = q3; }
+                    const float i1 = mine_first ? o1 : top.h1, i2 = mine_first ? o2 : top.h2, i3 = mine_first ? o3 : top.h3;
+                    const float i4 = mine_first ? o4 : top.h4;
+                    const unsigned j1 = mine_first ? q1 : top.p1, j2 = mine_first ? q2 : top.p2, j3 = mine_first ? q3 : top.p3;
+                    t2.insert(i1, j1);
+                    t2.insert(i2, j2);
+                    t2.insert(i3, j3);
+                    t2.h4 = fminf(t2.h4, i4);
+                    top = t2;
+                }
+            }
+            // decisive?  the candidates inside the rounding band of the best are ranked in f64
+            if (sub == 0 && top.p1 != 0xFFFFFFFFu) {
+                const float s1 = sqrtf(top.h1) + 2.0f * hyb_E;
+                const bool in2 = s1 >= sqrtf(top.h2), in3 = in2 && s1 >= sqrtf(top.h3);
+                const bool in4 = in3 && s1 >= sqrtf(top.h4);
+                auto rank = [&](unsigned pos) {
+                    const Pt64 c8 = sorted64[pos];
+                    // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
+                    const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
+                    double d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    const unsigned id = (unsigned)c8.w;
+                    const bool lt = d < bd || (d == bd && id < bidx && bidx != 0xFFFFFFFFu);
+                    bd = lt ? d : bd;
+                    bidx = lt ? id : bidx;
+                    bpos = lt ? pos : bpos;
+                };
+                if (!in4) {
+                    rank(top.p1);
+                    if (in2 && top.p2 != 0xFFFFFFFFu) rank(top.p2);
+                    if (in3 && top.p3 != 0xFFFFFFFFu) rank(top.p3);
+                } else {
+                    // four or more candidates inside one band: every candidate of the 27 cells that the
+                    // fp32 filter cannot exclude, in f64
+                    const float sl = fminf(sqrtf(top.h1), hyb_rup) + 2.0f * hyb_E;
+                    const float L = sl * sl * (1.0f + 6e-7f);
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        unsigned rb, re;
+                        row_range(k % 3 - 1, k / 3 - 1, true, rb, re);
+#pragma unroll 1
+                        for (unsigned j = rb; j < re; j++)
+                            if (sqdist_f32(sorted[j], px, py, pz) <= L) rank(j);
+                    }
+                }
+            }
+            if (G > 1) {                                       // every lane of the group learns the winner
+                bpos = (unsigned)__shfl((int)bpos, (threadIdx.x & 63) & ~(G - 1), 64);
+                bidx = (unsigned)__shfl((int)bidx, (threadIdx.x & 63) & ~(G - 1), 64);
+                bd = __shfl(bd, (threadIdx.x & 63) & ~(G - 1), 64);
+            }
+        } else if (G > 1) {
             // butterfly merge over the G lanes: smallest (d2, index) wins everywhere
 #pragma unroll
             for (int m = G >> 1; m > 0; m >>= 1) {
@@ -603,7 +736,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             }
         }
         if (sub == 0) {
-            if constexpr (F64) {
+            if constexpr (S64) {
                 idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
                 d2_out[i] = (float)bd;
             } else {
@@ -616,7 +749,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         if (!ONE && (it % G) == G - 1) flush();
     }
     flush();
-    block_reduce_store<NACC>(acc, partials);
+    block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
     if (cand_count) {
         // profiling only: candidates examined / candidates in the full 27-cell blocks.
         // One slot pair per workgroup (mod 4096) -- thousands of atomics on ONE address
@@ -633,6 +766,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             atomicAdd(slot + 1, ca);
         }
     }
+    if (fold.tickets) fused_fold<PLANE, kBlock>(fold, partials, row0, lb, bpp, prob);
 }
 
 template <bool PLANE, int G, int U>
@@ -642,32 +776,24 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
                           double *partials, unsigned long long *cand, const DevIcpState *st,
                           int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d,
-                          const Pt64 *nrm64)
+                          const Pt64 *nrm64, int exact, const FoldArgs &fold)
 {
     // one query per lane? (see ONE above)
     const long long total_groups = (long long)nblocks * (kBlock / G);
     const bool one = ((long long)ns + total_groups - 1) / total_groups <= G;
-    if (src64) {
-        if (one)
-            hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, true, true>), dim3(nblocks * nprob), dim3(kBlock),
-                               0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
-                               partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,
-                               sorted64, r2d, nrm64);
-        else
-            hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, false, true>), dim3(nblocks * nprob), dim3(kBlock),
-                               0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
-                               partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,
-                               sorted64, r2d, nrm64);
-        return;
+#define VISMA_GRID_LAUNCH(ONE_, F64_, HYB_)                                                                     \
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, ONE_, F64_, HYB_>), dim3(nblocks * nprob),             \
+                       dim3(kBlock), 0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out,      \
+                       d2_out, partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,  \
+                       sorted64, r2d, nrm64, fold)
+    if (src64 && exact) {
+        if (one) VISMA_GRID_LAUNCH(true, false, true); else VISMA_GRID_LAUNCH(false, false, true);
+    } else if (src64) {
+        if (one) VISMA_GRID_LAUNCH(true, true, false); else VISMA_GRID_LAUNCH(false, true, false);
+    } else {
+        if (one) VISMA_GRID_LAUNCH(true, false, false); else VISMA_GRID_LAUNCH(false, false, false);
     }
-    if (one)
-        hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, true>), dim3(nblocks * nprob), dim3(kBlock), 0,
-                           stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
-                           partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
-    else
-        hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, false>), dim3(nblocks * nprob), dim3(kBlock), 0,
-                           stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out, d2_out,
-                           partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob);
+#undef VISMA_GRID_LAUNCH
 }
 
 hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *sorted,
@@ -678,11 +804,13 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int max_partial_blocks, int *nblocks_out, int lanes_per_query,
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
-                                 const Pt64 *sorted64, double r2d, const Pt64 *nrm64)
+                                 const Pt64 *sorted64, double r2d, const Pt64 *nrm64, int exact,
+                                 const FoldArgs *fold)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
+    const FoldArgs fa = fold ? *fold : FoldArgs{};
     const int G = lanes_per_query % 100;
     int U = lanes_per_query / 100;
     if (U == 0) U = (G >= 8) ? 2 : 4;
@@ -694,16 +822,16 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,           \
                                         tgt_normals, T32, T64, off, r2f, idx_out, d2_out,          \
-                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64);   \
+                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa);   \
         else                                                                                       \
             launch_grid_t<false, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,          \
                                          tgt_normals, T32, T64, off, r2f, idx_out, d2_out,         \
-                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64);  \
+                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa);  \
         launched = true;                                                                           \
     }
     bool launched = false;
     // the (G, U) pairs the driver's policies use, plus a few neighbours for VISMA_ICP_GRID_LANES
-    // experiments (every pair is 8 kernel instantiations: PLANE x ONE x F64)
+    // experiments (every pair is 12 kernel instantiations: PLANE x ONE x {fp32, f64, exact})
     VISMA_GRID_CASE(1, 8) VISMA_GRID_CASE(1, 12) VISMA_GRID_CASE(2, 4) VISMA_GRID_CASE(2, 8)
     VISMA_GRID_CASE(4, 4) VISMA_GRID_CASE(4, 8) VISMA_GRID_CASE(8, 4) VISMA_GRID_CASE(1, 4)
     if (!launched) return hipErrorInvalidValue;
@@ -712,51 +840,57 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     return hipGetLastError();
 }
 
-template <int G, int U, bool ONE, bool F64>
+template <int G, int U, bool ONE, bool F64, bool HYB>
 static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const float4 *src,
                                 const float4 *sorted, const unsigned *start, const ProbDesc *descs,
                                 int nprob, int *idx_out, float *d2_out, double *partials,
-                                const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64)
+                                const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64, const FoldArgs &fold)
 {
     const Xform32 T32{};
     const Xform64 T64{};
     const Offset64 off{};
     const GridParams g{};
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE, F64>), dim3(total_blocks), dim3(kBlock), 0, stream,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE, F64, HYB>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
-                       d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0);
+                       d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0,
+                       (const Pt64 *)nullptr, fold);
 }
 
 // lanes_per_query = G + 100 * U; one_per_lane: every problem has at most G queries per lane group;
-// src64 / sorted64 (both or neither): the f64 search, arrays concatenated like src / sorted
+// src64 / sorted64 (both or neither): the f64 search (exact = 0) or the exact fp32+f64 search (exact = 1),
+// arrays concatenated like src / sorted
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
                                        const ProbDesc *descs, int nprob, int total_blocks,
                                        int32_t *idx_out, float *d2_out, double *partials,
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
-                                       hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64)
+                                       hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64, int exact,
+                                       const FoldArgs *fold)
 {
     if (!st || !descs || (src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
+    const FoldArgs fa = fold ? *fold : FoldArgs{};
     const int G = lanes_per_query % 100, U = lanes_per_query / 100;
     bool launched = false;
+#define VISMA_BATCH_ARGS total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st
 #define VISMA_BATCH_CASE(GG, UU)                                                                              \
     if (G == GG && U == UU) {                                                                                 \
-        if (src64 && one_per_lane)                                                                            \
-            launch_grid_batch_t<GG, UU, true, true>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out,  \
-                                                    d2_out, partials, st, src64, sorted64);                   \
+        if (src64 && exact && one_per_lane)                                                                   \
+            launch_grid_batch_t<GG, UU, true, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa);            \
+        else if (src64 && exact)                                                                              \
+            launch_grid_batch_t<GG, UU, false, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa);           \
+        else if (src64 && one_per_lane)                                                                       \
+            launch_grid_batch_t<GG, UU, true, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa);            \
         else if (src64)                                                                                       \
-            launch_grid_batch_t<GG, UU, false, true>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
-                                                     d2_out, partials, st, src64, sorted64);                  \
+            launch_grid_batch_t<GG, UU, false, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa);           \
         else if (one_per_lane)                                                                                \
-            launch_grid_batch_t<GG, UU, true, false>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
-                                                     d2_out, partials, st, nullptr, nullptr);                 \
+            launch_grid_batch_t<GG, UU, true, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa);          \
         else                                                                                                  \
-            launch_grid_batch_t<GG, UU, false, false>(total_blocks, stream, src, sorted, start, descs, nprob, idx_out, \
-                                                      d2_out, partials, st, nullptr, nullptr);                \
+            launch_grid_batch_t<GG, UU, false, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa);         \
         launched = true;                                                                                      \
     }
     VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
     VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4)
 #undef VISMA_BATCH_CASE
+#undef VISMA_BATCH_ARGS
     if (!launched) return hipErrorInvalidValue;
     return hipGetLastError();
 }

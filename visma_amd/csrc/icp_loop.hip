@@ -79,8 +79,10 @@ __global__ __launch_bounds__(kSolveThreads) void finalize_solve_kernel(const dou
     if (do_solve && threadIdx.x == 0) advance_state(st);   // same thread wrote the stats
 }
 
+// one workgroup per problem: the statistics are already in st->stats (fused fold / all-reduce)
 __global__ void solve_state_kernel(DevIcpState *st)
 {
+    st += blockIdx.x;
     if (threadIdx.x == 0 && st->active) advance_state(st);
 }
 
@@ -128,9 +130,9 @@ hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *d
     return hipGetLastError();
 }
 
-hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream)
+hipError_t launch_solve_state(DevIcpState *st, int nprob, hipStream_t stream)
 {
-    hipLaunchKernelGGL(solve_state_kernel, dim3(1), dim3(64), 0, stream, st);
+    hipLaunchKernelGGL(solve_state_kernel, dim3(nprob), dim3(64), 0, stream, st);
     return hipGetLastError();
 }
 

@@ -38,6 +38,17 @@ struct DevIcpState {
     int pad_;
 };
 
+// The fold of the partial rows inside the search launch (device_common.h: fused_fold).
+struct FoldArgs {
+    unsigned *tickets;            // ticket_stride words per problem, zero; NULL = fold in a separate launch
+    double *partials2;            // ticket_stride rows of kReduceAcc per problem
+    int ticket_stride;            // >= 1 + ceil(workgroups per problem / 32)
+    double *stats_out;            // the 38 statistics of problem b at stats_out + b * stats_stride
+    long long stats_stride;
+    double *host_out;             // mapped host memory for tagged publication (or NULL)
+    unsigned long long seq;
+};
+
 struct NNLaunch {
     int src_tiles;
     int tgt_splits;
@@ -99,7 +110,7 @@ hipError_t launch_finalize_solve(const double *partials, int nblocks, DevIcpStat
                                  int nprob, hipStream_t stream);
 hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpState *st, int plane,
                                  hipStream_t stream);
-hipError_t launch_solve_state(DevIcpState *st, hipStream_t stream);
+hipError_t launch_solve_state(DevIcpState *st, int nprob, hipStream_t stream);
 
 // ---- radius-cell uniform grid (grid.hip) -------------------------------------
 // A point in f64 for the double-precision search (32 B: x, y, z, original index).
@@ -126,6 +137,45 @@ struct ProbDesc {
     int ns, first_block, nblocks, pad_;
     GridParams g;
 };
+
+// ---- streamed radius-cell search with exact (f64) tie-breaks and fused fold (tile.hip) ------
+struct TileArgs {
+    const Pt64 *src64;            // source, f64 (centred), Morton order
+    int ns;
+    const float4 *sorted;         // cell-sorted target, fp32 view (w = original index)
+    const Pt64 *sorted64;         // ... and the f64 points in the same slots
+    const unsigned *start;        // cell table
+    GridParams g;
+    const float4 *nrm;            // target normals by original index (point-to-plane)
+    const Pt64 *nrm64;
+    Xform64 T64;
+    Offset64 off;
+    float r2f;
+    int *idx_out;
+    float *d2_out;
+    double *partials;             // one row of kReduceAcc per workgroup
+    double *partials2;            // ticket_stride rows per problem (level-2 rows of the fused fold)
+    unsigned *tickets;            // ticket_stride words per problem, zero; NULL = no fused fold
+    int ticket_stride;            // >= 1 + ceil(workgroups per problem / 32)
+    double *stats_out;            // the 38 statistics of problem b at stats_out + b * stats_stride
+    long long stats_stride;
+    double *host_out;             // mapped host memory for tagged publication (or NULL)
+    unsigned long long seq;
+    unsigned long long *stats;    // profiling counters, 512 x 8 (or NULL)
+    const DevIcpState *st;        // device loop state (or NULL)
+    int bpp;                      // workgroups per problem (shared clouds)
+    long long out_stride;
+    const ProbDesc *descs;        // problems with their own clouds (or NULL)
+    int nprob;
+    int force_fallback;           // testing: search from global memory in every workgroup
+};
+// workgroup size of a tile configuration (queries per workgroup)
+int tile_threads(int config);
+// total_blocks = sum over problems of ceil(ns / tile_threads(config))
+hipError_t launch_nn_tile_reduce(const TileArgs &a, int point_to_plane, int config, int total_blocks,
+                                 hipStream_t stream);
+// float4 (x, y, z, .) -> Pt64 (x, y, z, index): f64 view of clouds uploaded as fp32
+hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStream_t stream);
 
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
@@ -167,7 +217,8 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream,
                                  const Pt64 *src64 = nullptr, const Pt64 *sorted64 = nullptr,
-                                 double r2d = 0.0, const Pt64 *nrm64 = nullptr);
+                                 double r2d = 0.0, const Pt64 *nrm64 = nullptr, int exact = 0,
+                                 const FoldArgs *fold = nullptr);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
 // offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
@@ -175,7 +226,8 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int32_t *idx_out, float *d2_out, double *partials,
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64 = nullptr,
-                                       const Pt64 *sorted64 = nullptr);
+                                       const Pt64 *sorted64 = nullptr, int exact = 0,
+                                       const FoldArgs *fold = nullptr);
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
                                        int nprob, hipStream_t stream);
 

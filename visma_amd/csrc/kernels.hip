@@ -313,25 +313,6 @@ hipError_t launch_shard_accumulate(const float4 *src, int64_t ns, const unsigned
     return hipGetLastError();
 }
 
-// Publish the 38 statistics to mapped (fine-grained, uncached) host memory as
-// self-validating 16-byte granules {value, sequence tag}: each granule is ONE
-// global_store_dwordx4, so the host can accept a value as soon as its tag shows
-// the expected sequence number -- no system-scope fence (whose L2 write-back of
-// the launch's ~2 MB of dirty index output cost ~10 us per iteration).
-__device__ __forceinline__ void publish_tagged(const double *stats, double *host_out,
-                                               unsigned long long seq)
-{
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    __syncthreads();                                   // stats[] was written by thread 0
-    if (threadIdx.x < kNStats) {
-        const unsigned long long v = (unsigned long long)__double_as_longlong(stats[threadIdx.x]);
-        u4 g;
-        g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
-        g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
-        __builtin_nontemporal_store(g, reinterpret_cast<u4 *>(host_out) + threadIdx.x);
-    }
-}
-
 template <bool PLANE>
 __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict__ partials,
                                                         int nblocks,
@@ -340,7 +321,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict
 {
     fold_partials<PLANE>(partials, nblocks, stats);
     // optional: publish straight to mapped host memory (saves the publish launch)
-    if (host_out) publish_tagged(stats, host_out, seq);
+    if (host_out) publish_tagged_stats(stats, host_out, seq);
 }
 
 // Copy the statistics into host-visible (mapped, coherent) memory and then raise
@@ -349,7 +330,7 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const double *__restrict
 __global__ void publish_stats_kernel(const double *__restrict__ stats, double *host_out,
                                      unsigned long long seq)
 {
-    publish_tagged(stats, host_out, seq);
+    publish_tagged_stats(stats, host_out, seq);
 }
 
 hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned long long seq,

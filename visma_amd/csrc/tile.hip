@@ -1,0 +1,761 @@
+// tile.hip -- the streamed radius-cell search: ONE kernel per ICP iteration that
+//   (A) transforms a chunk of Morton-ordered source points (the reference's f64 transform,
+//       PointCloud.cpp:75-80) and finds the chunk's footprint in the cell grid,
+//   (B) fetches every query's 9 cell-run bounds and reduces them, per (y,z) row of the
+//       footprint, to ONE contiguous range of the cell-sorted target,
+//   (C) streams those ranges into LDS with coalesced 16-byte loads (each target point is read
+//       once per workgroup instead of once per query that examines it),
+//   (D) searches every query's 3x3x3 neighbourhood FROM LDS with fp32 arithmetic, keeping the
+//       best and the runner-up squared distance,
+//   (E) re-ranks in the reference's f64 arithmetic (flann dist.h:159-176, KDTreeFlann.cpp:184-185)
+//       exactly those queries whose fp32 ranking is not decisive -- runner-up or search radius
+//       within the rounding band of the best -- so the correspondences ARE the reference's
+//       for every K at fp32 cost,
+//   (F) forms the Jacobian/residual moments of the winner from the f64 coordinates, reduces them
+//       with wave shuffles, and folds the per-workgroup rows IN THE SAME LAUNCH (two-level
+//       last-arriver fold, fixed summation order: bit-reproducible), publishing the 38
+//       statistics to the host / the device loop state.
+// Replaces KDTreeFlann::SearchHybrid + GetRegistrationResultAndCorrespondences
+// (O3D/Core/Registration/Registration.cpp:41-96) + the estimator's accumulation
+// (src/constrained_ICP.cpp:25-37, O3D/Core/Utility/Eigen.cpp:137-182).
+//
+// A workgroup whose footprint does not fit LDS (a Morton chunk that straddles a large jump of
+// the curve, a degenerate grid) runs the same search straight from global memory: slower, same
+// answers.
+#include "device_common.h"
+
+#include <limits.h>
+
+#include <type_traits>
+
+namespace visma {
+
+namespace {
+
+constexpr unsigned kNone = 0xFFFFFFFFu;
+constexpr int kGroupRows = 32;          // partial rows folded by one level-1 last arriver
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+__device__ __forceinline__ float med3_f32(float a, float b, float c)
+{
+    float r;
+    asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+// visiting order of the 9 (dy, dz) rows: centre, the 4 edge neighbours, the 4 corners.
+// k = (dz + 1) * 3 + (dy + 1)
+__device__ __forceinline__ int row_of_visit(int kk)
+{
+    // {4, 1, 3, 5, 7, 0, 2, 6, 8} packed 4 bits each
+    return (int)((0x862075314ull >> (4 * kk)) & 15ull);
+}
+
+// lane <-> lane exchanges inside groups of 2 / 4 / 8 lanes as DPP moves (no LDS crossbar trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppXor1 = 0xB1;          // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;          // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;   // row_half_mirror: lane i <-> 7 - i of each 8
+
+// minimum over the G lanes of a query (G = 1, 2, 4, 8), every lane gets it
+template <int G>
+__device__ __forceinline__ float group_min(float v)
+{
+    if (G >= 8) v = fminf(v, dpp_f32<kDppHalfMirror>(v));
+    if (G >= 4) v = fminf(v, dpp_f32<kDppXor2>(v));
+    if (G >= 2) v = fminf(v, dpp_f32<kDppXor1>(v));
+    return v;
+}
+
+// (best, runner-up, position of the best) over the G lanes of a query
+template <int CTRL>
+__device__ __forceinline__ void merge_step(float &b1, float &b2, unsigned &pos)
+{
+    const float o1 = dpp_f32<CTRL>(b1), o2 = dpp_f32<CTRL>(b2);
+    const unsigned op = dpp_u32<CTRL>(pos);
+    const float n2 = fminf(fmaxf(b1, o1), fminf(b2, o2));
+    // equal d2 at two different candidates: n2 == b1, decided in f64 later; either position will do,
+    // but every lane must pick the same one
+    const bool take = o1 < b1 || (o1 == b1 && op < pos);
+    pos = take ? op : pos;
+    b1 = fminf(b1, o1);
+    b2 = n2;
+}
+template <int G>
+__device__ __forceinline__ void group_merge(float &b1, float &b2, unsigned &pos)
+{
+    if (G >= 8) merge_step<kDppHalfMirror>(b1, b2, pos);
+    if (G >= 4) merge_step<kDppXor2>(b1, b2, pos);
+    if (G >= 2) merge_step<kDppXor1>(b1, b2, pos);
+}
+
+}  // namespace
+
+// LDS carve (dynamic, every offset a multiple of 16):
+//   tx,ty,tz float[CAP] x3   the streamed footprint, structure of arrays (12 B per point)
+//   rowlo  u32[MAXR]         first target slot of a footprint row
+//   rowoff u32[MAXR]         (first: one-past-last target slot) LDS offset of the row
+//   clist  u32[MAXR]         footprint rows that hold points, compacted
+//   rbeg   u32[9][QPB]       per query, visiting order: first candidate of the run (LDS offset in tile
+//                            mode, target slot otherwise)
+//   rlen   u32[9][QPB]       ... its length
+//   rgl    u32[9][QPB]       ... its first target slot
+//   scr    int[128]          bounding box / scan / flags scratch
+// G consecutive lanes work on one query (QPB = NTH / G queries per workgroup): a tile serves
+// NT/NS target points per query whatever the geometry, so one query per lane would leave room
+// for only one or two workgroups per CU; G lanes per query shrink the tile G-fold and split
+// the bound loads and the candidates of a query between them.
+template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE>
+__global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    constexpr int NW = NTH / 64;
+    constexpr int QPB = NTH / G;
+    constexpr int U = G >= 8 ? 2 : 4;                      // candidates per lane per trip of the search loop
+    constexpr int RPL = (9 + G - 1) / G;                   // rows per lane
+    static_assert(MAXR % NTH == 0, "MAXR must be a multiple of the workgroup size");
+    static_assert(CAP <= 65535 && CAP % 4 == 0, "CAP out of range");
+    static_assert((size_t)CAP * 12 >= (size_t)QPB * NACC * 8, "moment scratch does not fit the tile region");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *tx = reinterpret_cast<float *>(smem);
+    float *ty = tx + CAP;
+    float *tz = ty + CAP;
+    unsigned *rowlo = reinterpret_cast<unsigned *>(tz + CAP);
+    unsigned *rowoff = rowlo + MAXR;
+    unsigned *clist = rowoff + MAXR;
+    unsigned *rbeg = clist + MAXR;
+    unsigned *rlen = rbeg + 9 * QPB;
+    unsigned *rgl = rlen + 9 * QPB;
+    int *scr = reinterpret_cast<int *>(rgl + 9 * QPB);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = tid / G, sub = tid % G;
+    long long tstamp[10];
+    int nstamp = 0;
+#define VISMA_STAMP() do { if (a.stats) tstamp[nstamp] = clock64(); ++nstamp; } while (0)
+    VISMA_STAMP();                                            // 0: start
+
+    // ---- which problem, which chunk of its queries -------------------------------------
+    int prob, lb, bpp = a.bpp, ns = a.ns;
+    const Pt64 *src64 = a.src64;
+    const float4 *sorted = a.sorted;
+    const Pt64 *sorted64 = a.sorted64;
+    const unsigned *start = a.start;
+    GridParams g = a.g;
+    int *idx_out = a.idx_out;
+    float *d2_out = a.d2_out;
+    long long row0;                                        // first partial row of this problem
+    if (a.descs) {
+        int lo = 0, hi = a.nprob - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (a.descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        }
+        prob = lo;
+        const ProbDesc d = a.descs[prob];
+        lb = (int)blockIdx.x - d.first_block;
+        bpp = d.nblocks;
+        ns = d.ns;
+        src64 += d.src_off;
+        sorted += d.sorted_off;
+        sorted64 += d.sorted_off;
+        start += d.start_off;
+        g = d.g;
+        idx_out += d.out_off;
+        d2_out += d.out_off;
+        row0 = d.first_block;
+    } else {
+        prob = blockIdx.x / bpp;
+        lb = blockIdx.x - prob * bpp;
+        idx_out += (long long)prob * a.out_stride;
+        d2_out += (long long)prob * a.out_stride;
+        row0 = (long long)prob * bpp;
+    }
+    Xform64 T64 = a.T64;
+    Offset64 off = a.off;
+    float r2f = a.r2f;
+    {
+        Xform32 T32unused;
+        if (!load_loop_state(a.st ? a.st + prob : nullptr, T32unused, T64, off, r2f)) return;
+    }
+    const double r2d = (double)r2f;                        // (double)(float)(r*r): KDTreeFlann.cpp:184-185
+
+    // XCD-aware chunking: workgroup b runs on XCD b % 8; give each XCD one contiguous share
+    // of the Morton-ordered queries so that its private L2 holds one region of the target.
+    int vb;
+    {
+        const int x = lb & 7, qq = bpp >> 3, r = bpp & 7;
+        vb = x * qq + min(x, r) + (lb >> 3);
+    }
+    const int i = vb * QPB + q;
+    const bool valid = i < ns;
+
+    // ---- (A) transform, cell -------------------------------------------------------------
+    Pt64 s8;
+    s8.x = s8.y = s8.z = 0.0;
+    s8.w = 0ull;
+    if (valid) s8 = src64[i];
+    const double pxd = T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0;
+    const double pyd = T64.m[4] * s8.x + T64.m[5] * s8.y + T64.m[6] * s8.z + T64.m[7] * 1.0;
+    const double pzd = T64.m[8] * s8.x + T64.m[9] * s8.y + T64.m[10] * s8.z + T64.m[11] * 1.0;
+    const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
+    const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
+    const int cy = cell_coord(py, g.mn[1], g.inv_hs, g.dim[1]);
+    const int cz = cell_coord(pz, g.mn[2], g.inv_hs, g.dim[2]);
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
+    const int ylo = max(cy - 1, 0), yhi = min(cy + 1, g.dim[1] - 1);
+    const int zlo = max(cz - 1, 0), zhi = min(cz + 1, g.dim[2] - 1);
+    const bool contrib = valid && x0 <= x1 && ylo <= yhi && zlo <= zhi;
+    VISMA_STAMP();                                            // 1: source loaded, transformed
+
+    // ---- (B) run bounds: lane `sub` of a query fetches the rows it visits kk = sub, sub+G, ... ----
+    unsigned rb[RPL], rl[RPL];
+    int ry[RPL], rz[RPL];
+#pragma unroll
+    for (int m = 0; m < RPL; m++) {
+        const int kk = sub + m * G;
+        const int k = row_of_visit(kk < 9 ? kk : 0);
+        const int dy = k % 3 - 1, dz = k / 3 - 1;
+        const int z = cz + dz, y = cy + dy;
+        const bool ok = kk < 9 && valid && (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+        const int row = ((ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
+        const unsigned b = ok ? start[row + x0] : 0u;
+        const unsigned e = ok ? start[row + x1 + 1] : 0u;
+        rb[m] = b;
+        rl[m] = e > b ? e - b : 0u;
+        ry[m] = y;
+        rz[m] = z;
+    }
+
+    // Rounding band.  p32 = fl(p64), q32 = fl(q64): the difference vector is off by at most
+    // u (|p|+|q|) per component, u = 2^-24, and the fp32 evaluation of d2 adds 3u relative, so
+    // |d64 - sqrt(d2_32)| <= u (2 |p| + 2.5 r).  E is more than twice that.
+    const float r_f = sqrtf(r2f);
+    const float r_up = r_f * (1.0f + 2.4e-7f), r_dn = r_f * (1.0f - 2.4e-7f);
+    const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + r_up) + 4.8e-7f * r_up;
+    float lim;                                               // candidates at or beyond it never matter
+    {
+        const float t = r_up + 2.0f * E;
+        lim = t * t * (1.0f + 6e-7f);
+    }
+    // A row (dy,dz) is SKIPPED when its slab cannot hold a candidate that matters: every point
+    // of it is at least |(dist to the slab in y, in z)| away.  Margins: 1e-3 cell (fp32 binning
+    // of query and candidates, kGridMaxDim) plus the rounding band, 1e-5 relative on the square.
+    const float fy = (py - g.mn[1]) * g.inv_hs - (float)cy;
+    const float fz = (pz - g.mn[2]) * g.inv_hs - (float)cz;
+    const float mgn = 1e-3f + 4.0f * E * g.inv_hs;
+    const float lo_y = fmaxf(fy - mgn, 0.f), hi_y = fmaxf(1.0f - fy - mgn, 0.f);
+    const float lo_z = fmaxf(fz - mgn, 0.f), hi_z = fmaxf(1.0f - fz - mgn, 0.f);
+    const float h2 = g.hs * g.hs * (1.0f - 1e-5f);
+
+    // results of the query (valid on every lane of its group after the search)
+    float b1 = lim, b2 = lim;
+    unsigned gpos1 = kNone;                                  // target slot of the fp32 winner
+    Pt64 q8;                                                 // the winner, f64
+    q8.x = q8.y = q8.z = 0.0;
+    q8.w = 0ull;
+    double bd = r2d;
+    bool hit = false, amb = false;
+    unsigned ncand = 0, ncand_all = 0;
+    unsigned total_pts = 0, total_rows = 0;
+    int passes_run = 0, global_passes = 0;
+
+    // The chunk is searched in `npass` parts (1 unless its footprint does not fit the tile):
+    // part p = queries [p, p+1) * QPB / npass.
+    int npass = a.force_fallback ? 0 : 1;
+    bool global_mode = a.force_fallback != 0;
+    for (int pass = 0; pass < (npass ? npass : 1);) {
+        const int qlo = npass ? pass * (QPB / npass) : 0, qhi = npass ? qlo + QPB / npass : QPB;
+        const bool active = q >= qlo && q < qhi;
+        bool tile = !global_mode;
+        int ymin = 0, zmin = 0, nzs = 0, nslots = 0;
+        unsigned total = 0, nrows = 0;
+        if (tile) {
+            // ---- footprint rows of this part: bounding box of (y, z) -----------------------
+            {
+                const bool c = contrib && active;
+                int m0 = c ? ylo : INT_MAX, m1 = c ? -yhi : INT_MAX;
+                int m2 = c ? zlo : INT_MAX, m3 = c ? -zhi : INT_MAX;
+#pragma unroll
+                for (int o = 32; o >= G; o >>= 1) {          // the G lanes of a query hold the same values
+                    m0 = min(m0, __shfl_xor(m0, o, 64));
+                    m1 = min(m1, __shfl_xor(m1, o, 64));
+                    m2 = min(m2, __shfl_xor(m2, o, 64));
+                    m3 = min(m3, __shfl_xor(m3, o, 64));
+                }
+                if (lane == 0) { scr[wave * 4] = m0; scr[wave * 4 + 1] = m1; scr[wave * 4 + 2] = m2; scr[wave * 4 + 3] = m3; }
+            }
+#pragma unroll
+            for (int s = 0; s < MAXR / NTH; s++) {
+                rowlo[tid + s * NTH] = kNone;
+                rowoff[tid + s * NTH] = 0u;                  // "rowhi" until the scan
+            }
+            __syncthreads();
+            int ymaxn = INT_MAX, zmaxn = INT_MAX;
+            ymin = INT_MAX; zmin = INT_MAX;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                ymin = min(ymin, scr[w * 4]); ymaxn = min(ymaxn, scr[w * 4 + 1]);
+                zmin = min(zmin, scr[w * 4 + 2]); zmaxn = min(zmaxn, scr[w * 4 + 3]);
+            }
+            const bool any = ymin != INT_MAX;
+            nzs = any ? (-zmaxn - zmin + 1) : 0;
+            const int nys = any ? (-ymaxn - ymin + 1) : 0;
+            const long long nslots_ll = (long long)nys * nzs;
+            if (nslots_ll > MAXR) tile = false;
+            nslots = tile ? (int)nslots_ll : 0;
+            // ---- per-row union of the runs ---------------------------------------------------
+            if (tile && active) {
+#pragma unroll
+                for (int m = 0; m < RPL; m++)
+                    if (rl[m]) {
+                        const int sl = (ry[m] - ymin) * nzs + (rz[m] - zmin);
+                        atomicMin(&rowlo[sl], rb[m]);
+                        atomicMax(&rowoff[sl], rb[m] + rl[m]);
+                    }
+            }
+            __syncthreads();
+            // ---- exclusive scan of (row length, row holds points) -> LDS offsets, compact list --
+            if (tile) {
+                constexpr int SPT = MAXR / NTH;
+                unsigned len[SPT], sum = 0;                  // sum = points | rows << 16
+#pragma unroll
+                for (int s = 0; s < SPT; s++) {
+                    const int sl = tid * SPT + s;
+                    const unsigned l = rowlo[sl], h = rowoff[sl];
+                    len[s] = (sl < nslots && h > l) ? h - l : 0u;
+                    if (len[s] > 0xFFFFu) len[s] = 0xFFFFu;  // (too large anyway; keeps the packed sum valid)
+                    sum += len[s] ? (len[s] | 0x10000u) : 0u;
+                }
+                // points of a part can exceed 16 bits only when it does not fit: detect by a second, clamped sum
+                unsigned inc = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned t = __shfl_up(inc, o, 64);
+                    if (lane >= o) inc += t;
+                }
+                unsigned long long wide = sum & 0xFFFFu;     // exact point count of the workgroup
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) wide += __shfl_xor(wide, o, 64);
+                if (lane == 63) scr[16 + wave] = (int)inc;
+                if (lane == 0) scr[24 + wave] = (int)(wide > 0x7FFFFFFFull ? 0x7FFFFFFF : wide);
+                __syncthreads();
+                unsigned wbase = 0, packed_total = 0;
+                unsigned long long wtot = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    const unsigned t = (unsigned)scr[16 + w];
+                    if (w < wave) wbase += t;
+                    packed_total += t;
+                    wtot += (unsigned)scr[24 + w];
+                }
+                if (wtot > (unsigned long long)CAP) {
+                    tile = false;                            // block-uniform
+                } else {
+                    total = packed_total & 0xFFFFu;
+                    nrows = packed_total >> 16;
+                    unsigned run = wbase + inc - sum;
+#pragma unroll
+                    for (int s = 0; s < SPT; s++) {
+                        const int sl = tid * SPT + s;
+                        rowoff[sl] = run & 0xFFFFu;
+                        if (len[s]) clist[run >> 16] = (unsigned)sl;
+                        run += len[s] ? (len[s] | 0x10000u) : 0u;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (!tile && !global_mode) {
+            // does not fit: halve the part; a single query that does not fit is searched from global memory
+            if (QPB / npass > 1 && npass < 8) {
+                npass *= 2;
+                pass *= 2;
+                continue;
+            }
+        }
+        VISMA_STAMP();                                        // 2 (first pass): rows, unions, scan
+
+        // ---- (C) stream the footprint into LDS: one wave per row, four rows in flight ----------
+        if (tile && total > 0) {
+            for (unsigned c0 = wave; c0 < nrows; c0 += 4 * NW) {
+                unsigned lo[4], of[4], ln[4];
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned c = c0 + u * NW;
+                    const unsigned sl = clist[c < nrows ? c : 0];
+                    lo[u] = rowlo[sl];
+                    of[u] = rowoff[sl];
+                    // length from the neighbour offsets is not available (empty rows share offsets): recompute
+                    ln[u] = 0;
+                    if (c < nrows) {
+                        const unsigned nxt = (c + 1 < nrows) ? rowoff[clist[c + 1]] : total;
+                        ln[u] = nxt - of[u];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if ((unsigned)lane < ln[u]) v[u] = sorted[lo[u] + lane];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if ((unsigned)lane < ln[u]) {
+                        tx[of[u] + lane] = v[u].x; ty[of[u] + lane] = v[u].y; tz[of[u] + lane] = v[u].z;
+                    }
+#pragma unroll 1
+                for (int u = 0; u < 4; u++)
+                    for (unsigned j = lane + 64; j < ln[u]; j += 64) {
+                        const float4 w4 = sorted[lo[u] + j];
+                        tx[of[u] + j] = w4.x; ty[of[u] + j] = w4.y; tz[of[u] + j] = w4.z;
+                    }
+            }
+        }
+
+        // ---- row lists of the active queries (visiting order) ------------------------------
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < RPL; m++) {
+                const int kk = sub + m * G;
+                if (kk < 9) {
+                    ncand_all += rl[m];
+                    unsigned o = rb[m];
+                    if (tile) {
+                        const int sl = (ry[m] - ymin) * nzs + (rz[m] - zmin);
+                        o = rl[m] ? rowoff[sl] + (rb[m] - rowlo[sl]) : 0u;
+                    }
+                    rbeg[kk * QPB + q] = o;
+                    rlen[kk * QPB + q] = rl[m];
+                    rgl[kk * QPB + q] = rb[m];
+                }
+            }
+        }
+        __syncthreads();                                     // tile + lists complete
+        VISMA_STAMP();                                        // 3 (first pass): tile streamed
+
+        // ---- (D) fp32 search of the active queries: best and runner-up --------------------------
+        if (active) {
+            float c1 = lim, c2 = lim;
+            unsigned cpos = kNone;
+            auto search = [&](auto tile_tag) {
+                constexpr bool TILE = decltype(tile_tag)::value;
+                unsigned s_n = rbeg[q], l_n = rlen[q], g_n = rgl[q];
+#pragma unroll 1
+                for (int kk = 0; kk < 9; kk++) {
+                    const unsigned s = s_n, gs = g_n;
+                    unsigned l = l_n;
+                    if (kk < 8) {                            // next row's list entries: in flight during this row
+                        s_n = rbeg[(kk + 1) * QPB + q]; l_n = rlen[(kk + 1) * QPB + q]; g_n = rgl[(kk + 1) * QPB + q];
+                    }
+                    if (PRUNE && kk > 0) {
+                        const int k = row_of_visit(kk);
+                        const int dy = k % 3 - 1, dz = k / 3 - 1;
+                        const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
+                        const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
+                        const float bound = (ey * ey + ez * ez) * h2;
+                        if (bound > group_min<G>(c1)) l = 0u;
+                    }
+                    if (sub == 0) ncand += l;
+                    for (unsigned j0 = 0; j0 < l; j0 += G * U) {
+                        float qx[U], qy[U], qz[U];
+                        unsigned jc[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const unsigned j = j0 + sub + u * G;
+                            jc[u] = j < l ? j : l - 1;
+                            if constexpr (TILE) {
+                                qx[u] = tx[s + jc[u]]; qy[u] = ty[s + jc[u]]; qz[u] = tz[s + jc[u]];
+                            } else {
+                                const float4 w4 = sorted[s + jc[u]];
+                                qx[u] = w4.x; qy[u] = w4.y; qz[u] = w4.z;
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const float ddx = qx[u] - px, ddy = qy[u] - py, ddz = qz[u] - pz;
+                            float d = __builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx));
+                            d = (j0 + sub + u * G < l) ? d : INFINITY;   // a padding slot is not a second candidate
+                            const bool lt = d < c1;
+                            c2 = med3_f32(c1, c2, d);
+                            cpos = lt ? gs + jc[u] : cpos;
+                            c1 = lt ? d : c1;
+                        }
+                    }
+                }
+            };
+            if (tile) search(std::true_type{}); else search(std::false_type{});
+            group_merge<G>(c1, c2, cpos);
+            b1 = c1; b2 = c2; gpos1 = cpos;
+
+            // ---- (E) decisive?  otherwise re-rank in f64 (lane 0 of the query) -------------------
+            if (sub == 0 && gpos1 != kNone) {
+                const float s1 = sqrtf(b1), s2 = sqrtf(b2);
+                amb = (s1 + 2.0f * E >= s2) || (s1 + E >= r_dn);
+            }
+            if (amb) {
+                // exact: every candidate inside the band, ranked by the reference's f64 sum of squares,
+                // lowest original index on exact ties, accepted iff d2 < (double)(float)(r*r)
+                const float sl = fminf(sqrtf(b1), r_up) + 2.0f * E;
+                const float L = sl * sl * (1.0f + 6e-7f);
+                unsigned bidx = kNone;
+#pragma unroll 1
+                for (int kk = 0; kk < 9; kk++) {
+                    const unsigned s = rbeg[kk * QPB + q], l = rlen[kk * QPB + q], gs = rgl[kk * QPB + q];
+#pragma unroll 1
+                    for (unsigned j = 0; j < l; j++) {
+                        float cx_, cy_, cz_;
+                        if (tile) { cx_ = tx[s + j]; cy_ = ty[s + j]; cz_ = tz[s + j]; }
+                        else { const float4 w4 = sorted[s + j]; cx_ = w4.x; cy_ = w4.y; cz_ = w4.z; }
+                        const float ddx = cx_ - px, ddy = cy_ - py, ddz = cz_ - pz;
+                        if (!(__builtin_fmaf(ddz, ddz, __builtin_fmaf(ddy, ddy, ddx * ddx)) <= L)) continue;
+                        const Pt64 c8 = sorted64[gs + j];
+                        // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
+                        const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
+                        double d = dx * dx;
+                        d += dy * dy;
+                        d += dz * dz;
+                        const unsigned id = (unsigned)c8.w;
+                        const bool lt = d < bd || (d == bd && id < bidx && bidx != kNone);
+                        if (lt) { bd = d; bidx = id; q8 = c8; }
+                    }
+                }
+                hit = bidx != kNone;
+            }
+        }
+        if (passes_run == 0) { total_pts = total; total_rows = (unsigned)nslots; }
+        ++passes_run;
+        if (!tile) ++global_passes;
+        ++pass;
+        if (pass < (npass ? npass : 1)) __syncthreads();     // the next part reuses the tile and the lists
+    }
+    VISMA_STAMP();                                            // 4: search (+ re-rank) done
+
+    // the decisive queries fetch their winner in f64
+    if (sub == 0 && !amb && gpos1 != kNone) {
+        q8 = sorted64[gpos1];
+        const double dx = q8.x - pxd, dy = q8.y - pyd, dz = q8.z - pzd;
+        double d = dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        bd = d;
+        hit = true;
+    }
+    if (valid && sub == 0) {
+        idx_out[i] = hit ? (int)(unsigned)q8.w : -1;
+        d2_out[i] = (float)bd;
+    }
+    VISMA_STAMP();                                            // 5: winner fetched
+
+    // ---- (F) moments of the winner; workgroup sum through LDS in a fixed order -------------
+    __syncthreads();                                         // everyone is done with the tile and the lists
+    double *mom = reinterpret_cast<double *>(smem);          // [QPB][NACC]   (tile region)
+    double *part = reinterpret_cast<double *>(rowlo);        // [NTH/32][33]  (rows / lists region)
+    double *tot = part + (NTH / 32) * 33;                    // [32]
+    static_assert((size_t)MAXR * 12 + (size_t)27 * QPB * 4 >= (size_t)((NTH / 32) * 33 + 32) * 8, "fold scratch does not fit");
+    if (sub == 0) {
+        double acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; k++) acc[k] = 0.0;
+        if (hit) {
+            double nx = 0.0, ny = 0.0, nz = 0.0;
+            if (PLANE) {
+                if (a.nrm64) { const Pt64 n8 = a.nrm64[(unsigned)q8.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                else { const float4 n4 = a.nrm[(unsigned)q8.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
+            }
+            accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
+        }
+#pragma unroll
+        for (int k = 0; k < NACC; k++) mom[q * NACC + k] = acc[k];
+    }
+    __syncthreads();
+    const int sa = tid & 31, sg = tid >> 5;
+    constexpr int NG = NTH / 32;
+    {
+        double v = 0.0;
+        if (sa < NACC)
+            for (int r = sg; r < QPB; r += NG) v += mom[r * NACC + sa];
+        part[sg * 33 + sa] = v;
+    }
+    __syncthreads();
+    double *rows = a.partials + (row0 + lb) * kReduceAcc;
+    if (tid < NACC) {
+        double v = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) v += part[gg * 33 + tid];
+        if (a.tickets) store_agent_f64(rows + tid, v);
+        else rows[tid] = v;
+    }
+    VISMA_STAMP();                                            // 6: row stored
+    if (a.stats && tid == 0) {
+        // profiling: tiles / global-memory parts / streamed points / f64 re-ranks / footprint rows / histogram
+        unsigned long long *t = a.stats + 24 * (blockIdx.x & 511);
+        atomicAdd(t + 0, 1ull);
+        atomicAdd(t + 1, (unsigned long long)global_passes);
+        atomicAdd(t + 2, (unsigned long long)total_pts);
+        atomicAdd(t + 4, (unsigned long long)total_rows);
+        atomicAdd(t + 7, (unsigned long long)passes_run);
+#pragma unroll
+        for (int k = 0; k < 6; k++) atomicAdd(t + 8 + k, (unsigned long long)(tstamp[k + 1] - tstamp[k]));
+    }
+    if (a.stats) {
+        unsigned long long c = ncand, ca = ncand_all, am = amb ? 1ull : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            c += __shfl_down(c, o, 64);
+            ca += __shfl_down(ca, o, 64);
+            am += __shfl_down(am, o, 64);
+        }
+        if (lane == 0) {
+            unsigned long long *t = a.stats + 24 * (blockIdx.x & 511);
+            atomicAdd(t + 3, am);
+            atomicAdd(t + 5, c);
+            atomicAdd(t + 6, ca);
+        }
+    }
+#undef VISMA_STAMP
+    if (!a.tickets) return;
+
+    // ---- fused fold: the last arriver of each group of rows folds it, the last group folder
+    //      folds the group rows; every sum in a fixed order -------------------------------
+    const int ngroups = (bpp + kGroupRows - 1) / kGroupRows;
+    unsigned *tk = a.tickets + (long long)prob * a.ticket_stride;   // [0]: level 2, [1 + g]: level 1
+    const int grp = lb / kGroupRows;
+    const int gsize = min(kGroupRows, bpp - grp * kGroupRows);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains (write-through stores)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tk + 1 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scr[32] = (t == (unsigned)(gsize - 1)) ? 1 : 0;
+        if (scr[32]) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tk + 1 + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+    }
+    __syncthreads();
+    if (!scr[32]) return;
+    {
+        const double *grows = a.partials + (row0 + (long long)grp * kGroupRows) * kReduceAcc;
+        double v = 0.0;
+        if (sa < NACC)
+            for (int r = sg; r < gsize; r += NG) v += load_agent_f64(grows + (long long)r * kReduceAcc + sa);
+        part[sg * 33 + sa] = v;
+    }
+    __syncthreads();
+    double *rows2 = a.partials2 + ((long long)prob * a.ticket_stride + grp) * kReduceAcc;
+    if (tid < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) t += part[gg * 33 + tid];
+        if (tid < NACC) store_agent_f64(rows2 + tid, t);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scr[33] = (t == (unsigned)(ngroups - 1)) ? 1 : 0;
+        if (scr[33]) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (!scr[33]) return;
+    {
+        const double *g2 = a.partials2 + (long long)prob * a.ticket_stride * kReduceAcc;
+        double v = 0.0;
+        if (sa < NACC)
+            for (int r = sg; r < ngroups; r += NG) v += load_agent_f64(g2 + (long long)r * kReduceAcc + sa);
+        part[sg * 33 + sa] = v;
+    }
+    __syncthreads();
+    if (tid < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) t += part[gg * 33 + tid];
+        tot[tid] = t;
+    }
+    __syncthreads();
+    double *stats = a.stats_out + (long long)prob * a.stats_stride;
+    if (tid == 0) expand_moments<PLANE>(tot, stats);
+    if (a.host_out) publish_tagged_stats(stats, a.host_out, a.seq);
+}
+
+__global__ void promote_pt64_kernel(const float4 *__restrict__ src, Pt64 *__restrict__ dst, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = src[i];
+    Pt64 o;
+    o.x = (double)q.x; o.y = (double)q.y; o.z = (double)q.z;
+    o.w = (unsigned long long)i;
+    dst[i] = o;
+}
+
+hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(promote_pt64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst,
+                       (long long)n);
+    return hipGetLastError();
+}
+
+// ---- launch ------------------------------------------------------------------------------
+template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE>
+static hipError_t launch_tile_t(const TileArgs &a, int total_blocks, hipStream_t stream)
+{
+    constexpr size_t lds = (size_t)CAP * 12 + (size_t)MAXR * 12 + (size_t)27 * (NTH / G) * 4 + 128 * 4;
+    static bool once = false;
+    if (!once) {
+        hipError_t e = hipFuncSetAttribute(
+            reinterpret_cast<const void *>(&nn_tile_reduce_kernel<PLANE, NTH, G, CAP, MAXR, PRUNE>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        once = true;
+    }
+    hipLaunchKernelGGL((nn_tile_reduce_kernel<PLANE, NTH, G, CAP, MAXR, PRUNE>), dim3(total_blocks), dim3(NTH), lds,
+                       stream, a);
+    return hipGetLastError();
+}
+
+// queries per workgroup of a tile configuration
+int tile_threads(int config)
+{
+    switch (config % 8) {
+    case 1: return 128;    // 256 threads, 2 lanes per query
+    case 2: return 32;     // 128 threads, 4 lanes per query
+    case 3: return 32;     // 256 threads, 8 lanes per query
+    default: return 64;    // 256 threads, 4 lanes per query
+    }
+}
+
+#define VISMA_TILE_CASES(PL)                                                                       \
+    switch (config) {                                                                              \
+    case 1: return launch_tile_t<PL, 256, 2, 4864, 512, true>(a, total_blocks, stream);            \
+    case 2: return launch_tile_t<PL, 128, 4, 1280, 256, true>(a, total_blocks, stream);            \
+    case 3: return launch_tile_t<PL, 256, 8, 1280, 256, true>(a, total_blocks, stream);            \
+    case 8: return launch_tile_t<PL, 256, 4, 2432, 256, false>(a, total_blocks, stream);           \
+    case 9: return launch_tile_t<PL, 256, 2, 4864, 512, false>(a, total_blocks, stream);           \
+    case 10: return launch_tile_t<PL, 128, 4, 1280, 256, false>(a, total_blocks, stream);          \
+    case 11: return launch_tile_t<PL, 256, 8, 1280, 256, false>(a, total_blocks, stream);          \
+    default: return launch_tile_t<PL, 256, 4, 2432, 256, true>(a, total_blocks, stream);           \
+    }
+
+hipError_t launch_nn_tile_reduce(const TileArgs &a, int point_to_plane, int config, int total_blocks,
+                                 hipStream_t stream)
+{
+    if (point_to_plane) { VISMA_TILE_CASES(true) }
+    VISMA_TILE_CASES(false)
+}
+#undef VISMA_TILE_CASES
+
+}  // namespace visma
