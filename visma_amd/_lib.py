@@ -74,11 +74,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = os.environ.get("VISMA_ICP_LIB", LIB_PATH)     # (experiments: an alternative build of the same library)
+    if not os.path.exists(lib_path):
         raise ImportError(
             "%s is missing: build it with `python -m visma_amd.build` (hipcc, gfx950). "
-            "visma_amd has no non-HIP implementation." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+            "visma_amd has no non-HIP implementation." % lib_path)
+    L = C.CDLL(lib_path)
     L.visma_icp_last_error.restype = C.c_char_p
     L.visma_icp_last_error.argtypes = [C.c_void_p]
     L.visma_icp_version.restype = C.c_char_p

@@ -26,15 +26,17 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False):
+def build_lib(force=False, verbose=False, defines=(), out=None):
     """Compile visma_amd/lib/libvisma_icp.so for gfx950 (cross-compiles without a GPU).
     One hipcc process per source file, run side by side, then one link."""
-    if not force and not is_stale():
+    if out is None and not force and not is_stale():
         return LIB_PATH
+    lib_path = out or LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "_obj")
+    obj_dir = os.path.join(LIB_DIR, "_obj" + ("" if out is None else "_" + os.path.basename(out)))
     os.makedirs(obj_dir, exist_ok=True)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
+    flags += ["-D" + d for d in defines]
     procs, objs = [], []
     for src in SOURCES:
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
@@ -46,12 +48,12 @@ def build_lib(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB_PATH, "-ldl", "-lpthread"]
+    link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib_path, "-ldl", "-lpthread"]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)
     shutil.rmtree(obj_dir, ignore_errors=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":

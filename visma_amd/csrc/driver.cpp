@@ -800,7 +800,8 @@ public:
         if (cell_tot > bt_cell_cap_) {
             free_dev(bt_count_); free_dev(bt_start_);
             HIP_TRY(hipMalloc(&bt_count_, sizeof(unsigned) * cell_tot));
-            HIP_TRY(hipMalloc(&bt_start_, sizeof(unsigned) * cell_tot));
+            HIP_TRY(hipMalloc(&bt_start_, sizeof(unsigned) * (cell_tot + 8)));      // (16-byte reads near the end)
+            HIP_TRY(hipMemsetAsync(bt_start_, 0, sizeof(unsigned) * (cell_tot + 8), stream_));
             bt_cell_cap_ = cell_tot;
         }
         if (grid_scan_blocks(max_ncell) + 1 > bt_bsum_cap_) {
@@ -1116,7 +1117,8 @@ private:
         if (grid_.ncell + 1 > cell_cap_) {
             free_dev(d_count_); free_dev(d_start_); free_dev(d_bsum_);
             HIP_TRY(hipMalloc(&d_count_, sizeof(unsigned) * (grid_.ncell + 1)));
-            HIP_TRY(hipMalloc(&d_start_, sizeof(unsigned) * (grid_.ncell + 1)));
+            HIP_TRY(hipMalloc(&d_start_, sizeof(unsigned) * (grid_.ncell + 8)));    // (16-byte reads near the end)
+            HIP_TRY(hipMemsetAsync(d_start_, 0, sizeof(unsigned) * (grid_.ncell + 8), stream_));
             HIP_TRY(hipMalloc(&d_bsum_, sizeof(unsigned) * (grid_scan_blocks(grid_.ncell) + 1)));
             cell_cap_ = grid_.ncell + 1;
         }
