@@ -1,36 +1,45 @@
 #!/usr/bin/env python3
 """bench.py -- ICP iterations/s of the MI355X-native registration path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--nn auto|grid|brute]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c3|c5] [--nn auto|grid|brute]
 
-Workload (BASELINE.json metric "ICP iterations/sec + corresp. M-pairs/sec,
-64k->4M-pt target"): synthetic S-surf clouds, source
-262,144 points -> target 4,194,304 points, fp32 search / f64 statistics.
-One STEP = one ICP iteration = one fused transform + nearest-neighbour pass of
-every source point against the target, one Jacobian/residual reduction, one
-host solve, T <- update*T.  Inputs are resident in HBM before the timed region
-(the radius-cell grid is built once per target/radius, outside the timed
-region, like the reference's KD-tree; its build time is reported).
+`--gpus N` with N > 1 starts its own ranks (re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`);
+started under torch.distributed.run already, it reads RANK / LOCAL_RANK / WORLD_SIZE.
 
-NN search: `auto` (default) = the radius-cell uniform grid (exact radius-limited
-1-NN; HBM-bound); `brute` = the LDS-tiled brute-force kernel north_star names
-(fp32-VALU-bound).  Both give bit-identical correspondences.  A few brute-force
+Workloads (BASELINE.json configs):
+  c4 (default; the configuration the metric is quoted on): synthetic S-surf clouds, source
+      262,144 points -> target 4,194,304 points.  One STEP = one ICP iteration = one fused
+      transform + exact nearest-neighbour pass of every source point against the target, the
+      Jacobian/residual reduction, the fold to the 38 statistics (same launch), one host solve,
+      T <- update*T.  Clouds resident in HBM before the timed region; the radius-cell grid is built
+      once per target/radius outside it, like the reference's KD-tree (build time reported).
+      N > 1: the SOURCE is sharded (each rank holds the full target), every rank reduces its shard
+      and ONE all-reduce of the 38 f64 accumulators per iteration sums them; total work is fixed:
+      "scaling": "strong".  A weak-scaling line (source N x 262,144 -> target N x 4,194,304) is
+      measured after the timed region and reported under "weak_scaling".
+  c3: all objects of one scene in flight on ONE GPU: 12 objects x 24 yaw starts = 288 small ICPs
+      (source 4k..40k points, target half of it, r = 0.02, 30 iterations).  One STEP = one
+      visma_icp_run_batch over the set.  N > 1: problems dealt round-robin by size, no collective.
+  c5: the corpus: every scene x every CAD candidate, each a 24-yaw orientation-constrained sweep
+      (src/annotation.cpp:29-64).  Ranks PULL work items from a shared counter; no collective.
+      One STEP = one pass over the corpus.
+
+NN search: `auto` (default) = the radius-cell grid, exact mode (fp32 ranking of the candidates,
+the ones inside the rounding band re-ranked in f64: the reference's correspondences);
+`brute` = the LDS-tiled brute-force kernel north_star names (fp32-VALU-bound).  A few brute-force
 steps are always run after the timed region and reported under `brute_force`.
 
-N > 1: the SOURCE is sharded across ranks (each rank holds the full target),
-every rank reduces its shard to the 38 f64 normal-equation accumulators and
-ONE ncclAllReduce (RCCL over xGMI) per iteration sums them; total work is
-fixed, so "scaling" is "strong" and `value` is the job's iterations/s.
-
-Prints ONE JSON line on rank 0 (contract in the task description), with the
-extra objects `roofline` (dominant kernel = NN correspondence) and
-`cpu_baseline` (the reference itself, oracle/_ref, timed on this host).
+Prints ONE JSON line on rank 0 (contract in the task description), with the extra objects
+`roofline` (dominant kernel = NN correspondence) and `cpu_baseline` (the reference itself,
+oracle/_ref, timed on this host).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,7 +51,7 @@ import numpy as np  # noqa: E402
 NS_DEFAULT = 262144
 NT_DEFAULT = 4194304
 PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-PEAK_FP32_TFLOPS = 157.3        # ... FP32 vector == FP32 (f32-input) MFMA dense peak
+PEAK_FP32_TFLOPS = 157.3        # ... FP32 vector peak
 
 
 def parse():
@@ -50,57 +59,187 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["c4", "c3", "c5"], default="c4")
     ap.add_argument("--ns", type=int, default=NS_DEFAULT)
     ap.add_argument("--nt", type=int, default=NT_DEFAULT)
     ap.add_argument("--nn", choices=["auto", "grid", "brute"], default="auto")
     ap.add_argument("--shard", choices=["source", "target"], default="source",
-                    help="multi-GPU decomposition: source points (one all-reduce of 38 f64 per iteration; "
+                    help="multi-GPU decomposition of c4: source points (one all-reduce of 38 f64 per iteration; "
                          "default) or target points (north_star's wording: MIN all-reduce of NS keys + the "
                          "same sum; for targets that exceed one GPU)")
     ap.add_argument("--brute-steps", type=int, default=3)
-    ap.add_argument("--f64-steps", type=int, default=10)
+    ap.add_argument("--f32-steps", type=int, default=10)
+    ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling line of c4 at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=20)
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-repeats", type=int, default=5)
     return ap.parse_args()
 
 
-def cpu_baseline(src, tgt, radius, iters):
-    """Time the CPU path on this host: the real reference (oracle/_ref, Open3D
-    RegistrationICP with the KD-tree) when the prebuilt library is present,
-    else our C restatement with its uniform-grid search ("port").
-    Bounded sample: the SAME clouds, `iters` iterations; steady-state rate =
-    (t(iters+1 its) - t(1 it)) / iters, so the one-off KD-tree build is reported
-    separately and not charged to the iteration rate."""
+# ------------------------------------------------------------------------------------------
+# multi-rank plumbing
+# ------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` started without ranks: start them (one process per GPU)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class Ranks:
+    """torch.distributed, only where there is more than one rank."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        self.tdev = "cpu"
+        self.force_comm = os.environ.get("VISMA_ICP_FORCE_COMM") == "1"   # exercise the collective at N = 1
+        if self.world > 1 or self.force_comm:
+            import torch
+            import torch.distributed as dist
+            # VISMA_BENCH_BACKEND=gloo: dry run of the multi-rank logic on a box with fewer GPUs than ranks
+            self.backend = os.environ.get("VISMA_BENCH_BACKEND", "nccl")
+            self.local_rank = self.local_rank % max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(self.local_rank)
+            if self.backend == "nccl":
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+                self.tdev = "cuda"
+            else:
+                dist.init_process_group(backend=self.backend)
+            self.dist = dist
+            self.torch = torch
+
+    def barrier_sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def reduce_max(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def reduce_sum(self, x):
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def attach_comm(R, ctx, make_ctx, args):
+    """Bring up the library's all-reduce on every rank together.  Preference: the library's own RCCL
+    communicator (ncclAllReduce of 38 f64 on the context's stream); should it fail to come up on this
+    node, every rank falls back TOGETHER to the same exchange through torch.distributed."""
+    from visma_amd import _lib
+    torch, dist = R.torch, R.dist
+    ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or R.backend != "nccl") else 1
+    uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
+    if R.rank == 0 and ok:
+        try:
+            uid_bytes = _lib.comm_unique_id()
+        except Exception as e:      # noqa: BLE001
+            print("bench: ncclGetUniqueId failed (%s)" % e, file=sys.stderr)
+            ok = 0
+    uid = torch.tensor(list(uid_bytes), dtype=torch.uint8, device=R.tdev)
+    dist.broadcast(uid, 0)
+    flag = torch.tensor([ok], dtype=torch.int32, device=R.tdev)
+    dist.broadcast(flag, 0)
+    ok = int(flag.item())
+    if ok:
+        try:
+            ctx.comm_init(R.rank, R.world, bytes(uid.cpu().tolist()))
+        except Exception as e:      # noqa: BLE001
+            print("bench: rank %d: ncclCommInitRank failed (%s)" % (R.rank, e), file=sys.stderr)
+            ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=R.tdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()):
+        return ctx, "rccl (ncclAllReduce inside the library, saw %d ranks)" % R.world
+    if args.shard == "target" and not (R.world == 1 and not R.force_comm):
+        raise SystemExit("bench: the target-sharded mode needs the library's own RCCL communicator")
+    ctx = make_ctx()                                          # a context without the half-made communicator
+
+    def torch_allreduce(a):
+        t = torch.from_numpy(a.copy()).to(R.tdev)
+        dist.all_reduce(t)
+        a[:] = t.cpu().numpy()
+    ctx.set_allreduce(torch_allreduce, R.rank, R.world)
+    return ctx, "torch.distributed callback (%s, %d ranks)" % (R.backend, R.world)
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline: the reference itself where oracle/_ref is present
+# ------------------------------------------------------------------------------------------
+def cpu_registration():
     from oracle.oracle import Oracle, Ref
-    threads = os.cpu_count() or 1
     if Ref.available():
         r = Ref()
-        kind = "reference"
+        return "reference", (os.cpu_count() or 1), lambda s, t, rad, m, init=None: r.registration_icp(
+            s, t, rad, init=init, max_iter=m, rel_fitness=0.0, rel_rmse=0.0)
+    o = Oracle()
+    return "port", o.num_threads(), lambda s, t, rad, m, init=None: o.registration_icp(
+        s, t, rad, init=init, max_iter=m, rel_fitness=0.0, rel_rmse=0.0, grid=True)
 
-        def run(m):
-            t0 = time.perf_counter()
-            res = r.registration_icp(src, tgt, radius, max_iter=m, rel_fitness=0.0, rel_rmse=0.0)
-            return time.perf_counter() - t0, res
-    else:
-        o = Oracle()
-        kind = "port"
-        threads = o.num_threads()
 
-        def run(m):
-            t0 = time.perf_counter()
-            res = o.registration_icp(src, tgt, radius, max_iter=m, rel_fitness=0.0, rel_rmse=0.0, grid=True)
-            return time.perf_counter() - t0, res
-    t1, _ = run(1)
-    t2, res = run(1 + iters)
-    per_iter = max((t2 - t1) / iters, 1e-9)
+def cpu_baseline_c4(src, tgt, radius, iters, repeats):
+    """Steady-state rate = (t[1 + iters its] - t[1 it]) / iters (the one-off KD-tree build is not charged to
+    the iterations), median over `repeats` pairs of runs.  Bounded sample: the SAME clouds."""
+    kind, threads, run = cpu_registration()
+    rates, t1s = [], []
+    res = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        run(src, tgt, radius, 1)
+        t1 = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        res = run(src, tgt, radius, 1 + iters)
+        t2 = time.perf_counter() - t0
+        rates.append(iters / max(t2 - t1, 1e-9))
+        t1s.append(t1)
     return {
-        "value": 1.0 / per_iter, "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
-        "sample": "same clouds %d->%d, r=%.4g: %d steady-state iterations "
-                  "(t[%d its]-t[1 it]); setup (KD-tree build) + 2 passes %.2fs"
-                  % (len(src), len(tgt), radius, iters, iters + 1, t1),
-        "ms_per_iter": per_iter * 1e3, "setup_plus_first_iter_s": t1,
-        "T": np.asarray(res.T).tolist(),
+        "value": float(np.median(rates)), "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
+        "sample": "same clouds %d->%d, r=%.4g: %d steady-state iterations (t[%d its]-t[1 it]), median of %d; "
+                  "KD-tree build + 2 passes %.2fs; OMP_PROC_BIND=%s" % (
+                      len(src), len(tgt), radius, iters, iters + 1, repeats, float(np.median(t1s)),
+                      os.environ.get("OMP_PROC_BIND", "unset")),
+        "runs": [float(x) for x in rates], "ms_per_iter": 1e3 / float(np.median(rates)),
+        "setup_plus_first_iter_s": float(np.median(t1s)), "T": np.asarray(res.T).tolist(),
     }
+
+
+# ------------------------------------------------------------------------------------------
+# rooflines
+# ------------------------------------------------------------------------------------------
+def load_traffic(kind, ns_local, nt):
+    """HBM bytes per launch from the PMC passes of a PROFILED run of this same command (profiles/traffic.json);
+    not collected in this run."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        return tj.get("%s:%dx%d" % (kind, ns_local, nt), {}).get("hbm_bytes_per_nn_launch")
+    except Exception:
+        return None
 
 
 def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
@@ -112,11 +251,11 @@ def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
     b_alg = math.ceil(ns_local / s_tile) * nt * 16.0 + ns_local * 24.0
     tf = flops / (nn_ms * 1e-3) / 1e12
     return {
-        "kernel": "nn_brute_kernel", "bound": "mfma", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
+        "kernel": "nn_brute_kernel", "bound": "valu", "achieved": tf, "peak": PEAK_FP32_TFLOPS,
         "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS, "traffic": traffic,
-        "note": "fp32 compute roof: the brute-force pair loop is VALU-bound (~1e5 flop/B); gfx950's "
-                "dense f32 MFMA peak equals its f32 vector peak (157.3 TF); the kernel issues VALU "
-                "ops, no MFMA",
+        "traffic_source": "profiles/traffic.json (PMC passes of a profiled run, not this run)",
+        "note": "fp32 VALU roof (157.3 TF): the brute-force pair loop is VALU-bound (~1e5 flop/B) and issues "
+                "no MFMA",
         "avg_launch_ms": nn_ms, "alg_flops_per_launch": flops,
         "pairs_per_launch": float(ns_local) * nt,
         "hbm_streamed": {"alg_bytes_per_launch": b_alg, "s_tile": s_tile,
@@ -126,174 +265,91 @@ def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
     }
 
 
-def grid_roofline(ns_local, nt, nn_ms, cand_per_launch, cand27_per_launch, traffic):
-    # ALGORITHMIC bytes of ONE grid launch on one rank: per query 16 B source +
-    # 18 x 4 B cell-range lookups + 8 B (index, d2) out, plus 16 B per candidate
-    # target point EXAMINED (counted by the kernel; rows of cells that provably
-    # cannot hold a better candidate are skipped, so this is less than the full
-    # 3x3x3 neighbourhood, whose byte count is given for reference).
-    b_alg = ns_local * (16.0 + 72.0 + 8.0) + 16.0 * cand_per_launch
-    b_27 = ns_local * (16.0 + 72.0 + 8.0) + 16.0 * cand27_per_launch
+def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, cand27_per_launch, traffic, exact):
+    # ALGORITHMIC bytes of ONE grid launch on one rank.  Per query: the source point (32 B f64 in the exact
+    # search, 16 B fp32 otherwise) + 9 x 16 B cell-run lookups + 8 B (index, d2) out (+ 32 B: the winner in
+    # f64), plus 16 B per candidate target point EXAMINED (counted by the kernel; rows of cells that provably
+    # cannot hold a better candidate are skipped, so this is less than the full 3x3x3 neighbourhood, whose
+    # byte count is given for reference).
+    per_query = (32.0 + 144.0 + 8.0 + 32.0) if exact else (16.0 + 144.0 + 8.0)
+    b_alg = queries * per_query + 16.0 * cand_per_launch
+    b_27 = queries * per_query + 16.0 * cand27_per_launch
+    comp = nt_total * 16.0 + queries * (per_query - 144.0)
     gbps = b_alg / (nn_ms * 1e-3) / 1e9
     return {
-        "kernel": "nn_grid_reduce_kernel", "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
+        "kernel": "nn_grid_reduce_kernel" + (" (exact: fp32 ranking + f64 re-rank of the rounding band; fold fused)"
+                                             if exact else ""),
+        "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
         "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
+        "traffic_source": "profiles/traffic.json (PMC passes of a profiled run, not this run)",
         "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_alg,
-        "candidates_per_query": cand_per_launch / max(ns_local, 1),
+        "candidates_per_query": cand_per_launch / max(queries, 1),
         "full_27cell": {"bytes_per_launch": b_27, "gbps": b_27 / (nn_ms * 1e-3) / 1e9,
-                        "candidates_per_query": cand27_per_launch / max(ns_local, 1)},
-        "compulsory_bytes": nt * 16.0 + ns_local * 24.0,
-        "note": "fused transform + grid NN + Jacobian/residual reduction: ~10 dependent memory round trips "
-                "per query (source, 18 cell bounds, row after row, winner); PMC: texture-address unit 45 % "
-                "busy, L1 tag rate 53 % of its measured ceiling, HBM+MALL 40 %, VALU 30 % -- no unit saturated",
+                        "candidates_per_query": cand27_per_launch / max(queries, 1)},
+        "compulsory_bytes": comp,
+        "frac_on_compulsory_bytes": comp / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+        "note": "one launch per iteration: transform + grid NN + f64 re-rank + Jacobian/residual reduction + fold. "
+                "Bound in practice by per-lane gathers (one L1 line access per 16-B candidate) alternating with "
+                "VALU phases, not by HBM: see DESIGN.md 4.1b",
     }
 
 
-def load_traffic(kind, ns_local, nt):
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        tj = json.load(open(tpath))
-        return tj.get("%s:%dx%d" % (kind, ns_local, nt), {}).get("hbm_bytes_per_nn_launch")
-    except Exception:
-        return None
-
-
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d`"
-                             % (args.gpus, args.gpus))
-        args.gpus = world
-
-    force_comm = os.environ.get("VISMA_ICP_FORCE_COMM") == "1"   # exercise RCCL even at N=1
-    dist = None
-    if world > 1 or force_comm:
-        import torch
-        import torch.distributed as dist
-        # VISMA_BENCH_BACKEND=gloo: a dry run of the multi-rank logic on a box with fewer GPUs than ranks
-        # (ranks share devices, torch tensors stay on the CPU, the exchange is the torch callback)
-        backend = os.environ.get("VISMA_BENCH_BACKEND", "nccl")
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-        tdev = "cuda" if backend == "nccl" else "cpu"
-
-    from visma_amd import _lib, build, synth
-    if rank == 0:
-        build.build_lib()
-    if dist is not None:
-        dist.barrier()
-
-    ns, nt = args.ns, args.nt
-    src, tgt, T_gt, radius = synth.make_pair(ns, nt, motion="radius")
-
-    ctx = _lib.Context(local_rank)
-    # the library's default searches clouds of up to 131,072 source points in f64 (exact ties);
-    # what counts here is the GLOBAL problem, not a rank's slice of it
-    ctx.set_search_precision("auto" if ns <= 131072 else "f32")
-    if args.shard == "source" or (world == 1 and not force_comm):
-        # source shard of this rank (contiguous slice; full target everywhere)
-        lo = (ns * rank) // world
-        hi = (ns * (rank + 1)) // world
-        ns_local, nt_local = hi - lo, nt
-        # every rank must centre on the SAME point: set_clouds_f64 centres on the
-        # (full) target centroid, which all ranks share.
-        ctx.set_clouds_f64(src[lo:hi], tgt)
+# ------------------------------------------------------------------------------------------
+# workload c4
+# ------------------------------------------------------------------------------------------
+def c4_context(R, args, src, tgt, ns, nt, prec="exact"):
+    from visma_amd import _lib
+    ctx = _lib.Context(R.local_rank)
+    ctx.set_search_precision(prec)
+    sharded = not (R.world == 1 and not R.force_comm)
+    if args.shard == "source" or not sharded:
+        lo, hi = (ns * R.rank) // R.world, (ns * (R.rank + 1)) // R.world
+        ctx.set_clouds_f64(src[lo:hi], tgt)       # every rank centres on the (full) target centroid
         ctx.set_global_source_count(ns)
-    else:
-        # target shard of this rank (contiguous slice of the global index space; all sources)
-        lo = (nt * rank) // world
-        hi = (nt * (rank + 1)) // world
-        ns_local, nt_local = ns, hi - lo
-        ctx.set_target_shard(lo, nt, tgt.mean(0))
-        ctx.set_clouds_f64(src, tgt[lo:hi])
-    comm_kind = "none"
-    if dist is not None:
-        import torch
-        # the library's own RCCL communicator (dlopen'ed librccl): one ncclAllReduce of 38 f64 per
-        # iteration on the context's stream.  Should it fail to come up on this node, every rank falls
-        # back TOGETHER to the same exchange through torch.distributed (RCCL as well, but via a host
-        # callback: slower) rather than leaving the job without a number.
-        ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or backend != "nccl") else 1
-        uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
-        if rank == 0 and ok:
-            try:
-                uid_bytes = _lib.comm_unique_id()
-            except Exception as e:      # noqa: BLE001
-                print("bench: ncclGetUniqueId failed (%s)" % e, file=sys.stderr)
-                ok = 0
-        uid = torch.tensor(list(uid_bytes), dtype=torch.uint8, device=tdev)
-        dist.broadcast(uid, 0)
-        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
-        dist.broadcast(flag, 0)
-        ok = int(flag.item())
-        if ok:
-            try:
-                ctx.comm_init(rank, world, bytes(uid.cpu().tolist()))
-            except Exception as e:      # noqa: BLE001
-                print("bench: rank %d: ncclCommInitRank failed (%s)" % (rank, e), file=sys.stderr)
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=tdev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()):
-            comm_kind = "rccl"
-        else:
-            comm_kind = "torch.distributed callback"
-            if args.shard == "target" and not (world == 1 and not force_comm):
-                raise SystemExit("bench: the target-sharded mode needs the library's own RCCL communicator")
-            ctx2 = _lib.Context(local_rank)                   # a context without the half-made communicator
-            ctx2.set_search_precision("auto" if ns <= 131072 else "f32")
-            ctx2.set_clouds_f64(src[(ns * rank) // world:(ns * (rank + 1)) // world], tgt)
-            ctx2.set_global_source_count(ns)
-            ctx = ctx2
+        return ctx, hi - lo, nt
+    lo, hi = (nt * R.rank) // R.world, (nt * (R.rank + 1)) // R.world
+    ctx.set_target_shard(lo, nt, tgt.mean(0))
+    ctx.set_clouds_f64(src, tgt[lo:hi])
+    return ctx, ns, hi - lo
 
-            def torch_allreduce(a):
-                t = torch.from_numpy(a.copy()).to(tdev)
-                dist.all_reduce(t)
-                a[:] = t.cpu().numpy()
-            ctx.set_allreduce(torch_allreduce, rank, world)
 
-    def sync_all():
-        if dist is not None:
-            import torch
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def reduce_max(x):
-        if dist is None:
-            return x
-        import torch
-        t = torch.tensor([x], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
-    ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID, "brute": _lib.NN_BRUTE}[args.nn])
-    # HIP-event timing of the kernels: every launch with brute force (117 ms each), every
-    # 4th ICP pass with the grid (four event records cost ~14 us of a ~70 us iteration)
-    prof_every = 1 if args.nn == "brute" else 4
+def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every):
+    """W untimed + K timed ICP iterations, barrier + synchronize on both sides, max over ranks."""
+    from visma_amd import _lib
+    ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID, "brute": _lib.NN_BRUTE}[nn_mode])
     ctx.set_profiling(prof_every)
     T = np.eye(4)
     ctx.get_timing(reset=True)
-    if args.warmup > 0:
-        T, _ = ctx.iterate(T, radius, args.warmup)       # also builds the grid (one-off)
+    if warmup > 0:
+        T, _ = ctx.iterate(T, radius, warmup)       # also builds the grid (one-off)
     setup = ctx.get_timing(reset=True)
-    mode = "grid" if ctx.nn_mode_used() == _lib.NN_GRID else "brute"
-    sync_all()
+    R.barrier_sync()
     t0 = time.perf_counter()
-    T, last = ctx.iterate(T, radius, args.steps)       # every step ends with a stream sync
-    sync_all()
-    elapsed = reduce_max(time.perf_counter() - t0)
+    T, last = ctx.iterate(T, radius, steps)          # every step ends with the statistics on the host
+    R.barrier_sync()
+    elapsed = R.reduce_max(time.perf_counter() - t0)
     tm = ctx.get_timing(reset=True)
-    nn_ms = reduce_max(tm["nn_ms"] / max(tm["nn_launches"], 1))
-    cand = tm["grid_candidates"] / max(tm["nn_launches"], 1)
-    cand27 = tm["grid_candidates_27cell"] / max(tm["nn_launches"], 1)
+    ctx.set_profiling(0)
+    return T, last, elapsed, tm, setup
+
+
+def run_c4(R, args):
+    from visma_amd import _lib, synth
+    ns, nt = args.ns, args.nt
+    src, tgt, T_gt, radius = synth.make_pair(ns, nt, motion="radius")
+    ctx, ns_local, nt_local = c4_context(R, args, src, tgt, ns, nt)
+    comm_kind = "none"
+    if R.dist is not None:
+        ctx, comm_kind = attach_comm(R, ctx, lambda: c4_context(R, args, src, tgt, ns, nt)[0], args)
+    # HIP-event timing of the kernels: every launch with brute force (117 ms each), every 4th ICP pass with
+    # the grid (two event records cost ~7 us of a ~60 us iteration)
+    prof_every = 1 if args.nn == "brute" else 4
+    T, last, elapsed, tm, setup = timed_iterations(R, ctx, radius, args.warmup, args.steps, args.nn, prof_every)
+    mode = "grid" if ctx.nn_mode_used() == _lib.NN_GRID else "brute"
+    search = ctx.search_mode_used()
+    nl = max(tm["nn_launches"], 1)
+    nn_ms = R.reduce_max(tm["nn_ms"] / nl)
+    cand, cand27 = tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl
 
     # a few brute-force steps (outside the timed region) for the north_star kernel's own numbers
     brute = None
@@ -306,57 +362,75 @@ def main():
         Tb, _ = ctx.iterate(np.eye(4), radius, args.brute_steps)
         tb = time.perf_counter() - tb0
         tmb = ctx.get_timing(reset=True)
-        # same answer as the grid from the same start (bit-identical correspondences)
+        ctx.set_profiling(0)
         Tg, _ = (ctx.set_nn_mode(_lib.NN_GRID), ctx.iterate(np.eye(4), radius, args.brute_steps))[1]
         brute = {"steps": args.brute_steps, "ms_per_step": tb / args.brute_steps * 1e3,
-                 "nn_ms": reduce_max(tmb["nn_ms"] / max(tmb["nn_launches"], 1)),
+                 "nn_ms": R.reduce_max(tmb["nn_ms"] / max(tmb["nn_launches"], 1)),
                  "rel_frobenius_vs_grid": synth.rel_frobenius(Tb, Tg)}
         ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID}[args.nn])
 
-    # the same workload with the double-precision search (outside the timed region; 1 GPU only):
-    # what exact tie-breaking would cost at this size
-    f64_extra = None
-    if world == 1 and mode == "grid" and not ctx.search_is_f64() and args.f64_steps > 0:
-        c64 = _lib.Context(local_rank)
-        c64.set_search_precision("f64")
-        c64.set_clouds_f64(src, tgt)
-        c64.set_nn_mode(_lib.NN_GRID)
-        c64.set_profiling(1)
-        T64w, _ = c64.iterate(np.eye(4), radius, 2)
-        c64.get_timing(reset=True)
+    # the same workload with the plain fp32 search of round 1 (no f64 re-rank), outside the timed region
+    f32_extra = None
+    if R.world == 1 and mode == "grid" and search == "exact" and args.f32_steps > 0:
+        c32 = _lib.Context(R.local_rank)
+        c32.set_search_precision("f32")
+        c32.set_clouds_f64(src, tgt)
+        c32.set_nn_mode(_lib.NN_GRID)
+        c32.iterate(np.eye(4), radius, 2)
         t0f = time.perf_counter()
-        T64, _ = c64.iterate(np.eye(4), radius, args.f64_steps)
+        T32, _ = c32.iterate(np.eye(4), radius, args.f32_steps)
         tf = time.perf_counter() - t0f
-        tm64 = c64.get_timing(reset=True)
-        Tf32, _ = ctx.iterate(np.eye(4), radius, args.f64_steps)
-        f64_extra = {"steps": args.f64_steps, "iterations_per_sec": args.f64_steps / tf,
-                     "nn_ms": tm64["nn_ms"] / max(tm64["nn_launches"], 1),
-                     "rel_frobenius_vs_f32_search": synth.rel_frobenius(T64, Tf32)}
-        del c64
+        Tex, _ = ctx.iterate(np.eye(4), radius, args.f32_steps)
+        f32_extra = {"steps": args.f32_steps, "iterations_per_sec": args.f32_steps / tf,
+                     "rel_frobenius_vs_exact_search": synth.rel_frobenius(T32, Tex),
+                     "note": "fp32 ranking only (round-1 kernel): may decide near-ties / radius cases "
+                             "differently from the reference"}
+        c32.close()
 
-    if rank == 0:
+    # weak scaling: source N x 262,144 -> target N x 4,194,304, same sharding (after the timed region)
+    weak = None
+    if R.world > 1 and not args.no_weak and args.shard == "source":
+        wns, wnt = ns * R.world, nt * R.world
+        wsrc, wtgt, _, wr = synth.make_pair(wns, wnt, motion="radius")
+        wctx, wns_local, _ = c4_context(R, args, wsrc, wtgt, wns, wnt)
+        wctx, _ = attach_comm(R, wctx, lambda: c4_context(R, args, wsrc, wtgt, wns, wnt)[0], args)
+        _, wlast, welapsed, wtm, _ = timed_iterations(R, wctx, wr, args.warmup, args.steps, args.nn, 4)
+        weak = {"ns": wns, "nt": wnt, "radius": wr, "ms_per_step": welapsed / args.steps * 1e3,
+                "icp_iterations_per_sec": args.steps / welapsed,
+                "point_iterations_per_sec": float(wns) * args.steps / welapsed,
+                "nn_kernel_ms": R.reduce_max(wtm["nn_ms"] / max(wtm["nn_launches"], 1)),
+                "fitness": wlast.fitness_,
+                "note": "per-rank work fixed (262,144 queries against a target N times denser): ideal weak "
+                        "scaling keeps icp_iterations_per_sec at the N = 1 value"}
+        wctx.close()
+
+    out = None
+    if R.rank == 0:
         tile = _lib.tile_config()
+        exact = search != "f32"
         if mode == "grid":
-            roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, cand27, load_traffic("grid", ns_local, nt_local))
+            roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, cand27, load_traffic("grid", ns_local, nt_local), exact)
         else:
             roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
         roofline["launches_timed"] = tm["nn_launches"]
         roofline["timed_every_nth_pass"] = prof_every
-        roofline["reduce_finalize_avg_ms"] = tm["reduce_ms"] / max(tm["reduce_launches"], 1)
+        roofline["separate_fold_launch_avg_ms"] = tm["reduce_ms"] / max(tm["reduce_launches"], 1)
+        par = ("source-sharded x%d, 1 all-reduce(38 f64)/iter via %s" % (R.world, comm_kind)
+               if args.shard == "source" else
+               "target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter via %s" % (R.world, ns, comm_kind))
         out = {
             "metric": "icp_iterations_per_sec", "value": args.steps / elapsed,
-            "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps,
+            "unit": "ICP iterations/s", "n_gpus": R.world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64" if ctx.search_is_f64() else "f32", "data": "synthetic",
-            "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, "
-                                   "nn=%s" % (ns, nt, args.steps, mode),
-                       "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode,
-                       "parallelism": ("source-sharded x%d, 1 ncclAllReduce(38 f64)/iter%s" % (
-                           world, "" if comm_kind in ("rccl", "none") else " [" + comm_kind + "]"))
-                       if args.shard == "source" else
-                       ("target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter" % (world, ns))},
-            "mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, nn=%s, "
+                                   "search=%s" % (ns, nt, args.steps, mode, search),
+                       "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode, "search": search,
+                       "arithmetic": "fp32 candidate ranking, f64 re-rank of the rounding band, f64 statistics",
+                       "parallelism": par},
+            "candidates_evaluated_per_sec": cand * R.world * args.steps / elapsed if mode == "grid" else float(ns) * nt * args.steps / elapsed,
+            "equivalent_bruteforce_mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
             "matched_corr_per_sec": last.num_correspondences * args.steps / elapsed,
             "fitness": last.fitness_, "inlier_rmse": last.inlier_rmse_,
             "err_vs_T_gt": synth.rel_frobenius(T, T_gt),
@@ -370,20 +444,242 @@ def main():
                      mpairs_per_sec=float(ns) * nt / brute["ms_per_step"] / 1e3,
                      rel_frobenius_vs_grid=brute["rel_frobenius_vs_grid"])
             out["brute_force"] = b
-        if f64_extra is not None:
-            out["f64_search"] = f64_extra
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(src, tgt, radius, args.cpu_iters)
-            # parity of the two paths on this workload, same iteration count
-            Tg = ctx.run(None, radius, 1 + args.cpu_iters, 0.0, 0.0).transformation_
-            cb["gpu_vs_cpu_rel_frobenius"] = synth.rel_frobenius(Tg, np.array(cb.pop("T")))
+        if f32_extra is not None:
+            out["f32_search"] = f32_extra
+        if weak is not None:
+            out["weak_scaling"] = weak
+        if R.world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline_c4(src, tgt, radius, args.cpu_iters, args.cpu_repeats)
+            Tg = ctx.run(None, radius, 1 + args.cpu_iters, 0.0, 0.0)       # parity on this workload, same iteration count
+            cb["gpu_vs_cpu_rel_frobenius"] = synth.rel_frobenius(Tg.transformation_, np.array(cb.pop("T")))
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
+    ctx.close()
+    return out
 
-    if dist is not None:
-        dist.barrier()
-        ctx.close()
-        dist.destroy_process_group()
+
+# ------------------------------------------------------------------------------------------
+# workloads c3 / c5: independent problems, replicas only
+# ------------------------------------------------------------------------------------------
+def c3_problems():
+    """12 objects x 24 yaw starts: source 4k..40k points, target half of it, r = 0.02."""
+    from visma_amd import synth
+    rng = np.random.default_rng(3)
+    objs = []
+    for i in range(12):
+        ns = int(rng.integers(4000, 40000))
+        src, tgt, _, _ = synth.make_pair(ns, ns // 2, seed_t=300 + i, seed_s=400 + i)
+        objs.append((src, tgt))
+    probs = []
+    for oi, (src, tgt) in enumerate(objs):
+        for k in range(24):
+            probs.append((src, tgt, synth.make_T(synth.rot_y(2 * np.pi * k / 24), [0, 0, 0]), 0.02, oi))
+    return objs, probs
+
+
+def run_c3(R, args):
+    from visma_amd import _lib, synth
+    objs, probs = c3_problems()
+    # static deal: objects (with their 24 yaw starts, which share clouds) sorted by size, round-robin
+    order = sorted(range(len(objs)), key=lambda i: -len(objs[i][0]) * len(objs[i][1]))
+    mine = set(order[R.rank::R.world])
+    my = [p[:4] for p in probs if p[4] in mine]
+    ctx = _lib.Context(R.local_rank)
+    iters = 30
+    for _ in range(max(args.warmup, 1)):
+        ctx.run_batch(my, max_iter=iters)
+    ctx.set_profiling(1)
+    ctx.get_timing(reset=True)
+    R.barrier_sync()
+    t0 = time.perf_counter()
+    its = 0
+    for _ in range(args.steps):
+        res = ctx.run_batch(my, max_iter=iters)
+        its += sum(r.iterations for r in res)
+    R.barrier_sync()
+    elapsed = R.reduce_max(time.perf_counter() - t0)
+    tm = ctx.get_timing(reset=True)
+    ctx.set_profiling(0)
+    total_its = R.reduce_sum(float(its))
+    nl = max(tm["nn_launches"], 1)
+    nn_ms = R.reduce_max(tm["nn_ms"] / nl)
+    out = None
+    if R.rank == 0:
+        queries = sum(len(p[0]) for p in my)
+        nt_total = sum(len(objs[i][1]) for i in mine)
+        roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True)
+        roofline["launches_timed"] = tm["nn_launches"]
+        out = {
+            "metric": "icp_iterations_per_sec", "value": total_its / elapsed, "unit": "ICP iterations/s",
+            "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3 all objects of one scene in flight: 12 objects x 24 yaw starts = 288 ICPs, "
+                                   "source 4k..40k -> target half, r=0.02, <= 30 iterations each",
+                       "problems": len(probs), "source_points_per_pass": sum(len(p[0]) for p in probs),
+                       "search": ctx.search_mode_used(),
+                       "parallelism": "replicas only: objects dealt round-robin by size over %d rank(s), no collective" % R.world},
+            "problems_per_sec": len(probs) * args.steps / elapsed,
+            "roofline": roofline,
+        }
+        if R.world == 1 and not args.no_cpu_baseline:
+            kind, threads, run = cpu_registration()
+            t0 = time.perf_counter()
+            n_it, worst = 0, 0.0
+            sample = probs[::24][:6]                     # the yaw-0 start of six objects
+            for src, tgt, init, r, _ in sample:
+                w = run(src, tgt, r, iters, init)
+                n_it += iters
+            dt = time.perf_counter() - t0
+            one = _lib.Context(R.local_rank)
+            for src, tgt, init, r, _ in sample[:3]:
+                one.set_clouds_f64(src, tgt)
+                g = one.run(init, r, iters, 0.0, 0.0)
+                w = run(src, tgt, r, iters, init)
+                worst = max(worst, synth.rel_frobenius(g.transformation_, w.T))
+            one.close()
+            out["cpu_baseline"] = {"value": n_it / dt, "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
+                                   "sample": "6 of the 288 problems, %d iterations each, one after another "
+                                             "(KD-tree builds included)" % iters,
+                                   "gpu_vs_cpu_rel_frobenius": worst}
+    ctx.close()
+    return out
+
+
+def c5_corpus():
+    """Synthetic corpus: 6 scenes x 8 CAD candidates; a work item = one orientation-constrained registration
+    (24 yaw starts, src/annotation.cpp:29-64) of a candidate against a scene."""
+    from visma_amd import synth
+    rng = np.random.default_rng(5)
+    scenes = [synth.surface_points(int(rng.integers(15000, 40000)), 900 + s).astype(np.float32).astype(np.float64)
+              for s in range(6)]
+    cads = []
+    for c in range(8):
+        n = int(rng.integers(3000, 12000))
+        p = synth.surface_points(n, 950 + c)
+        Ti = np.linalg.inv(synth.make_T(synth.rot_y(rng.uniform(-0.05, 0.05)), rng.standard_normal(3) * 0.01))
+        cads.append((p @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32).astype(np.float64))
+    items = [(s, c) for s in range(len(scenes)) for c in range(len(cads))]
+    return scenes, cads, items
+
+
+def run_c5(R, args):
+    from visma_amd import _lib
+    scenes, cads, items = c5_corpus()
+    radius, level, iters = 0.05, 24, 30
+    ctx = _lib.Context(R.local_rank)
+    store = None
+    if R.dist is not None:
+        store = R.torch.distributed.distributed_c10d._get_default_store()
+
+    def pull(step):
+        """next work item of this pass: a shared counter when there are several ranks"""
+        if store is None:
+            for i in range(len(items)):
+                yield i
+            return
+        while True:
+            i = store.add("c5_next_%d" % step, 1) - 1
+            if i >= len(items):
+                return
+            yield i
+
+    def one_pass(step):
+        its, done = 0, 0
+        for i in pull(step):
+            s, c = items[i]
+            ctx.set_clouds_f64(cads[c], scenes[s])
+            best, lvl, per = ctx.run_yaw_sweep(level, radius, iters)
+            its += sum(p.iterations for p in per)
+            done += 1
+        return its, done
+
+    for w in range(max(args.warmup, 1)):
+        one_pass(-1 - w)
+    R.barrier_sync()
+    t0 = time.perf_counter()
+    its = done = 0
+    for step in range(args.steps):
+        a, b = one_pass(step)
+        its += a
+        done += b
+    R.barrier_sync()
+    elapsed = R.reduce_max(time.perf_counter() - t0)
+    total_its = R.reduce_sum(float(its))
+    per_rank_items = done
+    # roofline of the sweep kernel: one profiled pass over the first items (after the timed region)
+    roofline = None
+    if R.rank == 0:
+        ctx.set_profiling(1)
+        b_alg = b_comp = ms = 0.0
+        launches = 0
+        for s, c in items[:8]:
+            ctx.set_clouds_f64(cads[c], scenes[s])
+            ctx.get_timing(reset=True)
+            ctx.run_yaw_sweep(level, radius, iters)
+            tm = ctx.get_timing(reset=True)
+            nl = tm["nn_launches"]
+            q = len(cads[c]) * level
+            b_alg += nl * q * (32.0 + 144.0 + 8.0 + 32.0) + 16.0 * tm["grid_candidates"]
+            b_comp += nl * (len(scenes[s]) * 16.0 + q * 72.0)
+            ms += tm["nn_ms"]
+            launches += nl
+        ctx.set_profiling(0)
+        if ms > 0:
+            gbps = b_alg / (ms * 1e-3) / 1e9
+            roofline = {"kernel": "nn_grid_reduce_kernel (24 problems per launch over shared clouds, exact search, fold fused)",
+                        "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                        "traffic": None, "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": b_alg / max(launches, 1),
+                        "compulsory_bytes": b_comp / max(launches, 1), "launches_timed": launches,
+                        "note": "small clouds: launch- and latency-bound (every launch is a few tens of microseconds)"}
+    out = None
+    if R.rank == 0:
+        out = {
+            "metric": "icp_iterations_per_sec", "value": total_its / elapsed, "unit": "ICP iterations/s",
+            "n_gpus": R.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C5 corpus: %d scenes x %d CAD candidates = %d orientation-constrained registrations "
+                                   "(24 yaw starts each, <= %d iterations, r=%.3g) per pass" % (
+                                       len(scenes), len(cads), len(items), iters, radius),
+                       "items": len(items), "search": ctx.search_mode_used(),
+                       "parallelism": "replicas only: %d rank(s) pull work items from a shared counter, no collective" % R.world},
+            "registrations_per_sec": len(items) * args.steps / elapsed,
+            "items_done_by_rank0": per_rank_items,
+            "roofline": roofline,
+        }
+        if R.world == 1 and not args.no_cpu_baseline:
+            kind, threads, run = cpu_registration()
+            from visma_amd import synth
+            t0 = time.perf_counter()
+            n_it = 0
+            for s, c in items[:2]:
+                for k in range(0, level, 6):                          # 4 of the 24 yaw starts of two items
+                    run(cads[c], scenes[s], radius, iters, synth.make_T(synth.rot_y(2 * np.pi * k / level), [0, 0, 0]))
+                    n_it += iters
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": n_it / dt, "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
+                                   "sample": "8 of the %d yaw starts (4 each of two work items), %d iterations each, "
+                                             "KD-tree builds included" % (len(items) * level, iters)}
+    ctx.close()
+    return out
+
+
+def main():
+    args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        respawn_under_torchrun(args.gpus)
+    R = Ranks()
+    if R.world != args.gpus:
+        args.gpus = R.world
+    from visma_amd import build
+    if R.rank == 0:
+        build.build_lib()
+    if R.dist is not None:
+        R.dist.barrier()
+    out = {"c4": run_c4, "c3": run_c3, "c5": run_c5}[args.workload](R, args)
+    if R.rank == 0 and out is not None:
+        print(json.dumps(out), flush=True)
+    R.close()
 
 
 if __name__ == "__main__":

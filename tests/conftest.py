@@ -64,6 +64,30 @@ def gpu_ctx(request, lib, _gpu_ctx_session):
     ctx.set_nn_mode(lib.NN_AUTO)
 
 
+@pytest.fixture(scope="session")
+def _gpu_ctx_exact_session(lib):
+    """A context with the DEFAULT search: exact (fp32 ranking, f64 re-rank of the rounding band)."""
+    return lib.Context(0)
+
+
+@pytest.fixture(params=["brute", "grid", "exact"])
+def gpu_ctx_any(request, lib, _gpu_ctx_session, _gpu_ctx_exact_session):
+    """Every search the library has: the two fp32-specification kernels (brute force, grid) and the
+    default exact grid search.  `ctx.exact` tells the test which bar applies: the fp32 kernels may
+    decide a near-tie or a pair at the radius differently from the reference (a few in 1e5 queries);
+    the exact search may not."""
+    if request.param == "exact":
+        ctx = _gpu_ctx_exact_session
+        ctx.set_nn_mode(lib.NN_AUTO)
+    else:
+        ctx = _gpu_ctx_session
+        ctx.set_nn_mode({"brute": lib.NN_BRUTE, "grid": lib.NN_GRID}[request.param])
+    ctx.nn_mode_name = request.param
+    ctx.exact = request.param == "exact"
+    yield ctx
+    ctx.set_nn_mode(lib.NN_AUTO)
+
+
 @pytest.fixture()
 def gpu_ctx_auto(lib, _gpu_ctx_session):
     _gpu_ctx_session.set_nn_mode(lib.NN_AUTO)

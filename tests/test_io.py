@@ -55,13 +55,19 @@ def test_ply_semantics_spelled_out(io):
     assert p["normals"].shape == (0, 3) and p["colors"].shape == (0, 3) and p["faces"].shape == (0, 3)
 
 
-@pytest.mark.parametrize("name", ["bad_truncated.ply", "bad_novertex.ply", "does_not_exist.ply", "tri.obj"])
+@pytest.mark.parametrize("name", ["bad_truncated.ply", "bad_novertex.ply", "does_not_exist.ply", "tri.obj",
+                                  "bad_hugecount.ply", "bad_hugecount_ascii.ply"])
 def test_ply_failures_are_reported(io, gold, name):
     key = name.replace(".", "_") + "_ok"
     if key in gold and name.endswith(".ply"):
         assert not gold[key].any()                       # the reference fails on it too
     with pytest.raises(io.IoError):
         io.read_ply(os.path.join(D, name))               # (an OBJ file is "not a PLY file")
+
+
+def test_repeated_face_element_keeps_the_first(io):
+    c = io.read_ply(os.path.join(D, "two_faces.ply"))
+    assert c["faces"].shape == (1, 3) and c["xyz"].shape == (3, 3)
 
 
 OBJ_OK = ["tri.obj", "mixed_syntax.obj", "negative.obj", "quads.obj", "colors.obj"]

@@ -259,8 +259,10 @@ public:
         HIP_TRY(hipStreamSynchronize(stream_));
         return VISMA_ICP_OK;
     }
-    bool search_is_f64() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr && !exact_; }
-    bool search_is_exact() const override { return use_grid_ && d_src64_ != nullptr && d_sorted64_ != nullptr; }
+    // arithmetic of the last pass / loop / batch: 0 fp32 ranking only, 1 exact (fp32 + f64 re-rank), 2 f64
+    bool search_is_f64() const override { return last_mode_ == 2; }
+    bool search_is_exact() const override { return last_mode_ != 0; }
+    int grid_search_mode() const { return (use_grid_ && d_src64_ && d_sorted64_) ? (exact_ ? 1 : 2) : 0; }
     void set_exact(bool on) override { exact_ = on; }
     int set_target_normals64(const Pt64 *n) override
     {
@@ -348,6 +350,7 @@ public:
         int rc = choose_mode(max_dist);
         if (rc) return rc;
         view_offset_ = 0;
+        last_mode_ = grid_search_mode();
         if (use_grid_) {
             // the grid search is fused with the reduction: it runs in reduce()
             // (or in get_correspondences() if no reduction is asked for)
@@ -570,6 +573,7 @@ public:
         const int64_t ns_rounded = ((ns_ + kBlock - 1) / kBlock) * kBlock;
         view_offset_ = 0;
         loop_out_stride_ = ns_rounded;
+        last_mode_ = grid_search_mode();
         if (use_grid_) {
             rc = ensure_aux(ns_rounded * nprob);
             if (rc) return rc;
@@ -826,6 +830,7 @@ public:
             HIP_TRY(hipHostMalloc((void **)&h_state_, sizeof(DevIcpState) * B, hipHostMallocDefault));
             state_cap_ = B;
         }
+        last_mode_ = f64 ? (exact_ ? 1 : 2) : 0;
         // ---- uploads + per-problem grid builds (stream ordered, no host sync)
         int e0 = -1;
         if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -890,7 +895,8 @@ public:
                                                     (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_,
                                                     f64 ? (const Pt64 *)bt_src64_ : nullptr,
                                                     f64 ? (const Pt64 *)bt_sorted64_ : nullptr, exact_ ? 1 : 0,
-                                                    fused_fold_ ? &bfa : nullptr));
+                                                    fused_fold_ ? &bfa : nullptr,
+                                                    profiling_ ? (unsigned long long *)d_cand_ : nullptr));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
                 if (fused_fold_) HIP_TRY(launch_solve_state(st, B, stream_));
@@ -1257,6 +1263,7 @@ private:
     void *d_partials2_ = nullptr, *d_tickets_ = nullptr, *d_tstats_ = nullptr;
     size_t tickets_cap_ = 0;     // words in d_tickets_ (= rows in d_partials2_)
     Xform64 T64_last_{};         // transform of the last nn_pass, f64
+    int last_mode_ = 0;          // see search_is_f64()
     bool use_tile() const
     {
         return tile_enabled_ && use_grid_ && exact_ && d_src64_ && d_sorted64_ && grid_.sub == 1 && !tshard_;

@@ -851,7 +851,8 @@ template <int G, int U, bool ONE, bool F64, bool HYB>
 static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const float4 *src,
                                 const float4 *sorted, const unsigned *start, const ProbDesc *descs,
                                 int nprob, int *idx_out, float *d2_out, double *partials,
-                                const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64, const FoldArgs &fold)
+                                const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64, const FoldArgs &fold,
+                                unsigned long long *cand)
 {
     const Xform32 T32{};
     const Xform64 T64{};
@@ -859,7 +860,7 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
     const GridParams g{};
     hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE, F64, HYB>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
-                       d2_out, partials, (unsigned long long *)nullptr, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0,
+                       d2_out, partials, cand, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0,
                        (const Pt64 *)nullptr, fold);
 }
 
@@ -871,7 +872,7 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int32_t *idx_out, float *d2_out, double *partials,
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64, int exact,
-                                       const FoldArgs *fold)
+                                       const FoldArgs *fold, unsigned long long *cand_count)
 {
     if (!st || !descs || (src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     const FoldArgs fa = fold ? *fold : FoldArgs{};
@@ -881,17 +882,17 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
 #define VISMA_BATCH_CASE(GG, UU)                                                                              \
     if (G == GG && U == UU) {                                                                                 \
         if (src64 && exact && one_per_lane)                                                                   \
-            launch_grid_batch_t<GG, UU, true, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa);            \
+            launch_grid_batch_t<GG, UU, true, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);            \
         else if (src64 && exact)                                                                              \
-            launch_grid_batch_t<GG, UU, false, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa);           \
+            launch_grid_batch_t<GG, UU, false, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);           \
         else if (src64 && one_per_lane)                                                                       \
-            launch_grid_batch_t<GG, UU, true, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa);            \
+            launch_grid_batch_t<GG, UU, true, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);            \
         else if (src64)                                                                                       \
-            launch_grid_batch_t<GG, UU, false, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa);           \
+            launch_grid_batch_t<GG, UU, false, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);           \
         else if (one_per_lane)                                                                                \
-            launch_grid_batch_t<GG, UU, true, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa);          \
+            launch_grid_batch_t<GG, UU, true, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count);          \
         else                                                                                                  \
-            launch_grid_batch_t<GG, UU, false, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa);         \
+            launch_grid_batch_t<GG, UU, false, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count);         \
         launched = true;                                                                                      \
     }
     VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)

@@ -250,9 +250,19 @@ int visma_io_read_ply(const char *path, visma_io_cloud *out)
     visma_io_cloud c;
     std::memset(&c, 0, sizeof(c));
     auto bail = [&](const std::string &m) { visma_io_free_cloud(&c); return fail(VISMA_IO_ERR_FORMAT, m); };
+    bool have_faces = false;
     for (const auto &e : elems) {
         const bool is_vertex = &e == ve;
         const bool is_face = e.name == "face";
+        // A declared count is not trusted: it must fit 32-bit indices and the bytes that are left
+        // (a record, or an ASCII value, takes at least one byte).  A wrapped 3 * count would
+        // otherwise size a tiny buffer that the decode below overruns.
+        if (e.count < 0 || e.count > 0x7fffffffll) return bail("element count out of range");
+        {
+            const int64_t left = (int64_t)(end - p);
+            const int64_t per = (format != 0 && e.fixed()) ? std::max(1, e.record()) : 1;
+            if (!e.props.empty() && e.count > left / per) return bail("unable to read file: truncated element data");
+        }
         int fprop = is_face ? e.find("vertex_indices") : -1;
         if (is_face && fprop < 0) fprop = e.find("vertex_index");
         if (is_face && fprop >= 0 && !e.props[fprop].list) fprop = -1;
@@ -276,7 +286,11 @@ int visma_io_read_ply(const char *path, visma_io_cloud *out)
             if (c.normals && (want[4] < 0 || want[5] < 0)) std::memset(c.normals, 0, sizeof(double) * 3 * (size_t)c.n);
             if (c.colors && (want[7] < 0 || want[8] < 0)) std::memset(c.colors, 0, sizeof(double) * 3 * (size_t)c.n);
         }
+        // (rply hands an element's values to the callbacks of the FIRST element of that name only:
+        //  a repeated "face" element is walked, not stored)
+        if (is_face && have_faces) fprop = -1;
         if (is_face && fprop >= 0) {
+            have_faces = true;
             c.n_faces = e.count;
             c.faces = alloc_arr<int32_t>(3 * c.n_faces);
             if (!c.faces) return bail("out of memory");

@@ -227,7 +227,7 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64 = nullptr,
                                        const Pt64 *sorted64 = nullptr, int exact = 0,
-                                       const FoldArgs *fold = nullptr);
+                                       const FoldArgs *fold = nullptr, unsigned long long *cand_count = nullptr);
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
                                        int nprob, hipStream_t stream);
 
