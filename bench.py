@@ -154,7 +154,32 @@ def attach_comm(R, ctx, make_ctx, args):
     node, every rank falls back TOGETHER to the same exchange through torch.distributed."""
     from visma_amd import _lib
     torch, dist = R.torch, R.dist
-    ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or R.backend != "nccl") else 1
+    want = os.environ.get("VISMA_BENCH_COMM", "")            # "", "ipc", "rccl", "torch"
+    # 1. peer-to-peer mailboxes mapped through hipIpc: one small launch per iteration, no RCCL call
+    if want in ("", "ipc") and args.shard == "source":
+        ok = 1
+        try:
+            mine = ctx.comm_ipc_export()
+        except Exception as e:      # noqa: BLE001
+            print("bench: rank %d: mailbox export failed (%s)" % (R.rank, e), file=sys.stderr)
+            mine, ok = bytes(_lib.IPC_HANDLE_BYTES), 0
+        t = torch.tensor(list(mine), dtype=torch.uint8, device=R.tdev)
+        lst = [torch.zeros_like(t) for _ in range(R.world)]
+        dist.all_gather(lst, t)
+        flag = torch.tensor([ok], dtype=torch.int32, device=R.tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            try:
+                ctx.comm_ipc_init(R.rank, R.world, [bytes(x.cpu().tolist()) for x in lst])
+            except Exception as e:      # noqa: BLE001
+                print("bench: rank %d: mailbox mapping failed (%s)" % (R.rank, e), file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=R.tdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()):
+                return ctx, "peer-to-peer mailboxes over xGMI (hipIpc, %d ranks; one launch per iteration)" % R.world
+            ctx = make_ctx()                                  # some ranks mapped, some did not: start clean
+    ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or R.backend != "nccl" or want == "torch") else 1
     uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
     if R.rank == 0 and ok:
         try:

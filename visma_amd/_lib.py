@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libvisma_icp.so")
 
 NSTATS = 38
 UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
 SOLVER_KABSCH, SOLVER_GN_EULER, SOLVER_GN_EXPMAP = 0, 1, 2
 NN_AUTO, NN_BRUTE, NN_GRID = 0, 1, 2
 OK = 0
@@ -132,6 +133,8 @@ def load():
     L.visma_icp_comm_unique_id.argtypes = [C.c_void_p]
     L.visma_icp_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.visma_icp_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]
+    L.visma_icp_comm_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
+    L.visma_icp_comm_ipc_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.visma_icp_set_global_source_count.argtypes = [C.c_void_p, C.c_int64]
     _lib = L
     return L
@@ -403,6 +406,19 @@ class Context:
         return a.value, b.value
 
     # ---- multi-GPU ----
+    def comm_ipc_export(self):
+        """-> 64-byte handle of this context's all-reduce mailbox (all-gather them, then comm_ipc_init)."""
+        buf = C.create_string_buffer(IPC_HANDLE_BYTES)
+        self._chk(self.L.visma_icp_comm_ipc_export(self._h, buf))
+        return buf.raw
+
+    def comm_ipc_init(self, rank, nranks, handles):
+        """handles: the nranks exported handles in rank order (bytes, nranks * 64)."""
+        raw = b"".join(bytes(h) for h in handles) if not isinstance(handles, (bytes, bytearray)) else bytes(handles)
+        assert len(raw) == nranks * IPC_HANDLE_BYTES
+        buf = C.create_string_buffer(raw, len(raw))
+        self._chk(self.L.visma_icp_comm_ipc_init(self._h, int(rank), int(nranks), buf))
+
     def comm_init(self, rank, nranks, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._chk(self.L.visma_icp_comm_init(self._h, int(rank), int(nranks), buf))

@@ -143,6 +143,8 @@ public:
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
     virtual bool has_device_allreduce() const { return false; }
+    virtual int ipc_export(void *) { err_ = "the peer-to-peer all-reduce needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    virtual int ipc_init(int, int, const void *) { err_ = "the peer-to-peer all-reduce needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     // f64 copies of the clouds for the double-precision search (after set_source / set_target;
     // same order as those: source in Morton order).  nullptr pair = drop them.
     virtual int set_clouds64(const Pt64 *, const Pt64 *) { err_ = "double-precision search needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
@@ -181,6 +183,9 @@ public:
         if (!inited_) { (void)hipGetLastError(); return; }   // never touched the device
         (void)hipSetDevice(device_);
         if (comm_) g_rccl.CommDestroy(comm_);
+        for (int r = 0; r < ipc_n_; r++)
+            if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
+        free_dev(d_mbox_); free_dev(d_ipc_flag_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
@@ -395,7 +400,8 @@ public:
         const bool prof = profiling_ > 0 && (++prof_tick_ % profiling_) == 0;
         // without RCCL the fold kernel publishes to mapped host memory itself
         const unsigned long long seq = ++pub_seq_;
-        double *pub = comm_ ? nullptr : h_stats_dev_;
+        const bool ipc = ipc_n_ > 1;
+        double *pub = (comm_ || ipc) ? nullptr : h_stats_dev_;
         if (use_tile()) {
             // ONE launch: streamed search + exact re-rank + moments + fused fold + publication
             const int cfg = tile_config(ns_);
@@ -465,7 +471,12 @@ public:
             int rc = shard_exchange(T64, plane, offset, pub, seq);
             if (rc) return rc;
         }
-        if (comm_) {
+        if (ipc) {
+            // ONE exchange of the 38 f64 accumulators per ICP iteration: remote stores into the peers'
+            // mailboxes over xGMI, rank-ordered sum, publication to the host -- one tiny launch
+            HIP_TRY(launch_ipc_allreduce((const double *)d_stats_, (double *)d_stats_, peers_, ipc_rank_, ipc_n_,
+                                         ++ipc_seq_, h_stats_dev_, seq, (int *)d_ipc_flag_, stream_));
+        } else if (comm_) {
             // ONE all-reduce of the 38 f64 accumulators per ICP iteration
             int rc = g_rccl.AllReduce(d_stats_, d_stats_, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
             if (rc != 0) {
@@ -475,7 +486,7 @@ public:
         }
         // publish to mapped host memory and spin on the sequence word (no DMA
         // packet, no interrupt wake-up: ~10 us less per iteration than memcpy+sync)
-        if (comm_) HIP_TRY(launch_publish_stats((const double *)d_stats_, h_stats_dev_, seq, stream_));
+        if (comm_ && !ipc) HIP_TRY(launch_publish_stats((const double *)d_stats_, h_stats_dev_, seq, stream_));
         // every granule carries the sequence number it was written for
         volatile unsigned long long *g = reinterpret_cast<volatile unsigned long long *>(h_stats_);
         auto all_tagged = [&]() {
@@ -493,7 +504,13 @@ public:
         }
         if (!seen) {
             HIP_TRY(hipStreamSynchronize(stream_));   // surfaces a kernel fault, if any
-            if (!all_tagged()) { err_ = "statistics were not published"; return VISMA_ICP_ERR_HIP; }
+            if (!all_tagged()) {
+                int flag = 0;
+                if (d_ipc_flag_) (void)hipMemcpy(&flag, d_ipc_flag_, sizeof(int), hipMemcpyDeviceToHost);
+                err_ = flag ? "all-reduce: rank " + std::to_string(flag - 1) + " never delivered its statistics"
+                            : std::string("statistics were not published");
+                return VISMA_ICP_ERR_HIP;
+            }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         for (int i = 0; i < kNStats; i++) {
@@ -566,7 +583,7 @@ public:
         r2f_ = (float)(lp.max_dist * lp.max_dist);
         r2d_ = (double)r2f_;
         for (int i = 0; i < 12; i++) T32_.m[i] = (float)lp.Tc0.m[i];
-        if (nprob > 1 && (!use_grid_ || comm_)) {
+        if (nprob > 1 && (!use_grid_ || comm_ || ipc_n_ > 1)) {
             err_ = "batched loop needs the grid search on a single GPU";
             return VISMA_ICP_ERR_STATE;
         }
@@ -661,7 +678,12 @@ public:
                                           (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
                                           reduce_max_blocks(), nullptr, st, &nblocks, stream_));
                 }
-                if (comm_) {
+                if (ipc_n_ > 1) {
+                    if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
+                    HIP_TRY(launch_ipc_allreduce(st->stats, st->stats, peers_, ipc_rank_, ipc_n_, ++ipc_seq_, nullptr, 0,
+                                                 (int *)d_ipc_flag_, stream_));
+                    HIP_TRY(launch_solve_state(st, 1, stream_));
+                } else if (comm_) {
                     if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
                     // ONE all-reduce of the 38 f64 accumulators per ICP iteration
                     int nrc = g_rccl.AllReduce(st->stats, st->stats, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
@@ -998,7 +1020,61 @@ public:
         }
         return VISMA_ICP_OK;
     }
-    bool has_device_allreduce() const override { return comm_ != nullptr; }
+    bool has_device_allreduce() const override { return comm_ != nullptr || ipc_n_ > 1; }
+
+    // ---- one-shot all-reduce through IPC-mapped mailboxes (kernels.hip: ipc_allreduce_kernel) ----
+    int ensure_mailbox()
+    {
+        if (d_mbox_) return VISMA_ICP_OK;
+        const size_t bytes = sizeof(double) * 2 * kNStats * kIpcMaxRanks;
+        // uncached device memory: remote stores and local polls both go to memory
+        if (hipExtMallocWithFlags(&d_mbox_, bytes, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipExtMallocWithFlags(&d_mbox_, bytes, hipDeviceMallocFinegrained));
+        }
+        HIP_TRY(hipMemset(d_mbox_, 0, bytes));
+        HIP_TRY(hipMalloc(&d_ipc_flag_, sizeof(int)));
+        HIP_TRY(hipMemset(d_ipc_flag_, 0, sizeof(int)));
+        return VISMA_ICP_OK;
+    }
+    int ipc_export(void *out) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_mailbox();
+        if (rc) return rc;
+        hipIpcMemHandle_t h;
+        HIP_TRY(hipIpcGetMemHandle(&h, d_mbox_));
+        static_assert(sizeof(h) <= VISMA_ICP_IPC_HANDLE_BYTES, "handle size");
+        std::memset(out, 0, VISMA_ICP_IPC_HANDLE_BYTES);
+        std::memcpy(out, &h, sizeof(h));
+        return VISMA_ICP_OK;
+    }
+    int ipc_init(int rank, int nranks, const void *handles) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (nranks < 1 || nranks > kIpcMaxRanks || rank < 0 || rank >= nranks) { err_ = "bad rank arguments"; return VISMA_ICP_ERR_INVALID; }
+        int rc = ensure_mailbox();
+        if (rc) return rc;
+        for (int r = 0; r < nranks; r++) {
+            if (r == rank) { peers_.box[r] = d_mbox_; continue; }
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, (const char *)handles + (size_t)r * VISMA_ICP_IPC_HANDLE_BYTES, sizeof(h));
+            void *p = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                for (int q = 0; q < r; q++)
+                    if (q != rank && peers_.box[q]) { (void)hipIpcCloseMemHandle(peers_.box[q]); peers_.box[q] = nullptr; }
+                err_ = std::string("hipIpcOpenMemHandle(rank ") + std::to_string(r) + "): " + hipGetErrorString(e);
+                return VISMA_ICP_ERR_HIP;
+            }
+            peers_.box[r] = p;
+        }
+        ipc_rank_ = rank;
+        ipc_n_ = nranks;
+        ipc_seq_ = 0;
+        return VISMA_ICP_OK;
+    }
 
     void set_profiling(int level) override { profiling_ = level < 0 ? 0 : level; prof_tick_ = 0; }
     void get_timing(visma_icp_timing *t, bool reset) override
@@ -1197,6 +1273,10 @@ private:
     float *pin_[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging (see staging())
     size_t pin_cap_[4] = {0, 0, 0, 0};
     NcclComm comm_ = nullptr;
+    void *d_mbox_ = nullptr, *d_ipc_flag_ = nullptr;      // peer-to-peer all-reduce: own mailbox, timeout flag
+    IpcPeers peers_{};
+    int ipc_rank_ = 0, ipc_n_ = 0;
+    unsigned long long ipc_seq_ = 0;
     bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
     int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
     void *d_gkeys_ = nullptr;
@@ -2309,6 +2389,26 @@ int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks, const void *un
     CTX_CHECK();
     if (!unique_id || nranks < 1 || rank < 0 || rank >= nranks) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad comm arguments");
     int rc = ctx->eng->comm_init(rank, nranks, unique_id);
+    if (rc) return ctx->eng_fail(rc);
+    ctx->rank = rank;
+    ctx->nranks = nranks;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_comm_ipc_export(visma_icp_ctx *ctx, void *out_handle)
+{
+    CTX_CHECK();
+    if (!out_handle) return ctx->fail(VISMA_ICP_ERR_INVALID, "out_handle is NULL");
+    int rc = ctx->eng->ipc_export(out_handle);
+    if (rc) return ctx->eng_fail(rc);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_comm_ipc_init(visma_icp_ctx *ctx, int rank, int nranks, const void *handles)
+{
+    CTX_CHECK();
+    if (!handles || nranks < 1 || rank < 0 || rank >= nranks) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad comm arguments");
+    int rc = ctx->eng->ipc_init(rank, nranks, handles);
     if (rc) return ctx->eng_fail(rc);
     ctx->rank = rank;
     ctx->nranks = nranks;

@@ -82,6 +82,12 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          unsigned long long seq = 0);
 
 int reduce_max_blocks();
+// one-shot all-reduce of the 38 statistics through IPC-mapped mailboxes (kernels.hip)
+constexpr int kIpcMaxRanks = 16;
+struct IpcPeers { void *box[kIpcMaxRanks]; };     // box[r]: rank r's mailbox as mapped HERE (box[rank] = own)
+hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
+                                int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
+                                int *timeout_flag, hipStream_t stream);
 // target-sharded ranks: keys of the local winners / moments of the global winners owned here
 hipError_t launch_shard_keys(const int32_t *idx, const float *d2, int64_t ns, unsigned offset,
                              unsigned long long *keys, hipStream_t stream);

@@ -340,6 +340,66 @@ hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned 
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------
+// One-shot all-reduce of the 38 statistics over xGMI (no RCCL call, no host hop)
+// ------------------------------------------------------------------------
+// Every rank owns a mailbox of nranks x 38 granules {value, sequence tag} (16 bytes each, in
+// uncached device memory, mapped into the peers through hipIpc).  Lane a of ONE workgroup
+// stores its statistic as ONE 16-byte granule into slot [rank][a] of every peer's mailbox
+// (remote stores over xGMI; a granule is written by one store, so its tag validates its value:
+// no flag, no fence), then waits for the nranks granules of statistic a in its OWN mailbox and
+// sums them in rank order -- every rank forms the same sum, bit for bit, so the ranks keep
+// identical transforms without a broadcast.  Tags are the call count: nothing to reset.
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
+{
+    u4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_in, double *stats_out,
+                                                           IpcPeers peers, int rank, int nranks,
+                                                           unsigned long long seq, double *host_out,
+                                                           unsigned long long host_seq, int *timeout_flag)
+{
+    const int a = threadIdx.x;
+    if (a < kNStats) {
+        const unsigned long long v = (unsigned long long)__double_as_longlong(stats_in[a]);
+        u4_t g;
+        g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
+        g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
+        for (int p = 0; p < nranks; p++)
+            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + rank * kNStats + a);
+        const u4_t *mine = reinterpret_cast<const u4_t *>(peers.box[rank]);
+        double sum = 0.0;
+        for (int r = 0; r < nranks; r++) {
+            u4_t w;
+            long long spins = 0;
+            for (;;) {
+                w = load_granule_sys(mine + r * kNStats + a);
+                const unsigned long long tag = ((unsigned long long)w.w << 32) | w.z;
+                if (tag == seq) break;
+                if (++spins > 200000000ll) { *timeout_flag = 1 + r; break; }   // a peer never arrived
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sum += __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
+        }
+        stats_out[a] = sum;
+    }
+    if (host_out) publish_tagged_stats(stats_out, host_out, host_seq);
+}
+
+hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
+                                int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
+                                int *timeout_flag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(1), dim3(64), 0, stream, stats_in, stats_out, peers, rank, nranks,
+                       seq, host_out, host_seq, timeout_flag);
+    return hipGetLastError();
+}
+
 int reduce_max_blocks() { return 1024; }
 
 hipError_t launch_finalize(const double *partials, int nblocks, int point_to_plane,
