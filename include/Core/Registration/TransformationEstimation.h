@@ -15,19 +15,16 @@ using CorrespondenceSet = std::vector<Eigen::Vector2i>;   // (source index, targ
 
 enum class TransformationEstimationType { Unspecified = 0, PointToPoint = 1, PointToPlane = 2, ColoredICP = 3 };
 
-// The two operations an estimator provides, as seen by the registration loop.  QUAL closes the
-// declaration: "= 0" in the interface, "override" in the estimators.
-#define VISMA_ICP_ESTIMATOR_OPS(QUAL)                                                               \
-    virtual double ComputeRMSE(const PointCloud &src, const PointCloud &dst,                        \
-                               const CorrespondenceSet &pairs) const QUAL;                          \
-    virtual Eigen::Matrix4d ComputeTransformation(const PointCloud &src, const PointCloud &dst,     \
-                                                  const CorrespondenceSet &pairs) const QUAL;
-
+// The plugin interface: what open3d::RegistrationICP calls on an estimator
+// (O3D/Core/Registration/TransformationEstimation.h:51-66).
 class TransformationEstimation {
 public:
     virtual ~TransformationEstimation() = default;
     virtual TransformationEstimationType GetTransformationEstimationType() const = 0;
-    VISMA_ICP_ESTIMATOR_OPS(= 0)
+    virtual double ComputeRMSE(const PointCloud &source, const PointCloud &target,
+                               const CorrespondenceSet &corres) const = 0;
+    virtual Eigen::Matrix4d ComputeTransformation(const PointCloud &source, const PointCloud &target,
+                                                  const CorrespondenceSet &corres) const = 0;
 };
 
 // p' = c R p + t minimising sum |q - p'|^2 over the pairs (Umeyama); c = 1 unless with_scaling_.
@@ -35,7 +32,10 @@ class TransformationEstimationPointToPoint : public TransformationEstimation {
 public:
     explicit TransformationEstimationPointToPoint(bool with_scaling = false) : with_scaling_(with_scaling) {}
     TransformationEstimationType GetTransformationEstimationType() const override { return kind; }
-    VISMA_ICP_ESTIMATOR_OPS(override)
+    double ComputeRMSE(const PointCloud &source, const PointCloud &target,
+                       const CorrespondenceSet &corres) const override;
+    Eigen::Matrix4d ComputeTransformation(const PointCloud &source, const PointCloud &target,
+                                          const CorrespondenceSet &corres) const override;
     bool with_scaling_;
     static constexpr TransformationEstimationType kind = TransformationEstimationType::PointToPoint;
 };
@@ -44,10 +44,11 @@ public:
 class TransformationEstimationPointToPlane : public TransformationEstimation {
 public:
     TransformationEstimationType GetTransformationEstimationType() const override { return kind; }
-    VISMA_ICP_ESTIMATOR_OPS(override)
+    double ComputeRMSE(const PointCloud &source, const PointCloud &target,
+                       const CorrespondenceSet &corres) const override;
+    Eigen::Matrix4d ComputeTransformation(const PointCloud &source, const PointCloud &target,
+                                          const CorrespondenceSet &corres) const override;
     static constexpr TransformationEstimationType kind = TransformationEstimationType::PointToPlane;
 };
-
-#undef VISMA_ICP_ESTIMATOR_OPS
 
 }  // namespace open3d

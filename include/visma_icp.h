@@ -129,7 +129,12 @@ VISMA_ICP_API int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src
                                            int64_t ns, int src_stride,
                                            const double *tgt_xyz, int64_t nt,
                                            int tgt_stride);
-/* fp32 uploads, no centring (the caller's coordinates are used as they are). */
+/* fp32 uploads, no centring (the caller's coordinates are used as they are; the exact search
+ * takes the fp32 values as its f64 coordinates).  FRAME RULE: visma_icp_set_clouds_f64 centres
+ * BOTH clouds on one point; these setters (and the _device ones) upload in the caller's frame.
+ * The two frames cannot be combined: the first uncentred upload after a centred one INVALIDATES
+ * the other cloud -- set it again (the next run fails with VISMA_ICP_ERR_STATE "clouds not set"
+ * otherwise). */
 VISMA_ICP_API int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt,
                                        int stride_floats);
 VISMA_ICP_API int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns,
@@ -392,6 +397,27 @@ VISMA_ICP_API int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const doub
  * w (3n doubles) computes, ON THE GPU, R = rodrigues(w) (9n) and
  * w_back = invrodrigues(R) (3n). */
 VISMA_ICP_API int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n);
+/* The same ON THE GPU with the derivatives and the projection: for n axis-angle vectors w,
+ * R (9n), dR/dw (27n), w_back (3n), dw/dR (27n) and project_so3 of a sheared copy of R (9n). */
+VISMA_ICP_API int visma_icp_selftest_so3_jac(const double *w, int n, double *R, double *dR_dw,
+                                             double *w_back, double *dw_dR, double *proj);
+
+/* ---- SO(3) maps and their derivatives (host; the device versions are the same code) ----------
+ * core/rodrigues.h of the reference on plain arrays.  3x3 matrices row-major; a derivative of
+ * (or with respect to) a matrix indexes it by its ROW-MAJOR vectorisation, as the reference
+ * (built with EIGEN_DEFAULT_TO_ROW_MAJOR) does:
+ *   rodrigues      R = exp(hat(w)),  dR_dw[(3i+j)*3 + k] = dR(i,j)/dw(k)     (:143-182; th < 1e-8 -> I + hat(w))
+ *   invrodrigues   w = log(R),       dw_dR[k*9 + 3i+j]   = dw(k)/dR(i,j)     (:184-226; tr -> 3 branch)
+ *   project        U V^T of the SVD (projectSO3 :229-237, SO3Type::fitToSO3 core/se3.h:58-61)
+ *   matrix_derivatives   dAB_dA, dAB_dB (:87-141), dAt_dA (:58-69), dhat (:17-35), dvee (:43-56);
+ *                        any output may be NULL.
+ * Jacobian arguments may be NULL. */
+VISMA_ICP_API int visma_so3_rodrigues(const double w[3], double R[9], double dR_dw[27]);
+VISMA_ICP_API int visma_so3_invrodrigues(const double R[9], double w[3], double dw_dR[27]);
+VISMA_ICP_API int visma_so3_project(const double A[9], double R[9]);
+VISMA_ICP_API int visma_so3_matrix_derivatives(const double A[9], const double B[9],
+                                               double dAB_dA[81], double dAB_dB[81],
+                                               double dAt_dA[81], double dhat[27], double dvee[27]);
 
 /* ---- engine injection (test seam) --------------------------------------- */
 

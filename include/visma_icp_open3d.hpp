@@ -29,6 +29,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <typeinfo>
 #include <vector>
 
 #include "visma_icp.h"
@@ -254,9 +255,17 @@ inline RegistrationResult RegistrationICP(
     detail::to_rowmajor(init, T);
     visma_icp_result r;
 
-    const auto *four = dynamic_cast<const TransformationEstimationPointToPoint4DoF *>(&estimation);
-    const auto *p2p = dynamic_cast<const TransformationEstimationPointToPoint *>(&estimation);
-    const auto *p2l = dynamic_cast<const TransformationEstimationPointToPlane *>(&estimation);
+    // The built-in solves replace ComputeTransformation only for EXACTLY the three stock
+    // estimators.  A user class derived from one of them may override the virtual methods: it
+    // takes the generic plugin loop below, which calls them like the reference does
+    // (Registration.cpp:172-173).
+    const std::type_info &dyn = typeid(estimation);
+    const auto *four = dyn == typeid(TransformationEstimationPointToPoint4DoF)
+                           ? static_cast<const TransformationEstimationPointToPoint4DoF *>(&estimation) : nullptr;
+    const auto *p2p = dyn == typeid(TransformationEstimationPointToPoint)
+                          ? static_cast<const TransformationEstimationPointToPoint *>(&estimation) : nullptr;
+    const auto *p2l = dyn == typeid(TransformationEstimationPointToPlane)
+                          ? static_cast<const TransformationEstimationPointToPlane *>(&estimation) : nullptr;
     if (four || p2p) {
         const bool scaling = four ? four->with_scaling_ : p2p->with_scaling_;
         detail::check(ctx, visma_icp_run(ctx, T, max_correspondence_distance, criteria.max_iteration_,

@@ -6,6 +6,9 @@
  *                       (O3D/IO/FileFormat/FilePLY.cpp:206-264, :336-397; rply):
  *                       scene and scan clouds, src/evaluation.cpp:124,211,
  *                       src/annotation.cpp:76,80,111,157
+ *   visma_io_read_pcd   open3d::ReadPointCloudFromPCD (O3D/IO/FileFormat/FilePCD.cpp:727-760)
+ *   visma_io_read_alignment_json / _write_ / visma_io_read_result_json   the pose files
+ *                       (core/utils.h:305-339, src/evaluation.cpp:126-181, src/annotation.cpp:147-153)
  *   visma_io_read_obj   igl::readOBJ(path, V, F) (libigl readOBJ.cpp:20-236): the
  *                       CAD models, src/evaluation.cpp:140,183, src/annotation.cpp:125,159,
  *                       core/utils.cpp:125-135 (LoadMesh keeps the first 3 columns)
@@ -58,6 +61,31 @@ VISMA_IO_API int visma_io_read_obj(const char *path, double **V, int64_t *nv, in
                                    int64_t *nf, int *face_size);
 VISMA_IO_API void visma_io_free(void *p);
 VISMA_IO_API const char *visma_io_last_error(void);
+
+/* open3d::ReadPointCloudFromPCD (O3D/IO/FileFormat/FilePCD.cpp:727-760): the format of the
+ * reference's real-scan fixtures (fragment.pcd, cloud_bin_*.pcd).  DATA ascii / binary /
+ * binary_compressed (LZF); fields x y z [normal_x normal_y normal_z] [rgb | rgba]; numeric types
+ * I / U of 1, 2, 4 bytes and F of 4 bytes (anything else reads as 0, like the reference); colours
+ * are the bytes of the 4-byte field as B, G, R, each / 255.0; rows whose x or y is NaN are
+ * removed (the reference tests x twice and never z: a NaN z stays).  n_faces = 0. */
+VISMA_IO_API int visma_io_read_pcd(const char *path, visma_io_cloud *out);
+
+/* The pose files of the two callers.  A pose is the 3x4 matrix [R | t], 12 doubles row by row
+ * (GetMatrixFromJson<double,3,4> / WriteMatrixToJson, core/utils.h:305-339).
+ *   alignment.json   { "<model>_<k>": [12 numbers], ... }  read by src/evaluation.cpp:126-137, written by
+ *                    src/annotation.cpp:147-153; poses come back in key order (jsoncpp iterates a
+ *                    std::map), id = -1
+ *   result.json      [ packet, ... ], packet = [ {"id", "status", "model_name", "model_pose": [12]}, ... ];
+ *                    src/evaluation.cpp:166-181 evaluates the LAST packet: packet = -1
+ * Arrays are calloc'ed: release with visma_io_free. */
+typedef struct visma_io_pose {
+    char name[256];
+    int id, status;
+    double T[12];
+} visma_io_pose;
+VISMA_IO_API int visma_io_read_alignment_json(const char *path, visma_io_pose **poses, int64_t *n);
+VISMA_IO_API int visma_io_write_alignment_json(const char *path, const visma_io_pose *poses, int64_t n);
+VISMA_IO_API int visma_io_read_result_json(const char *path, int64_t packet, visma_io_pose **poses, int64_t *n);
 
 #ifdef __cplusplus
 }

@@ -415,6 +415,28 @@ class Ref:
                     normals=self._take(nrm, 3 * nn.value, np.float64).reshape(-1, 3),
                     colors=self._take(col, 3 * nc.value, np.float64).reshape(-1, 3))
 
+    def read_pcd_cloud(self, path):
+        """open3d::ReadPointCloudFromPCD -> dict(xyz, normals, colors) or None when the reference reader fails."""
+        xyz, nrm, col = _dp(), _dp(), _dp()
+        n, nn, nc = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.lib.ref_io_free.argtypes = [C.c_void_p]
+        if not self.lib.ref_read_pcd_cloud(str(path).encode(), C.byref(xyz), C.byref(n), C.byref(nrm), C.byref(nn),
+                                           C.byref(col), C.byref(nc)):
+            return None
+        return dict(xyz=self._take(xyz, 3 * n.value, np.float64).reshape(-1, 3),
+                    normals=self._take(nrm, 3 * nn.value, np.float64).reshape(-1, 3),
+                    colors=self._take(col, 3 * nc.value, np.float64).reshape(-1, 3))
+
+    def write_pcd(self, path, xyz, normals=None, colors=None, ascii=False, compressed=False):
+        """open3d::WritePointCloudToPCD (the reference's writer: makes the binary_compressed fixtures)."""
+        xyz = _f64(xyz, (-1, 3))
+        nn = None if normals is None else _f64(normals, (-1, 3))
+        cc = None if colors is None else _f64(colors, (-1, 3))
+        self.lib.ref_write_pcd.argtypes = [C.c_char_p, _dp, C.c_int64, _dp, _dp, C.c_int, C.c_int]
+        return bool(self.lib.ref_write_pcd(str(path).encode(), _ptr(xyz, _dp), len(xyz),
+                                           None if nn is None else _ptr(nn, _dp), None if cc is None else _ptr(cc, _dp),
+                                           int(ascii), int(compressed)))
+
     def read_ply_mesh(self, path):
         xyz, tri = _dp(), _ip()
         n, nt = C.c_int64(0), C.c_int64(0)

@@ -5,6 +5,9 @@
 // (oracle/Makefile, target `ref`):
 //   open3d::ReadPointCloudFromPLY   O3D/IO/FileFormat/FilePLY.cpp:206-264
 //   open3d::ReadTriangleMeshFromPLY O3D/IO/FileFormat/FilePLY.cpp:336-397
+// and with O3D/IO/FileFormat/FilePCD.cpp + O3D/3rdparty/liblzf/lzf_{c,d}.c:
+//   open3d::ReadPointCloudFromPCD   O3D/IO/FileFormat/FilePCD.cpp:727-760
+//   open3d::WritePointCloudToPCD    O3D/IO/FileFormat/FilePCD.cpp:762-788  (writes the binary_compressed fixtures)
 #include <Core/Geometry/PointCloud.h>
 #include <Core/Geometry/TriangleMesh.h>
 #include <IO/ClassIO/PointCloudIO.h>
@@ -44,6 +47,27 @@ int ref_read_ply_mesh(const char *path, double **xyz, int64_t *n, int32_t **tri,
     *tri = (int32_t *)std::malloc(sizeof(int32_t) * 3 * (m.triangles_.size() ? m.triangles_.size() : 1));
     for (size_t i = 0; i < m.triangles_.size(); i++) for (int a = 0; a < 3; a++) (*tri)[3 * i + a] = m.triangles_[i](a);
     return 1;
+}
+
+int ref_read_pcd_cloud(const char *path, double **xyz, int64_t *n, double **nrm, int64_t *nn, double **col, int64_t *nc)
+{
+    open3d::PointCloud pc;
+    if (!open3d::ReadPointCloudFromPCD(path, pc)) return 0;
+    *n = (int64_t)pc.points_.size(); *nn = (int64_t)pc.normals_.size(); *nc = (int64_t)pc.colors_.size();
+    *xyz = dump(pc.points_); *nrm = dump(pc.normals_); *col = dump(pc.colors_);
+    return 1;
+}
+
+int ref_write_pcd(const char *path, const double *xyz, int64_t n, const double *nrm, const double *col, int ascii,
+                  int compressed)
+{
+    open3d::PointCloud pc;
+    for (int64_t i = 0; i < n; i++) {
+        pc.points_.push_back(Eigen::Vector3d(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+        if (nrm) pc.normals_.push_back(Eigen::Vector3d(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]));
+        if (col) pc.colors_.push_back(Eigen::Vector3d(col[3 * i], col[3 * i + 1], col[3 * i + 2]));
+    }
+    return open3d::WritePointCloudToPCD(path, pc, ascii != 0, compressed != 0) ? 1 : 0;
 }
 
 void ref_io_free(void *p) { std::free(p); }

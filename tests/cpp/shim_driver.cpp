@@ -35,6 +35,19 @@ public:
     mutable int calls = 0;
 };
 
+// a class DERIVED from a stock estimator that overrides the solve: the override must be the one
+// that runs (the reference always calls the virtual method, Registration.cpp:172-173)
+class DerivedFromStock : public TransformationEstimationPointToPoint {
+public:
+    Eigen::Matrix4d ComputeTransformation(const PointCloud &s, const PointCloud &t,
+                                          const CorrespondenceSet &c) const override
+    {
+        ++calls;
+        return TransformationEstimationPointToPoint::ComputeTransformation(s, t, c);
+    }
+    mutable int calls = 0;
+};
+
 static void read_cloud(FILE *f, std::vector<Eigen::Vector3d> &v, int64_t n)
 {
     v.resize((size_t)n);
@@ -79,6 +92,11 @@ int main(int argc, char **argv)
                                              open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
         } else if (mode == "plugin") {
             MyEstimator est;
+            result = open3d::RegistrationICP(*model, *scene, radius, init, est,
+                                             open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
+            extra = est.calls;
+        } else if (mode == "derived") {
+            DerivedFromStock est;
             result = open3d::RegistrationICP(*model, *scene, radius, init, est,
                                              open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
             extra = est.calls;

@@ -245,6 +245,8 @@ def gen_io(ref):
     for name in sorted(os.listdir(d)):
         path = os.path.join(d, name)
         key = name.replace(".", "_")
+        if name.endswith(".pcd") or name.endswith(".json") or name.startswith("bad_hugecount") or name == "two_faces.ply":
+            continue                                  # gen_pcd / hand-written hardening cases
         if name.endswith(".ply"):
             c = ref.read_ply_cloud(path)
             m = ref.read_ply_mesh(path)
@@ -263,6 +265,79 @@ def gen_io(ref):
     print("io fixture:", {k: v.tolist() for k, v in out.items() if k.endswith("_ok")})
 
 
+def gen_pcd(ref):
+    """PCD files in the layouts PCL / Open3D write, and what the reference's ReadPointCloudFromPCD
+    (O3D/IO/FileFormat/FilePCD.cpp:727-760, compiled into oracle/_ref) returns for them.  The ascii and
+    binary files are written by THIS script; the binary_compressed ones by the reference's own writer."""
+    import struct
+    d = os.path.join(HERE, "io")
+    os.makedirs(d, exist_ok=True)
+    rng = np.random.default_rng(92)
+    n = 257
+    xyz = rng.standard_normal((n, 3)).astype(np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    col = rng.integers(0, 256, (n, 4)).astype(np.uint8)        # b g r a
+    xyz[5, 0] = np.nan; xyz[9, 1] = np.nan; xyz[13, 2] = np.nan  # rows 5 and 9 go, row 13 stays (FilePCD.cpp:521-523)
+
+    def hdr(fields, sizes, types, counts, width, height, data, points=None, first="FIELDS"):
+        h = "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\n%s %s\n" % (first, " ".join(fields))
+        if sizes: h += "SIZE %s\n" % " ".join(str(x) for x in sizes)
+        if types: h += "TYPE %s\n" % " ".join(types)
+        if counts: h += "COUNT %s\n" % " ".join(str(x) for x in counts)
+        h += "WIDTH %d\nHEIGHT %d\nVIEWPOINT 0 0 0 1 0 0 0\n" % (width, height)
+        if points is not None: h += "POINTS %d\n" % points
+        return (h + "DATA %s\n" % data).encode()
+
+    rgbf = col.view(np.float32).reshape(n)                      # the 4 colour bytes read as a float (PCL's "rgb")
+    # (1) ascii, normals + float-packed rgb, a short line in the data, tabs
+    t = hdr(["x", "y", "z", "normal_x", "normal_y", "normal_z", "rgb"], [4] * 7, ["F"] * 7, [1] * 7, n, 1, "ascii", n).decode()
+    for i in range(n):
+        if i == 20: t += "1 2 3\n"                             # too few tokens: skipped (FilePCD.cpp:362-364)
+        t += ("%r\t%r %r %.6g %.6g %.6g %.9g\n" % (float(xyz[i, 0]), float(xyz[i, 1]), float(xyz[i, 2]), *nrm[i], rgbf[i]))
+    open(os.path.join(d, "gen_ascii.pcd"), "w").write(t)
+    # (2) binary, mixed types, an extra field with COUNT 3 in between, rgba as U4, HEIGHT > 1
+    b = hdr(["x", "y", "intensity", "z", "hist", "label", "rgba"], [4, 4, 4, 4, 2, 1, 4], ["F", "F", "F", "F", "U", "I", "U"],
+            [1, 1, 1, 1, 3, 1, 1], 32, 8, "binary")
+    for i in range(256):
+        b += struct.pack("<ffff3Hb4B", xyz[i, 0], xyz[i, 1], 0.5, xyz[i, 2], 1, 2, 3, -3, *col[i])
+    open(os.path.join(d, "gen_binary.pcd"), "wb").write(b)
+    # (3) integer coordinates: ascii I / U with hex and octal text (strtol base 0), colour as ascii U
+    t = hdr(["x", "y", "z", "rgb"], [4, 2, 1, 4], ["I", "I", "U", "U"], [1, 1, 1, 1], 6, 1, "ascii", first="COLUMNS").decode()
+    t += "0x10 -7 3 255\n010 5 200 16711680\n-2147483648 32767 0 65280\n12 0x7f 9 4278190335\n1 2 3 0\n7 8 9 1\n"
+    open(os.path.join(d, "gen_int.pcd"), "w").write(t)
+    # (4) binary: 8-byte floats and 2-byte colour read as 0 (FilePCD.cpp:268-281, :289-296)
+    b = hdr(["x", "y", "z", "rgb"], [8, 4, 4, 2], ["F", "F", "F", "U"], [1, 1, 1, 1], 9, 1, "binary")
+    for i in range(9):
+        b += struct.pack("<dffH", float(xyz[i, 0]), xyz[i, 1], xyz[i, 2], 7)
+    open(os.path.join(d, "gen_wide.pcd"), "wb").write(b)
+    # (5) the reference's own writer: binary_compressed (LZF) and ascii, with normals and colours
+    keep = ~(np.isnan(xyz).any(1))
+    assert ref.write_pcd(os.path.join(d, "ref_compressed.pcd"), xyz[keep].astype(np.float64), nrm[keep].astype(np.float64),
+                         col[keep, :3] / 255.0, ascii=False, compressed=True)
+    big = np.repeat(xyz[keep][:40].astype(np.float64), 30, axis=0) + np.arange(1200)[:, None] * 1e-3   # long LZF matches
+    assert ref.write_pcd(os.path.join(d, "ref_compressed_xyz.pcd"), big, None, None, ascii=False, compressed=True)
+    assert ref.write_pcd(os.path.join(d, "ref_ascii.pcd"), xyz[keep][:50].astype(np.float64), nrm[keep][:50].astype(np.float64), None, ascii=True)
+    # (6) broken files
+    open(os.path.join(d, "bad_truncated.pcd"), "wb").write(open(os.path.join(d, "gen_binary.pcd"), "rb").read()[:-10])
+    open(os.path.join(d, "bad_nofields.pcd"), "wb").write(hdr(["a", "b", "z"], [4] * 3, ["F"] * 3, [1] * 3, 3, 1, "ascii") + b"1 2 3\n1 2 3\n1 2 3\n")
+    open(os.path.join(d, "bad_nopoints.pcd"), "wb").write(hdr(["x", "y", "z"], [4] * 3, ["F"] * 3, [1] * 3, 0, 1, "ascii"))
+    open(os.path.join(d, "bad_sizecount.pcd"), "wb").write(hdr(["x", "y", "z"], [4, 4], ["F"] * 3, [1] * 3, 2, 1, "ascii") + b"1 2 3\n1 2 3\n")
+    comp = open(os.path.join(d, "ref_compressed.pcd"), "rb").read()
+    open(os.path.join(d, "bad_lzf.pcd"), "wb").write(comp[:-7] + b"\xff" * 7)
+    out = {}
+    for name in sorted(os.listdir(d)):
+        if not name.endswith(".pcd"):
+            continue
+        c = ref.read_pcd_cloud(os.path.join(d, name))
+        key = name.replace(".", "_")
+        out[key + "_ok"] = np.array([c is not None])
+        if c is not None:
+            for k in ("xyz", "normals", "colors"):
+                out[key + "_" + k] = c[k]
+    np.savez_compressed(os.path.join(HERE, "pcd.npz"), **out)
+    print("pcd fixture:", {k: (v.tolist(), out.get(k[:-3] + "_xyz", np.zeros((0, 3))).shape) for k, v in out.items() if k.endswith("_ok")})
+
+
 def main():
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Ref()
@@ -272,6 +347,8 @@ def main():
         return gen_mesh(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "io":
         return gen_io(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "pcd":
+        return gen_pcd(ref)
     V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
 
     # ---- C1/C2: chair CAD 5k samples -> 20k partial noisy scan ------------
@@ -469,6 +546,7 @@ def main():
     gen_voxel(ref)
     gen_mesh(ref)
     gen_io(ref)
+    gen_pcd(ref)
     print("golden fixtures written to", HERE)
 
 

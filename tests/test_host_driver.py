@@ -40,7 +40,7 @@ def hctx(lib, oracle):
 def test_abi_exports_every_declared_symbol(lib):
     """Every VISMA_ICP_API function of include/visma_icp.h is exported."""
     hdr = open(os.path.join(ROOT, "include", "visma_icp.h")).read()
-    names = sorted(set(re.findall(r"VISMA_ICP_API\s+[\w\s\*]+?\b(visma_icp_\w+)\s*\(", hdr)))
+    names = sorted(set(re.findall(r"VISMA_ICP_API\s+[\w\s\*]+?\b(visma_(?:icp|so3)_\w+)\s*\(", hdr)))
     assert len(names) >= 25
     L = ctypes.CDLL(lib.LIB_PATH)
     missing = [n for n in names if not hasattr(L, n)]
@@ -54,7 +54,7 @@ def test_abi_exports_the_io_symbols_and_headers_are_plain_c(lib, tmp_path):
     import shutil, subprocess
     hdr = open(os.path.join(ROOT, "include", "visma_io.h")).read()
     names = sorted(set(re.findall(r"VISMA_IO_API\s+[\w\s\*]+?\b(visma_io_\w+)\s*\(", hdr)))
-    assert len(names) == 5, names
+    assert len(names) == 9, names
     L = ctypes.CDLL(lib.LIB_PATH)
     assert not [n for n in names if not hasattr(L, n)]
     if shutil.which("gcc") is None:
@@ -237,3 +237,22 @@ def test_iterate_is_k_fixed_steps(hctx):
     assert hctx.engine.calls["nn"] == 5 and hctx.engine.calls["reduce"] == 5
     assert rel(T, g["trace"][5, :16].reshape(4, 4)) < 1e-6
     assert last.num_correspondences == g["trace"][4, 18]     # last pass was taken at T_4
+
+
+def test_mixing_centred_and_uncentred_uploads_is_refused(hctx, lib):
+    """set_clouds_f64 centres both clouds on the target centroid; a later fp32 upload of ONE cloud
+    is in the caller's frame.  Combining the two silently gave wrong transforms: now the other
+    cloud is invalidated and the run says so."""
+    src, tgt, _, r = synth.make_pair(600, 900, offset=[3.0, -2.0, 1.0])
+    hctx.set_clouds_f64(src, tgt)
+    assert hctx.run(None, 0.1, 2, 0, 0).num_correspondences > 0
+    hctx.set_source(src.astype(np.float32))                 # uncentred source, centred target: not combinable
+    with pytest.raises(lib.IcpError) as e:
+        hctx.run(None, 0.1, 2, 0, 0)
+    assert "clouds not set" in str(e.value)
+    hctx.set_target(tgt.astype(np.float32))                 # both in the caller's frame again: fine
+    a = hctx.run(None, 0.1, 5, 0, 0)
+    hctx.set_clouds_f64(src, tgt)
+    b = hctx.run(None, 0.1, 5, 0, 0)
+    assert a.num_correspondences == b.num_correspondences
+    assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-4     # fp32 uncentred vs f64 centred inputs

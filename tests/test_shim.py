@@ -113,6 +113,11 @@ def test_shim_registration_icp_matches_reference(bins, tmp_path):
         assert p["extra"] == 6
         assert synth.rel_frobenius(p["T"], g["trace"][6][:16].reshape(4, 4)) < 1e-5
         assert p["k"] == g["trace"][6][18]
+        # a class derived from a stock estimator keeps ITS ComputeTransformation (no silent fast path)
+        rc, err, d = run(b, "derived", tmp_path, src, tgt, float(g["radius"]), iters=5)
+        assert rc == 0, err
+        assert d["extra"] == 5
+        assert synth.rel_frobenius(d["T"], g["trace"][5][:16].reshape(4, 4)) < 1e-5
     e = np.load(os.path.join(G, "estimators.npz"))
     rc, err, r = run(bins[0], "default", tmp_path, src, tgt, 0.075)   # default estimator + criteria
     assert rc == 0, err

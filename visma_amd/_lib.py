@@ -133,6 +133,11 @@ def load():
     L.visma_icp_comm_unique_id.argtypes = [C.c_void_p]
     L.visma_icp_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.visma_icp_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int, C.c_int]
+    L.visma_so3_rodrigues.argtypes = [_dp, _dp, _dp]
+    L.visma_so3_invrodrigues.argtypes = [_dp, _dp, _dp]
+    L.visma_so3_project.argtypes = [_dp, _dp]
+    L.visma_so3_matrix_derivatives.argtypes = [_dp] * 7
+    L.visma_icp_selftest_so3_jac.argtypes = [_dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
     L.visma_icp_comm_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
     L.visma_icp_comm_ipc_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.visma_icp_set_global_source_count.argtypes = [C.c_void_p, C.c_int64]
@@ -487,14 +492,14 @@ class IoError(RuntimeError):
     pass
 
 
-def read_ply(path):
+def read_ply(path, _fn="visma_io_read_ply"):
     """open3d::ReadPointCloudFromPLY / ReadTriangleMeshFromPLY -> dict(xyz, normals, colors, faces)."""
     L = load()
     L.visma_io_last_error.restype = C.c_char_p
     c = CIoCloud()
-    rc = L.visma_io_read_ply(str(path).encode(), C.byref(c))
+    rc = getattr(L, _fn)(str(path).encode(), C.byref(c))
     if rc != OK:
-        raise IoError("visma_io_read_ply: %s" % L.visma_io_last_error().decode())
+        raise IoError("%s: %s" % (_fn, L.visma_io_last_error().decode()))
     def take(ptr, n, cols, dt):
         if n == 0:
             return np.zeros((0, cols), dt)
@@ -503,6 +508,55 @@ def read_ply(path):
                colors=take(c.colors, c.n_colors, 3, np.float64), faces=take(c.faces, c.n_faces, 3, np.int32))
     L.visma_io_free_cloud(C.byref(c))
     return out
+
+
+def read_pcd(path):
+    """open3d::ReadPointCloudFromPCD -> dict(xyz, normals, colors, faces=empty)."""
+    return read_ply(path, "visma_io_read_pcd")
+
+
+class CIoPose(C.Structure):
+    _fields_ = [("name", C.c_char * 256), ("id", C.c_int), ("status", C.c_int), ("T", C.c_double * 12)]
+
+
+def _poses(fn, *args):
+    L = load()
+    L.visma_io_last_error.restype = C.c_char_p
+    L.visma_io_free.argtypes = [C.c_void_p]
+    ptr = C.POINTER(CIoPose)()
+    n = C.c_int64(0)
+    rc = getattr(L, fn)(*args, C.byref(ptr), C.byref(n))
+    if rc != OK:
+        raise IoError("%s: %s" % (fn, L.visma_io_last_error().decode()))
+    out = [dict(name=ptr[i].name.decode(), id=ptr[i].id, status=ptr[i].status,
+                T=np.array(list(ptr[i].T)).reshape(3, 4)) for i in range(n.value)]
+    L.visma_io_free(ptr)
+    return out
+
+
+def read_alignment_json(path):
+    """alignment.json (name -> 3x4 pose) -> list of dict(name, T), in key order like the reference's loop."""
+    return _poses("visma_io_read_alignment_json", str(path).encode())
+
+
+def read_result_json(path, packet=-1):
+    """result.json -> the objects of one packet (default: the last): dict(id, status, name, T)."""
+    return _poses("visma_io_read_result_json", str(path).encode(), C.c_int64(packet))
+
+
+def write_alignment_json(path, poses):
+    """poses: iterable of (name, 3x4 or 4x4 matrix)."""
+    L = load()
+    L.visma_io_last_error.restype = C.c_char_p
+    poses = list(poses)
+    arr = (CIoPose * max(len(poses), 1))()
+    for i, (name, T) in enumerate(poses):
+        arr[i].name = str(name).encode()
+        T = np.asarray(T, np.float64)[:3, :4]
+        arr[i].T = (C.c_double * 12)(*T.reshape(12))
+    rc = L.visma_io_write_alignment_json(str(path).encode(), arr, C.c_int64(len(poses)))
+    if rc != OK:
+        raise IoError("visma_io_write_alignment_json: %s" % L.visma_io_last_error().decode())
 
 
 def read_obj(path):

@@ -143,6 +143,9 @@ public:
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
     virtual bool has_device_allreduce() const { return false; }
+    // aux entry points (voxel / mesh steps) run on THIS context's device and stream
+    virtual int bind_device() { return VISMA_ICP_OK; }
+    virtual hipStream_t aux_stream() { return nullptr; }
     virtual int ipc_export(void *) { err_ = "the peer-to-peer all-reduce needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     virtual int ipc_init(int, int, const void *) { err_ = "the peer-to-peer all-reduce needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     // f64 copies of the clouds for the double-precision search (after set_source / set_target;
@@ -1021,6 +1024,8 @@ public:
         return VISMA_ICP_OK;
     }
     bool has_device_allreduce() const override { return comm_ != nullptr || ipc_n_ > 1; }
+    int bind_device() override { HIP_TRY(hipSetDevice(device_)); return VISMA_ICP_OK; }
+    hipStream_t aux_stream() override { return stream_; }
 
     // ---- one-shot all-reduce through IPC-mapped mailboxes (kernels.hip: ipc_allreduce_kernel) ----
     int ensure_mailbox()
@@ -1495,6 +1500,18 @@ struct visma_icp_ctx {
     bool fixed_centre = false;        // centre given by the caller (target-sharded ranks share one)
     bool target_sharded = false;
     bool have_src = false, have_tgt = false;
+    // Frame bookkeeping: visma_icp_set_clouds_f64 centres BOTH clouds on one point; the fp32 / device
+    // setters upload a cloud as given (centre 0).  A cloud uploaded in the other frame cannot be combined
+    // with it: the setter that changes the frame invalidates the other cloud (it has to be set again).
+    bool centred_upload = false;
+    void enter_uncentred_frame(bool setting_source)
+    {
+        if (centred_upload && (centre[0] != 0.0 || centre[1] != 0.0 || centre[2] != 0.0)) {
+            if (setting_source) have_tgt = false; else have_src = false;
+        }
+        centred_upload = false;
+        centre[0] = centre[1] = centre[2] = 0.0;
+    }
     visma_icp_allreduce_fn host_allreduce = nullptr;
     void *host_allreduce_user = nullptr;
     int rank = 0, nranks = 1;
@@ -1896,6 +1913,7 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     }
     std::memcpy(ctx->centre, c, sizeof(c));
     ctx->have_src = ctx->have_tgt = true;
+    ctx->centred_upload = true;
     return VISMA_ICP_OK;
 }
 
@@ -1907,7 +1925,7 @@ int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt, int s
     pack_f32_to(xyz, nt, stride, buf);
     int rc = ctx->eng->set_target(buf, nt);
     if (rc) return ctx->eng_fail(rc);
-    ctx->centre[0] = ctx->centre[1] = ctx->centre[2] = 0.0;
+    ctx->enter_uncentred_frame(false);
     ctx->have_tgt = true;
     return VISMA_ICP_OK;
 }
@@ -1921,6 +1939,7 @@ int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns, int s
     morton_order_ptr(buf, ns, ctx->src_order, true);
     int rc = ctx->eng->set_source(buf, ns);
     if (rc) return ctx->eng_fail(rc);
+    ctx->enter_uncentred_frame(true);
     ctx->have_src = true;
     return VISMA_ICP_OK;
 }
@@ -1931,7 +1950,7 @@ int visma_icp_set_target_device(visma_icp_ctx *ctx, const void *d, int64_t nt)
     if (nt < 0 || (nt > 0 && !d)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad target arguments");
     int rc = ctx->eng->set_target_device(d, nt);
     if (rc) return ctx->eng_fail(rc);
-    ctx->centre[0] = ctx->centre[1] = ctx->centre[2] = 0.0;
+    ctx->enter_uncentred_frame(false);
     ctx->have_tgt = true;
     return VISMA_ICP_OK;
 }
@@ -1943,6 +1962,7 @@ int visma_icp_set_source_device(visma_icp_ctx *ctx, const void *d, int64_t ns)
     int rc = ctx->eng->set_source_device(d, ns);
     if (rc) return ctx->eng_fail(rc);
     ctx->src_order.clear();   // device-resident source is used in the caller's order
+    ctx->enter_uncentred_frame(true);
     ctx->have_src = true;
     return VISMA_ICP_OK;
 }
@@ -2472,8 +2492,9 @@ int visma_icp_voxel_down_sample(visma_icp_ctx *ctx, const double *xyz, int64_t n
     if (!ctx->eng->supports_device_loop())   // only the HIP engine owns a GPU
         return ctx->fail(VISMA_ICP_ERR_STATE, "voxel_down_sample needs the HIP engine");
     int too_fine = 0;
+    if (int rc = ctx->eng->bind_device()) return ctx->eng_fail(rc);
     hipError_t e = voxel_down_sample_device(xyz, normals, colors, n, voxel_size, out_xyz, out_normals,
-                                            out_colors, n_out, &too_fine, nullptr);
+                                            out_colors, n_out, &too_fine, ctx->eng->aux_stream());
     if (e != hipSuccess) return ctx->fail(VISMA_ICP_ERR_HIP, std::string("voxel_down_sample: ") + hipGetErrorString(e));
     if (too_fine) return ctx->fail(VISMA_ICP_ERR_INVALID, "voxel grid too fine to key in 62 bits");
     return VISMA_ICP_OK;
@@ -2488,8 +2509,9 @@ int visma_icp_point_mesh_distance(visma_icp_ctx *ctx, const double *P, int64_t n
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad point_mesh_distance arguments");
     if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "needs the HIP engine");
     float ms = 0.f, bms = 0.f;
+    if (int rc = ctx->eng->bind_device()) return ctx->eng_fail(rc);
     hipError_t e = point_mesh_distance_device(P, np, V, nv, F, nf, ctx->mesh_method, d2, face, closest, &ms, &bms,
-                                              nullptr);
+                                              ctx->eng->aux_stream());
     if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
                                           std::string("point_mesh_distance: ") + hipGetErrorString(e));
     ctx->last_aux_kernel_ms = ms;
@@ -2522,8 +2544,9 @@ int visma_icp_sample_mesh(visma_icp_ctx *ctx, const double *V, int64_t nv, const
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad sample_mesh arguments");
     if (n > 0x7fffffff) return ctx->fail(VISMA_ICP_ERR_INVALID, "too many samples for 32-bit indices");
     if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "needs the HIP engine");
+    if (int rc = ctx->eng->bind_device()) return ctx->eng_fail(rc);
     hipError_t e = sample_mesh_device(V, nv, F, nf, n, reference_quirks, (unsigned long long)seed, uniforms,
-                                      out_xyz, n_out, nullptr);
+                                      out_xyz, n_out, ctx->eng->aux_stream());
     if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
                                           std::string("sample_mesh: ") + hipGetErrorString(e));
     return VISMA_ICP_OK;
@@ -2565,9 +2588,10 @@ int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const double *Vs, int64_
     std::vector<double> dist((size_t)num_samples);
     int64_t m = 0;
     float ms = 0.f, bms = 0.f;
+    if (int rc = ctx->eng->bind_device()) return ctx->eng_fail(rc);
     hipError_t e = surface_distances_device(Vs, nvs, Fs, nfs, Vt, nvt, Ft, nft, num_samples, reference_quirks,
                                             (unsigned long long)seed, ctx->mesh_method, dist.data(), &m, &ms, &bms,
-                                            nullptr);
+                                            ctx->eng->aux_stream());
     if (e != hipSuccess) return ctx->fail(e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP,
                                           std::string("measure_surface_error: ") + hipGetErrorString(e));
     ctx->last_aux_kernel_ms = ms;
@@ -2591,6 +2615,61 @@ int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n)
         rc = VISMA_ICP_OK;
     if (rc != VISMA_ICP_OK) g_create_error = "so3 selftest: HIP call failed (no GPU?)";
     (void)hipFree(dw); (void)hipFree(dR); (void)hipFree(dw2);
+    return rc;
+}
+
+int visma_so3_rodrigues(const double w[3], double R[9], double dR_dw[27])
+{
+    if (!w || !R) return VISMA_ICP_ERR_INVALID;
+    double D[27];
+    rodrigues_jac(w, R, D);
+    if (dR_dw) std::memcpy(dR_dw, D, sizeof(D));
+    return VISMA_ICP_OK;
+}
+
+int visma_so3_invrodrigues(const double R[9], double w[3], double dw_dR[27])
+{
+    if (!w || !R) return VISMA_ICP_ERR_INVALID;
+    double D[27];
+    invrodrigues_jac(R, w, D);
+    if (dw_dR) std::memcpy(dw_dR, D, sizeof(D));
+    return VISMA_ICP_OK;
+}
+
+int visma_so3_project(const double A[9], double R[9])
+{
+    if (!A || !R) return VISMA_ICP_ERR_INVALID;
+    project_so3(A, R);
+    return VISMA_ICP_OK;
+}
+
+int visma_so3_matrix_derivatives(const double A[9], const double B[9], double dAB_dA_out[81], double dAB_dB_out[81],
+                                 double dAt_dA_out[81], double dhat_out[27], double dvee_out[27])
+{
+    if (dAB_dA_out) { if (!B) return VISMA_ICP_ERR_INVALID; dAB_dA(B, dAB_dA_out); }
+    if (dAB_dB_out) { if (!A) return VISMA_ICP_ERR_INVALID; dAB_dB(A, dAB_dB_out); }
+    if (dAt_dA_out) dAt_dA(dAt_dA_out);
+    if (dhat_out) dhat(dhat_out);
+    if (dvee_out) dvee(dvee_out);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_selftest_so3_jac(const double *w, int n, double *R, double *dR_dw, double *w_back, double *dw_dR,
+                               double *proj)
+{
+    if (!w || !R || !dR_dw || !w_back || !dw_dR || !proj || n <= 0) return VISMA_ICP_ERR_INVALID;
+    double *d[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t sz[6] = {3, 9, 27, 3, 27, 9};
+    int rc = VISMA_ICP_ERR_HIP;
+    bool ok = true;
+    for (int k = 0; k < 6 && ok; k++) ok = hipMalloc(&d[k], sizeof(double) * sz[k] * n) == hipSuccess;
+    ok = ok && hipMemcpy(d[0], w, sizeof(double) * 3 * n, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && launch_so3_selftest_jac(d[0], n, d[1], d[2], d[3], d[4], d[5], nullptr) == hipSuccess;
+    double *out[6] = {nullptr, R, dR_dw, w_back, dw_dR, proj};
+    for (int k = 1; k < 6 && ok; k++) ok = hipMemcpy(out[k], d[k], sizeof(double) * sz[k] * n, hipMemcpyDeviceToHost) == hipSuccess;
+    if (ok) rc = VISMA_ICP_OK;
+    else g_create_error = "so3 selftest: HIP call failed (no GPU?)";
+    for (int k = 0; k < 6; k++) (void)hipFree(d[k]);
     return rc;
 }
 

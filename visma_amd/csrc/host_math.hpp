@@ -193,6 +193,18 @@ VISMA_HD Svd3 svd3(const double A[9])
     return out;
 }
 
+// projectSO3 (core/rodrigues.h:229-237) and SO3Type::fitToSO3 (core/se3.h:58-61): U V^T of the SVD,
+// the orthogonal factor nearest to A (no determinant fix, like the reference: a reflection stays one).
+VISMA_HD void project_so3(const double A[9], double R[9])
+{
+    const Svd3 d = svd3(A);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            R[i * 3 + j] = d.U[i * 3] * d.V[j * 3] + d.U[i * 3 + 1] * d.V[j * 3 + 1] + d.U[i * 3 + 2] * d.V[j * 3 + 2];
+}
+
 struct NormalEq {
     double K, r2;
     double JTJ[36];

@@ -16,6 +16,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <cmath>
@@ -435,3 +436,530 @@ int visma_io_read_obj(const char *path, double **V, int64_t *nv, int32_t **F, in
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- PCD
+namespace {
+
+struct PcdField {
+    std::string name;
+    int size = 4;
+    char type = 'F';
+    int count = 1;
+    int count_offset = 0, offset = 0;
+};
+
+void split_ws(const std::string &line, std::vector<std::string> &out)
+{
+    out.clear();
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && std::strchr("\t\r\n ", line[i])) i++;
+        size_t j = i;
+        while (j < line.size() && !std::strchr("\t\r\n ", line[j])) j++;
+        if (j > i) out.push_back(line.substr(i, j - i));
+        i = j;
+    }
+}
+
+// `sstream >> int` of the reference: the value stays what it was when the token is not a number
+int stream_int(const std::vector<std::string> &st, size_t k, int keep)
+{
+    if (k >= st.size()) return keep;
+    char *end = nullptr;
+    const long v = std::strtol(st[k].c_str(), &end, 10);
+    if (end == st[k].c_str()) return keep;
+    return (int)v;
+}
+
+double pcd_unpack_bin(const unsigned char *p, char type, int size)   // FilePCD.cpp:234-282
+{
+    if (type == 'I') {
+        if (size == 1) { int8_t v; std::memcpy(&v, p, 1); return (double)v; }
+        if (size == 2) { int16_t v; std::memcpy(&v, p, 2); return (double)v; }
+        if (size == 4) { int32_t v; std::memcpy(&v, p, 4); return (double)v; }
+        return 0.0;
+    }
+    if (type == 'U') {
+        if (size == 1) { uint8_t v; std::memcpy(&v, p, 1); return (double)v; }
+        if (size == 2) { uint16_t v; std::memcpy(&v, p, 2); return (double)v; }
+        if (size == 4) { uint32_t v; std::memcpy(&v, p, 4); return (double)v; }
+        return 0.0;
+    }
+    if (type == 'F' && size == 4) { float v; std::memcpy(&v, p, 4); return (double)v; }
+    return 0.0;                                                 // (8-byte floats read as 0, like the reference)
+}
+
+void pcd_color_from_bytes(const unsigned char d[4], double *rgb)    // packed BGR, FilePCD.cpp:284-297
+{
+    rgb[0] = (double)d[2] / 255.0;
+    rgb[1] = (double)d[1] / 255.0;
+    rgb[2] = (double)d[0] / 255.0;
+}
+
+double pcd_unpack_ascii(const char *s, char type)              // FilePCD.cpp:299-312
+{
+    char *end;
+    if (type == 'I') return (double)std::strtol(s, &end, 0);
+    if (type == 'U') return (double)std::strtoul(s, &end, 0);
+    if (type == 'F') return std::strtod(s, &end);
+    return 0.0;
+}
+
+void pcd_color_ascii(const char *s, char type, int size, double *rgb)   // FilePCD.cpp:314-336
+{
+    rgb[0] = rgb[1] = rgb[2] = 0.0;
+    if (size != 4) return;
+    unsigned char d[4] = {0, 0, 0, 0};
+    char *end;
+    if (type == 'I') { const int32_t v = (int32_t)std::strtol(s, &end, 0); std::memcpy(d, &v, 4); }
+    else if (type == 'U') { const uint32_t v = (uint32_t)std::strtoul(s, &end, 0); std::memcpy(d, &v, 4); }
+    else if (type == 'F') { const float v = std::strtof(s, &end); std::memcpy(d, &v, 4); }
+    pcd_color_from_bytes(d, rgb);
+}
+
+// LZF (Marc Lehmann's format, the one PCL writes): a control byte c < 32 starts a literal run of c + 1
+// bytes; otherwise a back reference of length (c >> 5) + 2 (a length field of 7 takes one more byte)
+// at distance ((c & 31) << 8 | next byte) + 1.  Returns the bytes produced, 0 on malformed input.
+size_t lzf_decode(const unsigned char *in, size_t in_len, unsigned char *out, size_t out_len)
+{
+    size_t ip = 0, op = 0;
+    while (ip < in_len) {
+        unsigned c = in[ip++];
+        if (c < 32) {
+            const size_t run = (size_t)c + 1;
+            if (ip + run > in_len || op + run > out_len) return 0;
+            std::memcpy(out + op, in + ip, run);
+            ip += run;
+            op += run;
+        } else {
+            size_t len = c >> 5;
+            if (len == 7) {
+                if (ip >= in_len) return 0;
+                len += in[ip++];
+            }
+            if (ip >= in_len) return 0;
+            const size_t dist = (((size_t)c & 31u) << 8 | in[ip++]) + 1;
+            len += 2;
+            if (dist > op || op + len > out_len) return 0;
+            for (size_t k = 0; k < len; k++, op++) out[op] = out[op - dist];   // may overlap: byte by byte
+        }
+    }
+    return op;
+}
+
+}  // namespace
+
+extern "C" int visma_io_read_pcd(const char *path, visma_io_cloud *out)
+{
+    if (!path || !out) return fail(VISMA_IO_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    FileBytes f;
+    if (!f.open(path)) return fail(VISMA_IO_ERR_OPEN, std::string("Read PCD failed: unable to open file: ") + path);
+    const char *p = f.data, *end = f.data + f.size;
+
+    // ---- header (FilePCD.cpp:132-232): line by line up to the DATA line
+    std::vector<PcdField> fields;
+    int width = 0, height = 0, points = 0, elementnum = 0, pointsize = 0, datatype = 0;
+    std::vector<std::string> st;
+    bool bad = false;
+    while (p < end) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl + 1 : end;
+        const std::string line(p, le);
+        p = le;
+        split_ws(line, st);
+        if (st.empty()) continue;
+        const std::string &t = st[0];
+        const size_t nch = fields.size();
+        if (t[0] == '#') {
+        } else if (t.compare(0, 7, "VERSION") == 0) {
+        } else if (t.compare(0, 6, "FIELDS") == 0 || t.compare(0, 7, "COLUMNS") == 0) {
+            if (st.size() < 2) { bad = true; break; }
+            fields.assign(st.size() - 1, PcdField());
+            for (size_t i = 0; i < fields.size(); i++) {
+                fields[i].name = st[i + 1];
+                fields[i].count_offset = (int)i;
+                fields[i].offset = (int)(4 * i);
+            }
+            elementnum = (int)fields.size();
+            pointsize = (int)(4 * fields.size());
+        } else if (t.compare(0, 4, "SIZE") == 0) {
+            if (nch != st.size() - 1) { bad = true; break; }
+            int offset = 0, v = 0;
+            for (size_t i = 0; i < nch; i++) {
+                v = stream_int(st, i + 1, v);
+                fields[i].size = v;
+                fields[i].offset = offset;
+                offset += v;
+            }
+            pointsize = offset;
+        } else if (t.compare(0, 4, "TYPE") == 0) {
+            if (nch != st.size() - 1) { bad = true; break; }
+            for (size_t i = 0; i < nch; i++) fields[i].type = st[i + 1][0];
+        } else if (t.compare(0, 5, "COUNT") == 0) {
+            if (nch != st.size() - 1) { bad = true; break; }
+            int co = 0, offset = 0, v = 0;
+            for (size_t i = 0; i < nch; i++) {
+                v = stream_int(st, i + 1, v);
+                fields[i].count = v;
+                fields[i].count_offset = co;
+                fields[i].offset = offset;
+                co += v;
+                offset += v * fields[i].size;
+            }
+            elementnum = co;
+            pointsize = offset;
+        } else if (t.compare(0, 5, "WIDTH") == 0) {
+            width = stream_int(st, 1, width);
+        } else if (t.compare(0, 6, "HEIGHT") == 0) {
+            height = stream_int(st, 1, height);
+            points = (int)((long long)width * height);
+        } else if (t.compare(0, 9, "VIEWPOINT") == 0) {
+        } else if (t.compare(0, 6, "POINTS") == 0) {
+            points = stream_int(st, 1, points);
+        } else if (t.compare(0, 4, "DATA") == 0) {
+            datatype = 0;
+            if (st.size() >= 2) {
+                if (st[1].compare(0, 17, "binary_compressed") == 0) datatype = 2;
+                else if (st[1].compare(0, 6, "binary") == 0) datatype = 1;
+            }
+            break;
+        }
+    }
+    // CheckHeader (FilePCD.cpp:77-130)
+    int fx = -1, fy = -1, fz = -1, fnx = -1, fny = -1, fnz = -1, fc = -1;
+    for (size_t i = 0; i < fields.size(); i++) {
+        const std::string &n = fields[i].name;
+        if (n == "x") fx = (int)i; else if (n == "y") fy = (int)i; else if (n == "z") fz = (int)i;
+        else if (n == "normal_x") fnx = (int)i; else if (n == "normal_y") fny = (int)i;
+        else if (n == "normal_z") fnz = (int)i; else if (n == "rgb" || n == "rgba") fc = (int)i;
+    }
+    if (bad || points <= 0 || pointsize <= 0 || fields.empty() || fx < 0 || fy < 0 || fz < 0)
+        return fail(VISMA_IO_ERR_FORMAT, "Read PCD failed: unable to parse header.");
+    for (const auto &fd : fields)
+        if (fd.size < 0 || fd.count < 0 || fd.offset < 0) return fail(VISMA_IO_ERR_FORMAT, "Read PCD failed: unable to parse header.");
+    const bool has_n = fnx >= 0 && fny >= 0 && fnz >= 0, has_c = fc >= 0;
+    const int64_t n = points;
+
+    visma_io_cloud c;
+    std::memset(&c, 0, sizeof(c));
+    auto bail = [&](const std::string &m) { visma_io_free_cloud(&c); return fail(VISMA_IO_ERR_FORMAT, m); };
+    c.xyz = alloc_arr<double>(3 * n);
+    if (has_n) c.normals = alloc_arr<double>(3 * n);
+    if (has_c) c.colors = alloc_arr<double>(3 * n);
+    if (!c.xyz || (has_n && !c.normals) || (has_c && !c.colors)) return bail("out of memory");
+    std::memset(c.xyz, 0, sizeof(double) * 3 * (size_t)n);
+    if (has_n) std::memset(c.normals, 0, sizeof(double) * 3 * (size_t)n);
+    if (has_c) std::memset(c.colors, 0, sizeof(double) * 3 * (size_t)n);
+    // which destination a field feeds: 0..2 xyz, 3..5 normal, 6 colour, -1 none.  (A normal
+    // component of a file without all three normals has nowhere to go.)
+    std::vector<int> dest(fields.size(), -1);
+    for (size_t i = 0; i < fields.size(); i++) {
+        const std::string &nm = fields[i].name;
+        if (nm == "x") dest[i] = 0; else if (nm == "y") dest[i] = 1; else if (nm == "z") dest[i] = 2;
+        else if (has_n && nm == "normal_x") dest[i] = 3; else if (has_n && nm == "normal_y") dest[i] = 4;
+        else if (has_n && nm == "normal_z") dest[i] = 5; else if (nm == "rgb" || nm == "rgba") dest[i] = 6;
+    }
+    if (datatype == 0) {
+        // ascii (FilePCD.cpp:352-397): a line with fewer tokens than elements is skipped
+        int64_t idx = 0;
+        while (p < end && idx < n) {
+            const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+            const char *le = nl ? nl + 1 : end;
+            const std::string line(p, le);
+            p = le;
+            split_ws(line, st);
+            if ((int)st.size() < elementnum) continue;
+            for (size_t i = 0; i < fields.size(); i++) {
+                if (dest[i] < 0) continue;
+                const char *tok = st[(size_t)fields[i].count_offset].c_str();
+                if (dest[i] < 3) c.xyz[3 * idx + dest[i]] = pcd_unpack_ascii(tok, fields[i].type);
+                else if (dest[i] < 6) c.normals[3 * idx + dest[i] - 3] = pcd_unpack_ascii(tok, fields[i].type);
+                else pcd_color_ascii(tok, fields[i].type, fields[i].size, c.colors + 3 * idx);
+            }
+            idx++;
+        }
+    } else if (datatype == 1) {
+        // binary records (FilePCD.cpp:398-438)
+        if ((int64_t)(end - p) / pointsize < n) return bail("Read PCD failed: unable to read data.");
+        for (const auto &fd : fields)
+            if ((int64_t)fd.offset + fd.size > pointsize) return bail("Read PCD failed: unable to parse header.");
+        const unsigned char *base = (const unsigned char *)p;
+        parallel_chunks(n, 65536, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; i++) {
+                const unsigned char *r = base + (size_t)i * pointsize;
+                for (size_t k = 0; k < fields.size(); k++) {
+                    if (dest[k] < 0) continue;
+                    const PcdField &fd = fields[k];
+                    if (dest[k] < 3) c.xyz[3 * i + dest[k]] = pcd_unpack_bin(r + fd.offset, fd.type, fd.size);
+                    else if (dest[k] < 6) c.normals[3 * i + dest[k] - 3] = pcd_unpack_bin(r + fd.offset, fd.type, fd.size);
+                    else if (fd.size == 4) pcd_color_from_bytes(r + fd.offset, c.colors + 3 * i);
+                }
+            }
+        });
+    } else {
+        // binary_compressed (FilePCD.cpp:439-509): two u32 sizes, one LZF block, fields stored one
+        // after another (structure of arrays)
+        if (end - p < 8) return bail("Read PCD failed: unable to read data.");
+        uint32_t csize, usize;
+        std::memcpy(&csize, p, 4);
+        std::memcpy(&usize, p + 4, 4);
+        p += 8;
+        if ((uint64_t)(end - p) < csize) return bail("Read PCD failed: unable to read data.");
+        std::vector<unsigned char> buf((size_t)usize + 1);
+        if (lzf_decode((const unsigned char *)p, csize, buf.data(), usize) != usize)
+            return bail("Read PCD failed: unable to read data.");
+        for (size_t k = 0; k < fields.size(); k++) {
+            if (dest[k] < 0) continue;
+            const PcdField &fd = fields[k];
+            const uint64_t first = (uint64_t)fd.offset * (uint64_t)n, stride = (uint64_t)fd.size * (uint64_t)fd.count;
+            // (the reference does not check this; a short block would be read past its end there)
+            if (first + stride * (uint64_t)(n - 1) + (uint64_t)fd.size > usize) return bail("Read PCD failed: unable to read data.");
+            const unsigned char *b = buf.data() + first;
+            for (int64_t i = 0; i < n; i++) {
+                const unsigned char *e = b + (uint64_t)i * stride;
+                if (dest[k] < 3) c.xyz[3 * i + dest[k]] = pcd_unpack_bin(e, fd.type, fd.size);
+                else if (dest[k] < 6) c.normals[3 * i + dest[k] - 3] = pcd_unpack_bin(e, fd.type, fd.size);
+                else if (fd.size == 4) pcd_color_from_bytes(e, c.colors + 3 * i);
+            }
+        }
+    }
+    // RemoveNanData (FilePCD.cpp:514-534): the reference tests x, y and x again -- a NaN z stays
+    int64_t k = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (std::isnan(c.xyz[3 * i]) || std::isnan(c.xyz[3 * i + 1])) continue;
+        if (k != i) {
+            std::memcpy(c.xyz + 3 * k, c.xyz + 3 * i, 3 * sizeof(double));
+            if (has_n) std::memcpy(c.normals + 3 * k, c.normals + 3 * i, 3 * sizeof(double));
+            if (has_c) std::memcpy(c.colors + 3 * k, c.colors + 3 * i, 3 * sizeof(double));
+        }
+        k++;
+    }
+    c.n = k;
+    c.n_normals = has_n ? k : 0;
+    c.n_colors = has_c ? k : 0;
+    *out = c;
+    return VISMA_IO_OK;
+}
+
+// ---------------------------------------------------------------- pose files (JSON)
+namespace {
+
+// A JSON reader for what the pose files hold: objects, arrays, strings, numbers, true / false / null.
+struct JVal {
+    enum Kind { NUL, BOOL, NUM, STR, ARR, OBJ } kind = NUL;
+    double num = 0.0;
+    bool b = false;
+    std::string str;
+    std::vector<JVal> arr;
+    std::vector<std::pair<std::string, JVal>> obj;      // file order
+    const JVal *get(const std::string &k) const
+    {
+        for (const auto &kv : obj) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+
+struct JParser {
+    const char *p, *end;
+    std::string err;
+    int depth = 0;
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+    bool fail(const char *m) { if (err.empty()) err = m; return false; }
+    bool string(std::string &out)
+    {
+        if (p >= end || *p != '"') return fail("expected a string");
+        p++;
+        out.clear();
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return fail("bad escape");
+                switch (*p) {
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case 'u': {
+                    if (end - p < 5) return fail("bad \\u escape");
+                    unsigned v = 0;
+                    for (int i = 1; i <= 4; i++) {
+                        const char ch = p[i];
+                        v = v * 16 + (unsigned)(ch >= '0' && ch <= '9' ? ch - '0' : (ch | 32) >= 'a' && (ch | 32) <= 'f' ? (ch | 32) - 'a' + 10 : 0);
+                    }
+                    p += 4;
+                    if (v < 0x80) out += (char)v;
+                    else if (v < 0x800) { out += (char)(0xC0 | (v >> 6)); out += (char)(0x80 | (v & 63)); }
+                    else { out += (char)(0xE0 | (v >> 12)); out += (char)(0x80 | ((v >> 6) & 63)); out += (char)(0x80 | (v & 63)); }
+                    break;
+                }
+                default: out += *p;
+                }
+                p++;
+            } else {
+                out += *p++;
+            }
+        }
+        if (p >= end) return fail("unterminated string");
+        p++;
+        return true;
+    }
+    bool value(JVal &v)
+    {
+        if (++depth > 64) return fail("nesting too deep");
+        ws();
+        if (p >= end) return fail("unexpected end of file");
+        bool ok = true;
+        if (*p == '{') {
+            v.kind = JVal::OBJ;
+            p++;
+            ws();
+            if (p < end && *p == '}') { p++; }
+            else for (;;) {
+                ws();
+                std::string k;
+                JVal c;
+                if (!string(k)) { ok = false; break; }
+                ws();
+                if (p >= end || *p != ':') { ok = fail("expected ':'"); break; }
+                p++;
+                if (!value(c)) { ok = false; break; }
+                v.obj.emplace_back(std::move(k), std::move(c));
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == '}') { p++; break; }
+                ok = fail("expected ',' or '}'");
+                break;
+            }
+        } else if (*p == '[') {
+            v.kind = JVal::ARR;
+            p++;
+            ws();
+            if (p < end && *p == ']') { p++; }
+            else for (;;) {
+                JVal c;
+                if (!value(c)) { ok = false; break; }
+                v.arr.push_back(std::move(c));
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == ']') { p++; break; }
+                ok = fail("expected ',' or ']'");
+                break;
+            }
+        } else if (*p == '"') {
+            v.kind = JVal::STR;
+            ok = string(v.str);
+        } else if (end - p >= 4 && std::strncmp(p, "true", 4) == 0) { v.kind = JVal::BOOL; v.b = true; p += 4; }
+        else if (end - p >= 5 && std::strncmp(p, "false", 5) == 0) { v.kind = JVal::BOOL; v.b = false; p += 5; }
+        else if (end - p >= 4 && std::strncmp(p, "null", 4) == 0) { v.kind = JVal::NUL; p += 4; }
+        else {
+            char *e = nullptr;
+            const double d = std::strtod(p, &e);             // (the buffer is NUL-terminated)
+            if (e == p) ok = fail("unexpected character");
+            else { v.kind = JVal::NUM; v.num = d; p = e; }
+        }
+        --depth;
+        return ok;
+    }
+};
+
+bool json_load(const char *path, JVal &root, std::string &err)
+{
+    FileBytes f;
+    if (!f.open(path)) { err = std::string("unable to open ") + path; return false; }
+    JParser ps{f.data, f.data + f.size, "", 0};
+    if (!ps.value(root)) { err = "JSON: " + ps.err; return false; }
+    ps.ws();
+    if (ps.p != ps.end) { err = "JSON: trailing characters"; return false; }
+    return true;
+}
+
+// GetMatrixFromJson<double, 3, 4>(v, key): entry (i, j) = v[key][4 i + j].asDouble() (core/utils.h:305-322)
+bool pose_from(const JVal *a, double T[12])
+{
+    if (!a || a->kind != JVal::ARR || a->arr.size() < 12) return false;
+    for (int i = 0; i < 12; i++) {
+        const JVal &e = a->arr[(size_t)i];
+        if (e.kind == JVal::NUM) T[i] = e.num;
+        else if (e.kind == JVal::BOOL) T[i] = e.b ? 1.0 : 0.0;       // jsoncpp's asDouble() of a bool
+        else if (e.kind == JVal::NUL) T[i] = 0.0;                   // ... and of null
+        else return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" int visma_io_read_alignment_json(const char *path, visma_io_pose **poses, int64_t *n)
+{
+    if (!path || !poses || !n) return fail(VISMA_IO_ERR_INVALID, "null argument");
+    *poses = nullptr;
+    *n = 0;
+    JVal root;
+    std::string err;
+    if (!json_load(path, root, err)) return fail(VISMA_IO_ERR_OPEN, err);
+    if (root.kind != JVal::OBJ) return fail(VISMA_IO_ERR_FORMAT, "alignment file: the top level is not an object");
+    // jsoncpp iterates the members of an object in key order (std::map): so do the callers' loops
+    std::vector<const std::pair<std::string, JVal> *> items;
+    for (const auto &kv : root.obj) items.push_back(&kv);
+    std::stable_sort(items.begin(), items.end(), [](const std::pair<std::string, JVal> *a, const std::pair<std::string, JVal> *b) { return a->first < b->first; });
+    visma_io_pose *o = (visma_io_pose *)std::calloc(items.size() ? items.size() : 1, sizeof(visma_io_pose));
+    if (!o) return fail(VISMA_IO_ERR_FORMAT, "out of memory");
+    for (size_t i = 0; i < items.size(); i++) {
+        if (!pose_from(&items[i]->second, o[i].T)) { std::free(o); return fail(VISMA_IO_ERR_FORMAT, "alignment file: \"" + items[i]->first + "\" is not an array of 12 numbers"); }
+        std::snprintf(o[i].name, sizeof(o[i].name), "%s", items[i]->first.c_str());
+        o[i].id = -1;
+        o[i].status = 0;
+    }
+    *poses = o;
+    *n = (int64_t)items.size();
+    return VISMA_IO_OK;
+}
+
+extern "C" int visma_io_write_alignment_json(const char *path, const visma_io_pose *poses, int64_t n)
+{
+    if (!path || n < 0 || (n > 0 && !poses)) return fail(VISMA_IO_ERR_INVALID, "bad arguments");
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(VISMA_IO_ERR_OPEN, std::string("unable to open ") + path);
+    std::fputs("{\n", f);
+    for (int64_t i = 0; i < n; i++) {
+        std::fputs("  \"", f);
+        for (const char *c = poses[i].name; *c; c++) {
+            if (*c == '"' || *c == '\\') std::fputc('\\', f);
+            std::fputc(*c, f);
+        }
+        std::fputs("\": [", f);
+        for (int k = 0; k < 12; k++) std::fprintf(f, "%s%.17g", k ? ", " : "", poses[i].T[k]);   // WriteMatrixToJson: row by row
+        std::fprintf(f, "]%s\n", i + 1 < n ? "," : "");
+    }
+    std::fputs("}\n", f);
+    const bool ok = std::fclose(f) == 0;
+    return ok ? VISMA_IO_OK : fail(VISMA_IO_ERR_OPEN, "write failed");
+}
+
+extern "C" int visma_io_read_result_json(const char *path, int64_t packet, visma_io_pose **poses, int64_t *n)
+{
+    if (!path || !poses || !n) return fail(VISMA_IO_ERR_INVALID, "null argument");
+    *poses = nullptr;
+    *n = 0;
+    JVal root;
+    std::string err;
+    if (!json_load(path, root, err)) return fail(VISMA_IO_ERR_OPEN, err);
+    if (root.kind != JVal::ARR || root.arr.empty()) return fail(VISMA_IO_ERR_FORMAT, "result file: the top level is not a non-empty array");
+    const int64_t np = (int64_t)root.arr.size();
+    if (packet < 0) packet = np + packet;                      // -1: the last packet (src/evaluation.cpp:169)
+    if (packet < 0 || packet >= np) return fail(VISMA_IO_ERR_INVALID, "result file: no such packet");
+    const JVal &pk = root.arr[(size_t)packet];
+    if (pk.kind != JVal::ARR) return fail(VISMA_IO_ERR_FORMAT, "result file: a packet is not an array");
+    visma_io_pose *o = (visma_io_pose *)std::calloc(pk.arr.size() ? pk.arr.size() : 1, sizeof(visma_io_pose));
+    if (!o) return fail(VISMA_IO_ERR_FORMAT, "out of memory");
+    for (size_t i = 0; i < pk.arr.size(); i++) {
+        const JVal &ob = pk.arr[i];
+        const JVal *nm = ob.kind == JVal::OBJ ? ob.get("model_name") : nullptr;
+        if (ob.kind != JVal::OBJ || !pose_from(ob.get("model_pose"), o[i].T)) { std::free(o); return fail(VISMA_IO_ERR_FORMAT, "result file: object without a 12-number model_pose"); }
+        std::snprintf(o[i].name, sizeof(o[i].name), "%s", nm && nm->kind == JVal::STR ? nm->str.c_str() : "");
+        const JVal *id = ob.get("id"), *stt = ob.get("status");
+        o[i].id = id && id->kind == JVal::NUM ? (int)id->num : 0;
+        o[i].status = stt && stt->kind == JVal::NUM ? (int)stt->num : 0;
+    }
+    *poses = o;
+    *n = (int64_t)pk.arr.size();
+    return VISMA_IO_OK;
+}

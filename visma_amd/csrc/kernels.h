@@ -246,5 +246,7 @@ hipError_t launch_pack_float4(const float *src, int stride, float4 *dst, int64_t
 // SO(3) self-test kernel: R = rodrigues(w), w2 = invrodrigues(R), v2 = g*v
 hipError_t launch_so3_selftest(const double *w, double *R, double *w2, int n,
                                hipStream_t stream);
+hipError_t launch_so3_selftest_jac(const double *w, int n, double *R, double *dR, double *w2, double *dw, double *proj,
+                                   hipStream_t stream);
 
 }  // namespace visma

@@ -16,6 +16,7 @@
 //   accept iff d2 < r2f; lowest target index wins exact ties.
 // Statistics are accumulated in f64 from p = T64 * (double)s and q widened.
 #include "device_common.h"
+#include "host_math.hpp"
 
 #include <math.h>
 
@@ -488,6 +489,30 @@ __global__ void so3_selftest_kernel(const double *w, double *R, double *w2, int 
     invrodrigues(Ri, wo);
     for (int a = 0; a < 9; a++) R[9 * i + a] = Ri[a];
     for (int a = 0; a < 3; a++) w2[3 * i + a] = wo[a];
+}
+
+// the derivatives and the projection as well (core/rodrigues.h:143-237)
+__global__ void so3_selftest_jac_kernel(const double *w, int n, double *R, double *dR, double *w2, double *dw,
+                                        double *proj)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double wi[3] = {w[3 * i], w[3 * i + 1], w[3 * i + 2]}, Ri[9], D1[27], wo[3], D2[27], P[9], A[9];
+    rodrigues_jac(wi, Ri, D1);
+    invrodrigues_jac(Ri, wo, D2);
+    // a matrix near the rotation (sheared a little), projected back
+    for (int a = 0; a < 9; a++) A[a] = Ri[a] * (1.0 + 0.01 * (a % 3)) + 0.003 * a;
+    project_so3(A, P);
+    for (int a = 0; a < 9; a++) { R[9 * i + a] = Ri[a]; proj[9 * i + a] = P[a]; }
+    for (int a = 0; a < 27; a++) { dR[27 * i + a] = D1[a]; dw[27 * i + a] = D2[a]; }
+    for (int a = 0; a < 3; a++) w2[3 * i + a] = wo[a];
+}
+
+hipError_t launch_so3_selftest_jac(const double *w, int n, double *R, double *dR, double *w2, double *dw, double *proj,
+                                   hipStream_t stream)
+{
+    hipLaunchKernelGGL(so3_selftest_jac_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, w, n, R, dR, w2, dw, proj);
+    return hipGetLastError();
 }
 
 hipError_t launch_so3_selftest(const double *w, double *R, double *w2, int n,
