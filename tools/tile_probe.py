@@ -55,7 +55,7 @@ def check(ns, nt, npass, seed, radius=None, offset=None, label=""):
     variants = [("exact", {}), ("exact-2launch", {"VISMA_ICP_FUSED_FOLD": "0"}),
                 ("exact-g4", {"VISMA_ICP_GRID_LANES": "804"}), ("exact-g2", {"VISMA_ICP_GRID_LANES": "802"})]
     if os.environ.get("PROBE_TILE"):
-        variants += [("tile%d" % k, {"VISMA_ICP_TILE": "1", "VISMA_ICP_TILE_CONFIG": str(k)}) for k in (0, 1, 2, 3, 8)]
+        variants = [("tile%d" % k, {"VISMA_ICP_TILE": "1", "VISMA_ICP_TILE_CONFIG": str(k)}) for k in (0, 1, 2, 3, 4)]
     cs = [(n, ctx_with(e, "exact", src, tgt)) for n, e in variants]
     for p in range(npass):
         T = T_gt @ rand_T(rng, r * 0.8, r * 0.5) if p else np.eye(4)
@@ -116,6 +116,21 @@ def timing(ns, nt, steps, cfgs):
 def main():
     quick = "--quick" in sys.argv
     bad = 0
+    if "--tile" in sys.argv:
+        os.environ["PROBE_TILE"] = "1"
+        bad += check(5000, 20000, 4, 11, label="5k-20k")
+        bad += check(3000, 8000, 4, 12, radius=0.075, label="3k-8k big radius")
+        bad += check(2000, 500, 3, 13, radius=0.2, label="2k-500 degenerate")
+        bad += check(20000, 100000, 3, 14, offset=[3.0, -2.0, 1.0], label="offset 3m")
+        bad += check(65536, 1048576, 2, 15, label="64k-1M")
+        bad += check(262144, 4194304, 2, 16, label="C4")
+        cfgs = [("exact-gather", {}, "exact")] + [
+            ("tile%d" % k, {"VISMA_ICP_TILE": "1", "VISMA_ICP_TILE_CONFIG": str(k)}, "exact") for k in (0, 1, 2, 3, 4, 10)]
+        timing(5000, 20000, 40, cfgs)
+        timing(65536, 1048576, 30, cfgs)
+        timing(262144, 4194304, 30, cfgs)
+        print("TOTAL MISMATCHES", bad)
+        return
     if "--hyb" in sys.argv:
         bad += check(5000, 20000, 4, 11, label="5k-20k")
         bad += check(3000, 8000, 4, 12, radius=0.075, label="3k-8k big radius")

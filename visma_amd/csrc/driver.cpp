@@ -242,7 +242,7 @@ public:
             if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
         }
         if (const char *e = std::getenv("VISMA_ICP_TILE")) tile_enabled_ = std::atoi(e) != 0;
-        if (const char *e = std::getenv("VISMA_ICP_TILE_CONFIG")) { const int v = std::atoi(e); if (v >= 0 && v <= 11) tile_config_ = v; }
+        if (const char *e = std::getenv("VISMA_ICP_TILE_CONFIG")) { const int v = std::atoi(e); if (v >= 0 && v <= 10) tile_config_ = v; }
         if (const char *e = std::getenv("VISMA_ICP_TILE_FALLBACK")) tile_fallback_ = std::atoi(e) != 0;
         if (const char *e = std::getenv("VISMA_ICP_TILE_FOLD")) tile_fused_fold_ = std::atoi(e) != 0;
         if (const char *e = std::getenv("VISMA_ICP_FUSED_FOLD")) fused_fold_ = std::atoi(e) != 0;

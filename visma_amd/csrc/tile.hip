@@ -107,6 +107,7 @@ __device__ __forceinline__ void group_merge(float &b1, float &b2, unsigned &pos)
 //   rowlo  u32[MAXR]         first target slot of a footprint row
 //   rowoff u32[MAXR]         (first: one-past-last target slot) LDS offset of the row
 //   clist  u32[MAXR]         footprint rows that hold points, compacted
+//   hkey   u32[MAXR]         row table keys ((y << 16) | z, open addressing)
 //   rbeg   u32[9][QPB]       per query, visiting order: first candidate of the run (LDS offset in tile
 //                            mode, target slot otherwise)
 //   rlen   u32[9][QPB]       ... its length
@@ -116,15 +117,17 @@ __device__ __forceinline__ void group_merge(float &b1, float &b2, unsigned &pos)
 // NT/NS target points per query whatever the geometry, so one query per lane would leave room
 // for only one or two workgroups per CU; G lanes per query shrink the tile G-fold and split
 // the bound loads and the candidates of a query between them.
-template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE>
-__global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a)
+template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE, bool STAMPS>
+__global__ __launch_bounds__(NTH, 3) void nn_tile_reduce_kernel(const TileArgs a)
 {
     constexpr int NACC = Acc<PLANE>::N;
     constexpr int NW = NTH / 64;
     constexpr int QPB = NTH / G;
     constexpr int U = G >= 8 ? 2 : 4;                      // candidates per lane per trip of the search loop
     constexpr int RPL = (9 + G - 1) / G;                   // rows per lane
-    static_assert(MAXR % NTH == 0, "MAXR must be a multiple of the workgroup size");
+    static_assert(MAXR % NTH == 0 && (MAXR & (MAXR - 1)) == 0, "MAXR: a power of two, a multiple of the workgroup size");
+    constexpr int kLogR = MAXR == 256 ? 8 : (MAXR == 512 ? 9 : (MAXR == 1024 ? 10 : (MAXR == 2048 ? 11 : 7)));
+    static_assert((1 << kLogR) == MAXR, "MAXR out of range");
     static_assert(CAP <= 65535 && CAP % 4 == 0, "CAP out of range");
     static_assert((size_t)CAP * 12 >= (size_t)QPB * NACC * 8, "moment scratch does not fit the tile region");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -134,7 +137,8 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
     unsigned *rowlo = reinterpret_cast<unsigned *>(tz + CAP);
     unsigned *rowoff = rowlo + MAXR;
     unsigned *clist = rowoff + MAXR;
-    unsigned *rbeg = clist + MAXR;
+    unsigned *hkey = clist + MAXR;
+    unsigned *rbeg = hkey + MAXR;
     unsigned *rlen = rbeg + 9 * QPB;
     unsigned *rgl = rlen + 9 * QPB;
     int *scr = reinterpret_cast<int *>(rgl + 9 * QPB);
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
     const int q = tid / G, sub = tid % G;
     long long tstamp[10];
     int nstamp = 0;
-#define VISMA_STAMP() do { if (a.stats) tstamp[nstamp] = clock64(); ++nstamp; } while (0)
+#define VISMA_STAMP() do { if (STAMPS && a.stats && nstamp < 10) tstamp[nstamp] = clock64(); ++nstamp; } while (0)
+#define VISMA_STAMP_FIRST() do { if (passes_run == 0) VISMA_STAMP(); } while (0)
     VISMA_STAMP();                                            // 0: start
 
     // ---- which problem, which chunk of its queries -------------------------------------
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
     const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.dim[0] - 1);
     const int ylo = max(cy - 1, 0), yhi = min(cy + 1, g.dim[1] - 1);
     const int zlo = max(cz - 1, 0), zhi = min(cz + 1, g.dim[2] - 1);
-    const bool contrib = valid && x0 <= x1 && ylo <= yhi && zlo <= zhi;
+    (void)ylo; (void)yhi; (void)zlo; (void)zhi;
     VISMA_STAMP();                                            // 1: source loaded, transformed
 
     // ---- (B) run bounds: lane `sub` of a query fetches the rows it visits kk = sub, sub+G, ... ----
@@ -230,8 +235,12 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
         const int z = cz + dz, y = cy + dy;
         const bool ok = kk < 9 && valid && (x0 <= x1) && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
         const int row = ((ok ? z : 0) * g.dim[1] + (ok ? y : 0)) * g.dim[0];
-        const unsigned b = ok ? start[row + x0] : 0u;
-        const unsigned e = ok ? start[row + x1 + 1] : 0u;
+        // ONE 16-byte load (4-byte aligned): the starts of cells x0 .. x0+3 (the table has slack at its end)
+        typedef unsigned u4a __attribute__((ext_vector_type(4), aligned(4)));
+        u4a v = {0u, 0u, 0u, 0u};
+        if (ok) v = *reinterpret_cast<const u4a *>(start + row + x0);
+        const int span = x1 + 1 - x0;
+        const unsigned b = v.x, e = ok ? (span >= 3 ? v.w : (span == 2 ? v.z : v.y)) : 0u;
         rb[m] = b;
         rl[m] = e > b ? e - b : 0u;
         ry[m] = y;
@@ -279,53 +288,42 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
         const int qlo = npass ? pass * (QPB / npass) : 0, qhi = npass ? qlo + QPB / npass : QPB;
         const bool active = q >= qlo && q < qhi;
         bool tile = !global_mode;
-        int ymin = 0, zmin = 0, nzs = 0, nslots = 0;
         unsigned total = 0, nrows = 0;
-        if (tile) {
-            // ---- footprint rows of this part: bounding box of (y, z) -----------------------
-            {
-                const bool c = contrib && active;
-                int m0 = c ? ylo : INT_MAX, m1 = c ? -yhi : INT_MAX;
-                int m2 = c ? zlo : INT_MAX, m3 = c ? -zhi : INT_MAX;
+        int slot[RPL];                                       // where the row of visit slot kk lives in the row table
 #pragma unroll
-                for (int o = 32; o >= G; o >>= 1) {          // the G lanes of a query hold the same values
-                    m0 = min(m0, __shfl_xor(m0, o, 64));
-                    m1 = min(m1, __shfl_xor(m1, o, 64));
-                    m2 = min(m2, __shfl_xor(m2, o, 64));
-                    m3 = min(m3, __shfl_xor(m3, o, 64));
-                }
-                if (lane == 0) { scr[wave * 4] = m0; scr[wave * 4 + 1] = m1; scr[wave * 4 + 2] = m2; scr[wave * 4 + 3] = m3; }
-            }
+        for (int m = 0; m < RPL; m++) slot[m] = 0;
+        if (tile) {
+            // ---- footprint rows of this part: a hashed table keyed by (y, z) -- only rows that hold
+            //      candidates get an entry, whatever the shape of the chunk ----------------------
 #pragma unroll
             for (int s = 0; s < MAXR / NTH; s++) {
+                hkey[tid + s * NTH] = kNone;
                 rowlo[tid + s * NTH] = kNone;
                 rowoff[tid + s * NTH] = 0u;                  // "rowhi" until the scan
             }
+            if (tid == 0) scr[40] = 0;
             __syncthreads();
-            int ymaxn = INT_MAX, zmaxn = INT_MAX;
-            ymin = INT_MAX; zmin = INT_MAX;
-#pragma unroll
-            for (int w = 0; w < NW; w++) {
-                ymin = min(ymin, scr[w * 4]); ymaxn = min(ymaxn, scr[w * 4 + 1]);
-                zmin = min(zmin, scr[w * 4 + 2]); zmaxn = min(zmaxn, scr[w * 4 + 3]);
-            }
-            const bool any = ymin != INT_MAX;
-            nzs = any ? (-zmaxn - zmin + 1) : 0;
-            const int nys = any ? (-ymaxn - ymin + 1) : 0;
-            const long long nslots_ll = (long long)nys * nzs;
-            if (nslots_ll > MAXR) tile = false;
-            nslots = tile ? (int)nslots_ll : 0;
-            // ---- per-row union of the runs ---------------------------------------------------
-            if (tile && active) {
+            if (active) {
 #pragma unroll
                 for (int m = 0; m < RPL; m++)
                     if (rl[m]) {
-                        const int sl = (ry[m] - ymin) * nzs + (rz[m] - zmin);
-                        atomicMin(&rowlo[sl], rb[m]);
-                        atomicMax(&rowoff[sl], rb[m] + rl[m]);
+                        const unsigned key = ((unsigned)ry[m] << 16) | (unsigned)rz[m];
+                        unsigned h = (key * 2654435761u) >> (32 - kLogR);
+                        int probe = 0;
+                        for (; probe < MAXR; probe++) {
+                            const unsigned old = atomicCAS(&hkey[h], kNone, key);
+                            if (old == kNone || old == key) break;
+                            h = (h + 1) & (MAXR - 1);
+                        }
+                        if (probe == MAXR) { scr[40] = 1; continue; }     // table full: this part is split
+                        slot[m] = (int)h;
+                        atomicMin(&rowlo[h], rb[m]);
+                        atomicMax(&rowoff[h], rb[m] + rl[m]);
                     }
             }
             __syncthreads();
+            if (scr[40]) tile = false;
+            const int nslots = MAXR;
             // ---- exclusive scan of (row length, row holds points) -> LDS offsets, compact list --
             if (tile) {
                 constexpr int SPT = MAXR / NTH;
@@ -385,37 +383,40 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
                 continue;
             }
         }
-        VISMA_STAMP();                                        // 2 (first pass): rows, unions, scan
+        VISMA_STAMP_FIRST();                                  // 2 (first part): rows, unions, scan
 
-        // ---- (C) stream the footprint into LDS: one wave per row, four rows in flight ----------
+        // ---- (C) stream the footprint into LDS: 16 lanes per row, four rows x 48 points in flight ----
         if (tile && total > 0) {
-            for (unsigned c0 = wave; c0 < nrows; c0 += 4 * NW) {
+            constexpr int NG16 = NTH / 16;
+            const unsigned l16 = tid & 15, g16 = tid >> 4;
+            for (unsigned c0 = g16; c0 < nrows; c0 += 4 * NG16) {
                 unsigned lo[4], of[4], ln[4];
-                float4 v[4];
+                float4 v[4][3];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const unsigned c = c0 + u * NW;
+                    const unsigned c = c0 + u * NG16;
                     const unsigned sl = clist[c < nrows ? c : 0];
                     lo[u] = rowlo[sl];
                     of[u] = rowoff[sl];
-                    // length from the neighbour offsets is not available (empty rows share offsets): recompute
-                    ln[u] = 0;
-                    if (c < nrows) {
-                        const unsigned nxt = (c + 1 < nrows) ? rowoff[clist[c + 1]] : total;
-                        ln[u] = nxt - of[u];
-                    }
+                    ln[u] = 0;                               // (empty rows share offsets: length from the next row that holds points)
+                    if (c < nrows) ln[u] = ((c + 1 < nrows) ? rowoff[clist[c + 1]] : total) - of[u];
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if ((unsigned)lane < ln[u]) v[u] = sorted[lo[u] + lane];
+#pragma unroll
+                    for (int h = 0; h < 3; h++)
+                        if (l16 + 16 * h < ln[u]) v[u][h] = sorted[lo[u] + l16 + 16 * h];
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if ((unsigned)lane < ln[u]) {
-                        tx[of[u] + lane] = v[u].x; ty[of[u] + lane] = v[u].y; tz[of[u] + lane] = v[u].z;
-                    }
+#pragma unroll
+                    for (int h = 0; h < 3; h++)
+                        if (l16 + 16 * h < ln[u]) {
+                            const unsigned o = of[u] + l16 + 16 * h;
+                            tx[o] = v[u][h].x; ty[o] = v[u][h].y; tz[o] = v[u][h].z;
+                        }
 #pragma unroll 1
                 for (int u = 0; u < 4; u++)
-                    for (unsigned j = lane + 64; j < ln[u]; j += 64) {
+                    for (unsigned j = l16 + 48; j < ln[u]; j += 16) {
                         const float4 w4 = sorted[lo[u] + j];
                         tx[of[u] + j] = w4.x; ty[of[u] + j] = w4.y; tz[of[u] + j] = w4.z;
                     }
@@ -430,10 +431,7 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
                 if (kk < 9) {
                     ncand_all += rl[m];
                     unsigned o = rb[m];
-                    if (tile) {
-                        const int sl = (ry[m] - ymin) * nzs + (rz[m] - zmin);
-                        o = rl[m] ? rowoff[sl] + (rb[m] - rowlo[sl]) : 0u;
-                    }
+                    if (tile) o = rl[m] ? rowoff[slot[m]] + (rb[m] - rowlo[slot[m]]) : 0u;
                     rbeg[kk * QPB + q] = o;
                     rlen[kk * QPB + q] = rl[m];
                     rgl[kk * QPB + q] = rb[m];
@@ -441,7 +439,7 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
             }
         }
         __syncthreads();                                     // tile + lists complete
-        VISMA_STAMP();                                        // 3 (first pass): tile streamed
+        VISMA_STAMP_FIRST();                                  // 3 (first part): tile streamed
 
         // ---- (D) fp32 search of the active queries: best and runner-up --------------------------
         if (active) {
@@ -449,22 +447,8 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
             unsigned cpos = kNone;
             auto search = [&](auto tile_tag) {
                 constexpr bool TILE = decltype(tile_tag)::value;
-                unsigned s_n = rbeg[q], l_n = rlen[q], g_n = rgl[q];
-#pragma unroll 1
-                for (int kk = 0; kk < 9; kk++) {
-                    const unsigned s = s_n, gs = g_n;
-                    unsigned l = l_n;
-                    if (kk < 8) {                            // next row's list entries: in flight during this row
-                        s_n = rbeg[(kk + 1) * QPB + q]; l_n = rlen[(kk + 1) * QPB + q]; g_n = rgl[(kk + 1) * QPB + q];
-                    }
-                    if (PRUNE && kk > 0) {
-                        const int k = row_of_visit(kk);
-                        const int dy = k % 3 - 1, dz = k / 3 - 1;
-                        const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
-                        const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
-                        const float bound = (ey * ey + ez * ez) * h2;
-                        if (bound > group_min<G>(c1)) l = 0u;
-                    }
+                // one run: every lane of the query takes candidates sub, sub + G, ...
+                auto run_row = [&](const unsigned s, const unsigned l, const unsigned gs) {
                     if (sub == 0) ncand += l;
                     for (unsigned j0 = 0; j0 < l; j0 += G * U) {
                         float qx[U], qy[U], qz[U];
@@ -491,6 +475,34 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
                             c1 = lt ? d : c1;
                         }
                     }
+                };
+                // the centre row is never pruned
+                run_row(rbeg[q], rlen[q], rgl[q]);
+                // which of the other eight rows can still hold a candidate that matters: decided for all
+                // of them at once (straight-line code, the list reads overlap), then only those are walked
+                float gbest = PRUNE ? group_min<G>(c1) : INFINITY;
+                unsigned live = 0;
+#pragma unroll
+                for (int kk = 1; kk < 9; kk++) {
+                    constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+                    const int k = order[kk];
+                    const int dy = k % 3 - 1, dz = k / 3 - 1;
+                    const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
+                    const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
+                    const float bound = (ey * ey + ez * ez) * h2;
+                    if (rlen[kk * QPB + q] != 0u && !(bound > gbest)) live |= 1u << kk;
+                }
+                while (live) {                               // uniform over the G lanes of a query
+                    const int kk = __ffs((int)live) - 1;
+                    live &= live - 1u;
+                    if (PRUNE) {                             // the best may have improved since the mask was formed
+                        const int k = row_of_visit(kk);
+                        const int dy = k % 3 - 1, dz = k / 3 - 1;
+                        const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
+                        const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
+                        if ((ey * ey + ez * ez) * h2 > group_min<G>(c1)) continue;
+                    }
+                    run_row(rbeg[kk * QPB + q], rlen[kk * QPB + q], rgl[kk * QPB + q]);
                 }
             };
             if (tile) search(std::true_type{}); else search(std::false_type{});
@@ -532,12 +544,13 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
                 hit = bidx != kNone;
             }
         }
-        if (passes_run == 0) { total_pts = total; total_rows = (unsigned)nslots; }
+        if (passes_run == 0) { total_pts = total; total_rows = nrows; }
         ++passes_run;
         if (!tile) ++global_passes;
         ++pass;
         if (pass < (npass ? npass : 1)) __syncthreads();     // the next part reuses the tile and the lists
     }
+    nstamp = 4;
     VISMA_STAMP();                                            // 4: search (+ re-rank) done
 
     // the decisive queries fetch their winner in f64
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
     double *mom = reinterpret_cast<double *>(smem);          // [QPB][NACC]   (tile region)
     double *part = reinterpret_cast<double *>(rowlo);        // [NTH/32][33]  (rows / lists region)
     double *tot = part + (NTH / 32) * 33;                    // [32]
-    static_assert((size_t)MAXR * 12 + (size_t)27 * QPB * 4 >= (size_t)((NTH / 32) * 33 + 32) * 8, "fold scratch does not fit");
+    static_assert((size_t)MAXR * 16 + (size_t)27 * QPB * 4 >= (size_t)((NTH / 32) * 33 + 32) * 8, "fold scratch does not fit");
     if (sub == 0) {
         double acc[NACC];
 #pragma unroll
@@ -572,7 +585,11 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
                 if (a.nrm64) { const Pt64 n8 = a.nrm64[(unsigned)q8.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
                 else { const float4 n4 = a.nrm[(unsigned)q8.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
             }
-            accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
+            // p = T64 * s is at hand (pxd, pyd, pzd): the identity transform reproduces accumulate_pair_d's p + off
+        Xform64 I64;
+#pragma unroll
+        for (int k = 0; k < 12; k++) I64.m[k] = (k % 5 == 0) ? 1.0 : 0.0;
+        accumulate_pair_d<PLANE>(acc, pxd, pyd, pzd, q8.x, q8.y, q8.z, nx, ny, nz, I64, off);
         }
 #pragma unroll
         for (int k = 0; k < NACC; k++) mom[q * NACC + k] = acc[k];
@@ -604,8 +621,10 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
         atomicAdd(t + 2, (unsigned long long)total_pts);
         atomicAdd(t + 4, (unsigned long long)total_rows);
         atomicAdd(t + 7, (unsigned long long)passes_run);
+        if (STAMPS) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) atomicAdd(t + 8 + k, (unsigned long long)(tstamp[k + 1] - tstamp[k]));
+            for (int k = 0; k < 6; k++) atomicAdd(t + 8 + k, (unsigned long long)(tstamp[k + 1] - tstamp[k]));
+        }
     }
     if (a.stats) {
         unsigned long long c = ncand, ca = ncand_all, am = amb ? 1ull : 0ull;
@@ -623,6 +642,7 @@ __global__ __launch_bounds__(NTH, 4) void nn_tile_reduce_kernel(const TileArgs a
         }
     }
 #undef VISMA_STAMP
+#undef VISMA_STAMP_FIRST
     if (!a.tickets) return;
 
     // ---- fused fold: the last arriver of each group of rows folds it, the last group folder
@@ -710,19 +730,19 @@ hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStrea
 }
 
 // ---- launch ------------------------------------------------------------------------------
-template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE>
+template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE, bool STAMPS = false>
 static hipError_t launch_tile_t(const TileArgs &a, int total_blocks, hipStream_t stream)
 {
-    constexpr size_t lds = (size_t)CAP * 12 + (size_t)MAXR * 12 + (size_t)27 * (NTH / G) * 4 + 128 * 4;
+    constexpr size_t lds = (size_t)CAP * 12 + (size_t)MAXR * 16 + (size_t)27 * (NTH / G) * 4 + 128 * 4;
     static bool once = false;
     if (!once) {
         hipError_t e = hipFuncSetAttribute(
-            reinterpret_cast<const void *>(&nn_tile_reduce_kernel<PLANE, NTH, G, CAP, MAXR, PRUNE>),
+            reinterpret_cast<const void *>(&nn_tile_reduce_kernel<PLANE, NTH, G, CAP, MAXR, PRUNE, STAMPS>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         once = true;
     }
-    hipLaunchKernelGGL((nn_tile_reduce_kernel<PLANE, NTH, G, CAP, MAXR, PRUNE>), dim3(total_blocks), dim3(NTH), lds,
+    hipLaunchKernelGGL((nn_tile_reduce_kernel<PLANE, NTH, G, CAP, MAXR, PRUNE, STAMPS>), dim3(total_blocks), dim3(NTH), lds,
                        stream, a);
     return hipGetLastError();
 }
@@ -730,24 +750,24 @@ static hipError_t launch_tile_t(const TileArgs &a, int total_blocks, hipStream_t
 // queries per workgroup of a tile configuration
 int tile_threads(int config)
 {
-    switch (config % 8) {
-    case 1: return 128;    // 256 threads, 2 lanes per query
-    case 2: return 32;     // 128 threads, 4 lanes per query
-    case 3: return 32;     // 256 threads, 8 lanes per query
-    default: return 64;    // 256 threads, 4 lanes per query
+    switch (config) {
+    case 1: return 64;     // 256 threads, 4 lanes per query
+    case 2: return 256;    // 256 threads, 1 lane per query
+    case 3: return 64;     // 128 threads, 2 lanes per query
+    case 4: return 128;    // 128 threads, 1 lane per query
+    case 10: return 128;   // config 0 with the per-phase cycle stamps (profiling builds of the probe)
+    default: return 128;   // 256 threads, 2 lanes per query
     }
 }
 
 #define VISMA_TILE_CASES(PL)                                                                       \
     switch (config) {                                                                              \
-    case 1: return launch_tile_t<PL, 256, 2, 4864, 512, true>(a, total_blocks, stream);            \
-    case 2: return launch_tile_t<PL, 128, 4, 1280, 256, true>(a, total_blocks, stream);            \
-    case 3: return launch_tile_t<PL, 256, 8, 1280, 256, true>(a, total_blocks, stream);            \
-    case 8: return launch_tile_t<PL, 256, 4, 2432, 256, false>(a, total_blocks, stream);           \
-    case 9: return launch_tile_t<PL, 256, 2, 4864, 512, false>(a, total_blocks, stream);           \
-    case 10: return launch_tile_t<PL, 128, 4, 1280, 256, false>(a, total_blocks, stream);          \
-    case 11: return launch_tile_t<PL, 256, 8, 1280, 256, false>(a, total_blocks, stream);          \
-    default: return launch_tile_t<PL, 256, 4, 2432, 256, true>(a, total_blocks, stream);           \
+    case 1: return launch_tile_t<PL, 256, 4, 2176, 256, true>(a, total_blocks, stream);            \
+    case 2: return launch_tile_t<PL, 256, 1, 6144, 1024, true>(a, total_blocks, stream);           \
+    case 3: return launch_tile_t<PL, 128, 2, 2176, 256, true>(a, total_blocks, stream);            \
+    case 4: return launch_tile_t<PL, 128, 1, 3328, 512, true>(a, total_blocks, stream);            \
+    case 10: return launch_tile_t<PL, 256, 2, 3328, 512, true, true>(a, total_blocks, stream);     \
+    default: return launch_tile_t<PL, 256, 2, 3328, 512, true>(a, total_blocks, stream);           \
     }
 
 hipError_t launch_nn_tile_reduce(const TileArgs &a, int point_to_plane, int config, int total_blocks,
