@@ -231,6 +231,14 @@ typedef struct {
     double max_dist;
 } visma_icp_problem;
 
+/* The same sweep with the point-to-plane estimator (ICP.point_to_plane of cfg/tool.json,
+ * src/annotation.cpp:45-50): needs target normals (visma_icp_set_target_normals_f64); without
+ * them every start returns its initial transform, like Registration.cpp:152-157. */
+VISMA_ICP_API int visma_icp_run_yaw_sweep_point_to_plane(visma_icp_ctx *ctx, int level,
+                                                         double max_dist, int max_iter,
+                                                         double rel_fitness, double rel_rmse,
+                                                         visma_icp_result *best, int *best_level,
+                                                         visma_icp_result *per_level);
 /* n independent ICPs advanced in lock step, one grid launch per iteration. */
 VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs,
                                       int n, int max_iter, double rel_fitness,

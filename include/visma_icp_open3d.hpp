@@ -320,17 +320,24 @@ inline Eigen::Matrix4d RegisterModelToScene(const PointCloud &model, const Point
                                             RegistrationResult *best_out = nullptr)
 {
     RegistrationResult best;
-    if (!point_to_plane && rotation_level > 0 && distance_threshold > 0.0) {
-        // all levels in one library call (the sweep is advanced on the GPU)
-        visma_icp_ctx *ctx = detail::upload(model, scene, false);
+    const bool plane_ready = point_to_plane && model.HasNormals() && scene.HasNormals();
+    if ((!point_to_plane || plane_ready) && rotation_level > 0 && distance_threshold > 0.0) {
+        // all levels in one library call (the sweep is advanced on the GPU), either estimator
+        visma_icp_ctx *ctx = detail::upload(model, scene, point_to_plane);
         visma_icp_result b;
         int level = -1;
         const ICPConvergenceCriteria c;
-        detail::check(ctx, visma_icp_run_yaw_sweep(ctx, rotation_level, distance_threshold,
-                                                   c.max_iteration_, c.relative_fitness_,
-                                                   c.relative_rmse_, VISMA_ICP_SOLVER_KABSCH, &b,
-                                                   &level, nullptr),
-                      "visma_icp_run_yaw_sweep");
+        if (point_to_plane)
+            detail::check(ctx, visma_icp_run_yaw_sweep_point_to_plane(ctx, rotation_level, distance_threshold,
+                                                                      c.max_iteration_, c.relative_fitness_,
+                                                                      c.relative_rmse_, &b, &level, nullptr),
+                          "visma_icp_run_yaw_sweep_point_to_plane");
+        else
+            detail::check(ctx, visma_icp_run_yaw_sweep(ctx, rotation_level, distance_threshold,
+                                                       c.max_iteration_, c.relative_fitness_,
+                                                       c.relative_rmse_, VISMA_ICP_SOLVER_KABSCH, &b,
+                                                       &level, nullptr),
+                          "visma_icp_run_yaw_sweep");
         best.transformation_ = detail::from_rowmajor(b.transformation);
         best.fitness_ = b.fitness;
         best.inlier_rmse_ = b.inlier_rmse;

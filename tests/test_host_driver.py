@@ -256,3 +256,24 @@ def test_mixing_centred_and_uncentred_uploads_is_refused(hctx, lib):
     b = hctx.run(None, 0.1, 5, 0, 0)
     assert a.num_correspondences == b.num_correspondences
     assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-4     # fp32 uncentred vs f64 centred inputs
+
+
+def test_yaw_sweep_point_to_plane_is_the_sequential_sweep(hctx):
+    """src/annotation.cpp:35-61 with ICP.point_to_plane: the same starts, the plane estimator."""
+    g = load("fragments.npz")
+    src, tgt = g["src"].astype(np.float64), g["tgt"].astype(np.float64)
+    hctx.set_clouds_f64(src, tgt)
+    r = float(g["radius"])
+    # without normals every start returns its initial transform (Registration.cpp:152-157)
+    best, level, per = hctx.run_yaw_sweep_point_to_plane(4, r, 5)
+    assert level == -1 and best.num_correspondences == 0
+    assert np.allclose(per[1].transformation_[:3, :3], synth.rot_y(np.pi / 2))
+    hctx.set_target_normals_f64(g["tgt_normals"].astype(np.float64))
+    best, level, per = hctx.run_yaw_sweep_point_to_plane(4, r, 5)
+    ks = []
+    for i in range(4):
+        one = hctx.run_point_to_plane(synth.make_T(synth.rot_y(2 * np.pi * i / 4), [0, 0, 0]), r, 5)
+        assert one.num_correspondences == per[i].num_correspondences
+        assert rel(one.transformation_, per[i].transformation_) < 1e-12
+        ks.append(one.num_correspondences)
+    assert level == int(np.argmax(ks)) and best.num_correspondences == max(ks)

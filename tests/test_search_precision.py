@@ -6,6 +6,8 @@ moves the final transform past the 1e-5 tolerance (tools/fuzz_icp_vs_oracle.py: 
 registrations, worst 6.1e-5).  In f64 mode the correspondences must BE the f64 oracle's
 (the restatement of Registration.cpp:41-96 on FLANN's f64 L2), pass after pass.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -200,3 +202,28 @@ def test_point_to_plane_under_the_default_precision(lib):
         row = g["trace_p2plane"][it]
         assert r.num_correspondences == row[18]
         assert synth.rel_frobenius(r.transformation_, row[:16].reshape(4, 4)) < 1e-10    # f64 normals too
+
+
+def test_point_to_plane_sweep_on_the_device_equals_single_runs(lib):
+    """The batched device loop with the plane estimator (visma_icp_run_yaw_sweep_point_to_plane)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fragments.npz"))
+    src, tgt = g["src"].astype(np.float64), g["tgt"].astype(np.float64)
+    r = float(g["radius"])
+    ctx = _lib.Context(0)
+    ctx.set_clouds_f64(src, tgt)
+    ctx.set_target_normals_f64(g["tgt_normals"].astype(np.float64))
+    best, level, per = ctx.run_yaw_sweep_point_to_plane(6, r, 8)
+    one = _lib.Context(0)
+    one.set_device_loop(False)
+    one.set_clouds_f64(src, tgt)
+    one.set_target_normals_f64(g["tgt_normals"].astype(np.float64))
+    ks = []
+    for i in range(6):
+        w = one.run_point_to_plane(synth.make_T(synth.rot_y(2 * np.pi * i / 6), [0, 0, 0]), r, 8)
+        assert w.num_correspondences == per[i].num_correspondences and w.iterations == per[i].iterations
+        assert synth.rel_frobenius(per[i].transformation_, w.transformation_) < 1e-9
+        ks.append(w.num_correspondences)
+    assert level == int(np.argmax(ks))
+    # the reference trace of the identity start (fragments.npz is an output of oracle/_ref)
+    w = ctx.run_point_to_plane(g["init"], r, 10, 0.0, 0.0)
+    assert synth.rel_frobenius(w.transformation_, g["trace_p2plane"][10][:16].reshape(4, 4)) < 1e-9

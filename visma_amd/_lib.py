@@ -138,6 +138,9 @@ def load():
     L.visma_so3_project.argtypes = [_dp, _dp]
     L.visma_so3_matrix_derivatives.argtypes = [_dp] * 7
     L.visma_icp_selftest_so3_jac.argtypes = [_dp, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    L.visma_icp_run_yaw_sweep_point_to_plane.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double,
+                                                         C.c_double, C.POINTER(CResult), C.POINTER(C.c_int),
+                                                         C.POINTER(CResult)]
     L.visma_icp_comm_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
     L.visma_icp_comm_ipc_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.visma_icp_set_global_source_count.argtypes = [C.c_void_p, C.c_int64]
@@ -297,6 +300,13 @@ class Context:
                                                  int(max_iter), float(rel_fitness),
                                                  float(rel_rmse), int(solver), C.byref(best),
                                                  C.byref(bl), per))
+        return Result(best), bl.value, [Result(p) for p in per]
+
+    def run_yaw_sweep_point_to_plane(self, level, max_dist, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+        best = CResult(); bl = C.c_int(-1); per = (CResult * level)()
+        self._chk(self.L.visma_icp_run_yaw_sweep_point_to_plane(self._h, int(level), float(max_dist), int(max_iter),
+                                                                float(rel_fitness), float(rel_rmse), C.byref(best),
+                                                                C.byref(bl), per))
         return Result(best), bl.value, [Result(p) for p in per]
 
     def run_batch(self, problems, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,

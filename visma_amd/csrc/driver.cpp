@@ -2136,12 +2136,49 @@ int visma_icp_run_point_to_plane(visma_icp_ctx *ctx, const double init[16], doub
     return ctx->run(init, max_dist, max_iter, rel_fitness, rel_rmse, VISMA_ICP_SOLVER_GN_EULER, false, true, out);
 }
 
+static int yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int max_iter, double rel_fitness,
+                     double rel_rmse, int solver, bool plane, visma_icp_result *best, int *best_level,
+                     visma_icp_result *per_level);
+
 int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int max_iter,
                             double rel_fitness, double rel_rmse, int solver, visma_icp_result *best,
                             int *best_level, visma_icp_result *per_level)
 {
     CTX_CHECK();
+    if (solver < 0 || solver > VISMA_ICP_SOLVER_GN_EXPMAP) return ctx->fail(VISMA_ICP_ERR_INVALID, "unknown solver");
+    return yaw_sweep(ctx, level, max_dist, max_iter, rel_fitness, rel_rmse, solver, false, best, best_level, per_level);
+}
+
+int visma_icp_run_yaw_sweep_point_to_plane(visma_icp_ctx *ctx, int level, double max_dist, int max_iter,
+                                           double rel_fitness, double rel_rmse, visma_icp_result *best,
+                                           int *best_level, visma_icp_result *per_level)
+{
+    CTX_CHECK();
+    return yaw_sweep(ctx, level, max_dist, max_iter, rel_fitness, rel_rmse, VISMA_ICP_SOLVER_GN_EULER, true, best,
+                     best_level, per_level);
+}
+
+static int yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int max_iter, double rel_fitness,
+                     double rel_rmse, int solver, bool plane, visma_icp_result *best, int *best_level,
+                     visma_icp_result *per_level)
+{
     if (level <= 0 || !best || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad sweep arguments");
+    if (plane && ctx->have_tgt && !ctx->eng->has_normals() && max_dist > 0.0) {
+        // Registration.cpp:152-157: every start returns RegistrationResult(init); none has correspondences
+        const double interval0 = 2.0 * M_PI / (double)level;
+        std::memset(best, 0, sizeof(*best));
+        const Mat4 I = Mat4::identity();
+        std::memcpy(best->transformation, I.m, sizeof(I.m));
+        if (best_level) *best_level = -1;
+        for (int i = 0; per_level && i < level; i++) {
+            const double a = interval0 * i, c = std::cos(a), s = std::sin(a);
+            Mat4 init = Mat4::identity();
+            init(0, 0) = c; init(0, 2) = s; init(2, 0) = -s; init(2, 2) = c;
+            std::memset(&per_level[i], 0, sizeof(per_level[i]));
+            std::memcpy(per_level[i].transformation, init.m, sizeof(init.m));
+        }
+        return VISMA_ICP_OK;
+    }
     // src/annotation.cpp:35-61
     const double interval = 2.0 * M_PI / (double)level;
     if (ctx->use_device_loop_batched() && max_dist > 0.0 && ctx->have_src && ctx->have_tgt) {
@@ -2160,8 +2197,8 @@ int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int 
         std::memcpy(lp.centre, ctx->centre, sizeof(ctx->centre));
         lp.max_dist = max_dist; lp.rel_fit = rel_fitness; lp.rel_rmse = rel_rmse;
         lp.max_iter = max_iter; lp.solver = solver; lp.passes = max_iter + 1;
-        lp.scaling = false; lp.plane = false;
-        lp.world = visma_icp_ctx::wants_world_frame(solver, false);
+        lp.scaling = false; lp.plane = plane;
+        lp.world = visma_icp_ctx::wants_world_frame(solver, plane);
         lp.check_stop = true;
         lp.ns_total = ctx->ns_total > 0 ? ctx->ns_total : ctx->eng->ns();
         std::vector<Engine::LoopResult> rs((size_t)level);
@@ -2202,7 +2239,7 @@ int visma_icp_run_yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int 
         Mat4 init = Mat4::identity();
         init(0, 0) = c; init(0, 2) = s; init(2, 0) = -s; init(2, 2) = c;
         visma_icp_result r;
-        int rc = ctx->run(init.m, max_dist, max_iter, rel_fitness, rel_rmse, solver, false, false, &r);
+        int rc = ctx->run(init.m, max_dist, max_iter, rel_fitness, rel_rmse, solver, false, plane, &r);
         if (rc) return rc;
         if (per_level) per_level[i] = r;
         if (r.num_correspondences > b.num_correspondences) { b = r; bl = i; }
