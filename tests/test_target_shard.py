@@ -1,10 +1,12 @@
 """Target-sharded ranks (include/visma_icp.h: visma_icp_set_target_shard).
 
 Two contexts on ONE GPU, each holding half of the target and all of the source, driven by
-two host threads whose exchange callbacks meet at a barrier -- the same two collectives per
-iteration (MIN of the packed keys, SUM of the 38 statistics) that RCCL performs between
-GPUs.  The result must be the single-context result: identical correspondences (global
-indices, lowest index on ties), transform to summation order.
+two host threads whose exchange callbacks meet at a barrier -- the same collectives per
+iteration that RCCL performs between GPUs: with the exact grid search on every shard, MIN of the
+f64 distance bits, MIN of the global index among the shards that hold that distance, SUM of the
+38 statistics; with the fp32 brute-force kernel, MIN of the packed (fp32 d2, index) keys and the
+SUM.  The result must be the single-context result: identical correspondences (global indices,
+lowest index on ties), transform to summation order.
 """
 import threading
 
@@ -85,14 +87,15 @@ def test_target_sharded_equals_single_context(lib, nn_mode):
     src, tgt, T_gt, radius = synth.make_pair(20000, 60000, motion="radius")
     tgt = np.concatenate([tgt, tgt[:500]])                 # exact duplicates across the shards: ties
     ref = _lib.Context(0)
-    ref.set_search_precision("f32")          # sharded ranks exchange fp32 keys
-    ref.set_nn_mode(nn_mode)
+    ref.set_nn_mode(nn_mode)                 # grid: the default exact search; brute force: the fp32 kernel
     ref.set_clouds_f64(src, tgt)
     want = ref.run(None, radius, 12, 0, 0)
+    assert ref.search_mode_used() == ("exact" if nn_mode == _lib.NN_GRID else "f32")
     want_idx = ref.correspondence_index()
     cuts = [0, 23456, len(tgt)]                             # ragged shards
     out, ex = run_sharded(src, tgt, radius, 12, nn_mode, cuts)
-    assert ex.calls["min"] == 13 and ex.calls["sum"] == 13   # one of each per NN pass
+    # per NN pass: one SUM, and one MIN (fp32 keys) or two (f64 distance, then index)
+    assert ex.calls["sum"] == 13 and ex.calls["min"] == (26 if nn_mode == _lib.NN_GRID else 13)
     for res, idx in out:
         assert np.array_equal(idx, want_idx)                # global indices, lowest on ties
         assert res.num_correspondences == want.num_correspondences
@@ -106,7 +109,6 @@ def test_target_sharded_three_ranks_point_to_plane_and_empty_shard(lib):
     src, tgt, T_gt, radius = synth.make_pair(6000, 30000, motion="radius")
     nrm = tgt / np.linalg.norm(tgt, axis=1, keepdims=True)
     ref = _lib.Context(0)
-    ref.set_search_precision("f32")          # sharded ranks exchange fp32 keys
     ref.set_clouds_f64(src, tgt)
     ref.set_target_normals_f64(nrm)
     want = ref.run_point_to_plane(None, radius, 8, 0, 0)
@@ -164,3 +166,41 @@ def test_source_sharded_equals_single_context(lib):
         assert res.num_correspondences == want.num_correspondences and res.fitness_ == want.fitness_
         assert synth.rel_frobenius(res.transformation_, want.transformation_) < 1e-12
         assert np.array_equal(res.transformation_, out[0].transformation_)      # ranks agree to the bit
+
+
+@pytest.mark.gpu
+def test_target_sharded_ranks_reproduce_the_reference_fuzz_cases(lib):
+    """The exact search survives the sharding: the compiled reference's K and T on fuzz fixtures."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    from gen_fuzz import FIELDS, make_case
+    G = np.load(os.path.join(here, "golden", "fuzz_ref.npz"))
+    for i in range(0, len(G["ns"]), 9):
+        src, tgt, init, r, iters = make_case({k: G[k][i] for k in FIELDS})
+        n = len(tgt)
+        cuts = [0, n // 3, n // 3 + n // 5, n]
+        ex = Exchange(3)
+        out = [None] * 3
+        err = []
+
+        def worker(rank):
+            try:
+                ctx = _lib.Context(0)
+                ctx.set_target_shard(cuts[rank], n, tgt.mean(0))
+                ctx.set_clouds_f64(src, tgt[cuts[rank]:cuts[rank + 1]])
+                ctx.set_minreduce(ex.minreduce(rank))
+                ctx.set_allreduce(ex.allreduce(rank), rank, 3)
+                out[rank] = ctx.run(init, r, iters, 1e-6, 1e-6)
+            except Exception as e:              # pragma: no cover
+                err.append(e)
+                ex.barrier.abort()
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        if err:
+            raise err[0]
+        for res in out:
+            assert res.num_correspondences == int(G["ref_k"][i]), i
+            assert synth.rel_frobenius(res.transformation_, G["ref_T"][i]) < 1e-9, i

@@ -191,6 +191,7 @@ public:
         free_dev(d_mbox_); free_dev(d_ipc_flag_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
+        free_dev(d_claim_); free_dev(d_d64_);
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
@@ -447,7 +448,7 @@ public:
                                           &nblocks, grid_lanes(),
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                          exact_ ? 1 : 0, fused ? &fa : nullptr));
+                                          exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64()));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (!tshard_ && !fused) {
                 if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -977,28 +978,56 @@ public:
         if (tgt_offset_ + nt_ > tgt_global_) { err_ = "target shard exceeds the global target"; return VISMA_ICP_ERR_INVALID; }
         if (!comm_ && !minreduce_) { err_ = "target-sharded mode needs visma_icp_comm_init or visma_icp_set_minreduce"; return VISMA_ICP_ERR_STATE; }
         if (ns_ > gkeys_cap_) {
-            free_dev(d_gkeys_);
+            free_dev(d_gkeys_); free_dev(d_claim_);
             HIP_TRY(hipMalloc(&d_gkeys_, sizeof(unsigned long long) * std::max<int64_t>(ns_, 1)));
+            HIP_TRY(hipMalloc(&d_claim_, sizeof(unsigned long long) * std::max<int64_t>(ns_, 1)));
             gkeys_cap_ = ns_;
         }
-        HIP_TRY(launch_shard_keys((const int32_t *)d_idx_, (const float *)d_d2_, ns_, (unsigned)tgt_offset_,
-                                  (unsigned long long *)d_gkeys_, stream_));
-        if (comm_) {
-            int rc = g_rccl.AllReduce(d_gkeys_, d_gkeys_, (size_t)ns_, kNcclUint64, kNcclMin, comm_, stream_);
-            if (rc != 0) {
-                err_ = std::string("ncclAllReduce(min): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
-                return VISMA_ICP_ERR_RCCL;
+        // MIN over the ranks of `keys` (RCCL on the stream, or the host-supplied exchange)
+        auto min_reduce = [&](void *keys) -> int {
+            if (comm_) {
+                int rc = g_rccl.AllReduce(keys, keys, (size_t)ns_, kNcclUint64, kNcclMin, comm_, stream_);
+                if (rc != 0) {
+                    err_ = std::string("ncclAllReduce(min): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+                    return VISMA_ICP_ERR_RCCL;
+                }
+                return VISMA_ICP_OK;
             }
-        } else {
-            // host-supplied exchange (tests, other transports): through host memory
             h_gkeys_.resize((size_t)ns_);
-            HIP_TRY(hipMemcpyAsync(h_gkeys_.data(), d_gkeys_, sizeof(unsigned long long) * ns_, hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipMemcpyAsync(h_gkeys_.data(), keys, sizeof(unsigned long long) * ns_, hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipStreamSynchronize(stream_));
             if (ns_ > 0 && minreduce_(minreduce_user_, (uint64_t *)h_gkeys_.data(), ns_) != 0) {
                 err_ = "min-reduce callback failed";
                 return VISMA_ICP_ERR_ENGINE;
             }
-            HIP_TRY(hipMemcpyAsync(d_gkeys_, h_gkeys_.data(), sizeof(unsigned long long) * ns_, hipMemcpyHostToDevice, stream_));
+            HIP_TRY(hipMemcpyAsync(keys, h_gkeys_.data(), sizeof(unsigned long long) * ns_, hipMemcpyHostToDevice, stream_));
+            return VISMA_ICP_OK;
+        };
+        if (shard_d64()) {
+            // Every shard ran the EXACT search: compare the shards in f64.  (1) MIN of the f64 d2 bits =
+            // the global nearest distance; (2) MIN of the global index over the shards that hold it =
+            // lowest index on exact ties, like one GPU; the owner accumulates from the f64 coordinates.
+            HIP_TRY(launch_shard_keys64((const int32_t *)d_idx_, (const double *)d_d64_, ns_, (unsigned long long *)d_gkeys_, stream_));
+            int rc = min_reduce(d_gkeys_);
+            if (rc) return rc;
+            HIP_TRY(launch_shard_claim64((const int32_t *)d_idx_, (const double *)d_d64_, (const unsigned long long *)d_gkeys_,
+                                         ns_, (unsigned)tgt_offset_, (unsigned long long *)d_claim_, stream_));
+            rc = min_reduce(d_claim_);
+            if (rc) return rc;
+            int nb = 1;
+            HIP_TRY(launch_shard_accumulate64((const Pt64 *)d_src64_, ns_, (const unsigned long long *)d_gkeys_,
+                                              (const unsigned long long *)d_claim_, (const Pt64 *)d_tgt64_, nt_,
+                                              (unsigned)tgt_offset_, (const float4 *)d_nrm_, (const Pt64 *)d_nrm64_, T64,
+                                              offset, r2d_, plane ? 1 : 0, (int32_t *)d_idx_, (float *)d_d2_,
+                                              (double *)d_partials_, reduce_max_blocks(), &nb, stream_));
+            HIP_TRY(launch_finalize((const double *)d_partials_, nb, plane ? 1 : 0, (double *)d_stats_, stream_, pub, seq));
+            return VISMA_ICP_OK;
+        }
+        HIP_TRY(launch_shard_keys((const int32_t *)d_idx_, (const float *)d_d2_, ns_, (unsigned)tgt_offset_,
+                                  (unsigned long long *)d_gkeys_, stream_));
+        {
+            int rc = min_reduce(d_gkeys_);
+            if (rc) return rc;
         }
         int nblocks = 1;
         HIP_TRY(launch_shard_accumulate((const float4 *)d_src_, ns_, (const unsigned long long *)d_gkeys_,
@@ -1177,6 +1206,7 @@ private:
         // proper grid the fused kernel wins at every size measured: 20-22 us per
         // iteration against 33-37 for 500 ... 4000 target points.)
         use_grid_ = grid_.ncell >= 512;
+        if (shard_f64_protocol()) use_grid_ = true;              // sharded ranks: the exact search on every shard
         // Small f64 clouds keep the (f64) grid search even on a degenerate grid -- a radius that is
         // large against the cloud's extent -- so that their correspondences stay the reference's;
         // scanning most of a few-thousand-point target per query is cheap.
@@ -1284,7 +1314,23 @@ private:
     unsigned long long ipc_seq_ = 0;
     bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
     int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
-    void *d_gkeys_ = nullptr;
+    void *d_gkeys_ = nullptr, *d_claim_ = nullptr, *d_d64_ = nullptr;   // shard exchange: keys, index claims, local f64 d2
+    int64_t d64_cap_ = 0;
+    // target-sharded rank running the exact / f64 grid search: the buffer its f64 distances go to
+    // Which exchange the sharded ranks run must not depend on what a rank happens to hold (an empty
+    // shard, a degenerate grid): every rank with f64 clouds and without a forced brute-force search
+    // compares in f64.
+    bool shard_f64_protocol() const { return tshard_ && d_src64_ && d_tgt64_ && nn_mode_ != VISMA_ICP_NN_BRUTE; }
+    double *shard_d64()
+    {
+        if (!shard_f64_protocol()) return nullptr;
+        if (ns_ > d64_cap_) {
+            free_dev(d_d64_);
+            if (hipMalloc(&d_d64_, sizeof(double) * std::max<int64_t>(ns_, 1)) != hipSuccess) { (void)hipGetLastError(); d_d64_ = nullptr; d64_cap_ = 0; return nullptr; }
+            d64_cap_ = ns_;
+        }
+        return (double *)d_d64_;
+    }
     std::vector<unsigned long long> h_gkeys_;
     visma_icp_minreduce_fn minreduce_ = nullptr;
     void *minreduce_user_ = nullptr;
@@ -1438,7 +1484,7 @@ private:
     // f64 views of clouds that were uploaded as fp32 (the exact search needs them)
     int ensure_f64_views()
     {
-        if (!exact_ || tshard_) return VISMA_ICP_OK;
+        if (!exact_) return VISMA_ICP_OK;
         if (!d_src64_ && d_src_) {
             HIP_TRY(hipMalloc(&d_src64_, sizeof(Pt64) * std::max<int64_t>(ns_, 1)));
             HIP_TRY(launch_promote_pt64((const float4 *)d_src_, (Pt64 *)d_src64_, ns_, stream_));
@@ -1884,8 +1930,7 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     if (rc) return ctx->eng_fail(rc);
     // double-precision search: the caller's own f64 coordinates (centred in f64) go along
     // (the size-keyed policy of round 1 is gone: the exact search costs the same as the fp32 one)
-    const bool want64 = !ctx->target_sharded &&        // (sharded ranks exchange fp32 keys)
-                        ctx->search_precision != 0;
+    const bool want64 = ctx->search_precision != 0;     // (target-sharded ranks too: they compare shards in f64)
     ctx->eng->set_exact(ctx->search_precision == 1);
     if (want64 && ctx->eng->supports_device_loop()) {
         // (Pt64 = 8 floats of staging; pinned on the HIP engine)

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const DevIcpState *__restrict__ st, int bpp, long long out_stride,
     const ProbDesc *__restrict__ descs, int nprob, const Pt64 *__restrict__ src64 = nullptr,
     const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0, const Pt64 *__restrict__ nrm64 = nullptr,
-    const FoldArgs fold = FoldArgs{})
+    const FoldArgs fold = FoldArgs{}, double *__restrict__ d64_out = nullptr)
 {
     static_assert(!(F64 && HYB), "F64 and HYB are different searches");
     constexpr bool S64 = F64 || HYB;                       // f64 source, transform and statistics
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             if constexpr (S64) {
                 idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
                 d2_out[i] = (float)bd;
+                if (d64_out) d64_out[i] = bd;                // (target-sharded ranks compare shards in f64)
             } else {
                 idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)(unsigned)bkey;
                 d2_out[i] = __uint_as_float((unsigned)(bkey >> 32));
@@ -783,7 +784,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
                           double *partials, unsigned long long *cand, const DevIcpState *st,
                           int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d,
-                          const Pt64 *nrm64, int exact, const FoldArgs &fold)
+                          const Pt64 *nrm64, int exact, const FoldArgs &fold, double *d64_out)
 {
     // one query per lane? (see ONE above)
     const long long total_groups = (long long)nblocks * (kBlock / G);
@@ -792,7 +793,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
     hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, ONE_, F64_, HYB_>), dim3(nblocks * nprob),             \
                        dim3(kBlock), 0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out,      \
                        d2_out, partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,  \
-                       sorted64, r2d, nrm64, fold)
+                       sorted64, r2d, nrm64, fold, d64_out)
     if (src64 && exact) {
         if (one) VISMA_GRID_LAUNCH(true, false, true); else VISMA_GRID_LAUNCH(false, false, true);
     } else if (src64) {
@@ -812,7 +813,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
                                  const Pt64 *sorted64, double r2d, const Pt64 *nrm64, int exact,
-                                 const FoldArgs *fold)
+                                 const FoldArgs *fold, double *d64_out)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     Offset64 off;
@@ -829,11 +830,11 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,           \
                                         tgt_normals, T32, T64, off, r2f, idx_out, d2_out,          \
-                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa);   \
+                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa, d64_out);   \
         else                                                                                       \
             launch_grid_t<false, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,          \
                                          tgt_normals, T32, T64, off, r2f, idx_out, d2_out,         \
-                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa);  \
+                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa, d64_out);  \
         launched = true;                                                                           \
     }
     bool launched = false;

@@ -19,6 +19,11 @@ constexpr int kNStats = 38;
 struct Xform32 { float m[12]; };    // row-major 3x4, fp32 (NN search)
 struct Xform64 { double m[12]; };   // row-major 3x4, f64  (statistics)
 struct Offset64 { double v[3]; };   // frame shift applied to p and q in the statistics
+// A point in f64 for the double-precision search (32 B: x, y, z, original index).
+struct Pt64 {
+    double x, y, z;
+    unsigned long long w;
+};
 
 // State of one ICP problem advanced entirely on the device (icp_loop.hip): the
 // NN / reduction kernels read the current transform from it, the one-thread
@@ -97,6 +102,19 @@ hipError_t launch_shard_accumulate(const float4 *src, int64_t ns, const unsigned
                                    const double frame_offset[3], float r2f, int point_to_plane,
                                    int32_t *idx_out, float *d2_out, double *partials,
                                    int max_partial_blocks, int *nblocks_out, hipStream_t stream);
+// ... the same in f64 (exact search on every shard): key 1 = bits of the local f64 d2 (MIN over ranks =
+// the global nearest), key 2 = global index of the shards that hold it (MIN = lowest index on exact
+// ties); the owner accumulates from the f64 coordinates
+hipError_t launch_shard_keys64(const int32_t *idx, const double *d64, int64_t ns, unsigned long long *keys,
+                               hipStream_t stream);
+hipError_t launch_shard_claim64(const int32_t *idx, const double *d64, const unsigned long long *gkeys, int64_t ns,
+                                unsigned offset, unsigned long long *claim, hipStream_t stream);
+hipError_t launch_shard_accumulate64(const Pt64 *src64, int64_t ns, const unsigned long long *gkeys,
+                                     const unsigned long long *claim, const Pt64 *tgt64, int64_t nt_local,
+                                     unsigned offset, const float4 *tgt_normals, const Pt64 *nrm64,
+                                     const Xform64 &T64, const double frame_offset[3], double r2d,
+                                     int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
+                                     int max_partial_blocks, int *nblocks_out, hipStream_t stream);
 // stats (device) -> host_out[0..37] (mapped host memory), then host_out[38] = seq (u64 bits)
 hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned long long seq,
                                 hipStream_t stream);
@@ -119,11 +137,6 @@ hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpStat
 hipError_t launch_solve_state(DevIcpState *st, int nprob, hipStream_t stream);
 
 // ---- radius-cell uniform grid (grid.hip) -------------------------------------
-// A point in f64 for the double-precision search (32 B: x, y, z, original index).
-struct Pt64 {
-    double x, y, z;
-    unsigned long long w;
-};
 
 struct GridParams {
     float mn[3];      // lower corner of the target's bounding box
@@ -224,7 +237,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int nprob, int64_t out_stride, hipStream_t stream,
                                  const Pt64 *src64 = nullptr, const Pt64 *sorted64 = nullptr,
                                  double r2d = 0.0, const Pt64 *nrm64 = nullptr, int exact = 0,
-                                 const FoldArgs *fold = nullptr);
+                                 const FoldArgs *fold = nullptr, double *d64_out = nullptr);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
 // offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,

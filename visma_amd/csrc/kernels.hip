@@ -281,6 +281,99 @@ __global__ __launch_bounds__(kBlock) void shard_accumulate_kernel(
     block_reduce_store<NACC>(acc, partials);
 }
 
+// ---- f64 variant: every shard ran the exact search -------------------------------------------
+__global__ __launch_bounds__(256) void shard_keys64_kernel(const int *__restrict__ idx, const double *__restrict__ d64,
+                                                           int ns, unsigned long long *__restrict__ keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    // d2 >= 0: the bits of a double order like the value
+    keys[i] = idx[i] < 0 ? ~0ull : (unsigned long long)__double_as_longlong(d64[i]);
+}
+
+__global__ __launch_bounds__(256) void shard_claim64_kernel(const int *__restrict__ idx, const double *__restrict__ d64,
+                                                            const unsigned long long *__restrict__ gkeys, int ns,
+                                                            unsigned offset, unsigned long long *__restrict__ claim)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ns) return;
+    const bool mine = idx[i] >= 0 && (unsigned long long)__double_as_longlong(d64[i]) == gkeys[i];
+    claim[i] = mine ? (unsigned long long)((unsigned)idx[i] + offset) : ~0ull;
+}
+
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void shard_accumulate64_kernel(
+    const Pt64 *__restrict__ src64, int ns, const unsigned long long *__restrict__ gkeys,
+    const unsigned long long *__restrict__ claim, const Pt64 *__restrict__ tgt64, long long nt_local, unsigned offset,
+    const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, double r2d,
+    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < ns; i += gridDim.x * kBlock) {
+        const unsigned long long key = gkeys[i];
+        const bool hit = key != ~0ull;
+        const unsigned gj = (unsigned)claim[i];
+        idx_out[i] = hit ? (int)gj : -1;
+        d2_out[i] = hit ? (float)__longlong_as_double((long long)key) : (float)r2d;
+        const long long lj = (long long)gj - (long long)offset;
+        if (hit && lj >= 0 && lj < nt_local) {
+            const Pt64 s8 = src64[i], q8 = tgt64[lj];
+            double nx = 0.0, ny = 0.0, nz = 0.0;
+            if (PLANE) {
+                if (nrm64) { const Pt64 n8 = nrm64[lj]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                else { const float4 n4 = nrm[lj]; nx = n4.x; ny = n4.y; nz = n4.z; }
+            }
+            accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
+hipError_t launch_shard_keys64(const int32_t *idx, const double *d64, int64_t ns, unsigned long long *keys,
+                               hipStream_t stream)
+{
+    if (ns > 0)
+        hipLaunchKernelGGL(shard_keys64_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, idx, d64,
+                           (int)ns, keys);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_claim64(const int32_t *idx, const double *d64, const unsigned long long *gkeys, int64_t ns,
+                                unsigned offset, unsigned long long *claim, hipStream_t stream)
+{
+    if (ns > 0)
+        hipLaunchKernelGGL(shard_claim64_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, idx, d64,
+                           gkeys, (int)ns, offset, claim);
+    return hipGetLastError();
+}
+
+hipError_t launch_shard_accumulate64(const Pt64 *src64, int64_t ns, const unsigned long long *gkeys,
+                                     const unsigned long long *claim, const Pt64 *tgt64, int64_t nt_local,
+                                     unsigned offset, const float4 *tgt_normals, const Pt64 *nrm64,
+                                     const Xform64 &T64, const double frame_offset[3], double r2d,
+                                     int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
+                                     int max_partial_blocks, int *nblocks_out, hipStream_t stream)
+{
+    Offset64 off;
+    for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
+    int64_t want = (ns + kBlock - 1) / kBlock;
+    int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
+    if (nblocks < 1) nblocks = 1;
+    if (point_to_plane)
+        hipLaunchKernelGGL(shard_accumulate64_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src64, (int)ns,
+                           gkeys, claim, tgt64, (long long)nt_local, offset, tgt_normals, nrm64, T64, off, r2d, idx_out,
+                           d2_out, partials);
+    else
+        hipLaunchKernelGGL(shard_accumulate64_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src64, (int)ns,
+                           gkeys, claim, tgt64, (long long)nt_local, offset, tgt_normals, nrm64, T64, off, r2d, idx_out,
+                           d2_out, partials);
+    if (nblocks_out) *nblocks_out = nblocks;
+    return hipGetLastError();
+}
+
 hipError_t launch_shard_keys(const int32_t *idx, const float *d2, int64_t ns, unsigned offset,
                              unsigned long long *keys, hipStream_t stream)
 {
