@@ -114,7 +114,11 @@ def test_exact_search_is_the_default_at_every_size_and_in_sweeps(lib, oracle):
     assert a.num_correspondences == b.num_correspondences
     assert synth.rel_frobenius(a.transformation_, b.transformation_) < 1e-12
     assert np.array_equal(ctx.correspondence_index(), ref.correspondence_index())
-    ctx.set_nn_mode(_lib.NN_BRUTE)                         # brute force is the fp32 kernel
+    ctx.set_nn_mode(_lib.NN_BRUTE)                         # the brute-force kernels have an exact flavour too
+    ctx.set_clouds_f64(src, tgt)
+    ctx.run(None, r, 2, 0, 0)
+    assert ctx.search_mode_used() == "exact"
+    ctx.set_search_precision("f32")                        # ... and the fp32 specification on request
     ctx.set_clouds_f64(src, tgt)
     ctx.run(None, r, 2, 0, 0)
     assert ctx.search_mode_used() == "f32"

@@ -56,6 +56,25 @@ __device__ __forceinline__ float sqdist_f32(const float4 q, float px, float py, 
     return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// The exact search ranks candidates in fp32 and re-ranks in f64 what fp32 cannot decide.  With
+// p32 = fl(p64) and q32 = fl(q64) the difference vector is off by at most u (|p| + |q|) per
+// component (u = 2^-24) and the fp32 evaluation of d2 adds 3u relative, so
+// |d64 - sqrt(d2_32)| <= u (2 |p| + 2.5 r); the band half-width E is more than twice that.
+__device__ __forceinline__ float exact_band(float px, float py, float pz, float r2f, float *r_up_out = nullptr)
+{
+    const float r_up = sqrtf(r2f) * (1.0f + 2.4e-7f);
+    if (r_up_out) *r_up_out = r_up;
+    return 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + r_up) + 4.8e-7f * r_up;
+}
+// squared fp32 distance at or beyond which a candidate cannot be accepted in f64
+__device__ __forceinline__ float exact_band_limit(float px, float py, float pz, float r2f)
+{
+    float r_up;
+    const float E = exact_band(px, py, pz, r2f, &r_up);
+    const float t = r_up + 2.0f * E;
+    return t * t * (1.0f + 6e-7f);
+}
+
 // one VALU op: min of three (v_min3_f32); inputs are never NaN-producing here
 __device__ __forceinline__ float min3_f32(float a, float b, float c)
 {

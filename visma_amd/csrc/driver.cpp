@@ -197,7 +197,7 @@ public:
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
-        free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_);
+        free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
@@ -271,7 +271,37 @@ public:
     // arithmetic of the last pass / loop / batch: 0 fp32 ranking only, 1 exact (fp32 + f64 re-rank), 2 f64
     bool search_is_f64() const override { return last_mode_ == 2; }
     bool search_is_exact() const override { return last_mode_ != 0; }
-    int grid_search_mode() const { return (use_grid_ && d_src64_ && d_sorted64_) ? (exact_ ? 1 : 2) : 0; }
+    int grid_search_mode() const { return (use_grid_ && d_src64_ && d_sorted64_) ? (exact_ ? 1 : 2) : (brute_exact() ? 1 : 0); }
+    // the brute-force kernels run their exact flavour when the f64 clouds are there (not on sharded ranks,
+    // which exchange the fp32 keys of this path)
+    bool brute_exact() const { return !use_grid_ && exact_ && d_src64_ && d_tgt64_ && !tshard_; }
+    int ensure_second(int64_t ns_pad, int splits)
+    {
+        const size_t need = sizeof(float) * (size_t)ns_pad * (size_t)splits;
+        if (need > second_bytes_) {
+            free_dev(d_second_);
+            HIP_TRY(hipMalloc(&d_second_, need));
+            second_bytes_ = need;
+        }
+        return VISMA_ICP_OK;
+    }
+    BruteExact bex_store_{};
+    const BruteExact *bex_ptr()
+    {
+        if (!brute_exact()) return nullptr;
+        bex_store_ = brute_ex();
+        return &bex_store_;
+    }
+    BruteExact brute_ex() const
+    {
+        BruteExact e;
+        e.src64 = (const Pt64 *)d_src64_;
+        e.tgt64 = (const Pt64 *)d_tgt64_;
+        e.nrm64 = (const Pt64 *)d_nrm64_;
+        e.second = (const float *)d_second_;
+        e.nt = nt_;
+        return e;
+    }
     void set_exact(bool on) override { exact_ = on; }
     int set_target_normals64(const Pt64 *n) override
     {
@@ -380,10 +410,14 @@ public:
         rc = ensure_aux(ns_pad);
         if (rc) return rc;
         ns_pad_ = ns_pad;
+        const bool bex = brute_exact();
+        if (bex) { rc = ensure_second(ns_pad_, plan_.tgt_splits); if (rc) return rc; }
+        last_mode_ = grid_search_mode();
         int e0 = -1;
         if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
         HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_, T32_,
-                                r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, nullptr, stream_));
+                                r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, nullptr, stream_,
+                                bex ? (const Pt64 *)d_src64_ : nullptr, &T64_last_, bex ? (float *)d_second_ : nullptr));
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
         grid_pending_ = false;
         brute_reduced_ = false;
@@ -464,7 +498,7 @@ public:
                                   plan_.tgt_splits, ns_pad_, T32_, T64, offset, r2f_, plane ? 1 : 0,
                                   (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
                                   reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_,
-                                  tshard_ ? nullptr : pub, seq));
+                                  tshard_ ? nullptr : pub, seq, bex_ptr()));
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             brute_reduced_ = true;
         }
@@ -557,7 +591,7 @@ public:
                                   (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                   plan_.tgt_splits, ns_pad_, T32_, T64, nullptr, r2f_, 0,
                                   (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_));
+                                  reduce_max_blocks(), (double *)d_stats_, nullptr, nullptr, stream_, nullptr, 0, bex_ptr()));
             brute_reduced_ = true;
         }
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -615,6 +649,7 @@ public:
             }
             rc = ensure_aux(ns_pad_);
             if (rc) return rc;
+            if (brute_exact()) { rc = ensure_second(ns_pad_, plan_.tgt_splits); if (rc) return rc; }
         }
         if (nprob > state_cap_) {
             free_dev(d_state_);
@@ -671,7 +706,8 @@ public:
                 } else {
                     HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
                                             T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
-                                            stream_));
+                                            stream_, brute_exact() ? (const Pt64 *)d_src64_ : nullptr, nullptr,
+                                            brute_exact() ? (float *)d_second_ : nullptr));
                 }
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -680,7 +716,7 @@ public:
                                           (const float4 *)d_nrm_, (const unsigned long long *)d_keys_,
                                           plan_.tgt_splits, ns_pad_, T32_, T64, nullptr, r2f_, plane,
                                           (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
-                                          reduce_max_blocks(), nullptr, st, &nblocks, stream_));
+                                          reduce_max_blocks(), nullptr, st, &nblocks, stream_, nullptr, 0, bex_ptr()));
                 }
                 if (ipc_n_ > 1) {
                     if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
@@ -1394,6 +1430,8 @@ private:
     void *d_partials2_ = nullptr, *d_tickets_ = nullptr, *d_tstats_ = nullptr;
     size_t tickets_cap_ = 0;     // words in d_tickets_ (= rows in d_partials2_)
     Xform64 T64_last_{};         // transform of the last nn_pass, f64
+    void *d_second_ = nullptr;   // brute force, exact flavour: runner-up distances [splits][ns_pad]
+    size_t second_bytes_ = 0;
     int last_mode_ = 0;          // see search_is_f64()
     bool use_tile() const
     {

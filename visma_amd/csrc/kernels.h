@@ -69,13 +69,22 @@ NNLaunch nn_plan(int64_t ns, int64_t nt_pad);
 hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
                            int64_t nt_pad, const Xform32 &T, float r2f,
                            unsigned long long *keys, int64_t ns_pad,
-                           const NNLaunch &plan, const DevIcpState *st, hipStream_t stream);
+                           const NNLaunch &plan, const DevIcpState *st, hipStream_t stream,
+                           const Pt64 *src64 = nullptr, const Xform64 *T64 = nullptr, float *second = nullptr);
+// src64 + T64 + second ([splits][ns_pad] floats): the exact flavour (see nn_brute_kernel)
 
 // Merge the per-split keys, recover the exact target index inside the winning
 // sub-chunk, then accumulate the per-correspondence Jacobian/residual
 // statistics; per-workgroup partials go to `partials`, `finalize` folds them
 // (fixed order) into the 38 statistics at `stats_out` (device or mapped host).
 // idx_out/d2_out (ns) receive the final correspondence per source point.
+// the exact flavour of the brute-force path: f64 clouds (source in engine order, target in the caller's
+// order) and the runner-up array written by launch_nn_brute
+struct BruteExact {
+    const Pt64 *src64, *tgt64, *nrm64;
+    const float *second;
+    int64_t nt;
+};
 hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const float4 *tgt_normals, const unsigned long long *keys,
                          int nsplits, int64_t ns_pad, const Xform32 &T32,
@@ -84,7 +93,7 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out, const DevIcpState *st,
                          int *nblocks_out, hipStream_t stream, double *host_out = nullptr,
-                         unsigned long long seq = 0);
+                         unsigned long long seq = 0, const BruteExact *ex = nullptr);
 
 int reduce_max_blocks();
 // one-shot all-reduce of the 38 statistics through IPC-mapped mailboxes (kernels.hip)

@@ -32,19 +32,26 @@ namespace visma {
 // (v_min3_f32 over two targets); which 64-target sub-chunk produced it is
 // recorded once per sub-chunk, and the exact index is recovered by the
 // reduction kernel, which re-evaluates that one sub-chunk.
-template <int SPT>
+//
+// HYB (the exact search, brute-force flavour): the source point is transformed in f64 and rounded
+// (p32 = fl(p64)), the acceptance radius is widened by the rounding band, and besides the best
+// squared distance and its sub-chunk the kernel keeps `second`: the smallest sub-chunk minimum
+// among the OTHER sub-chunks (same min3 per pair of targets as before -- the minimum is taken per
+// sub-chunk and folded into (best, second) once per 64 targets).  The reduction kernel re-ranks in
+// f64 what the band leaves undecided.
+template <int SPT, bool HYB = false>
 __global__ __launch_bounds__(kBlock) void nn_brute_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
     int chunks_total, int chunks_per_split, int src_tiles, int nsplits, Xform32 T,
     float r2f, unsigned long long *__restrict__ keys, long long ns_pad,
-    const DevIcpState *__restrict__ st)
+    const DevIcpState *__restrict__ st, const Pt64 *__restrict__ src64 = nullptr, Xform64 T64 = Xform64{},
+    float *__restrict__ second_out = nullptr)
 {
     __shared__ float4 lds[2][kTChunk];
     const int tid = threadIdx.x;
     {
-        Xform64 t64;
         Offset64 o;
-        if (!load_loop_state(st, T, t64, o, r2f)) return;
+        if (!load_loop_state(st, T, T64, o, r2f)) return;
     }
 
     // XCD-aware (tile, split) decode: workgroup b runs on XCD b % 8, so give
@@ -63,15 +70,27 @@ __global__ __launch_bounds__(kBlock) void nn_brute_kernel(
         }
     }
 
-    float px[SPT], py[SPT], pz[SPT], best[SPT];
+    float px[SPT], py[SPT], pz[SPT], best[SPT], second[SPT];
     unsigned win[SPT];
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
         const int i = tile * (kBlock * SPT) + k * kBlock + tid;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < ns) s = src[i];
-        xform_point_f32(T, s, px[k], py[k], pz[k]);
-        best[k] = r2f;          // strict d2 < r2f acceptance is built in
+        if constexpr (HYB) {
+            Pt64 s8;
+            s8.x = s8.y = s8.z = 0.0;
+            s8.w = 0ull;
+            if (i < ns) s8 = src64[i];
+            px[k] = (float)(T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0);
+            py[k] = (float)(T64.m[4] * s8.x + T64.m[5] * s8.y + T64.m[6] * s8.z + T64.m[7] * 1.0);
+            pz[k] = (float)(T64.m[8] * s8.x + T64.m[9] * s8.y + T64.m[10] * s8.z + T64.m[11] * 1.0);
+            best[k] = exact_band_limit(px[k], py[k], pz[k], r2f);    // candidates at or beyond it never matter
+        } else {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < ns) s = src[i];
+            xform_point_f32(T, s, px[k], py[k], pz[k]);
+            best[k] = r2f;      // strict d2 < r2f acceptance is built in
+        }
+        second[k] = INFINITY;
         win[k] = 0xFFFFFFFFu;   // "no correspondence"
     }
 
@@ -97,7 +116,10 @@ __global__ __launch_bounds__(kBlock) void nn_brute_kernel(
             for (int sb = 0; sb < kTChunk / kSub; ++sb) {
                 float before[SPT];
 #pragma unroll
-                for (int k = 0; k < SPT; k++) before[k] = best[k];
+                for (int k = 0; k < SPT; k++) {
+                    before[k] = best[k];
+                    if constexpr (HYB) best[k] = INFINITY;     // the minimum of THIS sub-chunk
+                }
                 const float4 *t = &lds[buf][sb * kSub];
 #pragma unroll 8
                 for (int j = 0; j < kSub; j += 2) {
@@ -111,8 +133,17 @@ __global__ __launch_bounds__(kBlock) void nn_brute_kernel(
                 }
                 const unsigned sid = (unsigned)(c * (kTChunk / kSub) + sb);
 #pragma unroll
-                for (int k = 0; k < SPT; k++)
-                    win[k] = (best[k] < before[k]) ? sid : win[k];
+                for (int k = 0; k < SPT; k++) {
+                    if constexpr (HYB) {
+                        const float m = best[k];
+                        const bool improved = m < before[k];
+                        second[k] = fminf(second[k], improved ? before[k] : m);
+                        best[k] = improved ? m : before[k];
+                        win[k] = improved ? sid : win[k];
+                    } else {
+                        win[k] = (best[k] < before[k]) ? sid : win[k];
+                    }
+                }
             }
             if (has_next) {
                 lds[buf ^ 1][tid] = r0;
@@ -128,6 +159,7 @@ __global__ __launch_bounds__(kBlock) void nn_brute_kernel(
     for (int k = 0; k < SPT; k++) {
         const long long i = (long long)tile * (kBlock * SPT) + k * kBlock + tid;
         out[i] = ((unsigned long long)__float_as_uint(best[k]) << 32) | win[k];
+        if constexpr (HYB) second_out[(long long)split * ns_pad + i] = second[k];
     }
 }
 
@@ -162,11 +194,24 @@ NNLaunch nn_plan(int64_t ns, int64_t nt_pad)
 hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
                            int64_t nt_pad, const Xform32 &T, float r2f,
                            unsigned long long *keys, int64_t ns_pad,
-                           const NNLaunch &plan, const DevIcpState *st, hipStream_t stream)
+                           const NNLaunch &plan, const DevIcpState *st, hipStream_t stream,
+                           const Pt64 *src64, const Xform64 *T64, float *second)
 {
     const int chunks = (int)(nt_pad / kTChunk);
     const int per = (chunks + plan.tgt_splits - 1) / plan.tgt_splits;
     const dim3 grid((unsigned)(plan.src_tiles * plan.tgt_splits));
+    if (src64 && second) {
+        const Xform64 t64 = T64 ? *T64 : Xform64{};
+        if (plan.spt == kSptLarge)
+            hipLaunchKernelGGL((nn_brute_kernel<kSptLarge, true>), grid, dim3(kBlock), 0, stream, src, (int)ns, tgt,
+                               chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f, keys, (long long)ns_pad, st, src64,
+                               t64, second);
+        else
+            hipLaunchKernelGGL((nn_brute_kernel<kSptSmall, true>), grid, dim3(kBlock), 0, stream, src, (int)ns, tgt,
+                               chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f, keys, (long long)ns_pad, st, src64,
+                               t64, second);
+        return hipGetLastError();
+    }
     if (plan.spt == kSptLarge)
         hipLaunchKernelGGL(nn_brute_kernel<kSptLarge>, grid, dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, chunks, per, plan.src_tiles, plan.tgt_splits, T, r2f,
@@ -181,6 +226,137 @@ hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
 // ------------------------------------------------------------------------
 // Reduction: merge + refine + Jacobian/residual + wave-shuffle reduce
 // ------------------------------------------------------------------------
+// Exact flavour of the brute-force reduction (the search kernel ran with HYB): per query
+//   * the smallest (d2, sub-chunk) over the splits, and `so` = the smallest fp32 d2 any OTHER
+//     sub-chunk holds (the other splits' best, the winning split's `second`);
+//   * every candidate of the winning sub-chunk inside the rounding band of the best is ranked in
+//     f64 (flann dist.h:159-176; lowest index on exact ties; accepted iff d2 < (double)(float)(r*r));
+//   * if `so` reaches into the band, other sub-chunks may hold the true winner: the WAVE re-scans the
+//     whole target for that query (fp32 filter, f64 rank) -- about one query in a thousand.
+// Statistics from the f64 coordinates: the results equal the exact grid search's.
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void reduce_exact_kernel(
+    const Pt64 *__restrict__ src64, int ns, const float4 *__restrict__ tgt, const Pt64 *__restrict__ tgt64, int nt,
+    const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, const unsigned long long *__restrict__ keys,
+    const float *__restrict__ second, int nsplits, long long ns_pad, Xform64 T64, Offset64 off, float r2f,
+    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials,
+    const DevIcpState *__restrict__ st)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    {
+        Xform32 t32;
+        if (!load_loop_state(st, t32, T64, off, r2f)) return;
+    }
+    const double r2d = (double)r2f;
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+    const int lane = threadIdx.x & 63;
+    const int nloop = ((ns + kBlock - 1) / kBlock + gridDim.x - 1) / gridDim.x;   // uniform trip count (wave-wide scans inside)
+    for (int it = 0; it < nloop; it++) {
+        const int i = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        const bool valid = i < ns;
+        Pt64 s8;
+        s8.x = s8.y = s8.z = 0.0;
+        s8.w = 0ull;
+        if (valid) s8 = src64[i];
+        const double pxd = T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0;
+        const double pyd = T64.m[4] * s8.x + T64.m[5] * s8.y + T64.m[6] * s8.z + T64.m[7] * 1.0;
+        const double pzd = T64.m[8] * s8.x + T64.m[9] * s8.y + T64.m[10] * s8.z + T64.m[11] * 1.0;
+        const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
+        // (1) merge the splits
+        unsigned long long key = ~0ull;
+        int smin = 0;
+        if (valid) {
+            key = keys[i];
+            for (int s = 1; s < nsplits; s++) {
+                const unsigned long long k2 = keys[(long long)s * ns_pad + i];
+                if (k2 < key) { key = k2; smin = s; }
+            }
+        }
+        float so = INFINITY;
+        if (valid)
+            for (int s = 0; s < nsplits; s++) {
+                const float v = (s == smin) ? second[(long long)s * ns_pad + i]
+                                            : __uint_as_float((unsigned)(keys[(long long)s * ns_pad + i] >> 32));
+                so = fminf(so, v);
+            }
+        const unsigned win = (unsigned)(key & 0xFFFFFFFFull);
+        const float b1 = __uint_as_float((unsigned)(key >> 32));
+        float r_up;
+        const float E = exact_band(px, py, pz, r2f, &r_up);
+        const float sl = fminf(sqrtf(b1), r_up) + 2.0f * E;
+        const float L = sl * sl * (1.0f + 6e-7f);
+        double bd = r2d;
+        unsigned bidx = 0xFFFFFFFFu;
+        auto rank = [&](unsigned j, double qx, double qy, double qz) {
+            const double dx = qx - pxd, dy = qy - pyd, dz = qz - pzd;
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            const bool lt = d < bd || (d == bd && j < bidx && bidx != 0xFFFFFFFFu);
+            bd = lt ? d : bd;
+            bidx = lt ? j : bidx;
+        };
+        // (2) the winning sub-chunk, every candidate inside the band
+        if (valid && win != 0xFFFFFFFFu) {
+            const unsigned j0 = win * kSub;
+#pragma unroll 4
+            for (int j = 0; j < kSub; ++j) {
+                const unsigned jj = j0 + j;
+                if (jj < (unsigned)nt && sqdist_f32(tgt[jj], px, py, pz) <= L) {
+                    const Pt64 c8 = tgt64[jj];
+                    rank(jj, c8.x, c8.y, c8.z);
+                }
+            }
+        }
+        // (3) other sub-chunks reach into the band: the wave scans the whole target for that query
+        unsigned long long need = __ballot(valid && win != 0xFFFFFFFFu && so <= L);
+        while (need) {
+            const int srcl = __ffsll((long long)need) - 1;
+            need &= need - 1ull;
+            const float qpx = __shfl(px, srcl, 64), qpy = __shfl(py, srcl, 64), qpz = __shfl(pz, srcl, 64);
+            const float qL = __shfl(L, srcl, 64);
+            const double qxd = __shfl(pxd, srcl, 64), qyd = __shfl(pyd, srcl, 64), qzd = __shfl(pzd, srcl, 64);
+            double wd = r2d;
+            unsigned wi = 0xFFFFFFFFu;
+            for (int j = lane; j < nt; j += 64) {
+                if (sqdist_f32(tgt[j], qpx, qpy, qpz) <= qL) {
+                    const Pt64 c8 = tgt64[j];
+                    const double dx = c8.x - qxd, dy = c8.y - qyd, dz = c8.z - qzd;
+                    double d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    const bool lt = d < wd || (d == wd && (unsigned)j < wi && wi != 0xFFFFFFFFu);
+                    wd = lt ? d : wd;
+                    wi = lt ? (unsigned)j : wi;
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {                  // (d2, index) minimum over the wave
+                const double od = __shfl_xor(wd, o, 64);
+                const unsigned oi = (unsigned)__shfl_xor((int)wi, o, 64);
+                if (od < wd || (od == wd && oi < wi)) { wd = od; wi = oi; }
+            }
+            if (lane == srcl) { bd = wd; bidx = wi; }          // (a scan of everything supersedes the sub-chunk result)
+        }
+        if (valid) {
+            idx_out[i] = bidx == 0xFFFFFFFFu ? -1 : (int)bidx;
+            d2_out[i] = (float)bd;
+            if (bidx != 0xFFFFFFFFu) {
+                const Pt64 q8 = tgt64[bidx];
+                double nx = 0.0, ny = 0.0, nz = 0.0;
+                if (PLANE) {
+                    if (nrm64) { const Pt64 n8 = nrm64[bidx]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                    else { const float4 n4 = nrm[bidx]; nx = n4.x; ny = n4.y; nz = n4.z; }
+                }
+                accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
+            }
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
 template <bool PLANE>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(
     const float4 *__restrict__ src, int ns, const float4 *__restrict__ tgt,
@@ -516,14 +692,23 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
                          int max_partial_blocks, double *stats_out, const DevIcpState *st,
                          int *nblocks_out, hipStream_t stream, double *host_out,
-                         unsigned long long seq)
+                         unsigned long long seq, const BruteExact *ex)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
     int nblocks = (int)((ns + kBlock - 1) / kBlock);
     if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
     if (nblocks < 1) nblocks = 1;
-    if (point_to_plane)
+    if (ex && ex->src64) {
+        if (point_to_plane)
+            hipLaunchKernelGGL(reduce_exact_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, ex->src64, (int)ns, tgt,
+                               ex->tgt64, (int)ex->nt, tgt_normals, ex->nrm64, keys, ex->second, nsplits, (long long)ns_pad,
+                               T64, off, r2f, idx_out, d2_out, partials, st);
+        else
+            hipLaunchKernelGGL(reduce_exact_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, ex->src64, (int)ns, tgt,
+                               ex->tgt64, (int)ex->nt, tgt_normals, ex->nrm64, keys, ex->second, nsplits, (long long)ns_pad,
+                               T64, off, r2f, idx_out, d2_out, partials, st);
+    } else if (point_to_plane)
         hipLaunchKernelGGL(reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
                            T64, off, r2f, idx_out, d2_out, partials, st);
