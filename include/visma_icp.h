@@ -52,8 +52,7 @@ typedef enum {
 } visma_icp_solver;
 
 /* Nearest-neighbour search implementation (identical results at equal search
- * precision; the brute-force kernel is always fp32, see
- * visma_icp_set_search_precision). */
+ * precision, see visma_icp_set_search_precision). */
 typedef enum {
     VISMA_ICP_NN_AUTO = 0,
     VISMA_ICP_NN_BRUTE = 1, /* brute force over the whole target           */
@@ -251,26 +250,29 @@ VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_proble
  * one.  The grid is (re)built on the GPU when the target or the radius changes. */
 VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
 /* Arithmetic of the nearest-neighbour search.
- *   0            fp32 distances on the fp32-rounded, centred clouds (the kernel
- *                specification; what runs above 131,072 source points, e.g. in bench.py, and
- *                in the brute-force and target-sharded paths).  Near-ties between two candidates,
- *                and candidates within ~1e-6 of the radius, can be decided differently
- *                from the reference's f64 KD-tree; one flipped pair among K moves the
- *                update by ~(pair spacing)/K -- negligible for large clouds, but above
- *                1e-5 in about 2 % of random registrations with a few thousand points.
- *   1 (default)  f64 search whenever the clouds are given in f64 (visma_icp_set_clouds_f64),
- *                the grid search is in use, the source has at most 131,072 points and the
- *                target at most 8,388,608:
- *                the caller's f64 coordinates, the reference's f64 sum of squares and its
- *                strict d2 < (double)(float)(r*r) test, i.e. the reference's correspondences;
- *                statistics from the f64 coordinates too.  fp32 search otherwise.
- *   2            f64 search for any size (same conditions otherwise).  Choose it when a large
- *                source has only a few thousand matches (what matters is the number of matched
- *                pairs K, which the automatic choice can only guess from the source size).
- * Takes effect at the next visma_icp_set_clouds_f64.  Cost of the f64 search: +6 % per
- * iteration at 5k -> 20k points, +30 % at 64k -> 256k (measured on MI355X). */
+ *   0            fp32 only: fp32 distances on the fp32-rounded clouds centred on the target
+ *                centroid (the round-1 kernels).  Near-ties between two candidates, and
+ *                candidates within ~1e-6 of the radius, can be decided differently from the
+ *                reference's f64 KD-tree (about one query in 1e5); one flipped pair among K
+ *                moves the update by ~(pair spacing)/K.
+ *   1 (default)  exact: candidates are ranked in fp32, the best three are kept, and whenever
+ *                the runner-up or the radius lies within the rounding band of the best
+ *                (2.4e-7 (|p|_1 + r) + 4.8e-7 r on the distance, both operands fp32-rounded
+ *                f64 coordinates) the candidates concerned are re-ranked in f64 with the
+ *                reference's arithmetic: the f64 sum of squares of FLANN L2<double>, the
+ *                strict d2 < (double)(float)(r*r) test, lowest index on exact ties.  Four
+ *                candidates inside the band: the query rescans its cells in f64.  Source
+ *                transform and statistics in f64 from the caller's coordinates.  The
+ *                correspondences are those of mode 2 (and of the reference) for every input;
+ *                every path has this flavour -- grid (single, sweep, batch), brute force,
+ *                target-sharded.  Clouds given as fp32 are promoted on the device.
+ *   2            f64 search: every candidate distance in f64.  Same results as 1, slower
+ *                (+30 % at 64k -> 256k); kept as the in-library check of mode 1.
+ * Takes effect at the next cloud upload.  Cost of mode 1 over mode 0: +5 % per iteration at
+ * 64k -> 256k (measured on MI355X, profiles/r02_probe_hyb2.txt).
+ * visma_icp_get_search_precision_used reports what the last run executed (0 / 1 / 2). */
 VISMA_ICP_API int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode);
-/* 1 when the last pass ran the f64 search. */
+/* What the last pass ran: 0 fp32 ranking only, 1 exact (fp32 ranking + f64 re-rank), 2 f64. */
 VISMA_ICP_API int visma_icp_get_search_precision_used(visma_icp_ctx *ctx, int *is_f64);
 /* Which search the last nn_pass used (VISMA_ICP_NN_BRUTE or VISMA_ICP_NN_GRID). */
 VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);

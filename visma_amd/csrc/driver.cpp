@@ -1096,7 +1096,7 @@ public:
     int ensure_mailbox()
     {
         if (d_mbox_) return VISMA_ICP_OK;
-        const size_t bytes = sizeof(double) * 2 * kNStats * kIpcMaxRanks;
+        const size_t bytes = sizeof(double) * 2 * kNStats * kIpcMaxRanks * 2;   // two halves, see ipc_allreduce_kernel
         // uncached device memory: remote stores and local polls both go to memory
         if (hipExtMallocWithFlags(&d_mbox_, bytes, hipDeviceMallocUncached) != hipSuccess) {
             (void)hipGetLastError();

@@ -620,6 +620,9 @@ hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned 
 // no flag, no fence), then waits for the nranks granules of statistic a in its OWN mailbox and
 // sums them in rank order -- every rank forms the same sum, bit for bit, so the ranks keep
 // identical transforms without a broadcast.  Tags are the call count: nothing to reset.
+// The mailbox has two halves used alternately (call count parity): a rank can only start
+// call k+2 after every peer has SENT call k+1, which a peer does only after it has finished
+// reading call k, so a granule is never overwritten before its reader has seen it.
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
@@ -640,9 +643,10 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_i
         u4_t g;
         g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
         g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
+        const size_t half = (size_t)(seq & 1ull) * kIpcMaxRanks * kNStats;
         for (int p = 0; p < nranks; p++)
-            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + rank * kNStats + a);
-        const u4_t *mine = reinterpret_cast<const u4_t *>(peers.box[rank]);
+            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + half + rank * kNStats + a);
+        const u4_t *mine = reinterpret_cast<const u4_t *>(peers.box[rank]) + half;
         double sum = 0.0;
         for (int r = 0; r < nranks; r++) {
             u4_t w;

@@ -1,27 +1,27 @@
-// tile.hip -- the streamed radius-cell search: ONE kernel per ICP iteration that
-//   (A) transforms a chunk of Morton-ordered source points (the reference's f64 transform,
-//       PointCloud.cpp:75-80) and finds the chunk's footprint in the cell grid,
-//   (B) fetches every query's 9 cell-run bounds and reduces them, per (y,z) row of the
-//       footprint, to ONE contiguous range of the cell-sorted target,
-//   (C) streams those ranges into LDS with coalesced 16-byte loads (each target point is read
-//       once per workgroup instead of once per query that examines it),
-//   (D) searches every query's 3x3x3 neighbourhood FROM LDS with fp32 arithmetic, keeping the
-//       best and the runner-up squared distance,
-//   (E) re-ranks in the reference's f64 arithmetic (flann dist.h:159-176, KDTreeFlann.cpp:184-185)
-//       exactly those queries whose fp32 ranking is not decisive -- runner-up or search radius
-//       within the rounding band of the best -- so the correspondences ARE the reference's
-//       for every K at fp32 cost,
-//   (F) forms the Jacobian/residual moments of the winner from the f64 coordinates, reduces them
-//       with wave shuffles, and folds the per-workgroup rows IN THE SAME LAUNCH (two-level
-//       last-arriver fold, fixed summation order: bit-reproducible), publishing the 38
-//       statistics to the host / the device loop state.
+// tile.hip -- EXPERIMENTAL (off by default, VISMA_ICP_TILE=1): the LDS-streamed radius-cell
+// search.  Same contract and same answers as nn_grid_reduce_kernel's exact flavour (grid.hip),
+// different memory strategy; measured 2.4-3x SLOWER at the densities of BASELINE.json
+// (profiles/r02_probe_tile6.txt) and kept for radii >> point spacing and as
+// the record of the experiment.  ONE kernel per ICP iteration; a workgroup owns a
+// Morton-contiguous block of queries (G lanes per query) and
+//   (A) transforms them (the reference's f64 transform, PointCloud.cpp:75-80), computes their
+//       cell coordinates and enters the (y,z) rows they touch into a hashed row table in LDS,
+//   (B) fetches the run bounds of every live row once, prefix-sums the run lengths and
+//       compacts them into one LDS point array; a footprint above the LDS budget (CAP points,
+//       MAXR rows) is split into passes over subsets of the rows,
+//   (C) streams the runs into LDS with coalesced loads, 16 lanes per row, as 12-byte SoA
+//       points (each target point is read once per workgroup, not once per query),
+//   (D) searches every query's 3x3 rows FROM LDS in fp32 (Top3 + 4th value, slab pruning with
+//       a live-row mask),
+//   (E) re-ranks the rounding band in the reference's f64 arithmetic (flann dist.h:159-176,
+//       KDTreeFlann.cpp:184-185), exactly as grid.hip does,
+//   (F) forms the moments of the winner from the f64 coordinates, reduces them through LDS and
+//       folds the per-workgroup rows in the same launch (device_common.h: fused_fold).
 // Replaces KDTreeFlann::SearchHybrid + GetRegistrationResultAndCorrespondences
 // (O3D/Core/Registration/Registration.cpp:41-96) + the estimator's accumulation
 // (src/constrained_ICP.cpp:25-37, O3D/Core/Utility/Eigen.cpp:137-182).
-//
-// A workgroup whose footprint does not fit LDS (a Morton chunk that straddles a large jump of
-// the curve, a degenerate grid) runs the same search straight from global memory: slower, same
-// answers.
+// Template configurations: <NTH threads, G lanes/query, CAP points, MAXR rows>; STAMPS adds
+// per-phase s_memtime stamps (visma_icp_timing.tile_phase_cycles).
 #include "device_common.h"
 
 #include <limits.h>
