@@ -87,7 +87,11 @@ def test_target_sharded_equals_single_context(lib, nn_mode):
     src, tgt, T_gt, radius = synth.make_pair(20000, 60000, motion="radius")
     tgt = np.concatenate([tgt, tgt[:500]])                 # exact duplicates across the shards: ties
     ref = _lib.Context(0)
-    ref.set_nn_mode(nn_mode)                 # grid: the default exact search; brute force: the fp32 kernel
+    ref.set_nn_mode(nn_mode)
+    if nn_mode == _lib.NN_BRUTE:
+        # shards with a FORCED brute-force search exchange packed fp32 keys (the round-1 protocol):
+        # compare them with the fp32 brute-force kernel, not with its exact flavour
+        ref.set_search_precision("f32")
     ref.set_clouds_f64(src, tgt)
     want = ref.run(None, radius, 12, 0, 0)
     assert ref.search_mode_used() == ("exact" if nn_mode == _lib.NN_GRID else "f32")

@@ -859,7 +859,7 @@ public:
         if (tgt_tot > bt_tgt_cap_) {
             free_dev(bt_tgt_); free_dev(bt_sorted_); free_dev(bt_cell_of_);
             HIP_TRY(hipMalloc(&bt_tgt_, sizeof(float4) * std::max<int64_t>(tgt_tot, 1)));
-            HIP_TRY(hipMalloc(&bt_sorted_, sizeof(float4) * std::max<int64_t>(tgt_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_sorted_, sizeof(float4) * (std::max<int64_t>(tgt_tot, 1) + kSortedSlack)));
             HIP_TRY(hipMalloc(&bt_cell_of_, sizeof(unsigned) * std::max<int64_t>(tgt_tot, 1)));
             bt_tgt_cap_ = tgt_tot;
         }
@@ -1263,7 +1263,7 @@ private:
         grid_ = grid_plan(mn, mx, max_dist, kGridMaxCells, grid_sub_);
         if ((int64_t)nt_ > sorted_cap_) {
             free_dev(d_sorted_); free_dev(d_cell_of_);
-            HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * nt_));
+            HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * (nt_ + kSortedSlack)));   // batches read past a run's end
             HIP_TRY(hipMalloc(&d_cell_of_, sizeof(unsigned) * nt_));
             sorted_cap_ = nt_;
         }

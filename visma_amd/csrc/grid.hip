@@ -324,26 +324,69 @@ __device__ __forceinline__ float med3_f32(float a, float b, float c)
 }
 
 // sorted insertion of (d, pos) into the three best of a query; h4 = value of the fourth
-struct Top3 {
-    float h1, h2, h3, h4;
-    unsigned p1, p2, p3;
+// The N best (d2, position) of the candidates seen so far and the value of the (N+1)-th, as
+// straight-line VALU code: compares first, then the values (v_med3 / v_min), then the positions
+// (v_cndmask).  Written as one asm block per insertion: the compiler turns the equivalent selects
+// into nested exec-mask regions (it knows d < h1 implies d < h2), which costs more scalar
+// instructions than the selects it avoids.  d is never NaN here.
+#ifndef VISMA_GRID_NTOP
+#define VISMA_GRID_NTOP 2
+#endif
+template <int N>
+struct TopN {
+    static_assert(N >= 1 && N <= 3, "");
+    float h[4];                          // h[0..N-1] the best values, h[N] the next one
+    unsigned p[3];
     __device__ __forceinline__ void init(float lim)
     {
-        h1 = h2 = h3 = h4 = lim;
-        p1 = p2 = p3 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < 4; k++) h[k] = lim;
+#pragma unroll
+        for (int k = 0; k < 3; k++) p[k] = 0xFFFFFFFFu;
     }
+    __device__ __forceinline__ float next() const { return h[N]; }
     __device__ __forceinline__ void insert(float d, unsigned pos)
     {
-        const bool lt1 = d < h1, lt2 = d < h2, lt3 = d < h3;
-        h4 = med3_f32(h3, h4, d);
-        h3 = med3_f32(h2, h3, d);
-        h2 = med3_f32(h1, h2, d);
-        h1 = fminf(h1, d);
-        p3 = lt2 ? p2 : (lt3 ? pos : p3);
-        p2 = lt1 ? p1 : (lt2 ? pos : p2);
-        p1 = lt1 ? pos : p1;
+        unsigned long long c1, c2, c3;
+        if constexpr (N == 1) {
+            asm("v_cmp_lt_f32_e64 %[c1], %[d], %[h0]\n\t"
+                "v_med3_f32 %[h1], %[h0], %[h1], %[d]\n\t"
+                "v_min_f32_e32 %[h0], %[h0], %[d]\n\t"
+                "v_cndmask_b32_e64 %[p0], %[p0], %[pos], %[c1]"
+                : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [p0] "+v"(p[0]), [c1] "=&s"(c1)
+                : [d] "v"(d), [pos] "v"(pos));
+        } else if constexpr (N == 2) {
+            asm("v_cmp_lt_f32_e64 %[c1], %[d], %[h0]\n\t"
+                "v_cmp_lt_f32_e64 %[c2], %[d], %[h1]\n\t"
+                "v_med3_f32 %[h2], %[h1], %[h2], %[d]\n\t"
+                "v_med3_f32 %[h1], %[h0], %[h1], %[d]\n\t"
+                "v_min_f32_e32 %[h0], %[h0], %[d]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[pos], %[c2]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p0], %[c1]\n\t"
+                "v_cndmask_b32_e64 %[p0], %[p0], %[pos], %[c1]"
+                : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [p0] "+v"(p[0]), [p1] "+v"(p[1]),
+                  [c1] "=&s"(c1), [c2] "=&s"(c2)
+                : [d] "v"(d), [pos] "v"(pos));
+        } else {
+            asm("v_cmp_lt_f32_e64 %[c1], %[d], %[h0]\n\t"
+                "v_cmp_lt_f32_e64 %[c2], %[d], %[h1]\n\t"
+                "v_cmp_lt_f32_e64 %[c3], %[d], %[h2]\n\t"
+                "v_med3_f32 %[h3], %[h2], %[h3], %[d]\n\t"
+                "v_med3_f32 %[h2], %[h1], %[h2], %[d]\n\t"
+                "v_med3_f32 %[h1], %[h0], %[h1], %[d]\n\t"
+                "v_min_f32_e32 %[h0], %[h0], %[d]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[pos], %[c3]\n\t"
+                "v_cndmask_b32_e64 %[p2], %[p2], %[p1], %[c2]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[pos], %[c2]\n\t"
+                "v_cndmask_b32_e64 %[p1], %[p1], %[p0], %[c1]\n\t"
+                "v_cndmask_b32_e64 %[p0], %[p0], %[pos], %[c1]"
+                : [h0] "+v"(h[0]), [h1] "+v"(h[1]), [h2] "+v"(h[2]), [h3] "+v"(h[3]), [p0] "+v"(p[0]),
+                  [p1] "+v"(p[1]), [p2] "+v"(p[2]), [c1] "=&s"(c1), [c2] "=&s"(c2), [c3] "=&s"(c3)
+                : [d] "v"(d), [pos] "v"(pos));
+        }
     }
 };
+typedef TopN<VISMA_GRID_NTOP> TopK;
 
 template <bool PLANE, int G, int U, bool ONE, bool F64 = false, bool HYB = false>
 __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
@@ -470,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // u (|p|+|q|) per component, u = 2^-24, and the fp32 evaluation of d2 adds 3u relative, so
         // |d64 - sqrt(d2_32)| <= u (2 |p| + 2.5 r).  E is more than twice that.
         float hyb_E = 0.f, hyb_rup = 0.f;
-        Top3 top;
+        TopK top;
         if constexpr (HYB) {
             const float r_f = sqrtf(r2f);
             hyb_rup = r_f * (1.0f + 2.4e-7f);
@@ -481,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // what a row bound is compared with: the best squared distance so far, as fp32
         auto best_f32 = [&]() {
             if constexpr (F64) { const float f = (float)bd; return f + f * 1e-6f; }   // rounded UP a little
-            else if constexpr (HYB) return top.h1;
+            else if constexpr (HYB) return top.h[0];
             else return __uint_as_float((unsigned)(bkey >> 32));
         };
         // Rows (y,z) are visited nearest first and a row is SKIPPED when its slab cannot
@@ -547,18 +590,19 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     bpos = lt ? jc[u] : bpos;
                 }
             } else if constexpr (HYB) {
+                // the whole batch from ONE address (immediate offsets): slots past the run's end read
+                // whatever follows in the array (it has kSortedSlack entries of slack) and are masked
                 float4 q[U];
+                const unsigned b0 = base + sub;
+                const float4 *qp = sorted + b0;
+                const unsigned left = b0 < e ? e - b0 : 0u;
 #pragma unroll
-                for (int u = 0; u < U; u++) {
-                    const unsigned ju = base + sub + u * G;
-                    jc[u] = ju < e ? ju : base;
-                    q[u] = sorted[jc[u]];
-                }
+                for (int u = 0; u < U; u++) q[u] = qp[u * G];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     float d = sqdist_f32(q[u], px, py, pz);
-                    d = (base + sub + u * G < e) ? d : INFINITY;   // a padding slot is not another candidate
-                    top.insert(d, jc[u]);
+                    d = (unsigned)(u * G) < left ? d : INFINITY;      // a padding slot is not a candidate
+                    top.insert(d, b0 + u * G);
                 }
             } else {
                 float4 q[U];
@@ -657,35 +701,39 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             }
         }
         if constexpr (HYB) {
+            constexpr int NT = VISMA_GRID_NTOP;
             if (G > 1) {
-                // butterfly merge over the G lanes: the three best of the union, and the fourth value
+                // butterfly merge over the G lanes: the NT best of the union, and the next value
 #pragma unroll
                 for (int m = G >> 1; m > 0; m >>= 1) {
-                    const float o1 = __shfl_xor(top.h1, m, 64), o2 = __shfl_xor(top.h2, m, 64);
-                    const float o3 = __shfl_xor(top.h3, m, 64), o4 = __shfl_xor(top.h4, m, 64);
-                    const unsigned q1 = (unsigned)__shfl_xor((int)top.p1, m, 64);
-                    const unsigned q2 = (unsigned)__shfl_xor((int)top.p2, m, 64);
-                    const unsigned q3 = (unsigned)__shfl_xor((int)top.p3, m, 64);
-                    // (the lanes of a pair must end up with the SAME triple: insert in a fixed order)
-                    Top3 t2;
+                    float oh[NT + 1];
+                    unsigned op[NT];
+#pragma unroll
+                    for (int k = 0; k <= NT; k++) oh[k] = __shfl_xor(top.h[k], m, 64);
+#pragma unroll
+                    for (int k = 0; k < NT; k++) op[k] = (unsigned)__shfl_xor((int)top.p[k], m, 64);
+                    // (the lanes of a pair must end up with the SAME set: insert in a fixed order)
                     const bool mine_first = (threadIdx.x & m) == 0;
-                    t2 = top;
-                    if (!mine_first) { t2.h1 = o1; t2.h2 = o2; t2.h3 = o3; t2.h4 = o4; t2.p1 = q1; t2.p2 = q2; t2.p3 = q3; }
-                    const float i1 = mine_first ? o1 : top.h1, i2 = mine_first ? o2 : top.h2, i3 = mine_first ? o3 : top.h3;
-                    const float i4 = mine_first ? o4 : top.h4;
-                    const unsigned j1 = mine_first ? q1 : top.p1, j2 = mine_first ? q2 : top.p2, j3 = mine_first ? q3 : top.p3;
-                    t2.insert(i1, j1);
-                    t2.insert(i2, j2);
-                    t2.insert(i3, j3);
-                    t2.h4 = fminf(t2.h4, i4);
+                    TopK t2 = top;
+                    float ih[NT + 1];
+                    unsigned ip[NT];
+#pragma unroll
+                    for (int k = 0; k <= NT; k++) { ih[k] = mine_first ? oh[k] : top.h[k]; if (!mine_first) t2.h[k] = oh[k]; }
+#pragma unroll
+                    for (int k = 0; k < NT; k++) { ip[k] = mine_first ? op[k] : top.p[k]; if (!mine_first) t2.p[k] = op[k]; }
+#pragma unroll
+                    for (int k = 0; k < NT; k++) t2.insert(ih[k], ip[k]);
+                    t2.h[NT] = fminf(t2.h[NT], ih[NT]);
                     top = t2;
                 }
             }
             // decisive?  the candidates inside the rounding band of the best are ranked in f64
-            if (sub == 0 && top.p1 != 0xFFFFFFFFu) {
-                const float s1 = sqrtf(top.h1) + 2.0f * hyb_E;
-                const bool in2 = s1 >= sqrtf(top.h2), in3 = in2 && s1 >= sqrtf(top.h3);
-                const bool in4 = in3 && s1 >= sqrtf(top.h4);
+            if (sub == 0 && top.p[0] != 0xFFFFFFFFu) {
+                const float s1 = sqrtf(top.h[0]) + 2.0f * hyb_E;
+                bool in[NT + 1];
+                in[0] = true;
+#pragma unroll
+                for (int k = 1; k <= NT; k++) in[k] = in[k - 1] && s1 >= sqrtf(top.h[k]);
                 auto rank = [&](unsigned pos) {
                     const Pt64 c8 = sorted64[pos];
                     // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
@@ -699,14 +747,15 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     bidx = lt ? id : bidx;
                     bpos = lt ? pos : bpos;
                 };
-                if (!in4) {
-                    rank(top.p1);
-                    if (in2 && top.p2 != 0xFFFFFFFFu) rank(top.p2);
-                    if (in3 && top.p3 != 0xFFFFFFFFu) rank(top.p3);
+                if (!in[NT]) {
+                    rank(top.p[0]);
+#pragma unroll
+                    for (int k = 1; k < NT; k++)
+                        if (in[k] && top.p[k] != 0xFFFFFFFFu) rank(top.p[k]);
                 } else {
-                    // four or more candidates inside one band: every candidate of the 27 cells that the
-                    // fp32 filter cannot exclude, in f64
-                    const float sl = fminf(sqrtf(top.h1), hyb_rup) + 2.0f * hyb_E;
+                    // more candidates inside one band than positions kept: every candidate of the 27 cells
+                    // that the fp32 filter cannot exclude, in f64
+                    const float sl = fminf(sqrtf(top.h[0]), hyb_rup) + 2.0f * hyb_E;
                     const float L = sl * sl * (1.0f + 6e-7f);
 #pragma unroll 1
                     for (int k = 0; k < 9; k++) {

@@ -97,6 +97,8 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
 
 int reduce_max_blocks();
 // one-shot all-reduce of the 38 statistics through IPC-mapped mailboxes (kernels.hip)
+constexpr int kSortedSlack = 64;   // entries allocated past the end of a cell-sorted target: the exact grid
+                                   // search loads whole batches (<= U*G slots) from a run's first slot
 constexpr int kIpcMaxRanks = 16;
 struct IpcPeers { void *box[kIpcMaxRanks]; };     // box[r]: rank r's mailbox as mapped HERE (box[rank] = own)
 hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
