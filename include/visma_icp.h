@@ -243,6 +243,15 @@ VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_proble
                                       int n, int max_iter, double rel_fitness,
                                       double rel_rmse, int solver,
                                       visma_icp_result *out);
+/* The same with the point-to-plane estimator (TransformationEstimationPointToPlane,
+ * O3D/Core/Registration/TransformationEstimation.cpp:101-134): tgt_normals[i] are the normals of
+ * probs[i].tgt_xyz (AoS f64, stride 3; the same pointer wherever the same target pointer is
+ * passed).  A problem whose target has no normals (NULL) returns its initial transform, like
+ * Registration.cpp:152-157. */
+VISMA_ICP_API int visma_icp_run_batch_point_to_plane(visma_icp_ctx *ctx, const visma_icp_problem *probs,
+                                                     const double *const *tgt_normals, int n,
+                                                     int max_iter, double rel_fitness, double rel_rmse,
+                                                     visma_icp_result *out);
 
 /* ---- options / measurement --------------------------------------------- */
 /* AUTO (default) uses the radius-cell grid whenever the target/radius make it

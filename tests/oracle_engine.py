@@ -81,7 +81,7 @@ class OracleEngine:
         corr = np.stack([np.arange(len(p)), np.arange(len(p))], 1).astype(np.int32)
         JTJ, JTr, r2 = self.o.jtj_jtr(p, q, corr, tgt_normals=n)
         st = np.zeros(38)
-        st[0] = len(p); st[1] = r2
+        st[0] = len(p); st[1] = float(((p - q) ** 2).sum())   # Registration.cpp:65-68: the NN distance, not r2
         st[2:23] = JTJ[np.triu_indices(6)]
         st[23:29] = JTr
         return st

@@ -40,3 +40,78 @@ def test_288_problems_in_flight(lib, oracle):
         assert got[i].num_correspondences == w.k, i
         if w.k >= 3:
             assert synth.rel_frobenius(got[i].transformation_, w.T) < 1e-9, i
+
+
+def _ellipsoid(n, seed, axes=(0.5, 0.3, 0.2), centre=(0.3, -0.2, 1.0), noise=0.0):
+    """points on an ellipsoid with three different axes (all six degrees of freedom are constrained)
+    and their exact unit normals"""
+    rng = np.random.default_rng(seed)
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    a = np.asarray(axes)
+    p = u * a
+    nrm = p / a ** 2
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    p = p + rng.normal(size=p.shape) * noise + np.asarray(centre)
+    return p, nrm
+
+
+def _pp_problems():
+    probs = []
+    for k, (ns, nt, r) in enumerate([(3000, 9000, 0.03), (5000, 20000, 0.02), (1500, 4000, 0.045)]):
+        tgt, nrm = _ellipsoid(nt, 40 + k, noise=2e-4)
+        src, _ = _ellipsoid(ns, 50 + k)
+        a = 0.02
+        R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        c = tgt.mean(0)
+        src = (src - c) @ R.T + c + np.array([0.004, -0.003, 0.002])
+        for y in range(3):                                       # the same clouds from three starts: shared uploads
+            b = 0.01 * y
+            init = np.eye(4)
+            Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+            init[:3, :3] = Ry
+            init[:3, 3] = c - Ry @ c
+            probs.append((src, tgt, nrm, init, r))
+    return probs
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("precision", ["exact", "f32"])
+def test_batch_point_to_plane_equals_single_runs_and_oracle(lib, oracle, precision):
+    """visma_icp_run_batch_point_to_plane: problems with their own clouds and normals, shared targets
+    included, against one-at-a-time runs of the library and the oracle's point-to-plane ICP."""
+    from oracle.oracle import EST_POINT_TO_PLANE
+    probs = _pp_problems()
+    ctx = _lib.Context(0)
+    ctx.set_search_precision(precision)
+    got = ctx.run_batch_point_to_plane(probs, max_iter=15)
+    assert ctx.search_mode_used() == precision
+    one = _lib.Context(0)
+    one.set_search_precision(precision)
+    one.set_device_loop(False)
+    for i, (src, tgt, nrm, init, r) in enumerate(probs):
+        one.set_clouds_f64(src, tgt)
+        one.set_target_normals_f64(nrm)
+        w = one.run_point_to_plane(init, r, 15)
+        assert w.fitness_ > 0.9, (i, w)                            # the registrations do converge
+        assert got[i].num_correspondences == w.num_correspondences, i
+        assert got[i].iterations == w.iterations, i
+        assert synth.rel_frobenius(got[i].transformation_, w.transformation_) < (1e-10 if precision == "exact" else 1e-6), i
+        if precision == "exact" and i % 3 == 0:
+            o = oracle.registration_icp(src, tgt, r, init=init, max_iter=15, estimator=EST_POINT_TO_PLANE,
+                                        tgt_normals=nrm, grid=True)
+            assert got[i].num_correspondences == o.k, i
+            assert synth.rel_frobenius(got[i].transformation_, o.T) < 1e-9, i
+
+
+@pytest.mark.gpu
+def test_batch_point_to_plane_without_normals_returns_the_initial_transform(lib):
+    tgt, nrm = _ellipsoid(6000, 3)
+    src, _ = _ellipsoid(2000, 4)
+    r = 0.04
+    init = np.eye(4); init[0, 3] = 1e-3
+    ctx = _lib.Context(0)
+    got = ctx.run_batch_point_to_plane([(src, tgt, nrm, init, r), (src, tgt.copy(), None, init, r)], max_iter=5)
+    assert got[0].num_correspondences > 0 and not np.allclose(got[0].transformation_, init)
+    assert np.array_equal(got[1].transformation_, init)          # Registration.cpp:152-157

@@ -98,6 +98,8 @@ def test_fragments_p2p_and_p2plane(gpu_ctx_any):
         row = g["trace_p2plane"][it]
         assert rel(r.transformation_, row[:16].reshape(4, 4)) < tol(gpu_ctx_any)
         assert k_matches(gpu_ctx_any, r.num_correspondences, row[18])
+        # inlier_rmse is the nearest-neighbour distance, not the plane residual (Registration.cpp:65-68,93)
+        assert abs(r.inlier_rmse_ - row[17]) < (1e-9 if gpu_ctx_any.search_mode_used() == "exact" else 1e-4) * row[17]
 
 
 def test_edge_cases(gpu_ctx_any):

@@ -202,6 +202,9 @@ def test_point_to_plane(hctx):
         row = g["trace_p2plane"][it]
         assert rel(r.transformation_, row[:16].reshape(4, 4)) < 1e-5
         assert abs(r.num_correspondences - row[18]) <= 2
+        # inlier_rmse is the nearest-neighbour distance, not the plane residual (Registration.cpp:65-68,93)
+        assert abs(r.inlier_rmse_ - row[17]) < 1e-4 * row[17]
+        assert abs(r.fitness_ - row[16]) < 1e-3
     r = hctx.run(g["init"], float(g["radius"]), 10, 0.0, 0.0)
     assert rel(r.transformation_, g["trace_p2p"][10][:16].reshape(4, 4)) < 1e-6
 

@@ -106,6 +106,8 @@ def load():
     L.visma_icp_run_yaw_sweep.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double,
                                           C.c_double, C.c_int, C.POINTER(CResult),
                                           C.POINTER(C.c_int), C.POINTER(CResult)]
+    L.visma_icp_run_batch_point_to_plane.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(_dp), C.c_int, C.c_int,
+                                                     C.c_double, C.c_double, C.POINTER(CResult)]
     L.visma_icp_run_batch.argtypes = [C.c_void_p, C.POINTER(CProblem), C.c_int, C.c_int,
                                       C.c_double, C.c_double, C.c_int, C.POINTER(CResult)]
     L.visma_icp_voxel_down_sample.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, _dp, C.c_double, _dp, _dp,
@@ -322,6 +324,25 @@ class Context:
         out = (CResult * max(n, 1))()
         self._chk(self.L.visma_icp_run_batch(self._h, arr, n, int(max_iter), float(rel_fitness),
                                              float(rel_rmse), int(solver), out))
+        return [Result(out[i]) for i in range(n)]
+
+    def run_batch_point_to_plane(self, problems, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
+        """problems: (src, tgt, tgt_normals or None, init, radius) -- the point-to-plane estimator, all in flight."""
+        n = len(problems)
+        arr = (CProblem * max(n, 1))(); nrm = (_dp * max(n, 1))(); keep = []
+        for i, (src, tgt, normals, init, r) in enumerate(problems):
+            s = _f64(src, (-1, 3)); t = _f64(tgt, (-1, 3)); keep += [s, t]
+            arr[i].src_xyz = _p(s, _dp); arr[i].ns = len(s)
+            arr[i].tgt_xyz = _p(t, _dp); arr[i].nt = len(t)
+            arr[i].init = (C.c_double * 16)(*_f64(np.eye(4) if init is None else init, (16,)))
+            arr[i].max_dist = float(r)
+            if normals is not None:
+                q = _f64(normals, (-1, 3)); keep.append(q)
+                assert len(q) == len(t)
+                nrm[i] = _p(q, _dp)
+        out = (CResult * max(n, 1))()
+        self._chk(self.L.visma_icp_run_batch_point_to_plane(self._h, arr, nrm, n, int(max_iter), float(rel_fitness),
+                                                            float(rel_rmse), out))
         return [Result(out[i]) for i in range(n)]
 
     def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):

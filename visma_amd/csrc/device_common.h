@@ -150,7 +150,9 @@ __device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, 
         J[1] = H[3] * n[0] + H[4] * n[1] + H[5] * n[2];
         J[2] = H[6] * n[0] + H[7] * n[1] + H[8] * n[2];
         J[3] = n[0]; J[4] = n[1]; J[5] = n[2];
-        acc[1] += rr * rr;
+        // the result's inlier_rmse is the NEAREST-NEIGHBOUR distance whatever the estimator
+        // (Registration.cpp:65-68,93: error2 += dists[0]), not the plane residual
+        acc[1] += r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
         int o = 2;
 #pragma unroll
         for (int a = 0; a < 6; a++)

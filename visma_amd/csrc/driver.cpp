@@ -131,6 +131,9 @@ public:
         int src_share = -1, grid_share = -1;
         // f64 copies for the double-precision search (all problems of a batch or none)
         const Pt64 *src64 = nullptr, *tgt64 = nullptr;
+        // target normals (point-to-plane batches: every problem or none), indexed like the target
+        const float *nrm_xyzw = nullptr;
+        const Pt64 *nrm64 = nullptr;
     };
     virtual int run_loop_batch(const LoopParams &, const std::vector<BatchProblem> &, LoopResult *)
     {
@@ -199,6 +202,7 @@ public:
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
+        free_dev(bt_nrm_); free_dev(bt_nrm64_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
         if (h_state_) (void)hipHostFree(h_state_);
@@ -850,6 +854,26 @@ public:
             HIP_TRY(hipMalloc(&bt_sorted64_, sizeof(Pt64) * std::max<int64_t>(tgt_tot, 1)));
             bt_src64_cap_ = src_tot; bt_tgt64_cap_ = tgt_tot;
         }
+        if (lp.plane) {
+            for (int b = 0; b < B; b++) {
+                const BatchProblem &tq = pb[b].grid_share >= 0 ? pb[pb[b].grid_share] : pb[b];
+                if (pb[b].nt > 0 && !(f64 ? (const void *)tq.nrm64 : (const void *)tq.nrm_xyzw)) {
+                    err_ = "point-to-plane batch without target normals";
+                    return VISMA_ICP_ERR_STATE;
+                }
+            }
+            if (f64 && !exact_) { err_ = "point-to-plane batches run the exact or the fp32 search"; return VISMA_ICP_ERR_STATE; }
+            if (f64 && tgt_tot > bt_nrm64_cap_) {
+                free_dev(bt_nrm64_);
+                HIP_TRY(hipMalloc(&bt_nrm64_, sizeof(Pt64) * std::max<int64_t>(tgt_tot, 1)));
+                bt_nrm64_cap_ = tgt_tot;
+            }
+            if (!f64 && tgt_tot > bt_nrm_cap_) {
+                free_dev(bt_nrm_);
+                HIP_TRY(hipMalloc(&bt_nrm_, sizeof(float4) * std::max<int64_t>(tgt_tot, 1)));
+                bt_nrm_cap_ = tgt_tot;
+            }
+        }
         if (out_tot > bt_out_cap_) {
             free_dev(bt_idx_); free_dev(bt_d2_);
             HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(out_tot, 1)));
@@ -906,6 +930,10 @@ public:
             if (q.nt > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_tgt_ + d.sorted_off, q.tgt_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
             if (f64 && q.nt > 0)
                 HIP_TRY(hipMemcpyAsync((Pt64 *)bt_tgt64_ + d.sorted_off, q.tgt64, sizeof(Pt64) * q.nt, hipMemcpyHostToDevice, stream_));
+            if (lp.plane && q.nt > 0) {
+                if (f64) HIP_TRY(hipMemcpyAsync((Pt64 *)bt_nrm64_ + d.sorted_off, q.nrm64, sizeof(Pt64) * q.nt, hipMemcpyHostToDevice, stream_));
+                else HIP_TRY(hipMemcpyAsync((float4 *)bt_nrm_ + d.sorted_off, q.nrm_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
+            }
             HIP_TRY(launch_grid_build((const float4 *)bt_tgt_ + d.sorted_off, q.nt, d.g,
                                       (unsigned *)bt_cell_of_ + d.sorted_off, (unsigned *)bt_count_ + d.start_off,
                                       (unsigned *)bt_bsum_, (unsigned *)bt_start_ + d.start_off,
@@ -923,7 +951,7 @@ public:
             h.ns_total = pb[b].ns;
             h.active = 1;
             h.max_iter = lp.max_iter; h.solver = lp.solver; h.scaling = lp.scaling ? 1 : 0;
-            h.plane = 0; h.world_frame = lp.world ? 1 : 0; h.check_stop = lp.check_stop ? 1 : 0;
+            h.plane = lp.plane ? 1 : 0; h.world_frame = lp.world ? 1 : 0; h.check_stop = lp.check_stop ? 1 : 0;
             h.r2f = (float)(pb[b].max_dist * pb[b].max_dist);
         }
         HIP_TRY(hipMemcpyAsync(d_state_, h_state_, sizeof(DevIcpState) * B, hipMemcpyHostToDevice, stream_));
@@ -958,11 +986,13 @@ public:
                                                     f64 ? (const Pt64 *)bt_src64_ : nullptr,
                                                     f64 ? (const Pt64 *)bt_sorted64_ : nullptr, exact_ ? 1 : 0,
                                                     fused_fold_ ? &bfa : nullptr,
-                                                    profiling_ ? (unsigned long long *)d_cand_ : nullptr));
+                                                    profiling_ ? (unsigned long long *)d_cand_ : nullptr,
+                                                    (lp.plane && !f64) ? (const float4 *)bt_nrm_ : nullptr,
+                                                    (lp.plane && f64) ? (const Pt64 *)bt_nrm64_ : nullptr));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
                 if (fused_fold_) HIP_TRY(launch_solve_state(st, B, stream_));
-                else HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_));
+                else HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_, lp.plane ? 1 : 0));
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
             }
             done += n;
@@ -1385,6 +1415,8 @@ private:
     void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
     void *bt_src64_ = nullptr, *bt_tgt64_ = nullptr, *bt_sorted64_ = nullptr;
     int64_t bt_src64_cap_ = 0, bt_tgt64_cap_ = 0;
+    void *bt_nrm_ = nullptr, *bt_nrm64_ = nullptr;         // point-to-plane batches: target normals
+    int64_t bt_nrm_cap_ = 0, bt_nrm64_cap_ = 0;
     void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
     int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0, bt_out_cap_ = 0;
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
@@ -2332,12 +2364,19 @@ static int yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int max_ite
     return VISMA_ICP_OK;
 }
 
-int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int n, int max_iter,
-                        double rel_fitness, double rel_rmse, int solver, visma_icp_result *out)
+// normals == NULL: the point-to-point estimator with `solver`; otherwise normals[i] are the target
+// normals of problem i (AoS stride 3; NULL = that cloud has none) and the estimator is point-to-plane
+static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, const double *const *normals, int n,
+                          int max_iter, double rel_fitness, double rel_rmse, int solver, visma_icp_result *out)
 {
-    CTX_CHECK();
-    if (n < 0 || (n > 0 && (!probs || !out)) || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch arguments");
-    if (ctx->use_device_loop_batched() && n > 1) {
+    const bool plane = normals != nullptr;
+    bool all_normals = plane;
+    for (int i = 0; plane && i < n; i++)
+        if (probs[i].nt > 0 && !normals[i]) all_normals = false;
+    // (a problem without normals returns its initial transform, Registration.cpp:152-157: sequential path;
+    //  point-to-plane batches run the exact or the fp32 search)
+    const bool batch_ok = !plane || (all_normals && ctx->search_precision != 2);
+    if (ctx->use_device_loop_batched() && n > 1 && batch_ok) {
         // every problem in flight together: concatenated clouds, one grid per problem,
         // one NN launch + one fold/solve launch per pass for the whole batch
         std::vector<std::vector<float>> sbuf((size_t)n), tbuf((size_t)n);
@@ -2371,10 +2410,22 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
         std::vector<std::array<double, 3>> cen((size_t)n);
         // double-precision search for the whole batch when every problem qualifies
         const bool want64 = ctx->search_precision != 0;
-        std::vector<std::vector<Pt64>> s8((size_t)n), t8((size_t)n);
+        std::vector<std::vector<Pt64>> s8((size_t)n), t8((size_t)n), n8((size_t)n);
+        std::vector<std::vector<float>> nbuf((size_t)n);
+        if (plane)
+            for (int i = 0; ok && i < n; i++)                     // clouds passed twice carry the same normals
+                if (tshare[i] >= 0 && normals[tshare[i]] != normals[i]) ok = false;
         if (ok)
             parallel_for(n, 1, [&](int64_t i) {                    // targets: first occurrences only
                 if (tshare[i] >= 0) return;
+                if (plane && want64) {
+                    n8[i].resize((size_t)std::max<int64_t>(probs[i].nt, 1));
+                    for (int64_t j = 0; j < probs[i].nt; j++)
+                        n8[i][(size_t)j] = Pt64{normals[i][3 * j], normals[i][3 * j + 1], normals[i][3 * j + 2], 0ull};
+                } else if (plane) {
+                    const double zero[3] = {0, 0, 0};
+                    pack_f64(normals[i], probs[i].nt, 3, zero, nbuf[i]);
+                }
                 const visma_icp_problem &q = probs[i];
                 double c[3];
                 centroid_f64(q.tgt_xyz, q.nt, 3, c, false);       // the same value as set_clouds_f64 computes
@@ -2407,6 +2458,8 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
                 Engine::BatchProblem &b = pb[i];
                 b.src64 = (want64 && sshare[i] < 0) ? s8[i].data() : nullptr;
                 b.tgt64 = want64 ? t8[t].data() : nullptr;
+                b.nrm64 = (plane && want64) ? n8[t].data() : nullptr;
+                b.nrm_xyzw = (plane && !want64) ? nbuf[t].data() : nullptr;
                 b.src_xyzw = sshare[i] < 0 ? sbuf[i].data() : nullptr; b.ns = q.ns;
                 b.tgt_xyzw = tbuf[t].data(); b.nt = q.nt;
                 b.src_share = sshare[i];
@@ -2429,8 +2482,8 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
             lp.centre[0] = lp.centre[1] = lp.centre[2] = 0.0;
             lp.max_dist = 0.0; lp.rel_fit = rel_fitness; lp.rel_rmse = rel_rmse;
             lp.max_iter = max_iter; lp.solver = solver; lp.passes = max_iter + 1;
-            lp.scaling = false; lp.plane = false;
-            lp.world = visma_icp_ctx::wants_world_frame(solver, false);
+            lp.scaling = false; lp.plane = plane;
+            lp.world = visma_icp_ctx::wants_world_frame(solver, plane);
             lp.check_stop = true; lp.ns_total = 0;
             std::vector<Engine::LoopResult> rs((size_t)n);
             int rc = ctx->eng->run_loop_batch(lp, pb, rs.data());
@@ -2451,10 +2504,35 @@ int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int 
     for (int i = 0; i < n; i++) {
         int rc = visma_icp_set_clouds_f64(ctx, probs[i].src_xyz, probs[i].ns, 3, probs[i].tgt_xyz, probs[i].nt, 3);
         if (rc) return rc;
-        rc = ctx->run(probs[i].init, probs[i].max_dist, max_iter, rel_fitness, rel_rmse, solver, false, false, &out[i]);
+        if (plane && normals[i]) {
+            rc = visma_icp_set_target_normals_f64(ctx, normals[i], probs[i].nt, 3);
+            if (rc) return rc;
+        }
+        rc = ctx->run(probs[i].init, probs[i].max_dist, max_iter, rel_fitness, rel_rmse, solver, false, plane, &out[i]);
         if (rc) return rc;
     }
     return VISMA_ICP_OK;
+}
+
+int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_problem *probs, int n, int max_iter,
+                        double rel_fitness, double rel_rmse, int solver, visma_icp_result *out)
+{
+    CTX_CHECK();
+    if (n < 0 || (n > 0 && (!probs || !out)) || max_iter < 0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch arguments");
+    if (solver < 0 || solver > VISMA_ICP_SOLVER_GN_EXPMAP) return ctx->fail(VISMA_ICP_ERR_INVALID, "unknown solver");
+    return run_batch_impl(ctx, probs, nullptr, n, max_iter, rel_fitness, rel_rmse, solver, out);
+}
+
+int visma_icp_run_batch_point_to_plane(visma_icp_ctx *ctx, const visma_icp_problem *probs,
+                                       const double *const *tgt_normals, int n, int max_iter, double rel_fitness,
+                                       double rel_rmse, visma_icp_result *out)
+{
+    CTX_CHECK();
+    if (n < 0 || (n > 0 && (!probs || !out || !tgt_normals)) || max_iter < 0)
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad batch arguments");
+    static const double *const none[1] = {nullptr};
+    return run_batch_impl(ctx, probs, n > 0 ? tgt_normals : none, n, max_iter, rel_fitness, rel_rmse,
+                          VISMA_ICP_SOLVER_GN_EULER, out);
 }
 
 int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode)

@@ -420,6 +420,10 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         ns = d.ns;
         sorted += d.sorted_off;
         if constexpr (S64) { src64 += d.src_off; sorted64 += d.sorted_off; }
+        if constexpr (PLANE) {                             // normals are indexed like the (unsorted) target
+            if (nrm) nrm += d.sorted_off;
+            if (nrm64) nrm64 += d.sorted_off;
+        }
         row0 = d.first_block;
         start += d.start_off;
         g = d.g;
@@ -897,21 +901,21 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     return hipGetLastError();
 }
 
-template <int G, int U, bool ONE, bool F64, bool HYB>
+template <int G, int U, bool ONE, bool F64, bool HYB, bool PLANE = false>
 static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const float4 *src,
                                 const float4 *sorted, const unsigned *start, const ProbDesc *descs,
                                 int nprob, int *idx_out, float *d2_out, double *partials,
                                 const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64, const FoldArgs &fold,
-                                unsigned long long *cand)
+                                unsigned long long *cand, const float4 *nrm = nullptr, const Pt64 *nrm64 = nullptr)
 {
     const Xform32 T32{};
     const Xform64 T64{};
     const Offset64 off{};
     const GridParams g{};
-    hipLaunchKernelGGL((nn_grid_reduce_kernel<false, G, U, ONE, F64, HYB>), dim3(total_blocks), dim3(kBlock), 0, stream,
-                       src, 0, sorted, start, g, (const float4 *)nullptr, T32, T64, off, 0.f, idx_out,
+    hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, ONE, F64, HYB>), dim3(total_blocks), dim3(kBlock), 0, stream,
+                       src, 0, sorted, start, g, nrm, T32, T64, off, 0.f, idx_out,
                        d2_out, partials, cand, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0,
-                       (const Pt64 *)nullptr, fold);
+                       nrm64, fold);
 }
 
 // lanes_per_query = G + 100 * U; one_per_lane: every problem has at most G queries per lane group;
@@ -922,15 +926,28 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int32_t *idx_out, float *d2_out, double *partials,
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64, int exact,
-                                       const FoldArgs *fold, unsigned long long *cand_count)
+                                       const FoldArgs *fold, unsigned long long *cand_count,
+                                       const float4 *nrm, const Pt64 *nrm64)
 {
     if (!st || !descs || (src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
+    const bool plane = nrm != nullptr || nrm64 != nullptr;
+    if (plane && src64 && !exact) return hipErrorInvalidValue;      // point-to-plane batches: exact or fp32 search
     const FoldArgs fa = fold ? *fold : FoldArgs{};
     const int G = lanes_per_query % 100, U = lanes_per_query / 100;
     bool launched = false;
 #define VISMA_BATCH_ARGS total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st
 #define VISMA_BATCH_CASE(GG, UU)                                                                              \
-    if (G == GG && U == UU) {                                                                                 \
+    if (G == GG && U == UU && plane) {                                                                        \
+        if (src64 && one_per_lane)                                                                            \
+            launch_grid_batch_t<GG, UU, true, false, true, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nrm, nrm64);   \
+        else if (src64)                                                                                       \
+            launch_grid_batch_t<GG, UU, false, false, true, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nrm, nrm64);  \
+        else if (one_per_lane)                                                                                \
+            launch_grid_batch_t<GG, UU, true, false, false, true>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nrm, nrm64); \
+        else                                                                                                  \
+            launch_grid_batch_t<GG, UU, false, false, false, true>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nrm, nrm64); \
+        launched = true;                                                                                      \
+    } else if (G == GG && U == UU) {                                                                          \
         if (src64 && exact && one_per_lane)                                                                   \
             launch_grid_batch_t<GG, UU, true, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);            \
         else if (src64 && exact)                                                                              \

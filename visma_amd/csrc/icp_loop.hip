@@ -111,6 +111,7 @@ hipError_t launch_finalize_state(const double *partials, int nblocks, DevIcpStat
     return launch_fs(partials, nblocks, st, plane, 0, 1, stream);
 }
 
+template <bool PLANE>
 __global__ __launch_bounds__(kSolveThreads) void finalize_solve_batch_kernel(const double *__restrict__ partials,
                                                                    const ProbDesc *__restrict__ descs,
                                                                    DevIcpState *st)
@@ -118,15 +119,19 @@ __global__ __launch_bounds__(kSolveThreads) void finalize_solve_batch_kernel(con
     const ProbDesc d = descs[blockIdx.x];                    // one workgroup per problem
     st += blockIdx.x;
     if (!st->active) return;
-    fold_partials<false, kSolveThreads>(partials + (long long)d.first_block * kReduceAcc, d.nblocks, st->stats);
+    fold_partials<PLANE, kSolveThreads>(partials + (long long)d.first_block * kReduceAcc, d.nblocks, st->stats);
     if (threadIdx.x == 0) advance_state(st);
 }
 
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
-                                       int nprob, hipStream_t stream)
+                                       int nprob, hipStream_t stream, int plane)
 {
-    hipLaunchKernelGGL(finalize_solve_batch_kernel, dim3(nprob), dim3(kSolveThreads), 0, stream, partials, descs,
-                       st);
+    if (plane)
+        hipLaunchKernelGGL(finalize_solve_batch_kernel<true>, dim3(nprob), dim3(kSolveThreads), 0, stream, partials,
+                           descs, st);
+    else
+        hipLaunchKernelGGL(finalize_solve_batch_kernel<false>, dim3(nprob), dim3(kSolveThreads), 0, stream, partials,
+                           descs, st);
     return hipGetLastError();
 }
 

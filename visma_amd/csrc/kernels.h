@@ -257,9 +257,11 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64 = nullptr,
                                        const Pt64 *sorted64 = nullptr, int exact = 0,
-                                       const FoldArgs *fold = nullptr, unsigned long long *cand_count = nullptr);
+                                       const FoldArgs *fold = nullptr, unsigned long long *cand_count = nullptr,
+                                       const float4 *nrm = nullptr, const Pt64 *nrm64 = nullptr);
+// (nrm / nrm64: target normals concatenated like the UNSORTED targets -> the point-to-plane estimator)
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
-                                       int nprob, hipStream_t stream);
+                                       int nprob, hipStream_t stream, int plane = 0);
 
 // fill n float4 with +inf (target padding)
 hipError_t launch_fill_inf(float4 *dst, int64_t n, hipStream_t stream);
