@@ -116,15 +116,15 @@ struct Acc {
 // Jacobian / residual rows of ONE correspondence, in f64 (design rules R1/R2):
 // p = T64 * s (+ frame offset), q = target point (+ frame offset).
 // (sx,sy,sz) = source point, (qx,qy,qz) = its target point, both in the centred frame
+// (tx,ty,tz) = the TRANSFORMED source point T64 * s as the search computed it (same expression,
+// same order: the statistics do not depend on which entry point formed p)
 template <bool PLANE>
-__device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, const double sy, const double sz,
-                                                  const double qx, const double qy, const double qz,
-                                                  const double nx, const double ny, const double nz,
-                                                  const Xform64 &T64, const Offset64 &off)
+__device__ __forceinline__ void accumulate_pq_d(double *acc, const double tx, const double ty, const double tz,
+                                                const double qx, const double qy, const double qz,
+                                                const double nx, const double ny, const double nz,
+                                                const Offset64 &off)
 {
-    const double p[3] = {T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3] + off.v[0],
-                         T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7] + off.v[1],
-                         T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11] + off.v[2]};
+    const double p[3] = {tx + off.v[0], ty + off.v[1], tz + off.v[2]};
     const double q[3] = {qx + off.v[0], qy + off.v[1], qz + off.v[2]};
     const double r[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]};
     acc[0] += 1.0;
@@ -161,6 +161,17 @@ __device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, 
 #pragma unroll
         for (int a = 0; a < 6; a++) acc[23 + a] += J[a] * rr;
     }
+}
+
+template <bool PLANE>
+__device__ __forceinline__ void accumulate_pair_d(double *acc, const double sx, const double sy, const double sz,
+                                                  const double qx, const double qy, const double qz,
+                                                  const double nx, const double ny, const double nz,
+                                                  const Xform64 &T64, const Offset64 &off)
+{
+    accumulate_pq_d<PLANE>(acc, T64.m[0] * sx + T64.m[1] * sy + T64.m[2] * sz + T64.m[3],
+                           T64.m[4] * sx + T64.m[5] * sy + T64.m[6] * sz + T64.m[7],
+                           T64.m[8] * sx + T64.m[9] * sy + T64.m[10] * sz + T64.m[11], qx, qy, qz, nx, ny, nz, off);
 }
 
 template <bool PLANE>

@@ -17,6 +17,8 @@
 // per ICP iteration.
 #include "device_common.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 #include <string.h>
 
@@ -203,6 +205,12 @@ GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int6
 {
     GridParams g;
     float h = (float)(max_dist * 1.001);
+    // cells larger than the radius are as exact (the 27 cells still cover it): fewer, longer rows --
+    // fewer dependent trips per query, more candidates, a smaller table.  VISMA_ICP_GRID_CELL = factor
+    if (const char *e = getenv("VISMA_ICP_GRID_CELL")) {
+        const double f = atof(e);
+        if (f >= 1.0 && f <= 64.0) h = (float)(max_dist * 1.001 * f);
+    }
     if (!(h > 0.f) || !isfinite(h)) h = 1.0f;
     double ext[3];
     for (int a = 0; a < 3; a++) {
@@ -467,10 +475,22 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     float4 keep_s = make_float4(0.f, 0.f, 0.f, 0.f);      // the query this lane accumulates
     int keep_i = 0;                                        // (F64: its index instead)
     unsigned keep_pos = 0xFFFFFFFFu;                       // ... and its winner's slot in `sorted`
+    // exact search, one query per lane: the transformed query and the winner's f64 point stay in
+    // registers from the f64 decision to the statistics (no second trip to memory for them)
+    constexpr bool KEEPQ = HYB && ONE && G == 1;
+    double keep_p[3] = {0.0, 0.0, 0.0};
+    Pt64 keep_q = Pt64{0.0, 0.0, 0.0, 0ull};
     auto flush = [&]() {
         if (keep_pos != 0xFFFFFFFFu) {
             float4 n4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (S64) {
+            if constexpr (KEEPQ) {
+                double nx = 0.0, ny = 0.0, nz = 0.0;
+                if (PLANE) {
+                    if (nrm64) { const Pt64 n8 = nrm64[(unsigned)keep_q.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                    else { n4 = nrm[(unsigned)keep_q.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
+                }
+                accumulate_pq_d<PLANE>(acc, keep_p[0], keep_p[1], keep_p[2], keep_q.x, keep_q.y, keep_q.z, nx, ny, nz, off);
+            } else if constexpr (S64) {
                 const Pt64 s8 = src64[keep_i], q8 = sorted64[keep_pos];
                 double nx = 0.0, ny = 0.0, nz = 0.0;
                 if (PLANE) {
@@ -602,6 +622,13 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 const unsigned left = b0 < e ? e - b0 : 0u;
 #pragma unroll
                 for (int u = 0; u < U; u++) q[u] = qp[u * G];
+#ifdef VISMA_GRID_EXPERIMENT_EXTRA_LOADS  /* timing experiment only: one more gather per slot (a nearby line), result unused */
+                float dummy[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) dummy[u] = qp[u * G + 4 + U * G].w;
+#pragma unroll
+                for (int u = 0; u < U; u++) asm volatile("" ::"v"(dummy[u]));
+#endif
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     float d = sqdist_f32(q[u], px, py, pz);
@@ -733,11 +760,14 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             }
             // decisive?  the candidates inside the rounding band of the best are ranked in f64
             if (sub == 0 && top.p[0] != 0xFFFFFFFFu) {
+                // sqrt(h[k]) <= sqrt(h[0]) + 2E, tested on the squares (rounded UP: a candidate wrongly
+                // taken for "in the band" only costs its f64 evaluation)
                 const float s1 = sqrtf(top.h[0]) + 2.0f * hyb_E;
+                const float s1sq = s1 * s1 * (1.0f + 4e-7f);
                 bool in[NT + 1];
                 in[0] = true;
 #pragma unroll
-                for (int k = 1; k <= NT; k++) in[k] = in[k - 1] && s1 >= sqrtf(top.h[k]);
+                for (int k = 1; k <= NT; k++) in[k] = in[k - 1] && top.h[k] <= s1sq;
                 auto rank = [&](unsigned pos) {
                     const Pt64 c8 = sorted64[pos];
                     // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
@@ -750,6 +780,10 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     bd = lt ? d : bd;
                     bidx = lt ? id : bidx;
                     bpos = lt ? pos : bpos;
+                    if constexpr (KEEPQ) {
+                        keep_q.x = lt ? c8.x : keep_q.x; keep_q.y = lt ? c8.y : keep_q.y;
+                        keep_q.z = lt ? c8.z : keep_q.z; keep_q.w = lt ? c8.w : keep_q.w;
+                    }
                 };
                 if (!in[NT]) {
                     rank(top.p[0]);
@@ -807,6 +841,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         }
         // lane (it mod G) of the group keeps this query's winner
         if ((it % G) == sub) { keep_s = s4; keep_i = i; keep_pos = bpos; }
+        if constexpr (KEEPQ) { keep_p[0] = pxd; keep_p[1] = pyd; keep_p[2] = pzd; }
         if (!ONE && (it % G) == G - 1) flush();
     }
     flush();
