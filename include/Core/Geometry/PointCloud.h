@@ -5,6 +5,8 @@
 #include <memory>
 #include <vector>
 
+#include "KDTreeSearchParam.h"
+
 namespace open3d {
 
 class PointCloud {
@@ -50,5 +52,15 @@ public:
 /// Down-sample with a voxel grid (shape of O3D/Core/Geometry/PointCloud.h:101-105);
 /// implemented on the GPU in visma_icp_open3d.hpp.
 inline std::shared_ptr<PointCloud> VoxelDownSample(const PointCloud &input, double voxel_size);
+
+/// Normals from the covariance of each point's neighbours (shape of
+/// O3D/Core/Geometry/PointCloud.h:140-146); on the GPU, in visma_icp_open3d.hpp.  Existing normals
+/// keep their sign.
+inline bool EstimateNormals(PointCloud &cloud, const KDTreeSearchParam &search_param = KDTreeSearchParamKNN());
+/// (O3D/Core/Geometry/PointCloud.h:148-158) host loops, in visma_icp_open3d.hpp
+inline bool OrientNormalsToAlignWithDirection(PointCloud &cloud,
+                                              const Eigen::Vector3d &orientation_reference = Eigen::Vector3d(0.0, 0.0, 1.0));
+inline bool OrientNormalsTowardsCameraLocation(PointCloud &cloud,
+                                               const Eigen::Vector3d &camera_location = Eigen::Vector3d::Zero());
 
 }  // namespace open3d

@@ -385,6 +385,18 @@ VISMA_ICP_API int visma_icp_sample_mesh(visma_icp_ctx *ctx, const double *V, int
                                         const int32_t *F, int64_t nf, int64_t n,
                                         int reference_quirks, uint64_t seed,
                                         const double *uniforms, double *out_xyz, int64_t *n_out);
+/* open3d::EstimateNormals (O3D/Core/Geometry/EstimateNormals.cpp:114-153; PointCloud.h:140-146) on the
+ * GPU: the normal of every point from the covariance of its neighbours, found by one of KDTreeFlann's
+ * three searches (KDTreeFlann.cpp:114-189) --
+ *   search_type 0  KDTreeSearchParamKNN(knn)            the knn nearest points (the point itself included)
+ *               1  KDTreeSearchParamRadius(radius)      every point with d2 < (double)(float)(radius^2)
+ *               2  KDTreeSearchParamHybrid(radius, knn) the knn nearest of those
+ * -- fewer than 3 neighbours: (0,0,1); normals_in (may be NULL) are the cloud's existing normals, whose
+ * sign is kept (EstimateNormals.cpp:133-146).  n x 3 f64 in, n x 3 f64 out.  knn / max_nn <= 170. */
+VISMA_ICP_API int visma_icp_estimate_normals(visma_icp_ctx *ctx, const double *xyz, int64_t n,
+                                             const double *normals_in, int search_type, int knn,
+                                             double radius, double *normals_out);
+
 /* Point -> triangle-mesh squared distance, face and closest point for np query
  * points: what igl::AABB::squared_distance returns inside feh::MeasureSurfaceError
  * (include/geometry.h:123-136).  face / closest may be NULL; exact ties go to the

@@ -393,6 +393,93 @@ inline std::shared_ptr<PointCloud> VoxelDownSample(const PointCloud &input, doub
     return output;
 }
 
+// open3d::EstimateNormals (O3D/Core/Geometry/EstimateNormals.cpp:114-153) on the GPU: the three
+// KDTreeFlann searches, FastEigen3x3, (0,0,1) for fewer than 3 neighbours, the sign of existing normals
+// kept.  What a caller runs before the point-to-plane estimator on clouds without normals
+// (Registration.cpp:152-157 returns the initial transform otherwise).
+inline bool EstimateNormals(PointCloud &cloud, const KDTreeSearchParam &search_param = KDTreeSearchParamKNN())
+{
+    const int64_t n = (int64_t)cloud.points_.size();
+    const bool has_normal = cloud.HasNormals();
+    int type = 0, knn = 0;
+    double radius = 0.0;
+    switch (search_param.GetSearchType()) {
+    case KDTreeSearchParam::SearchType::Knn:
+        knn = static_cast<const KDTreeSearchParamKNN &>(search_param).knn_;
+        break;
+    case KDTreeSearchParam::SearchType::Radius:
+        type = 1;
+        radius = static_cast<const KDTreeSearchParamRadius &>(search_param).radius_;
+        break;
+    case KDTreeSearchParam::SearchType::Hybrid:
+        type = 2;
+        radius = static_cast<const KDTreeSearchParamHybrid &>(search_param).radius_;
+        knn = static_cast<const KDTreeSearchParamHybrid &>(search_param).max_nn_;
+        break;
+    }
+    std::vector<Eigen::Vector3d> out((size_t)n);
+    if (n > 0) {
+        visma_icp_ctx *ctx = detail::ThreadContext::instance().get();
+        detail::check(ctx, visma_icp_estimate_normals(ctx, detail::xyz(cloud.points_), n,
+                                                      has_normal ? detail::xyz(cloud.normals_) : nullptr, type, knn,
+                                                      radius, out[0].data()),
+                      "visma_icp_estimate_normals");
+    }
+    cloud.normals_.swap(out);
+    return true;
+}
+
+// O3D/Core/Geometry/EstimateNormals.cpp:155-174
+inline bool OrientNormalsToAlignWithDirection(PointCloud &cloud,
+                                              const Eigen::Vector3d &orientation_reference = Eigen::Vector3d(0.0, 0.0, 1.0))
+{
+    for (auto &normal : cloud.normals_) {
+        if (normal.norm() == 0.0) normal = orientation_reference;
+        else if (normal.dot(orientation_reference) < 0.0) normal *= -1.0;
+    }
+    return true;
+}
+
+// O3D/Core/Geometry/EstimateNormals.cpp:176-204
+inline bool OrientNormalsTowardsCameraLocation(PointCloud &cloud,
+                                               const Eigen::Vector3d &camera_location = Eigen::Vector3d::Zero())
+{
+    const size_t n = cloud.HasNormals() ? cloud.points_.size() : 0;
+    for (size_t i = 0; i < n; i++) {
+        const Eigen::Vector3d towards = camera_location - cloud.points_[i];
+        Eigen::Vector3d &normal = cloud.normals_[i];
+        if (normal.norm() == 0.0) {
+            normal = towards;
+            if (normal.norm() == 0.0) normal = Eigen::Vector3d(0.0, 0.0, 1.0);
+            else normal.normalize();
+        } else if (normal.dot(towards) < 0.0) {
+            normal *= -1.0;
+        }
+    }
+    return true;
+}
+
+// open3d::ReadPointCloudFromPCD (O3D/IO/FileFormat/FilePCD.cpp:727-742): ascii, binary and
+// binary_compressed files; the reader's values bit for bit (include/visma_io.h).
+inline bool ReadPointCloudFromPCD(const std::string &filename, PointCloud &pointcloud)
+{
+    visma_io_cloud c;
+    if (visma_io_read_pcd(filename.c_str(), &c) != VISMA_IO_OK) {
+        std::fprintf(stderr, "Read PCD failed: %s\n", visma_io_last_error());
+        return false;
+    }
+    pointcloud.points_.resize((size_t)c.n);
+    pointcloud.normals_.resize((size_t)c.n_normals);
+    pointcloud.colors_.resize((size_t)c.n_colors);
+    for (int64_t i = 0; i < c.n; i++) pointcloud.points_[(size_t)i] = Eigen::Vector3d(c.xyz[3 * i], c.xyz[3 * i + 1], c.xyz[3 * i + 2]);
+    for (int64_t i = 0; i < c.n_normals; i++)
+        pointcloud.normals_[(size_t)i] = Eigen::Vector3d(c.normals[3 * i], c.normals[3 * i + 1], c.normals[3 * i + 2]);
+    for (int64_t i = 0; i < c.n_colors; i++)
+        pointcloud.colors_[(size_t)i] = Eigen::Vector3d(c.colors[3 * i], c.colors[3 * i + 1], c.colors[3 * i + 2]);
+    visma_io_free_cloud(&c);
+    return true;
+}
+
 // open3d::ReadPointCloudFromPLY (O3D/IO/FileFormat/FilePLY.cpp:206-264): the scene and scan
 // clouds of both callers (src/evaluation.cpp:124,211; src/annotation.cpp:76-157).  Same
 // points / normals / colours as the rply-based reader; false (and a message on stderr) on
@@ -497,6 +584,22 @@ inline RegistrationResult EvaluateRegistration(const PointCloud &source, const P
 inline bool ReadPointCloudFromPLY(const std::string &filename, PointCloud &pointcloud)
 {
     return cicp::ReadPointCloudFromPLY(filename, pointcloud);
+}
+inline bool ReadPointCloudFromPCD(const std::string &filename, PointCloud &pointcloud)
+{
+    return cicp::ReadPointCloudFromPCD(filename, pointcloud);
+}
+inline bool EstimateNormals(PointCloud &cloud, const KDTreeSearchParam &search_param)
+{
+    return cicp::EstimateNormals(cloud, search_param);
+}
+inline bool OrientNormalsToAlignWithDirection(PointCloud &cloud, const Eigen::Vector3d &orientation_reference)
+{
+    return cicp::OrientNormalsToAlignWithDirection(cloud, orientation_reference);
+}
+inline bool OrientNormalsTowardsCameraLocation(PointCloud &cloud, const Eigen::Vector3d &camera_location)
+{
+    return cicp::OrientNormalsTowardsCameraLocation(cloud, camera_location);
 }
 inline RegistrationResult RegistrationICP(const PointCloud &source, const PointCloud &target,
                                           double max_correspondence_distance,

@@ -901,6 +901,124 @@ void vo_error_metric(const double *errors, int64_t n, double out[5])
     free(s);
 }
 
+/* ---- open3d::EstimateNormals (O3D/Core/Geometry/EstimateNormals.cpp) ---- */
+
+static double vo_sqr(double x) { return x * x; }
+
+/* FastEigen3x3, EstimateNormals.cpp:40-83: eigenvector of the smallest eigenvalue of the symmetric A
+ * by the trigonometric closed form; returns 0 for a zero vector.  A row-major. */
+static int vo_fast_eigen_3x3(const double A[9], double out[3])
+{
+    const double p1 = vo_sqr(A[1]) + vo_sqr(A[2]) + vo_sqr(A[5]);            /* :44 */
+    const double trace = A[0] + A[4] + A[8];
+    double ev0, ev1, ev2;
+    if (p1 == 0.0) {                                                         /* :46-49 */
+        ev2 = fmin(A[0], fmin(A[4], A[8]));
+        ev0 = fmax(A[0], fmax(A[4], A[8]));
+        ev1 = trace - ev0 - ev2;
+    } else {
+        const double q = trace / 3.0;                                        /* :51 */
+        const double p2 = vo_sqr(A[0] - q) + vo_sqr(A[4] - q) + vo_sqr(A[8] - q) + 2 * p1;
+        const double p = sqrt(p2 / 6.0);
+        const double ip = 1.0 / p;
+        double B[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) B[i * 3 + j] = ip * (A[i * 3 + j] - (i == j ? q : 0.0));   /* :55 */
+        /* Eigen's fixed-size 3x3 determinant (Eigen/src/LU/Determinant.h: bruteforce_det3_helper) */
+        const double det = B[0] * (B[4] * B[8] - B[5] * B[7]) - B[1] * (B[3] * B[8] - B[5] * B[6]) +
+                           B[2] * (B[3] * B[7] - B[4] * B[6]);
+        const double r = det / 2.0;                                          /* :56 */
+        double phi;
+        if (r <= -1) phi = M_PI / 3.0;
+        else if (r >= 1) phi = 0.0;
+        else phi = acos(r) / 3.0;
+        ev0 = q + 2.0 * p * cos(phi);                                        /* :65-67 */
+        ev2 = q + 2.0 * p * cos(phi + 2.0 * M_PI / 3.0);
+        ev1 = q * 3.0 - ev0 - ev2;
+    }
+    (void)ev2;
+    /* (A - I ev0) * (A.col(0) - (ev1, 0, 0))   :70-72 */
+    const double v[3] = {A[0] - ev1, A[3], A[6]};
+    double e[3];
+    for (int i = 0; i < 3; i++) {
+        const double m0 = A[i * 3] - (i == 0 ? ev0 : 0.0), m1 = A[i * 3 + 1] - (i == 1 ? ev0 : 0.0),
+                     m2 = A[i * 3 + 2] - (i == 2 ? ev0 : 0.0);
+        e[i] = m0 * v[0] + m1 * v[1] + m2 * v[2];
+    }
+    const double len = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    if (len == 0.0) return 0;                                                /* :74-75 */
+    out[0] = e[0] / len; out[1] = e[1] / len; out[2] = e[2] / len;
+    return 1;
+}
+
+typedef struct { double d; int32_t i; } vo_nbr;
+static int cmp_nbr(const void *a, const void *b)
+{
+    const vo_nbr *x = (const vo_nbr *)a, *y = (const vo_nbr *)b;
+    if (x->d < y->d) return -1;
+    if (x->d > y->d) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+/* EstimateNormals.cpp:114-153 with the neighbour searches of KDTreeFlann.cpp:114-189 restated as an
+ * exhaustive scan: search_type 0 = the knn nearest (SearchKNN), 1 = every point with
+ * d2 < (double)(float)(r*r) (SearchRadius: flann radiusSearch is strict), 2 = the knn nearest of
+ * those (SearchHybrid); results ascending in (d2, index) -- flann orders exactly equal distances by
+ * tree traversal instead.  d2 is flann's L2 (dist.h:159-176).  normals_in may be NULL. */
+void vo_estimate_normals(const double *xyz, int64_t n, const double *normals_in, int search_type,
+                         int knn, double radius, double *out)
+{
+    const double r2 = (double)(float)(radius * radius);
+    #pragma omp parallel
+    {
+        vo_nbr *nb = (vo_nbr *)malloc(sizeof(vo_nbr) * (size_t)(n > 0 ? n : 1));
+        #pragma omp for schedule(static)
+        for (int64_t i = 0; i < n; i++) {
+            const double *q = xyz + 3 * i;
+            int64_t m = 0;
+            for (int64_t j = 0; j < n; j++) {
+                const double dx = q[0] - xyz[3 * j], dy = q[1] - xyz[3 * j + 1], dz = q[2] - xyz[3 * j + 2];
+                double d = dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                if (search_type != 0 && !(d < r2)) continue;
+                nb[m].d = d; nb[m].i = (int32_t)j; m++;
+            }
+            qsort(nb, (size_t)m, sizeof(vo_nbr), cmp_nbr);
+            if (search_type != 1 && m > knn) m = knn < 0 ? 0 : knn;
+            if (search_type != 1 && knn < 0) m = 0;
+            double nrm[3] = {0.0, 0.0, 1.0};                                 /* :147-149 */
+            if (m >= 3) {
+                double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int64_t k = 0; k < m; k++) {                            /* :95-105 */
+                    const double *p = xyz + 3 * (int64_t)nb[k].i;
+                    c[0] += p[0]; c[1] += p[1]; c[2] += p[2];
+                    c[3] += p[0] * p[0]; c[4] += p[0] * p[1]; c[5] += p[0] * p[2];
+                    c[6] += p[1] * p[1]; c[7] += p[1] * p[2]; c[8] += p[2] * p[2];
+                }
+                for (int k = 0; k < 9; k++) c[k] /= (double)m;               /* :106 */
+                double A[9];
+                A[0] = c[3] - c[0] * c[0];
+                A[4] = c[6] - c[1] * c[1];
+                A[8] = c[8] - c[2] * c[2];
+                A[1] = A[3] = c[4] - c[0] * c[1];
+                A[2] = A[6] = c[5] - c[0] * c[2];
+                A[5] = A[7] = c[7] - c[1] * c[2];
+                if (!vo_fast_eigen_3x3(A, nrm)) {                             /* :134-140 */
+                    if (normals_in) { nrm[0] = normals_in[3 * i]; nrm[1] = normals_in[3 * i + 1]; nrm[2] = normals_in[3 * i + 2]; }
+                    else { nrm[0] = 0.0; nrm[1] = 0.0; nrm[2] = 1.0; }
+                }
+                if (normals_in &&
+                    nrm[0] * normals_in[3 * i] + nrm[1] * normals_in[3 * i + 1] + nrm[2] * normals_in[3 * i + 2] < 0.0) {
+                    nrm[0] *= -1.0; nrm[1] *= -1.0; nrm[2] *= -1.0;           /* :141-143 */
+                }
+            }
+            out[3 * i] = nrm[0]; out[3 * i + 1] = nrm[1]; out[3 * i + 2] = nrm[2];
+        }
+        free(nb);
+    }
+}
+
 /* ---- core/rodrigues.h ------------------------------------------------ */
 void vo_hat(const double u[3], double M[9]) /* rodrigues.h:8-15 */
 {

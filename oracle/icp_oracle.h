@@ -166,6 +166,8 @@ void vo_point_mesh_sqdist(const double *P, int64_t np, const double *V, const in
 /* feh::ComputeErrorMetric (include/geometry.h:85-101): out = mean, std, median
  * (errors[n >> 1] of the sorted list), min, max. */
 void vo_error_metric(const double *errors, int64_t n, double out[5]);
+void vo_estimate_normals(const double *xyz, int64_t n, const double *normals_in, int search_type,
+                         int knn, double radius, double *out);
 
 /* 3x3 SVD helper (one-sided Jacobi), exposed for tests. A = U diag(s) V^T,
  * s descending, row-major. */

@@ -246,6 +246,10 @@ class Oracle:
         """Returns (points, normals, colors) sorted by voxel index (ix, iy, iz)."""
         return _voxel(self.lib.vo_voxel_down_sample, xyz, voxel_size, normals, colors)
 
+    def estimate_normals(self, xyz, knn=30, radius=None, normals=None):
+        """open3d::EstimateNormals, neighbours by exhaustive scan (O(n^2): small clouds)."""
+        return _normals(self.lib.vo_estimate_normals, xyz, knn, radius, normals)
+
     def sample_mesh(self, V, F, uniforms, quirks=True):
         V = _f64(V, (-1, 3)); F = np.ascontiguousarray(F, np.int32).reshape(-1, 3)
         u = _f64(uniforms, (-1, 3)); n = len(u)
@@ -323,6 +327,18 @@ class Oracle:
                          rel_rmse, with_scaling, grid, None)
 
 
+def _normals(fn, xyz, knn, radius, normals):
+    """radius None: KNN(knn); knn None: Radius(radius); both: Hybrid(radius, knn)."""
+    p = _f64(xyz, (-1, 3)); n = len(p)
+    nin = None if normals is None else _f64(normals, (-1, 3))
+    kind = 0 if radius is None else (1 if knn is None else 2)
+    out = np.empty((max(n, 1), 3))
+    fn.restype = None
+    fn(_ptr(p, _dp), C.c_int64(n), _ptr(nin, _dp), C.c_int(kind), C.c_int(int(knn or 0)),
+       C.c_double(float(radius or 0.0)), _ptr(out, _dp))
+    return out[:n].copy()
+
+
 def _voxel(fn, xyz, voxel_size, normals, colors):
     fn.restype = C.c_int64
     p = _f64(xyz, (-1, 3)); n = len(p)
@@ -387,6 +403,10 @@ class Ref:
     def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):
         """In the reference's own (hash-map) output order."""
         return _voxel(self.lib.ref_voxel_down_sample, xyz, voxel_size, normals, colors)
+
+    def estimate_normals(self, xyz, knn=30, radius=None, normals=None):
+        """open3d::EstimateNormals itself (KD-tree searches of KDTreeFlann)."""
+        return _normals(self.lib.ref_estimate_normals, xyz, knn, radius, normals)
 
     def point_mesh_sqdist(self, P, V, F):
         """igl::AABB::squared_distance, as feh::MeasureSurfaceError calls it."""

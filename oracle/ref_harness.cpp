@@ -12,6 +12,7 @@
 //   O3D/Core/Geometry/PointCloud.cpp:75-87,122-142
 //   O3D/Core/Utility/Eigen.cpp:58-68,88-106
 //   O3D/Core/Geometry/DownSample.cpp:179-220        VoxelDownSample
+//   O3D/Core/Geometry/EstimateNormals.cpp:114-153   EstimateNormals
 //
 // NOTE on VISMA's own src/constrained_ICP.cpp: it includes "Core/Core.h",
 // which includes the CMake-GENERATED "../Open3DConfig.h"; that header does
@@ -20,6 +21,7 @@
 // :13-23, :25-37) are textually the same statements as Open3D's
 // TransformationEstimationPointToPoint (TransformationEstimation.cpp:35-59),
 // which IS compiled below and is what `estimator == 1` runs.
+#include <Core/Geometry/KDTreeSearchParam.h>
 #include <Core/Geometry/PointCloud.h>
 #include <Core/Registration/Registration.h>
 #include <Core/Registration/TransformationEstimation.h>
@@ -221,6 +223,20 @@ void ref_vector6d_to_matrix4d(const double x[6], double T_out[16])
     Eigen::Vector6d v;
     for (int i = 0; i < 6; i++) v(i) = x[i];
     to_rowmajor(open3d::TransformVector6dToMatrix4d(v), T_out);
+}
+
+// open3d::EstimateNormals; search_type 0 KNN(knn) | 1 Radius(radius) | 2 Hybrid(radius, knn);
+// normals_in may be NULL (the cloud has no normals)
+void ref_estimate_normals(const double *xyz, int64_t n, const double *normals_in, int search_type,
+                          int knn, double radius, double *out)
+{
+    PointCloud pc;
+    fill_cloud(pc, xyz, n, normals_in);
+    if (search_type == 0) open3d::EstimateNormals(pc, open3d::KDTreeSearchParamKNN(knn));
+    else if (search_type == 1) open3d::EstimateNormals(pc, open3d::KDTreeSearchParamRadius(radius));
+    else open3d::EstimateNormals(pc, open3d::KDTreeSearchParamHybrid(radius, knn));
+    for (int64_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) out[3 * i + a] = pc.normals_[i](a);
 }
 
 }  // extern "C"

@@ -108,6 +108,19 @@ int main(int argc, char **argv)
         } else if (mode == "refine") {      // src/evaluation.cpp:258-271: down-sample the scene, then ICP
             result = cicp::ICPRefinement(*scene, *model, init, /*voxel*/ 0.05, radius, false);
             extra = (double)open3d::VoxelDownSample(*scene, 0.05)->points_.size();
+        } else if (mode == "normals_plane") {
+            // clouds without normals: estimate them (hybrid search: radius = 2 x the ICP radius, 30 neighbours),
+            // orient them, then the point-to-plane estimator -- what a caller does before
+            // src/evaluation.cpp:261-265 when its PLY carries no normals
+            if (!open3d::EstimateNormals(*scene, open3d::KDTreeSearchParamHybrid(2.0 * radius, 30))) return 4;
+            if (!open3d::EstimateNormals(*model, open3d::KDTreeSearchParamKNN(level))) return 4;
+            open3d::OrientNormalsToAlignWithDirection(*scene);
+            open3d::OrientNormalsTowardsCameraLocation(*model, Eigen::Vector3d(0.0, 0.0, 10.0));
+            if (!scene->HasNormals() || !model->HasNormals()) return 5;
+            extra = scene->normals_[scene->normals_.size() / 2](2);
+            result = open3d::RegistrationICP(*model, *scene, radius, init,
+                                             open3d::TransformationEstimationPointToPlane(),
+                                             open3d::ICPConvergenceCriteria(0.0, 0.0, iters));
         } else if (mode == "evaluate") {
             result = open3d::EvaluateRegistration(*model, *scene, radius, init);
         } else if (mode == "mesh") {        // src/evaluation.cpp:320 MeasureSurfaceError / :252 sampling
@@ -144,6 +157,16 @@ int main(int argc, char **argv)
             Eigen::Matrix<int, Eigen::Dynamic, 3> F;
             if (!feh::gpu::LoadMesh(objf, V, F)) return 5;
             if (open3d::ReadPointCloudFromPLY("/nonexistent.ply", pc)) return 6;    // false, message on stderr
+            double pcd_n = 0.0, pcd_nn = 0.0, pcd_x = 0.0;
+            if (const char *pcd = std::getenv("SHIM_PCD")) {                        // FilePCD.cpp:727-742
+                PointCloud pd;
+                if (!open3d::ReadPointCloudFromPCD(pcd, pd)) return 7;
+                if (open3d::ReadPointCloudFromPCD("/nonexistent.pcd", pd)) return 8;
+                open3d::ReadPointCloudFromPCD(pcd, pd);
+                pcd_n = (double)pd.points_.size();
+                pcd_nn = (double)pd.normals_.size();
+                pcd_x = pd.points_.empty() ? 0.0 : pd.points_.back()(0);
+            }
             open3d::ReadPointCloudFromPLY(ply, pc);
             result.transformation_.setZero();
             result.transformation_(0, 0) = (double)pc.points_.size();
@@ -155,6 +178,8 @@ int main(int argc, char **argv)
             result.transformation_(1, 2) = V.rows() ? V(V.rows() - 1, 1) : 0.0;
             result.transformation_(1, 3) = F.rows() ? (double)F(F.rows() - 1, 2) : 0.0;
             result.transformation_(2, 0) = pc.colors_.empty() ? 0.0 : pc.colors_[0](1);
+            result.transformation_(2, 1) = pcd_n; result.transformation_(2, 2) = pcd_nn;
+            result.transformation_(2, 3) = pcd_x;
         } else if (mode == "estimator") {   // host-only: explicit correspondences, no GPU needed
             CorrespondenceSet cs;
             for (int64_t i = 0; i < ns; i++) cs.push_back(Eigen::Vector2i((int)i, (int)((i * 7919) % nt)));

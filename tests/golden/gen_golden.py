@@ -338,6 +338,38 @@ def gen_pcd(ref):
     print("pcd fixture:", {k: (v.tolist(), out.get(k[:-3] + "_xyz", np.zeros((0, 3))).shape) for k, v in out.items() if k.endswith("_ok")})
 
 
+def gen_normals(ref):
+    """open3d::EstimateNormals (O3D/Core/Geometry/EstimateNormals.cpp:114-153): outputs of the compiled
+    reference for the three searches, on chair CAD samples and on a real scan fragment, with and
+    without existing normals.  -> normals.npz"""
+    V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
+    chair = f32(sample_mesh(V, F, 4000, 21)).astype(np.float64)
+    frag, frag_n = load_pcd_xyz_normals(O3D_DATA + "/Feature/cloud_bin_0.pcd")
+    frag = f32(frag[::2][:5000]).astype(np.float64)
+    frag_n = f32(frag_n[::2][:5000]).astype(np.float64)
+    dup = np.concatenate([chair[:300], chair[:300], chair[300:600]])      # exact duplicates: zero distances
+    line = np.stack([np.linspace(0, 1, 40), np.zeros(40), np.zeros(40)], 1)   # rank-1 neighbourhoods: zero vector
+    out = {"chair": f32(chair), "frag": f32(frag), "frag_normals": f32(frag_n), "dup": f32(dup), "line": f32(line)}
+    cases = {
+        "chair_knn30": (chair, dict(knn=30)),
+        "chair_knn5": (chair, dict(knn=5)),
+        "chair_radius": (chair, dict(knn=None, radius=0.05)),
+        "chair_hybrid": (chair, dict(knn=30, radius=0.05)),
+        "chair_hybrid_small": (chair, dict(knn=10, radius=0.01)),          # many points with < 3 neighbours
+        "frag_knn30": (frag, dict(knn=30)),
+        "frag_hybrid_keep_sign": (frag, dict(knn=30, radius=0.1, normals=frag_n)),
+        "frag_knn_keep_sign": (frag, dict(knn=20, normals=-frag_n)),
+        "dup_knn10": (dup, dict(knn=10)),
+        "line_knn8": (line, dict(knn=8)),
+        "line_knn8_keep": (line, dict(knn=8, normals=np.tile([0.0, 1.0, 0.0], (40, 1)))),
+        "chair_knn2": (chair[:50], dict(knn=2)),                           # fewer than 3 neighbours everywhere
+    }
+    for name, (pts, kw) in cases.items():
+        out[name] = ref.estimate_normals(pts, **kw)
+        print("normals %-24s n=%d  (0,0,1): %d" % (name, len(pts), int((out[name] == [0, 0, 1]).all(1).sum())))
+    np.savez_compressed(os.path.join(HERE, "normals.npz"), **out)
+
+
 def main():
     os.environ.setdefault("OMP_NUM_THREADS", "8")
     ref = Ref()
@@ -349,6 +381,8 @@ def main():
         return gen_io(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "pcd":
         return gen_pcd(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "normals":
+        return gen_normals(ref)
     V, F = load_obj(REF + "/misc/hermanmiller_aeron.obj")
 
     # ---- C1/C2: chair CAD 5k samples -> 20k partial noisy scan ------------
@@ -547,6 +581,7 @@ def main():
     gen_mesh(ref)
     gen_io(ref)
     gen_pcd(ref)
+    gen_normals(ref)
     print("golden fixtures written to", HERE)
 
 

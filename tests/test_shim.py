@@ -75,7 +75,8 @@ def test_shim_file_readers_host_only(bins, tmp_path):
     from visma_amd import _lib
     ply = os.path.join(G, "io", "gen_le.ply"); objf = os.path.join(G, "io", "tri.obj")
     c = _lib.read_ply(ply); V, F = _lib.read_obj(objf)
-    os.environ["SHIM_PLY"], os.environ["SHIM_OBJ"] = ply, objf
+    pcd = os.path.join(G, "io", "ref_compressed.pcd"); d = _lib.read_pcd(pcd)
+    os.environ["SHIM_PLY"], os.environ["SHIM_OBJ"], os.environ["SHIM_PCD"] = ply, objf, pcd
     try:
         for b in bins:
             rc, err, r = run(b, "io", tmp_path, np.zeros((1, 3)), np.zeros((1, 3)), 0.1)
@@ -84,9 +85,10 @@ def test_shim_file_readers_host_only(bins, tmp_path):
             assert (t[0, 0], t[0, 1], t[0, 2]) == (len(c["xyz"]), len(c["normals"]), len(c["colors"]))
             assert t[0, 3] == c["xyz"][-1, 2] and t[2, 0] == c["colors"][0, 1]
             assert (t[1, 0], t[1, 1]) == (len(V), len(F)) and t[1, 2] == V[-1, 1] and t[1, 3] == F[-1, 2]
-            assert "Read PLY failed" in err
+            assert "Read PLY failed" in err and "Read PCD failed" in err
+            assert (t[2, 1], t[2, 2]) == (len(d["xyz"]), len(d["normals"])) and t[2, 3] == d["xyz"][-1, 0]
     finally:
-        del os.environ["SHIM_PLY"], os.environ["SHIM_OBJ"]
+        del os.environ["SHIM_PLY"], os.environ["SHIM_OBJ"], os.environ["SHIM_PCD"]
 
 
 def test_shim_without_gpu_fails_loudly(bins, tmp_path):
@@ -143,6 +145,29 @@ def test_shim_point_to_plane_sweep_evaluate(bins, tmp_path):
                      g["tgt"].astype(np.float64), 0.05, init=g["evaluate_T"])
     assert rc == 0, err
     assert r["k"] == g["evaluate_frk"][2] and abs(r["rmse"] - g["evaluate_frk"][1]) < 1e-6
+
+
+@pytest.mark.gpu
+def test_shim_estimate_normals_then_point_to_plane(bins, tmp_path):
+    """open3d::EstimateNormals + Orient* + the point-to-plane estimator on clouds WITHOUT normals."""
+    from oracle.oracle import Oracle, EST_POINT_TO_PLANE
+    o = Oracle()
+    f = np.load(os.path.join(G, "fragments.npz"))
+    model, scene = f["src"].astype(np.float64)[::2], f["tgt"].astype(np.float64)[::2]
+    r_icp = float(f["radius"])
+    sn = o.estimate_normals(scene, knn=30, radius=2.0 * r_icp)
+    sn[(sn @ [0.0, 0.0, 1.0]) < 0] *= -1.0                               # OrientNormalsToAlignWithDirection
+    mn = o.estimate_normals(model, knn=20)
+    flip = ((np.array([0.0, 0.0, 10.0]) - model) * mn).sum(1) < 0          # OrientNormalsTowardsCameraLocation
+    mn[flip] *= -1.0
+    want = o.registration_icp(model, scene, r_icp, init=f["init"], max_iter=8, rel_fitness=0, rel_rmse=0,
+                              estimator=EST_POINT_TO_PLANE, tgt_normals=sn)
+    for b in bins:
+        rc, err, r = run(b, "normals_plane", tmp_path, model, scene, r_icp, iters=8, level=20, init=f["init"])
+        assert rc == 0, err
+        assert r["k"] == want.k
+        assert synth.rel_frobenius(r["T"], want.T) < 1e-7
+        assert abs(r["extra"] - sn[len(sn) // 2, 2]) < 1e-9
 
 
 @pytest.mark.gpu

@@ -106,6 +106,7 @@ def load():
     L.visma_icp_run_yaw_sweep.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double,
                                           C.c_double, C.c_int, C.POINTER(CResult),
                                           C.POINTER(C.c_int), C.POINTER(CResult)]
+    L.visma_icp_estimate_normals.argtypes = [C.c_void_p, _dp, C.c_int64, _dp, C.c_int, C.c_int, C.c_double, _dp]
     L.visma_icp_run_batch_point_to_plane.argtypes = [C.c_void_p, C.POINTER(CProblem), C.POINTER(_dp), C.c_int, C.c_int,
                                                      C.c_double, C.c_double, C.POINTER(CResult)]
     L.visma_icp_run_batch.argtypes = [C.c_void_p, C.POINTER(CProblem), C.c_int, C.c_int,
@@ -344,6 +345,16 @@ class Context:
         self._chk(self.L.visma_icp_run_batch_point_to_plane(self._h, arr, nrm, n, int(max_iter), float(rel_fitness),
                                                             float(rel_rmse), out))
         return [Result(out[i]) for i in range(n)]
+
+    def estimate_normals(self, xyz, knn=30, radius=None, normals=None):
+        """open3d::EstimateNormals on the GPU.  radius None: KNN(knn); knn None: Radius(radius); both: Hybrid."""
+        p = _f64(xyz, (-1, 3)); n = len(p)
+        nin = None if normals is None else _f64(normals, (-1, 3))
+        kind = 0 if radius is None else (1 if knn is None else 2)
+        out = np.empty((max(n, 1), 3))
+        self._chk(self.L.visma_icp_estimate_normals(self._h, _p(p, _dp), n, None if nin is None else _p(nin, _dp),
+                                                    kind, int(knn or 0), float(radius or 0.0), _p(out, _dp)))
+        return out[:n].copy()
 
     def voxel_down_sample(self, xyz, voxel_size, normals=None, colors=None):
         """open3d::VoxelDownSample on the GPU -> (points, normals, colors), voxels in ascending index order."""

@@ -225,6 +225,12 @@ hipError_t surface_distances_device(const double *h_Vs, int64_t nvs, const int32
                                     int quirks, unsigned long long seed, int method, double *h_dist,
                                     int64_t *n_out, float *kernel_ms, float *build_ms, hipStream_t stream);
 
+// ---- normal estimation (normals.hip): host arrays in, host arrays out ----------
+// open3d::EstimateNormals; search_type 0 KNN(knn) | 1 Radius(radius) | 2 Hybrid(radius, max_nn = knn)
+constexpr int kNormalsMaxList = 170;     // knn / max_nn above it: hipErrorInvalidValue (the list is in LDS)
+hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double *h_nrm_in, int search_type,
+                                   int knn, double radius, double *h_out, hipStream_t stream);
+
 // ---- voxel down-sampling (voxel.hip): host arrays in, host arrays out ---------
 hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, const double *h_col,
                                     int64_t n, double voxel, double *h_out_xyz, double *h_out_nrm,
