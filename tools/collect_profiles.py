@@ -14,7 +14,8 @@ dst = os.path.join(ROOT, "profiles")
 pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.json"), ("bench_c5.json", "%s_bench_c5.json"),
          ("bench_c4_under_rocprof.json", "%s_bench_c4_under_rocprof.json"),
          ("stats_c4/c4_kernel_stats.csv", "%s_bench_c4_kernel_stats.csv"), ("stats_c3/c3_kernel_stats.csv", "%s_bench_c3_kernel_stats.csv"),
-         ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv")]
+         ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv"),
+         ("pmc_kernel_summary.csv", "%s_c4_exact_gather_kernel_pmc_summary.csv")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p):

@@ -9,6 +9,6 @@ groups=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_I
 i=0
 for g in "${groups[@]}"; do
   i=$((i+1))
-  ( cd /tmp && env "$@" rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$out" -o "g$i" -- python /root/repo/tools/run_c4_iterations.py > "$out/g$i.log" 2>&1 ) || echo "group '$g' failed"
+  ( cd /tmp && env "$@" timeout 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d "$out" -o "g$i" -- python /root/repo/tools/run_c4_iterations.py > "$out/g$i.log" 2>&1 ) || echo "group '$g' failed"
 done
 python /root/repo/tools/pmc_summarize.py "$out" nn_ | cut -c1-60,150-400

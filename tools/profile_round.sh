@@ -6,14 +6,17 @@ tag=${1:-r02}
 out=/root/repo/gpurun_out/prof_$tag
 mkdir -p $out; export TMPDIR=/tmp
 cd /root/repo
-python bench.py --steps 20 --warmup 5 > $out/bench_c4.json 2> $out/bench_c4.err
-python bench.py --workload c3 --steps 5 --warmup 1 > $out/bench_c3.json 2> $out/bench_c3.err
-python bench.py --workload c5 --steps 2 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c4 -o c4 -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_c4_under_rocprof.json 2> $out/rocprof_c4.err )
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3 -o c3 -- python /root/repo/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_c3_under_rocprof.json 2> $out/rocprof_c3.err )
+timeout 900 python bench.py --steps 20 --warmup 5 > $out/bench_c4.json 2> $out/bench_c4.err
+timeout 600 python bench.py --workload c3 --steps 5 --warmup 1 > $out/bench_c3.json 2> $out/bench_c3.err
+timeout 600 python bench.py --workload c5 --steps 2 --warmup 1 > $out/bench_c5.json 2> $out/bench_c5.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c4 -o c4 -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_c4_under_rocprof.json 2> $out/rocprof_c4.err )
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_c3 -o c3 -- python /root/repo/bench.py --workload c3 --steps 3 --warmup 1 --no-cpu-baseline > $out/bench_c3_under_rocprof.json 2> $out/rocprof_c3.err )
 for g in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   t=$(echo "$g" | tr ' ' '_' | cut -c1-16)
-  ( cd /tmp && rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out/pmc -o $t -- python /root/repo/tools/run_c4_iterations.py > $out/pmc_$t.log 2>&1 )
+  ( cd /tmp && timeout 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out/pmc -o $t -- python /root/repo/tools/run_c4_iterations.py > $out/pmc_$t.log 2>&1 )
 done
 python tools/pmc_summarize.py $out/pmc nn_ > $out/pmc_traffic_summary.csv
+# instruction mix / L1 / wait counters of the default kernel (every pass under its own timeout)
+tools/pmc_quick.sh $out/pmc_kernel > $out/pmc_kernel_summary.txt 2>&1
+python tools/pmc_summarize.py $out/pmc_kernel nn_ > $out/pmc_kernel_summary.csv
 ls $out
