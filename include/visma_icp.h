@@ -325,7 +325,10 @@ VISMA_ICP_API int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks,
  * each iteration's 38 statistics are exchanged by ONE small launch: remote 16-byte stores
  * {value, sequence tag} into the peers' mailboxes over xGMI, every rank sums in rank order
  * (identical transforms on all ranks, bit for bit), the result goes straight to the host.
- * nranks <= 16; ranks may share a device (tests). */
+ * nranks <= 16; ranks may share a device (tests).  comm_ipc_init is COLLECTIVE: it ends with a
+ * handshake (one all-reduce of known values, every rank must enter within tens of seconds) and
+ * fails with VISMA_ICP_ERR_HIP when a peer's stores do not arrive -- fall back to
+ * visma_icp_comm_init on every rank then. */
 #define VISMA_ICP_IPC_HANDLE_BYTES 64
 VISMA_ICP_API int visma_icp_comm_ipc_export(visma_icp_ctx *ctx, void *out_handle /* 64 bytes */);
 VISMA_ICP_API int visma_icp_comm_ipc_init(visma_icp_ctx *ctx, int rank, int nranks,

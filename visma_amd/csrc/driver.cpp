@@ -745,7 +745,13 @@ public:
             }
             done += n;
             HIP_TRY(hipMemcpyAsync(h_state_, d_state_, sizeof(DevIcpState) * nprob, hipMemcpyDeviceToHost, stream_));
+            int ipc_flag = 0;
+            if (ipc_n_ > 1) HIP_TRY(hipMemcpyAsync(&ipc_flag, d_ipc_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_));
             HIP_TRY(hipStreamSynchronize(stream_));
+            if (ipc_flag) {
+                err_ = "all-reduce: rank " + std::to_string(ipc_flag - 1) + " never delivered its statistics";
+                return VISMA_ICP_ERR_HIP;
+            }
             rc = maybe_collect_timing();
             if (rc) return rc;
             bool any = false;
@@ -1173,6 +1179,39 @@ public:
         ipc_rank_ = rank;
         ipc_n_ = nranks;
         ipc_seq_ = 0;
+        // Handshake (the call is collective): one all-reduce of known values proves that every peer's
+        // stores arrive in this rank's mailbox and the other way round -- a mapping that opens but does
+        // not carry traffic (no peer access between two devices) must fail HERE, not in the first iteration.
+        if (nranks > 1) {
+            double *d_hs = nullptr;
+            HIP_TRY(hipMalloc((void **)&d_hs, sizeof(double) * kNStats));
+            std::vector<double> hs((size_t)kNStats);
+            for (int a = 0; a < kNStats; a++) hs[(size_t)a] = (double)((rank + 1) * (a + 1));
+            hipError_t e = hipMemcpyAsync(d_hs, hs.data(), sizeof(double) * kNStats, hipMemcpyHostToDevice, stream_);
+            if (e == hipSuccess) e = hipMemsetAsync(d_ipc_flag_, 0, sizeof(int), stream_);
+            if (e == hipSuccess)
+                e = launch_ipc_allreduce(d_hs, d_hs, peers_, ipc_rank_, ipc_n_, ++ipc_seq_, nullptr, 0, (int *)d_ipc_flag_,
+                                         stream_, kIpcHandshakeSpins);
+            int flag = 0;
+            if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d_hs, sizeof(double) * kNStats, hipMemcpyDeviceToHost, stream_);
+            if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_ipc_flag_, sizeof(int), hipMemcpyDeviceToHost, stream_);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+            (void)hipFree(d_hs);
+            bool good = e == hipSuccess && flag == 0;
+            const double tri = 0.5 * (double)nranks * (double)(nranks + 1);
+            for (int a = 0; good && a < kNStats; a++) good = hs[(size_t)a] == tri * (double)(a + 1);
+            if (!good) {
+                (void)hipGetLastError();
+                (void)hipMemset(d_ipc_flag_, 0, sizeof(int));
+                for (int q = 0; q < nranks; q++)
+                    if (q != rank && peers_.box[q]) { (void)hipIpcCloseMemHandle(peers_.box[q]); peers_.box[q] = nullptr; }
+                ipc_n_ = 0;
+                err_ = e != hipSuccess ? std::string("peer-to-peer handshake: ") + hipGetErrorString(e)
+                     : flag ? "peer-to-peer handshake: rank " + std::to_string(flag - 1) + " did not answer"
+                            : std::string("peer-to-peer handshake: wrong sum");
+                return VISMA_ICP_ERR_HIP;
+            }
+        }
         return VISMA_ICP_OK;
     }
 

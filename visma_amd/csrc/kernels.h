@@ -100,10 +100,12 @@ int reduce_max_blocks();
 constexpr int kSortedSlack = 64;   // entries allocated past the end of a cell-sorted target: the exact grid
                                    // search loads whole batches (<= U*G slots) from a run's first slot
 constexpr int kIpcMaxRanks = 16;
+constexpr long long kIpcSpinLimit = 200000000ll;    // polls of the own mailbox before a peer counts as lost (minutes)
+constexpr long long kIpcHandshakeSpins = 15000000ll;  // ... in the handshake of visma_icp_comm_ipc_init (tens of seconds)
 struct IpcPeers { void *box[kIpcMaxRanks]; };     // box[r]: rank r's mailbox as mapped HERE (box[rank] = own)
 hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
                                 int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
-                                int *timeout_flag, hipStream_t stream);
+                                int *timeout_flag, hipStream_t stream, long long max_spins = kIpcSpinLimit);
 // target-sharded ranks: keys of the local winners / moments of the global winners owned here
 hipError_t launch_shard_keys(const int32_t *idx, const float *d2, int64_t ns, unsigned offset,
                              unsigned long long *keys, hipStream_t stream);

@@ -635,9 +635,11 @@ __device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
 __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_in, double *stats_out,
                                                            IpcPeers peers, int rank, int nranks,
                                                            unsigned long long seq, double *host_out,
-                                                           unsigned long long host_seq, int *timeout_flag)
+                                                           unsigned long long host_seq, int *timeout_flag,
+                                                           long long max_spins)
 {
     const int a = threadIdx.x;
+    bool late = false;
     if (a < kNStats) {
         const unsigned long long v = (unsigned long long)__double_as_longlong(stats_in[a]);
         u4_t g;
@@ -655,22 +657,24 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_i
                 w = load_granule_sys(mine + r * kNStats + a);
                 const unsigned long long tag = ((unsigned long long)w.w << 32) | w.z;
                 if (tag == seq) break;
-                if (++spins > 200000000ll) { *timeout_flag = 1 + r; break; }   // a peer never arrived
+                if (++spins > max_spins) { *timeout_flag = 1 + r; late = true; break; }   // a peer never arrived
                 __builtin_amdgcn_s_sleep(2);
             }
             sum += __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
         }
-        stats_out[a] = sum;
+        // (a sum with a missing term is never handed on: NaN stops the device loop's solve)
+        stats_out[a] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
     }
-    if (host_out) publish_tagged_stats(stats_out, host_out, host_seq);
+    // nothing is published after a timeout: the host sees no tags, then reads the flag
+    if (host_out && !__any(late)) publish_tagged_stats(stats_out, host_out, host_seq);
 }
 
 hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
                                 int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
-                                int *timeout_flag, hipStream_t stream)
+                                int *timeout_flag, hipStream_t stream, long long max_spins)
 {
     hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(1), dim3(64), 0, stream, stats_in, stats_out, peers, rank, nranks,
-                       seq, host_out, host_seq, timeout_flag);
+                       seq, host_out, host_seq, timeout_flag, max_spins);
     return hipGetLastError();
 }
 
