@@ -322,7 +322,8 @@ VISMA_ICP_API int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks,
  * 304-byte ncclAllReduce).  Every rank exports the handle of its mailbox (uncached device
  * memory), the host program all-gathers the handles (any transport), every rank calls
  * comm_ipc_init with ALL of them (nranks x VISMA_ICP_IPC_HANDLE_BYTES, rank order).  From then on
- * each iteration's 38 statistics are exchanged by ONE small launch: remote 16-byte stores
+ * each iteration's 38 statistics are exchanged inside the search launch (by the workgroup that
+ * finishes the fold; one small extra launch on the brute-force path): remote 16-byte stores
  * {value, sequence tag} into the peers' mailboxes over xGMI, every rank sums in rank order
  * (identical transforms on all ranks, bit for bit), the result goes straight to the host.
  * nranks <= 16; ranks may share a device (tests).  comm_ipc_init is COLLECTIVE: it ends with a

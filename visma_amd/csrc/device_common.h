@@ -338,6 +338,51 @@ __device__ __forceinline__ void publish_tagged_stats(const double *stats, double
     }
 }
 
+// One rank's part of the one-shot all-reduce over xGMI (see ipc_allreduce_kernel in kernels.hip): lane a
+// of ONE wave stores statistic a as a 16-byte granule {value, call count} into slot [rank][a] of every
+// peer's mailbox, then waits for the nranks granules of statistic a in its OWN mailbox and sums them in
+// rank order.  The mailbox has two halves used alternately (call count parity): a rank can only start
+// call k+2 after every peer has SENT call k+1, which a peer does only after it has finished reading call
+// k, so a granule is never overwritten before its reader has seen it.
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
+{
+    u4_t v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+__device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeers &peers, int rank, int nranks,
+                                               unsigned long long seq, int *timeout_flag, long long max_spins,
+                                               bool &late)
+{
+    double sum = 0.0;
+    if (a < kNStats) {
+        const unsigned long long v = (unsigned long long)__double_as_longlong(mine);
+        u4_t g;
+        g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
+        g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
+        const size_t half = (size_t)(seq & 1ull) * kIpcMaxRanks * kNStats;
+        for (int p = 0; p < nranks; p++)
+            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + half + rank * kNStats + a);
+        const u4_t *own = reinterpret_cast<const u4_t *>(peers.box[rank]) + half;
+        for (int r = 0; r < nranks; r++) {
+            u4_t w;
+            long long spins = 0;
+            for (;;) {
+                w = load_granule_sys(own + r * kNStats + a);
+                const unsigned long long tag = ((unsigned long long)w.w << 32) | w.z;
+                if (tag == seq) break;
+                if (++spins > max_spins) { *timeout_flag = 1 + r; late = true; break; }   // a peer never arrived
+                __builtin_amdgcn_s_sleep(2);
+            }
+            sum += __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
+        }
+    }
+    return sum;
+}
+
 // Fused fold.  Every workgroup of a problem has written its partial row (kReduceAcc doubles,
 // agent-scope stores) at partials[(row0 + lb) * kReduceAcc]; this folds them to the 38
 // statistics INSIDE the launch: the last workgroup to arrive in each group of kFoldGroup rows
@@ -419,6 +464,21 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
     __syncthreads();
     double *stats = f.stats_out + (long long)prob * f.stats_stride;
     if (tid == 0) expand_moments<PLANE>(f_tot, stats);
+    if (f.ipc_n > 1) {
+        // source-sharded ranks: this workgroup's first wave exchanges the statistics with the peers
+        // (remote stores over xGMI, rank-ordered sum) before anything is published
+        if (tid == 0) f_flag[0] = 0;
+        __syncthreads();                                   // stats[] was written by thread 0
+        if (tid < 64) {
+            bool late = false;
+            const double sum = ipc_exchange(tid, tid < kNStats ? stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n,
+                                            f.ipc_seq, f.ipc_flag, f.ipc_spins, late);
+            if (tid < kNStats) stats[tid] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
+            if (late) f_flag[0] = 1;
+        }
+        __syncthreads();
+        if (f_flag[0]) return;                             // a peer was lost: nothing is published
+    }
     if (f.host_out) publish_tagged_stats(stats, f.host_out, f.seq);
 }
 

@@ -443,6 +443,7 @@ public:
         // without RCCL the fold kernel publishes to mapped host memory itself
         const unsigned long long seq = ++pub_seq_;
         const bool ipc = ipc_n_ > 1;
+        bool ipc_done = false;                           // the exchange ran inside the search launch
         double *pub = (comm_ || ipc) ? nullptr : h_stats_dev_;
         if (use_tile()) {
             // ONE launch: streamed search + exact re-rank + moments + fused fold + publication
@@ -475,8 +476,11 @@ public:
             const bool fused = fused_fold_ && !tshard_;
             FoldArgs fa{};
             if (fused) {
-                int rc = make_fold(grid_launch_blocks(ns_, grid_lanes(), grid_blocks()), 1, (double *)d_stats_, 0, pub, seq, &fa);
+                // (peer-to-peer mailboxes: the folding workgroup exchanges with the peers and publishes itself)
+                int rc = make_fold(grid_launch_blocks(ns_, grid_lanes(), grid_blocks()), 1, (double *)d_stats_, 0,
+                                   ipc ? h_stats_dev_ : pub, seq, &fa);
                 if (rc) return rc;
+                if (ipc) { add_ipc(&fa); ipc_done = true; }
             }
             if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
             HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
@@ -513,7 +517,7 @@ public:
             int rc = shard_exchange(T64, plane, offset, pub, seq);
             if (rc) return rc;
         }
-        if (ipc) {
+        if (ipc && !ipc_done) {
             // ONE exchange of the 38 f64 accumulators per ICP iteration: remote stores into the peers'
             // mailboxes over xGMI, rank-ordered sum, publication to the host -- one tiny launch
             HIP_TRY(launch_ipc_allreduce((const double *)d_stats_, (double *)d_stats_, peers_, ipc_rank_, ipc_n_,
@@ -698,6 +702,7 @@ public:
                         rc = make_fold(grid_launch_blocks(ns_, grid_lanes(nprob), reduce_max_blocks()), nprob,
                                        st->stats, (long long)(sizeof(DevIcpState) / sizeof(double)), nullptr, 0, &fa);
                         if (rc) return rc;
+                        if (ipc_n_ > 1) add_ipc(&fa);      // (one problem per rank: ipc needs nprob == 1)
                     }
                     HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
                                                   (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
@@ -724,8 +729,9 @@ public:
                 }
                 if (ipc_n_ > 1) {
                     if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
-                    HIP_TRY(launch_ipc_allreduce(st->stats, st->stats, peers_, ipc_rank_, ipc_n_, ++ipc_seq_, nullptr, 0,
-                                                 (int *)d_ipc_flag_, stream_));
+                    if (!(fused && use_grid_))               // (fused: the folding workgroup exchanged already)
+                        HIP_TRY(launch_ipc_allreduce(st->stats, st->stats, peers_, ipc_rank_, ipc_n_, ++ipc_seq_, nullptr, 0,
+                                                     (int *)d_ipc_flag_, stream_));
                     HIP_TRY(launch_solve_state(st, 1, stream_));
                 } else if (comm_) {
                     if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
@@ -1575,6 +1581,15 @@ private:
         return nb < 1 ? 1 : nb;
     }
     // fold arguments for `nprob` problems of `bpp` workgroups each (buffers grown as needed)
+    void add_ipc(FoldArgs *fa)
+    {
+        fa->peers = peers_;
+        fa->ipc_rank = ipc_rank_;
+        fa->ipc_n = ipc_n_;
+        fa->ipc_seq = ++ipc_seq_;
+        fa->ipc_flag = (int *)d_ipc_flag_;
+        fa->ipc_spins = kIpcSpinLimit;
+    }
     int make_fold(int bpp, int nprob, double *stats_out, long long stats_stride, double *host_out,
                   unsigned long long seq, FoldArgs *out)
     {

@@ -44,6 +44,11 @@ struct DevIcpState {
 };
 
 // The fold of the partial rows inside the search launch (device_common.h: fused_fold).
+constexpr int kIpcMaxRanks = 16;
+constexpr long long kIpcSpinLimit = 200000000ll;    // polls of the own mailbox before a peer counts as lost (minutes)
+constexpr long long kIpcHandshakeSpins = 15000000ll;  // ... in the handshake of visma_icp_comm_ipc_init (tens of seconds)
+struct IpcPeers { void *box[kIpcMaxRanks]; };     // box[r]: rank r's mailbox as mapped HERE (box[rank] = own)
+
 struct FoldArgs {
     unsigned *tickets;            // ticket_stride words per problem, zero; NULL = fold in a separate launch
     double *partials2;            // ticket_stride rows of kReduceAcc per problem
@@ -52,6 +57,13 @@ struct FoldArgs {
     long long stats_stride;
     double *host_out;             // mapped host memory for tagged publication (or NULL)
     unsigned long long seq;
+    // source-sharded ranks with peer-to-peer mailboxes (ipc_n > 1): the folding workgroup exchanges the 38
+    // statistics with the peers itself before it publishes (no separate all-reduce launch)
+    IpcPeers peers;
+    int ipc_rank, ipc_n;
+    unsigned long long ipc_seq;
+    int *ipc_flag;
+    long long ipc_spins;
 };
 
 struct NNLaunch {
@@ -96,13 +108,9 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          unsigned long long seq = 0, const BruteExact *ex = nullptr);
 
 int reduce_max_blocks();
-// one-shot all-reduce of the 38 statistics through IPC-mapped mailboxes (kernels.hip)
 constexpr int kSortedSlack = 64;   // entries allocated past the end of a cell-sorted target: the exact grid
                                    // search loads whole batches (<= U*G slots) from a run's first slot
-constexpr int kIpcMaxRanks = 16;
-constexpr long long kIpcSpinLimit = 200000000ll;    // polls of the own mailbox before a peer counts as lost (minutes)
-constexpr long long kIpcHandshakeSpins = 15000000ll;  // ... in the handshake of visma_icp_comm_ipc_init (tens of seconds)
-struct IpcPeers { void *box[kIpcMaxRanks]; };     // box[r]: rank r's mailbox as mapped HERE (box[rank] = own)
+// one-shot all-reduce of the 38 statistics through IPC-mapped mailboxes (kernels.hip)
 hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
                                 int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
                                 int *timeout_flag, hipStream_t stream, long long max_spins = kIpcSpinLimit);

@@ -623,15 +623,6 @@ hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned 
 // The mailbox has two halves used alternately (call count parity): a rank can only start
 // call k+2 after every peer has SENT call k+1, which a peer does only after it has finished
 // reading call k, so a granule is never overwritten before its reader has seen it.
-typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
-{
-    u4_t v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-
 __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_in, double *stats_out,
                                                            IpcPeers peers, int rank, int nranks,
                                                            unsigned long long seq, double *host_out,
@@ -640,31 +631,10 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_i
 {
     const int a = threadIdx.x;
     bool late = false;
-    if (a < kNStats) {
-        const unsigned long long v = (unsigned long long)__double_as_longlong(stats_in[a]);
-        u4_t g;
-        g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
-        g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
-        const size_t half = (size_t)(seq & 1ull) * kIpcMaxRanks * kNStats;
-        for (int p = 0; p < nranks; p++)
-            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + half + rank * kNStats + a);
-        const u4_t *mine = reinterpret_cast<const u4_t *>(peers.box[rank]) + half;
-        double sum = 0.0;
-        for (int r = 0; r < nranks; r++) {
-            u4_t w;
-            long long spins = 0;
-            for (;;) {
-                w = load_granule_sys(mine + r * kNStats + a);
-                const unsigned long long tag = ((unsigned long long)w.w << 32) | w.z;
-                if (tag == seq) break;
-                if (++spins > max_spins) { *timeout_flag = 1 + r; late = true; break; }   // a peer never arrived
-                __builtin_amdgcn_s_sleep(2);
-            }
-            sum += __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
-        }
-        // (a sum with a missing term is never handed on: NaN stops the device loop's solve)
-        stats_out[a] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
-    }
+    const double sum = ipc_exchange(a, a < kNStats ? stats_in[a] : 0.0, peers, rank, nranks, seq, timeout_flag,
+                                    max_spins, late);
+    // (a sum with a missing term is never handed on: NaN stops the device loop's solve)
+    if (a < kNStats) stats_out[a] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
     // nothing is published after a timeout: the host sees no tags, then reads the flag
     if (host_out && !__any(late)) publish_tagged_stats(stats_out, host_out, host_seq);
 }
