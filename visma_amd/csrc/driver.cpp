@@ -798,7 +798,9 @@ public:
         {
             bool all64 = B > 0;
             for (int b = 0; b < B; b++) all64 = all64 && (pb[b].src64 || pb[b].src_share >= 0 || pb[b].ns == 0);
-            if (all64) lanes = queries >= 200000 ? 402 : 804;     // 32-byte candidates (measured on the yaw sweeps)
+            // the f64 search gathers 32-byte candidates (measured on the yaw sweeps); the exact search ranks
+            // 16-byte ones (config 3: 801 524 k it/s, 1201 458 k, 402 418 k, 802 351 k, 804 216 k)
+            if (all64 && !exact_) lanes = queries >= 200000 ? 402 : 804;
         }
         if (const char *e = std::getenv("VISMA_ICP_BATCH_LANES")) { const int v = std::atoi(e); if (v > 0) lanes = v; }
         const int G = lanes % 100;
@@ -1490,6 +1492,9 @@ private:
         const int64_t q = ns_ * (int64_t)nprob;                  // queries of one launch
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
         // (lanes per query, loads in flight per lane), encoded G + 100*U
+        if (f64_src() && exact_)   // exact search (re-measured with the branch-free insertion: tools/lanes_probe.py,
+                                   // bench.py --workload c5: sweeps of ~200 k queries 801 309 k it/s, 402 295 k, 802 274 k)
+            return q <= 32768 ? 408 : (nprob > 1 ? (q <= 98304 ? 402 : 801) : (q <= 131072 ? 802 : 801));
         if (f64_src())   // 32-byte candidates: fewer in flight per lane (measured 5k: 408 15.8 us vs 804 18.1)
             return q <= 32768 ? 408 : (nprob > 1 ? 402 : (q <= 131072 ? 802 : 801));
         if (nprob > 1) return q <= 32768 ? 804 : 402;          // sweeps: many queries per launch
