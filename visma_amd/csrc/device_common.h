@@ -393,6 +393,7 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
 // tickets: ticket_stride words per problem, zero before the first launch (the last arrivers
 // re-arm them); [0] = level 2, [1 + g] = level 1 of group g.
 constexpr int kFoldGroup = 32;
+constexpr int kFoldSingle = 256;      // up to this many rows: one level
 template <bool PLANE, int NTH>
 __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *partials, long long row0, int lb,
                                            int bpp, int prob)
@@ -403,10 +404,13 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
     __shared__ double f_tot[32];
     __shared__ int f_flag[2];
     const int tid = threadIdx.x;
-    const int ngroups = (bpp + kFoldGroup - 1) / kFoldGroup;
+    // few rows (small clouds, the problems of a batch): ONE level -- the last workgroup sums them all;
+    // otherwise groups of kFoldGroup rows, then the group sums
+    const bool single = bpp <= kFoldSingle;
+    const int ngroups = single ? 1 : (bpp + kFoldGroup - 1) / kFoldGroup;
     unsigned *tk = f.tickets + (long long)prob * f.ticket_stride;
-    const int grp = lb / kFoldGroup;
-    const int gsize = min(kFoldGroup, bpp - grp * kFoldGroup);
+    const int grp = single ? 0 : lb / kFoldGroup;
+    const int gsize = single ? bpp : min(kFoldGroup, bpp - grp * kFoldGroup);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains
     __syncthreads();
     if (tid == 0) {
@@ -424,7 +428,17 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
         const double *grows = partials + (row0 + (long long)grp * kFoldGroup) * kReduceAcc;
         double v = 0.0;
         if (sa < NACC)
-            for (int r = sg; r < gsize; r += NG) v += load_agent_f64(grows + (long long)r * kReduceAcc + sa);
+            // rows sg, sg + NG, ...: eight loads in flight, added in row order
+            for (int r0 = sg; r0 < gsize; r0 += 8 * NG) {
+                double w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int r = r0 + u * NG;
+                    w[u] = r < gsize ? load_agent_f64(grows + (long long)r * kReduceAcc + sa) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += w[u];
+            }
         f_part[sg][sa] = v;
     }
     __syncthreads();
@@ -433,8 +447,10 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
         double t = 0.0;
 #pragma unroll
         for (int gg = 0; gg < NG; gg++) t += f_part[gg][tid];
-        if (tid < NACC) store_agent_f64(rows2 + tid, t);
+        if (single) f_tot[tid] = t;
+        else if (tid < NACC) store_agent_f64(rows2 + tid, t);
     }
+    if (!single) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -460,6 +476,7 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
 #pragma unroll
         for (int gg = 0; gg < NG; gg++) t += f_part[gg][tid];
         f_tot[tid] = t;
+    }
     }
     __syncthreads();
     double *stats = f.stats_out + (long long)prob * f.stats_stride;
