@@ -339,7 +339,7 @@ __device__ __forceinline__ void publish_tagged_stats(const double *stats, double
 }
 
 // One rank's part of the one-shot all-reduce over xGMI (see ipc_allreduce_kernel in kernels.hip): lane a
-// of ONE wave stores statistic a as a 16-byte granule {value, call count} into slot [rank][a] of every
+// of ONE wave stores statistic a as a 16-byte granule (value + call-count tags) into slot [rank][a] of every
 // peer's mailbox, then waits for the nranks granules of statistic a in its OWN mailbox and sums them in
 // rank order.  The mailbox has two halves used alternately (call count parity): a rank can only start
 // call k+2 after every peer has SENT call k+1, which a peer does only after it has finished reading call
@@ -357,12 +357,16 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
                                                unsigned long long seq, int *timeout_flag, long long max_spins,
                                                bool &late)
 {
+    // granule = {value bits 0..31, tag, value bits 32..63, tag} with tag = the low 32 bits of the call count:
+    // each 8-byte half validates itself, so the protocol only needs 8-byte stores to arrive whole (the
+    // 16-byte store may be split in two on its way through the fabric)
     double sum = 0.0;
     if (a < kNStats) {
         const unsigned long long v = (unsigned long long)__double_as_longlong(mine);
+        const unsigned tag = (unsigned)seq;
         u4_t g;
-        g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
-        g.z = (unsigned)seq; g.w = (unsigned)(seq >> 32);
+        g.x = (unsigned)v; g.y = tag;
+        g.z = (unsigned)(v >> 32); g.w = tag;
         const size_t half = (size_t)(seq & 1ull) * kIpcMaxRanks * kNStats;
         for (int p = 0; p < nranks; p++)
             __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + half + rank * kNStats + a);
@@ -372,12 +376,11 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
             long long spins = 0;
             for (;;) {
                 w = load_granule_sys(own + r * kNStats + a);
-                const unsigned long long tag = ((unsigned long long)w.w << 32) | w.z;
-                if (tag == seq) break;
+                if (w.y == tag && w.w == tag) break;
                 if (++spins > max_spins) { *timeout_flag = 1 + r; late = true; break; }   // a peer never arrived
                 __builtin_amdgcn_s_sleep(2);
             }
-            sum += __longlong_as_double((long long)(((unsigned long long)w.y << 32) | w.x));
+            sum += __longlong_as_double((long long)(((unsigned long long)w.z << 32) | w.x));
         }
     }
     return sum;
