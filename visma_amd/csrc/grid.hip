@@ -589,7 +589,13 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // One batch of U*G candidates of the current run.  A slot past the end of the run
         // re-reads the run's first point: evaluating a candidate twice cannot change the
         // (d2, index) minimum, and it saves the per-slot guard.
+#ifdef VISMA_GRID_DEBUG_TRIPS
+        int dbg_trips = 0;
+#endif
         auto batch = [&]() {
+#ifdef VISMA_GRID_DEBUG_TRIPS
+            dbg_trips++;
+#endif
             unsigned jc[U];
             if constexpr (F64) {
                 Pt64 q[U];
@@ -831,7 +837,18 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         }
         if (sub == 0) {
             if constexpr (S64) {
+#ifdef VISMA_GRID_DEBUG_TRIPS   /* measurement build: trips of this query | of its wave | of its wave's matched queries */
+                {
+                    int wmax = dbg_trips, wmax_m = bpos == 0xFFFFFFFFu ? 0 : dbg_trips;
+                    for (int m = 32; m > 0; m >>= 1) {
+                        wmax = max(wmax, __shfl_xor(wmax, m, 64));
+                        wmax_m = max(wmax_m, __shfl_xor(wmax_m, m, 64));
+                    }
+                    idx_out[i] = dbg_trips | ((bpos != 0xFFFFFFFFu) << 7) | (wmax << 8) | (wmax_m << 16);
+                }
+#else
                 idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
+#endif
                 d2_out[i] = (float)bd;
                 if (d64_out) d64_out[i] = bd;                // (target-sharded ranks compare shards in f64)
             } else {
