@@ -641,6 +641,7 @@ def run_c5(R, args):
     elapsed = R.reduce_max(time.perf_counter() - t0)
     total_its = R.reduce_sum(float(its))
     per_rank_items = done
+    total_items = int(round(R.reduce_sum(float(done))))
     # roofline of the sweep kernel: one profiled pass over the first items (after the timed region)
     roofline = None
     if R.rank == 0:
@@ -679,7 +680,7 @@ def run_c5(R, args):
                        "items": len(items), "search": ctx.search_mode_used(),
                        "parallelism": "replicas only: %d rank(s) pull work items from a shared counter, no collective" % R.world},
             "registrations_per_sec": len(items) * args.steps / elapsed,
-            "items_done_by_rank0": per_rank_items,
+            "items_done_by_rank0": per_rank_items, "items_done_by_all_ranks": total_items,
             "roofline": roofline,
         }
         if R.world == 1 and not args.no_cpu_baseline:
