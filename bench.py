@@ -581,20 +581,45 @@ def run_c3(R, args):
 
 
 def c5_corpus():
-    """Synthetic corpus: 6 scenes x 8 CAD candidates; a work item = one orientation-constrained registration
+    """Synthetic corpus: 12 scenes x 16 CAD candidates; a work item = one orientation-constrained registration
     (24 yaw starts, src/annotation.cpp:29-64) of a candidate against a scene."""
     from visma_amd import synth
     rng = np.random.default_rng(5)
     scenes = [synth.surface_points(int(rng.integers(15000, 40000)), 900 + s).astype(np.float32).astype(np.float64)
-              for s in range(6)]
+              for s in range(12)]
     cads = []
-    for c in range(8):
+    for c in range(16):
         n = int(rng.integers(3000, 12000))
         p = synth.surface_points(n, 950 + c)
         Ti = np.linalg.inv(synth.make_T(synth.rot_y(rng.uniform(-0.05, 0.05)), rng.standard_normal(3) * 0.01))
         cads.append((p @ Ti[:3, :3].T + Ti[:3, 3]).astype(np.float32).astype(np.float64))
     items = [(s, c) for s in range(len(scenes)) for c in range(len(cads))]
     return scenes, cads, items
+
+
+C5_CHUNK = 8          # work items a rank takes from the counter at a time: 8 x 24 = 192 ICPs in flight per launch
+                      # (measured on one MI355X: 1 item per launch 167 k iterations/s, 2: 326 k, 4: 482 k, 8: 630 k)
+
+
+def c5_chunk_problems(scenes, cads, chunk_items, radius, level):
+    """The 24 yaw starts (src/annotation.cpp:35-39) of every item of a chunk as one batch: problems that pass
+    the same arrays share one upload and one grid inside visma_icp_run_batch."""
+    from visma_amd import synth
+    probs = []
+    for s, c in chunk_items:
+        for k in range(level):
+            probs.append((cads[c], scenes[s], synth.make_T(synth.rot_y(2 * np.pi * k / level), [0, 0, 0]), radius))
+    return probs
+
+
+def c5_pick(results, level):
+    """feh::RegisterModelToScene's choice per item: the first start with strictly the most correspondences."""
+    out = []
+    for a in range(0, len(results), level):
+        per = results[a:a + level]
+        best = max(range(level), key=lambda k: (per[k].num_correspondences, -k))
+        out.append((best, per[best]))
+    return out
 
 
 def run_c5(R, args):
@@ -607,25 +632,24 @@ def run_c5(R, args):
         store = R.torch.distributed.distributed_c10d._get_default_store()
 
     def pull(step):
-        """next work item of this pass: a shared counter when there are several ranks"""
+        """next chunk of work items of this pass: a shared counter when there are several ranks"""
         if store is None:
-            for i in range(len(items)):
-                yield i
+            for i in range(0, len(items), C5_CHUNK):
+                yield items[i:i + C5_CHUNK]
             return
         while True:
-            i = store.add("c5_next_%d" % step, 1) - 1
+            i = store.add("c5_next_%d" % step, C5_CHUNK) - C5_CHUNK
             if i >= len(items):
                 return
-            yield i
+            yield items[i:i + C5_CHUNK]
 
     def one_pass(step):
         its, done = 0, 0
-        for i in pull(step):
-            s, c = items[i]
-            ctx.set_clouds_f64(cads[c], scenes[s])
-            best, lvl, per = ctx.run_yaw_sweep(level, radius, iters)
-            its += sum(p.iterations for p in per)
-            done += 1
+        for chunk in pull(step):
+            res = ctx.run_batch(c5_chunk_problems(scenes, cads, chunk, radius, level), max_iter=iters)
+            c5_pick(res, level)
+            its += sum(p.iterations for p in res)
+            done += len(chunk)
         return its, done
 
     for w in range(max(args.warmup, 1)):
@@ -642,31 +666,32 @@ def run_c5(R, args):
     total_its = R.reduce_sum(float(its))
     per_rank_items = done
     total_items = int(round(R.reduce_sum(float(done))))
-    # roofline of the sweep kernel: one profiled pass over the first items (after the timed region)
+    # roofline of the batch kernel: one profiled pass over the first chunks (after the timed region)
     roofline = None
     if R.rank == 0:
         ctx.set_profiling(1)
         b_alg = b_comp = ms = 0.0
         launches = 0
-        for s, c in items[:8]:
-            ctx.set_clouds_f64(cads[c], scenes[s])
+        for a in range(0, 8, C5_CHUNK):
+            chunk = items[a:a + C5_CHUNK]
             ctx.get_timing(reset=True)
-            ctx.run_yaw_sweep(level, radius, iters)
+            ctx.run_batch(c5_chunk_problems(scenes, cads, chunk, radius, level), max_iter=iters)
             tm = ctx.get_timing(reset=True)
             nl = tm["nn_launches"]
-            q = len(cads[c]) * level
+            q = sum(len(cads[c]) for s, c in chunk) * level
             b_alg += nl * q * (32.0 + 144.0 + 8.0 + 32.0) + 16.0 * tm["grid_candidates"]
-            b_comp += nl * (len(scenes[s]) * 16.0 + q * 72.0)
+            b_comp += nl * (sum(len(scenes[s]) for s, c in chunk) * 16.0 + q * 72.0)
             ms += tm["nn_ms"]
             launches += nl
         ctx.set_profiling(0)
         if ms > 0:
             gbps = b_alg / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "nn_grid_reduce_kernel (24 problems per launch over shared clouds, exact search, fold fused)",
+            roofline = {"kernel": "nn_grid_reduce_kernel (%d problems per launch: %d items x 24 starts, exact search, fold fused)" % (
+                            C5_CHUNK * level, C5_CHUNK),
                         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                         "traffic": None, "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": b_alg / max(launches, 1),
                         "compulsory_bytes": b_comp / max(launches, 1), "launches_timed": launches,
-                        "note": "small clouds: launch- and latency-bound (every launch is a few tens of microseconds)"}
+                        "note": "small clouds: every launch is a few tens of microseconds"}
     out = None
     if R.rank == 0:
         out = {
@@ -678,7 +703,7 @@ def run_c5(R, args):
                                    "(24 yaw starts each, <= %d iterations, r=%.3g) per pass" % (
                                        len(scenes), len(cads), len(items), iters, radius),
                        "items": len(items), "search": ctx.search_mode_used(),
-                       "parallelism": "replicas only: %d rank(s) pull work items from a shared counter, no collective" % R.world},
+                       "parallelism": "replicas only: %d rank(s) pull chunks of %d work items from a shared counter, no collective" % (R.world, C5_CHUNK)},
             "registrations_per_sec": len(items) * args.steps / elapsed,
             "items_done_by_rank0": per_rank_items, "items_done_by_all_ranks": total_items,
             "roofline": roofline,

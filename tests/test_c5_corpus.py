@@ -11,7 +11,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from bench import c5_corpus  # noqa: E402
+from bench import c5_chunk_problems, c5_corpus, c5_pick  # noqa: E402
 from visma_amd import _lib, synth  # noqa: E402
 
 
@@ -19,7 +19,7 @@ from visma_amd import _lib, synth  # noqa: E402
 @pytest.mark.timeout(900)
 def test_corpus_items_equal_the_oracle_sweep(lib, oracle):
     scenes, cads, items = c5_corpus()
-    assert len(items) == 48
+    assert len(items) == 192
     ctx = _lib.Context(0)
     # the two cheapest items for the CPU oracle (24 starts x 30 iterations each)
     cost = [len(cads[c]) * np.log(len(scenes[s])) for s, c in items]
@@ -33,6 +33,11 @@ def test_corpus_items_equal_the_oracle_sweep(lib, oracle):
         assert best.num_correspondences == want.k, i
         assert synth.rel_frobenius(best.transformation_, want.T) < 1e-9, i
         assert len(per) == 24 and max(p.num_correspondences for p in per) == best.num_correspondences
+        # the same item as bench.py runs it: its 24 starts inside one batch
+        res = ctx.run_batch(c5_chunk_problems(scenes, cads, [(s, c)], 0.05, 24), max_iter=30)
+        lvl_b, best_b = c5_pick(res, 24)[0]
+        assert lvl_b == level and best_b.num_correspondences == best.num_correspondences
+        assert synth.rel_frobenius(best_b.transformation_, best.transformation_) < 1e-10
 
 
 @pytest.mark.gpu
@@ -49,8 +54,8 @@ def test_two_ranks_pull_the_corpus_from_one_counter(lib):
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["config"]["items"] == 48
+    assert d["n_gpus"] == 2 and d["config"]["items"] == 192
     assert "no collective" in d["config"]["parallelism"]
-    assert d["items_done_by_all_ranks"] == 2 * 48           # two timed passes: every item exactly once per pass
-    assert 0 < d["items_done_by_rank0"] < 2 * 48           # ... shared between the ranks
+    assert d["items_done_by_all_ranks"] == 2 * 192          # two timed passes: every item exactly once per pass
+    assert 0 < d["items_done_by_rank0"] < 2 * 192          # ... shared between the ranks
     assert d["registrations_per_sec"] > 0 and np.isfinite(d["value"])
