@@ -264,12 +264,12 @@ VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
  *                candidates within ~1e-6 of the radius, can be decided differently from the
  *                reference's f64 KD-tree (about one query in 1e5); one flipped pair among K
  *                moves the update by ~(pair spacing)/K.
- *   1 (default)  exact: candidates are ranked in fp32, the best three are kept, and whenever
+ *   1 (default)  exact: candidates are ranked in fp32, the best two are kept, and whenever
  *                the runner-up or the radius lies within the rounding band of the best
  *                (2.4e-7 (|p|_1 + r) + 4.8e-7 r on the distance, both operands fp32-rounded
  *                f64 coordinates) the candidates concerned are re-ranked in f64 with the
  *                reference's arithmetic: the f64 sum of squares of FLANN L2<double>, the
- *                strict d2 < (double)(float)(r*r) test, lowest index on exact ties.  Four
+ *                strict d2 < (double)(float)(r*r) test, lowest index on exact ties.  Three
  *                candidates inside the band: the query rescans its cells in f64.  Source
  *                transform and statistics in f64 from the caller's coordinates.  The
  *                correspondences are those of mode 2 (and of the reference) for every input;
@@ -277,8 +277,8 @@ VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
  *                target-sharded.  Clouds given as fp32 are promoted on the device.
  *   2            f64 search: every candidate distance in f64.  Same results as 1, slower
  *                (+30 % at 64k -> 256k); kept as the in-library check of mode 1.
- * Takes effect at the next cloud upload.  Cost of mode 1 over mode 0: +5 % per iteration at
- * 64k -> 256k (measured on MI355X, profiles/r02_probe_hyb2.txt).
+ * Takes effect at the next cloud upload.  Mode 1 runs at the speed of mode 0 (measured on MI355X,
+ * profiles/r02_probe_keepq.txt: 56.3 vs 58.6 us per iteration at C4, 30.7 vs 29.0 at 64k -> 1M).
  * visma_icp_get_search_precision_used reports what the last run executed (0 / 1 / 2). */
 VISMA_ICP_API int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode);
 /* What the last pass ran: 0 fp32 ranking only, 1 exact (fp32 ranking + f64 re-rank), 2 f64. */
