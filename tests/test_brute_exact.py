@@ -57,3 +57,21 @@ def test_brute_exact_reproduces_the_reference_fuzz_cases(lib):
         got = ctx.run(init, r, iters, 1e-6, 1e-6)
         assert got.num_correspondences == int(G["ref_k"][i]), i
         assert synth.rel_frobenius(got.transformation_, G["ref_T"][i]) < 1e-9, i
+
+
+def test_more_undecided_queries_than_the_rescan_list_holds(lib):
+    """A target given twice: EVERY query has two equally near targets in different sub-chunks, so every query
+    is left to the rescan passes; past their capacity (4096) the wave scans in place.  Either way the winner
+    is the lower index."""
+    src, tgt, T_gt, r = synth.make_pair(6000, 6000, seed_t=77, seed_s=78, motion="radius")
+    tgt2 = np.concatenate([tgt, tgt])
+    g, b = pair(_lib.NN_GRID), pair(_lib.NN_BRUTE)
+    g.set_clouds_f64(src, tgt2)
+    b.set_clouds_f64(src, tgt2)
+    for T in (np.eye(4), T_gt):
+        g.nn_pass(T, r); sg = g.reduce(); ig = g.correspondence_index()
+        b.nn_pass(T, r); sb = b.reduce(); ib = b.correspondence_index()
+        assert b.nn_mode_used() == _lib.NN_BRUTE and b.search_mode_used() == "exact"
+        assert (ib[ib >= 0] < len(tgt)).all()                     # the first copy wins every tie
+        assert np.array_equal(ig, ib)
+        assert sg[0] == sb[0] and sg[0] > 4096 and np.max(np.abs(sg - sb)) <= 1e-11 * np.max(np.abs(sg))

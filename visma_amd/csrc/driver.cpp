@@ -192,6 +192,7 @@ public:
         for (int r = 0; r < ipc_n_; r++)
             if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
         free_dev(d_mbox_); free_dev(d_ipc_flag_);
+        free_dev(d_pend_count_); free_dev(d_pend_q32_); free_dev(d_pend_q64_); free_dev(d_pend_best_); free_dev(d_pend_idx_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
         free_dev(d_claim_); free_dev(d_d64_);
@@ -281,6 +282,13 @@ public:
     bool brute_exact() const { return !use_grid_ && exact_ && d_src64_ && d_tgt64_ && !tshard_; }
     int ensure_second(int64_t ns_pad, int splits)
     {
+        if (!d_pend_count_) {              // the list of queries the reduce kernel leaves to the rescan passes
+            HIP_TRY(hipMalloc(&d_pend_count_, sizeof(int)));
+            HIP_TRY(hipMalloc(&d_pend_q32_, sizeof(float4) * kBrutePendCap));
+            HIP_TRY(hipMalloc(&d_pend_q64_, sizeof(Pt64) * kBrutePendCap));
+            HIP_TRY(hipMalloc(&d_pend_best_, sizeof(unsigned long long) * kBrutePendCap));
+            HIP_TRY(hipMalloc(&d_pend_idx_, sizeof(unsigned) * kBrutePendCap));
+        }
         const size_t need = sizeof(float) * (size_t)ns_pad * (size_t)splits;
         if (need > second_bytes_) {
             free_dev(d_second_);
@@ -289,6 +297,8 @@ public:
         }
         return VISMA_ICP_OK;
     }
+    void *d_pend_count_ = nullptr, *d_pend_q32_ = nullptr, *d_pend_q64_ = nullptr, *d_pend_best_ = nullptr,
+         *d_pend_idx_ = nullptr;
     BruteExact bex_store_{};
     const BruteExact *bex_ptr()
     {
@@ -304,6 +314,14 @@ public:
         e.nrm64 = (const Pt64 *)d_nrm64_;
         e.second = (const float *)d_second_;
         e.nt = nt_;
+        e.pend = BrutePend{};
+        if (d_pend_count_ && 2 * reduce_max_blocks() <= (int)partial_rows_) {
+            e.pend.count = (int *)d_pend_count_;
+            e.pend.q32 = (float4 *)d_pend_q32_;
+            e.pend.q64 = (Pt64 *)d_pend_q64_;
+            e.pend.best = (unsigned long long *)d_pend_best_;
+            e.pend.best_idx = (unsigned *)d_pend_idx_;
+        }
         return e;
     }
     void set_exact(bool on) override { exact_ = on; }

@@ -92,10 +92,22 @@ hipError_t launch_nn_brute(const float4 *src, int64_t ns, const float4 *tgt,
 // idx_out/d2_out (ns) receive the final correspondence per source point.
 // the exact flavour of the brute-force path: f64 clouds (source in engine order, target in the caller's
 // order) and the runner-up array written by launch_nn_brute
+// Queries whose winner cannot be decided inside the winning sub-chunk (another sub-chunk reaches into the
+// rounding band: about one in a thousand) are listed by the reduce kernel and resolved together by two
+// passes of ALL workgroups over the target (brute_rescan_kernel), not by a scan of their own.
+constexpr int kBrutePendCap = 4096;       // more pending queries than this: the wave scans in place (slow, exact)
+struct BrutePend {
+    int *count;                           // [0] pending queries (may exceed the capacity)
+    float4 *q32;                          // (px, py, pz, L): fp32 query and its squared fp32 filter radius
+    Pt64 *q64;                            // f64 query, w = source slot
+    unsigned long long *best;             // f64 bits of the best d2 (order preserving), r2d bits = none
+    unsigned *best_idx;                   // lowest index among the targets at that distance
+};
 struct BruteExact {
     const Pt64 *src64, *tgt64, *nrm64;
     const float *second;
     int64_t nt;
+    BrutePend pend;                       // pend.count == NULL: every scan in place
 };
 hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
                          const float4 *tgt_normals, const unsigned long long *keys,

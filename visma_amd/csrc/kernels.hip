@@ -16,6 +16,8 @@
 //   accept iff d2 < r2f; lowest target index wins exact ties.
 // Statistics are accumulated in f64 from p = T64 * (double)s and q widened.
 #include "device_common.h"
+
+#include <algorithm>
 #include "host_math.hpp"
 
 #include <math.h>
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void reduce_exact_kernel(
     const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, const unsigned long long *__restrict__ keys,
     const float *__restrict__ second, int nsplits, long long ns_pad, Xform64 T64, Offset64 off, float r2f,
     int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials,
-    const DevIcpState *__restrict__ st)
+    const DevIcpState *__restrict__ st, BrutePend pend)
 {
     constexpr int NACC = Acc<PLANE>::N;
     {
@@ -311,7 +313,21 @@ __global__ __launch_bounds__(kBlock) void reduce_exact_kernel(
             }
         }
         // (3) other sub-chunks reach into the band: the wave scans the whole target for that query
-        unsigned long long need = __ballot(valid && win != 0xFFFFFFFFu && so <= L);
+        bool undecided = valid && win != 0xFFFFFFFFu && so <= L;
+        bool deferred = false;
+        if (undecided && pend.count) {
+            // hand the query to the rescan passes (every workgroup, one sweep of the target for all of them)
+            const int slot = atomicAdd(pend.count, 1);
+            if (slot < kBrutePendCap) {
+                pend.q32[slot] = make_float4(px, py, pz, L);
+                pend.q64[slot] = Pt64{pxd, pyd, pzd, (unsigned long long)i};
+                pend.best[slot] = (unsigned long long)__double_as_longlong(r2d);
+                pend.best_idx[slot] = 0xFFFFFFFFu;
+                idx_out[i] = -2 - slot;                       // resolved by reduce_pending_kernel
+                deferred = true;
+            }
+        }
+        unsigned long long need = __ballot(undecided && !deferred);
         while (need) {
             const int srcl = __ffsll((long long)need) - 1;
             need &= need - 1ull;
@@ -340,7 +356,7 @@ __global__ __launch_bounds__(kBlock) void reduce_exact_kernel(
             }
             if (lane == srcl) { bd = wd; bidx = wi; }          // (a scan of everything supersedes the sub-chunk result)
         }
-        if (valid) {
+        if (valid && !deferred) {
             idx_out[i] = bidx == 0xFFFFFFFFu ? -1 : (int)bidx;
             d2_out[i] = (float)bd;
             if (bidx != 0xFFFFFFFFu) {
@@ -352,6 +368,81 @@ __global__ __launch_bounds__(kBlock) void reduce_exact_kernel(
                 }
                 accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
             }
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
+// The pending queries of reduce_exact_kernel against the whole target, all of them in one sweep: every
+// thread takes targets j, j + stride, ... and tests each against every pending query (fp32 filter, then
+// the reference's f64 distance).  PASS 0: the smallest f64 d2 per query (atomic minimum of its bits --
+// order preserving for d2 >= 0; the start value is the radius bound, so the acceptance stays strict).
+// PASS 1: the lowest index among the targets AT that distance.
+template <int PASS>
+__global__ __launch_bounds__(256) void brute_rescan_kernel(const float4 *__restrict__ tgt, const Pt64 *__restrict__ tgt64,
+                                                           int nt, BrutePend pend, const DevIcpState *__restrict__ st)
+{
+    if (st && !st->active) return;
+    const int F = min(*pend.count, kBrutePendCap);
+    if (F <= 0) return;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < nt; j += (long long)gridDim.x * 256) {
+        const float4 t = tgt[j];
+        for (int f = 0; f < F; f++) {
+            const float4 q = pend.q32[f];                         // (uniform: a scalar load)
+            if (sqdist_f32(t, q.x, q.y, q.z) <= q.w) {
+                const Pt64 c8 = tgt64[j], q8 = pend.q64[f];
+                // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
+                const double dx = c8.x - q8.x, dy = c8.y - q8.y, dz = c8.z - q8.z;
+                double d = dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(d);
+                if (PASS == 0) {
+                    if (bits < pend.best[f]) atomicMin(&pend.best[f], bits);
+                } else if (bits == pend.best[f]) {
+                    atomicMin(&pend.best_idx[f], (unsigned)j);
+                }
+            }
+        }
+    }
+}
+
+// ... and their correspondences and moments, by the thread that owns the source slot (same mapping as
+// reduce_exact_kernel, so the sums do not depend on the order in which the queries were listed)
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) void reduce_pending_kernel(
+    const Pt64 *__restrict__ src64, int ns, const Pt64 *__restrict__ tgt64, const float4 *__restrict__ nrm,
+    const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out,
+    float *__restrict__ d2_out, double *__restrict__ partials, const DevIcpState *__restrict__ st, BrutePend pend)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    {
+        Xform32 t32;
+        if (!load_loop_state(st, t32, T64, off, r2f)) return;
+    }
+    double acc[NACC];
+#pragma unroll
+    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+    const int nloop = ((ns + kBlock - 1) / kBlock + gridDim.x - 1) / gridDim.x;
+    for (int it = 0; it < nloop; it++) {
+        const int i = (it * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+        if (i >= ns) continue;
+        const int code = idx_out[i];
+        if (code > -2) continue;
+        const int slot = -2 - code;
+        const double bd = __longlong_as_double((long long)pend.best[slot]);
+        // (nothing strictly inside the radius in f64: the start value is still there, whatever pass 1 found at it)
+        const unsigned bidx = bd < (double)r2f ? pend.best_idx[slot] : 0xFFFFFFFFu;
+        idx_out[i] = bidx == 0xFFFFFFFFu ? -1 : (int)bidx;
+        d2_out[i] = (float)bd;
+        if (bidx != 0xFFFFFFFFu) {
+            const Pt64 s8 = src64[i], q8 = tgt64[bidx];
+            double nx = 0.0, ny = 0.0, nz = 0.0;
+            if (PLANE) {
+                if (nrm64) { const Pt64 n8 = nrm64[bidx]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                else { const float4 n4 = nrm[bidx]; nx = n4.x; ny = n4.y; nz = n4.z; }
+            }
+            accumulate_pair_d<PLANE>(acc, s8.x, s8.y, s8.z, q8.x, q8.y, q8.z, nx, ny, nz, T64, off);
         }
     }
     block_reduce_store<NACC>(acc, partials);
@@ -678,14 +769,34 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
     if (nblocks > max_partial_blocks) nblocks = max_partial_blocks;
     if (nblocks < 1) nblocks = 1;
     if (ex && ex->src64) {
+        const BrutePend pend = ex->pend;
+        if (pend.count) {
+            hipError_t e0 = hipMemsetAsync(pend.count, 0, sizeof(int), stream);
+            if (e0 != hipSuccess) return e0;
+        }
         if (point_to_plane)
             hipLaunchKernelGGL(reduce_exact_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, ex->src64, (int)ns, tgt,
                                ex->tgt64, (int)ex->nt, tgt_normals, ex->nrm64, keys, ex->second, nsplits, (long long)ns_pad,
-                               T64, off, r2f, idx_out, d2_out, partials, st);
+                               T64, off, r2f, idx_out, d2_out, partials, st, pend);
         else
             hipLaunchKernelGGL(reduce_exact_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, ex->src64, (int)ns, tgt,
                                ex->tgt64, (int)ex->nt, tgt_normals, ex->nrm64, keys, ex->second, nsplits, (long long)ns_pad,
-                               T64, off, r2f, idx_out, d2_out, partials, st);
+                               T64, off, r2f, idx_out, d2_out, partials, st, pend);
+        if (pend.count) {
+            // the undecided queries: two sweeps of the target by all workgroups, then their moments into a
+            // second set of partial rows (the fold sums 2 * nblocks rows)
+            const int rblocks = (int)std::min<int64_t>(2048, (ex->nt + 255) / 256);
+            hipLaunchKernelGGL(brute_rescan_kernel<0>, dim3(rblocks), dim3(256), 0, stream, tgt, ex->tgt64, (int)ex->nt, pend, st);
+            hipLaunchKernelGGL(brute_rescan_kernel<1>, dim3(rblocks), dim3(256), 0, stream, tgt, ex->tgt64, (int)ex->nt, pend, st);
+            double *p2 = partials + (size_t)nblocks * kReduceAcc;
+            if (point_to_plane)
+                hipLaunchKernelGGL(reduce_pending_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, ex->src64, (int)ns,
+                                   ex->tgt64, tgt_normals, ex->nrm64, T64, off, r2f, idx_out, d2_out, p2, st, pend);
+            else
+                hipLaunchKernelGGL(reduce_pending_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, ex->src64, (int)ns,
+                                   ex->tgt64, tgt_normals, ex->nrm64, T64, off, r2f, idx_out, d2_out, p2, st, pend);
+            nblocks *= 2;
+        }
     } else if (point_to_plane)
         hipLaunchKernelGGL(reduce_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src,
                            (int)ns, tgt, tgt_normals, keys, nsplits, (long long)ns_pad, T32,
