@@ -448,6 +448,12 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     }
     if (st) st += prob;
     if (!load_loop_state(st, T32, T64, off, r2f)) return;
+#ifdef VISMA_GRID_EXPERIMENT_STAGGER   /* timing experiment: workgroups of one CU start their chains at different times */
+    {
+        const int cls = (VISMA_GRID_EXPERIMENT_STAGGER >= 100) ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 8) & 3);
+        for (int k = 0; k < cls * (VISMA_GRID_EXPERIMENT_STAGGER % 100); k++) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
     if constexpr (S64) r2d = (double)r2f;                  // (double)(float)(r*r), also when the radius comes from the state
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
