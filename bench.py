@@ -16,7 +16,7 @@ Workloads (BASELINE.json configs):
       once per target/radius outside it, like the reference's KD-tree (build time reported).
       N > 1: the SOURCE is sharded (each rank holds the full target), every rank reduces its shard
       and ONE all-reduce of the 38 f64 accumulators per iteration sums them; total work is fixed:
-      "scaling": "strong".  A weak-scaling line (source N x 262,144 -> target N x 4,194,304) is
+      "scaling": "strong".  A weak-scaling line (source N x 262,144 -> the same 4,194,304-point target) is
       measured after the timed region and reported under "weak_scaling".
   c3: all objects of one scene in flight on ONE GPU: 12 objects x 24 yaw starts = 288 small ICPs
       (source 4k..40k points, target half of it, r = 0.02, 30 iterations).  One STEP = one
@@ -422,10 +422,11 @@ def run_c4(R, args):
                              "differently from the reference"}
         c32.close()
 
-    # weak scaling: source N x 262,144 -> target N x 4,194,304, same sharding (after the timed region)
+    # weak scaling (after the timed region): N x 262,144 source points against the SAME 4,194,304-point target
+    # at the same radius -- every rank's launch is the N = 1 launch, only the exchange is added
     weak = None
     if R.world > 1 and not args.no_weak and args.shard == "source":
-        wns, wnt = ns * R.world, nt * R.world
+        wns, wnt = ns * R.world, nt
         wsrc, wtgt, _, wr = synth.make_pair(wns, wnt, motion="radius")
         wctx, wns_local, _ = c4_context(R, args, wsrc, wtgt, wns, wnt)
         wctx, _ = attach_comm(R, wctx, lambda: c4_context(R, args, wsrc, wtgt, wns, wnt)[0], args)
@@ -435,8 +436,8 @@ def run_c4(R, args):
                 "point_iterations_per_sec": float(wns) * args.steps / welapsed,
                 "nn_kernel_ms": R.reduce_max(wtm["nn_ms"] / max(wtm["nn_launches"], 1)),
                 "fitness": wlast.fitness_,
-                "note": "per-rank work fixed (262,144 queries against a target N times denser): ideal weak "
-                        "scaling keeps icp_iterations_per_sec at the N = 1 value"}
+                "note": "per-rank work fixed (262,144 queries per rank against the same target and radius as at N = 1): "
+                        "ideal weak scaling keeps icp_iterations_per_sec at the N = 1 value of this line's `value`"}
         wctx.close()
 
     out = None
