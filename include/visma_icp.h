@@ -271,7 +271,8 @@ VISMA_ICP_API int visma_icp_set_nn_mode(visma_icp_ctx *ctx, int nn_mode);
  *                reference's arithmetic: the f64 sum of squares of FLANN L2<double>, the
  *                strict d2 < (double)(float)(r*r) test, lowest index on exact ties.  Three
  *                candidates inside the band: the query rescans its cells in f64.  Source
- *                transform and statistics in f64 from the caller's coordinates.  The
+ *                transform and statistics in f64 from the caller's f64 coordinates (shifted by
+ *                the target centroid in f64 on upload).  The
  *                correspondences are those of mode 2 (and of the reference) for every input;
  *                every path has this flavour -- grid (single, sweep, batch), brute force,
  *                target-sharded.  Clouds given as fp32 are promoted on the device.
