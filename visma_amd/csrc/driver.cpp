@@ -24,6 +24,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "host_math.hpp"
@@ -83,6 +84,30 @@ constexpr int kNcclMin = 3;      // ncclMin
 constexpr int kNcclUint64 = 5;   // ncclUint64
 
 // ---- engines --------------------------------------------------------------------
+// Run fn(i) for i in [0, n) on a few host threads (packing / ordering of clouds).
+template <typename F>
+void parallel_for(int64_t n, int64_t min_per_thread, F fn)
+{
+    int64_t nt = (int64_t)std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
+    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    std::atomic<int64_t> next(0);
+    for (int64_t t = 0; t < nt; t++)
+        th.emplace_back([&]() {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                fn(i);
+            }
+        });
+    for (auto &t : th) t.join();
+}
+
+constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
+
 class Engine {
 public:
     virtual ~Engine() {}
@@ -154,6 +179,11 @@ public:
     // f64 copies of the clouds for the double-precision search (after set_source / set_target;
     // same order as those: source in Morton order).  nullptr pair = drop them.
     virtual int set_clouds64(const Pt64 *, const Pt64 *) { err_ = "double-precision search needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
+    // The target straight from the caller's f64 array (stride doubles per point): uploaded as it is (24 bytes
+    // per point instead of 16 + 32) and expanded on the device into the fp32 copy (float)(x - c) and, with
+    // want64, the f64 copy {x - c, index}.  set_source64 then completes the pair of f64 clouds.
+    virtual int set_target_f64(const double *, int64_t, int, const double *, bool) { return VISMA_ICP_ERR_STATE; }
+    virtual int set_source64(const Pt64 *) { return VISMA_ICP_ERR_STATE; }
     virtual bool search_is_f64() const { return false; }
     virtual bool search_is_exact() const { return false; }
     virtual void set_exact(bool) {}
@@ -191,7 +221,7 @@ public:
         if (comm_) g_rccl.CommDestroy(comm_);
         for (int r = 0; r < ipc_n_; r++)
             if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
-        free_dev(d_mbox_); free_dev(d_ipc_flag_);
+        free_dev(d_mbox_); free_dev(d_ipc_flag_); free_dev(d_raw_);
         free_dev(d_pend_count_); free_dev(d_pend_q32_); free_dev(d_pend_q64_); free_dev(d_pend_best_); free_dev(d_pend_idx_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
@@ -208,6 +238,7 @@ public:
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
         if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
+        pool_trim(0);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
 
@@ -260,14 +291,63 @@ public:
         return VISMA_ICP_OK;
     }
 
+    int set_target_f64(const double *xyz, int64_t nt, int stride, const double *c, bool want64) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_target(nt);
+        if (rc) return rc;
+        if (want64) { rc = pool_alloc(&d_tgt64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt, 1)); if (rc) return rc; }
+        if (nt > 0) {
+            if ((size_t)nt * 24 > raw_bytes_) {
+                free_dev(d_raw_);
+                rc = pool_alloc(&d_raw_, (size_t)nt * 24);
+                if (rc) return rc;
+                raw_bytes_ = (size_t)nt * 24;
+            }
+            // caller's array -> pinned staging on a few host threads, chunk by chunk, each chunk's DMA
+            // running while the next one is copied
+            double *pin = reinterpret_cast<double *>(staging(2, (size_t)nt * 6));
+            const int64_t chunk = 1 << 20;                       // (a parallel_for starts its threads anew)
+            for (int64_t lo = 0; lo < nt; lo += chunk) {
+                const int64_t hi = std::min(nt, lo + chunk);
+                parallel_for((hi - lo + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
+                    const int64_t a = lo + ch * kHostChunk, b = std::min(hi, a + kHostChunk);
+                    if (stride == 3) std::memcpy(pin + 3 * a, xyz + 3 * a, sizeof(double) * 3 * (size_t)(b - a));
+                    else
+                        for (int64_t j = a; j < b; j++) {
+                            const double *q = xyz + (size_t)j * stride;
+                            pin[3 * j] = q[0]; pin[3 * j + 1] = q[1]; pin[3 * j + 2] = q[2];
+                        }
+                });
+                HIP_TRY(hipMemcpyAsync((double *)d_raw_ + 3 * lo, pin + 3 * lo, sizeof(double) * 3 * (size_t)(hi - lo),
+                                       hipMemcpyHostToDevice, stream_));
+            }
+            HIP_TRY(launch_expand_f64((const double *)d_raw_, nt, c, (float4 *)d_tgt_, (Pt64 *)d_tgt64_, stream_));
+        }
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_source64(const Pt64 *src) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        free_dev(d_src64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
+        grid_valid_ = false;
+        if (!src || !d_tgt64_) { err_ = "set_source64 without an f64 target"; return VISMA_ICP_ERR_STATE; }
+        { int prc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns_, 1)); if (prc) return prc; }
+        if (ns_ > 0) HIP_TRY(hipMemcpyAsync(d_src64_, src, sizeof(Pt64) * ns_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    void *d_raw_ = nullptr;
+    size_t raw_bytes_ = 0;
     int set_clouds64(const Pt64 *src, const Pt64 *tgt) override
     {
         HIP_TRY(hipSetDevice(device_));
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         grid_valid_ = false;                                     // the sorted f64 copy is built with the grid
         if (!src || !tgt) return VISMA_ICP_OK;
-        HIP_TRY(hipMalloc(&d_src64_, sizeof(Pt64) * std::max<int64_t>(ns_, 1)));
-        HIP_TRY(hipMalloc(&d_tgt64_, sizeof(Pt64) * std::max<int64_t>(nt_, 1)));
+        { int prc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns_, 1)); if (prc) return prc; }
+        { int prc = pool_alloc(&d_tgt64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt_, 1)); if (prc) return prc; }
         if (ns_ > 0) HIP_TRY(hipMemcpyAsync(d_src64_, src, sizeof(Pt64) * ns_, hipMemcpyHostToDevice, stream_));
         if (nt_ > 0) HIP_TRY(hipMemcpyAsync(d_tgt64_, tgt, sizeof(Pt64) * nt_, hipMemcpyHostToDevice, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
@@ -1280,13 +1360,62 @@ public:
     void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }
 
 private:
-    void free_dev(void *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+    // Cloud-sized device buffers are recycled: a registration after another of about the same size
+    // (every caller's loop) re-uses them instead of paying hipFree + hipMalloc (a device sync and ~0.5 ms
+    // per 100 MB).  pool_alloc'ed pointers are returned by the ordinary free_dev.
+    std::unordered_map<void *, size_t> pool_live_;
+    std::vector<std::pair<void *, size_t>> pool_free_;
+    int pool_alloc(void **p, size_t bytes)
+    {
+        bytes = std::max<size_t>(bytes, 256);
+        int best = -1;
+        for (int i = 0; i < (int)pool_free_.size(); i++)
+            if (pool_free_[i].second >= bytes && pool_free_[i].second <= 2 * bytes + (1u << 20) &&
+                (best < 0 || pool_free_[i].second < pool_free_[best].second))
+                best = i;
+        if (best >= 0) {
+            *p = pool_free_[best].first;
+            pool_live_[*p] = pool_free_[best].second;
+            pool_free_.erase(pool_free_.begin() + best);
+            return VISMA_ICP_OK;
+        }
+        const size_t want = bytes + bytes / 8;                 // a little head-room: the next cloud is rarely the same size
+        if (hipMalloc(p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            pool_trim(0);                                      // give the recycled buffers back and try the exact size
+            HIP_TRY(hipMalloc(p, bytes));
+            pool_live_[*p] = bytes;
+            return VISMA_ICP_OK;
+        }
+        pool_live_[*p] = want;
+        return VISMA_ICP_OK;
+    }
+    void pool_trim(size_t keep)
+    {
+        while (pool_free_.size() > keep) {
+            (void)hipFree(pool_free_.front().first);
+            pool_free_.erase(pool_free_.begin());
+        }
+    }
+    void free_dev(void *&p)
+    {
+        if (!p) return;
+        auto it = pool_live_.find(p);
+        if (it == pool_live_.end()) {
+            (void)hipFree(p);
+        } else {
+            pool_free_.push_back({p, it->second});
+            pool_live_.erase(it);
+            pool_trim(10);
+        }
+        p = nullptr;
+    }
     int ensure_source(int64_t ns)
     {
         if (ns < 0) { err_ = "negative point count"; return VISMA_ICP_ERR_INVALID; }
         if (ns > 0x7fffffff - 4096) { err_ = "source too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
         free_dev(d_src_);
-        HIP_TRY(hipMalloc(&d_src_, sizeof(float4) * (ns > 0 ? ns : 1)));
+        { int prc = pool_alloc(&d_src_, sizeof(float4) * (size_t)(ns > 0 ? ns : 1)); if (prc) return prc; }
         ns_ = ns;
         have_pass_ = false;
         free_dev(d_src64_);                                      // belongs to the previous source
@@ -1301,7 +1430,7 @@ private:
         // pad to a whole number of LDS chunks with +inf points (never accepted)
         nt_pad_ = ((nt + kTChunk - 1) / kTChunk) * kTChunk;
         if (nt_pad_ == 0) nt_pad_ = kTChunk;
-        HIP_TRY(hipMalloc(&d_tgt_, sizeof(float4) * nt_pad_));
+        { int prc = pool_alloc(&d_tgt_, sizeof(float4) * (size_t)nt_pad_); if (prc) return prc; }
         HIP_TRY(launch_fill_inf((float4 *)d_tgt_ + nt, nt_pad_ - nt, stream_));
         nt_ = nt;
         grid_valid_ = false;
@@ -1371,7 +1500,7 @@ private:
             cell_cap_ = grid_.ncell + 1;
         }
         free_dev(d_sorted64_);
-        if (d_tgt64_ && d_src64_) HIP_TRY(hipMalloc(&d_sorted64_, sizeof(Pt64) * std::max<int64_t>(nt_, 1)));
+        if (d_tgt64_ && d_src64_) { int prc = pool_alloc(&d_sorted64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt_, 1)); if (prc) return prc; }
         HIP_TRY(launch_grid_build((const float4 *)d_tgt_, nt_, grid_, (unsigned *)d_cell_of_,
                                   (unsigned *)d_count_, (unsigned *)d_bsum_, (unsigned *)d_start_,
                                   (float4 *)d_sorted_, stream_, d_sorted64_ ? (const Pt64 *)d_tgt64_ : nullptr,
@@ -1837,30 +1966,6 @@ struct visma_icp_ctx {
 
 namespace {
 
-// Run fn(i) for i in [0, n) on a few host threads (packing / ordering of clouds).
-template <typename F>
-void parallel_for(int64_t n, int64_t min_per_thread, F fn)
-{
-    int64_t nt = (int64_t)std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
-    if (nt < 1) nt = 1;
-    if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
-    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
-    std::vector<std::thread> th;
-    std::atomic<int64_t> next(0);
-    for (int64_t t = 0; t < nt; t++)
-        th.emplace_back([&]() {
-            for (;;) {
-                const int64_t i = next.fetch_add(1);
-                if (i >= n) break;
-                fn(i);
-            }
-        });
-    for (auto &t : th) t.join();
-}
-
-constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
-
 // (x - c) as fp32 (x,y,z,0) rows; `par`: spread over host threads
 void pack_f64_to(const double *xyz, int64_t n, int stride, const double c[3], float *out, bool par)
 {
@@ -2065,11 +2170,23 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     double c[3] = {0, 0, 0};
     if (ctx->fixed_centre) std::memcpy(c, ctx->centre, sizeof(c));
     else centroid_f64(tgt, nt, tstride, c, true);
-    // pack on a few host threads straight into the engine's (pinned) staging memory
-    float *tb = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
-    pack_f64_to(tgt, nt, tstride, c, tb, true);
-    int rc = ctx->eng->set_target(tb, nt);
-    if (rc) return ctx->eng_fail(rc);
+    const bool want64 = ctx->search_precision != 0;     // (target-sharded ranks too: they compare shards in f64)
+    // the target goes up as the caller's f64 values and is expanded on the device (HIP engine); otherwise it
+    // is packed on a few host threads straight into the engine's (pinned) staging memory
+    static const int64_t raw_min = []() {                 // VISMA_ICP_RAW_UPLOAD_MIN: smallest target sent up raw
+        const char *e = std::getenv("VISMA_ICP_RAW_UPLOAD_MIN");
+        return e ? (int64_t)std::atoll(e) : (int64_t)0;
+    }();
+    int rc = nt >= raw_min ? ctx->eng->set_target_f64(tgt, nt, tstride, c, want64 && ctx->eng->supports_device_loop())
+                           : (int)VISMA_ICP_ERR_STATE;
+    const bool raw_target = rc == VISMA_ICP_OK;
+    if (!raw_target) {
+        if (rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);
+        float *tb = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
+        pack_f64_to(tgt, nt, tstride, c, tb, true);
+        rc = ctx->eng->set_target(tb, nt);
+        if (rc) return ctx->eng_fail(rc);
+    }
     float *sb = ctx->eng->staging(1, (size_t)std::max<int64_t>(ns, 1) * 4);
     pack_f64_to(src, ns, sstride, c, sb, true);
     morton_order_ptr(sb, ns, ctx->src_order, true);
@@ -2077,13 +2194,12 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     if (rc) return ctx->eng_fail(rc);
     // double-precision search: the caller's own f64 coordinates (centred in f64) go along
     // (the size-keyed policy of round 1 is gone: the exact search costs the same as the fp32 one)
-    const bool want64 = ctx->search_precision != 0;     // (target-sharded ranks too: they compare shards in f64)
     ctx->eng->set_exact(ctx->search_precision == 1);
     if (want64 && ctx->eng->supports_device_loop()) {
         // (Pt64 = 8 floats of staging; pinned on the HIP engine)
-        Pt64 *t8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(2, (size_t)std::max<int64_t>(nt, 1) * 8));
+        Pt64 *t8 = raw_target ? nullptr : reinterpret_cast<Pt64 *>(ctx->eng->staging(2, (size_t)std::max<int64_t>(nt, 1) * 8));
         Pt64 *s8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(3, (size_t)std::max<int64_t>(ns, 1) * 8));
-        parallel_for((nt + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
+        if (!raw_target) parallel_for((nt + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
             const int64_t lo = ch * kHostChunk, hi = std::min(nt, lo + kHostChunk);
             for (int64_t j = lo; j < hi; j++) {
                 const double *q = tgt + (size_t)j * tstride;
@@ -2097,7 +2213,7 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
                 s8[(size_t)pos] = Pt64{q[0] - c[0], q[1] - c[1], q[2] - c[2], (unsigned long long)ctx->src_order[(size_t)pos]};
             }
         });
-        rc = ctx->eng->set_clouds64(s8, t8);
+        rc = raw_target ? ctx->eng->set_source64(s8) : ctx->eng->set_clouds64(s8, t8);
         if (rc) return ctx->eng_fail(rc);
     } else if (ctx->eng->supports_device_loop()) {
         rc = ctx->eng->set_clouds64(nullptr, nullptr);

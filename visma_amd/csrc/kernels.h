@@ -228,6 +228,8 @@ hipError_t launch_nn_tile_reduce(const TileArgs &a, int point_to_plane, int conf
                                  hipStream_t stream);
 // float4 (x, y, z, .) -> Pt64 (x, y, z, index): f64 view of clouds uploaded as fp32
 hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStream_t stream);
+// raw f64 xyz (3 doubles per point) -> f4[j] = ((float)(x - c), .., 0) and, when p8 != NULL, p8[j] = {x - c, .., j}
+hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream);
 
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
