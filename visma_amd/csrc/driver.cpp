@@ -156,6 +156,10 @@ public:
         int src_share = -1, grid_share = -1;
         // f64 copies for the double-precision search (all problems of a batch or none)
         const Pt64 *src64 = nullptr, *tgt64 = nullptr;
+        // the target as the caller's f64 array (stride 3) instead of tgt_xyzw / tgt64: uploaded as it is and
+        // expanded on the device around `centre` (tgt_f64: with the f64 copy)
+        const double *tgt_raw = nullptr;
+        bool tgt_f64 = false;
         // target normals (point-to-plane batches: every problem or none), indexed like the target
         const float *nrm_xyzw = nullptr;
         const Pt64 *nrm64 = nullptr;
@@ -233,7 +237,7 @@ public:
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
-        free_dev(bt_nrm_); free_dev(bt_nrm64_);
+        free_dev(bt_nrm_); free_dev(bt_nrm64_); free_dev(bt_raw_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
         if (h_state_) (void)hipHostFree(h_state_);
@@ -957,7 +961,7 @@ public:
         for (int b = 0; b < B; b++) {
             const BatchProblem &q = pb[b];
             const BatchProblem &sq = q.src_share >= 0 ? pb[q.src_share] : q, &tq = q.grid_share >= 0 ? pb[q.grid_share] : q;
-            f64 = f64 && (q.ns == 0 || sq.src64) && (q.nt == 0 || tq.tgt64);
+            f64 = f64 && (q.ns == 0 || sq.src64) && (q.nt == 0 || tq.tgt64 || (tq.tgt_raw && tq.tgt_f64));
         }
         if (f64 && (src_tot > bt_src64_cap_ || tgt_tot > bt_tgt64_cap_)) {
             free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
@@ -991,6 +995,15 @@ public:
             HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(out_tot, 1)));
             HIP_TRY(hipMalloc(&bt_d2_, sizeof(float) * std::max<int64_t>(out_tot, 1)));
             bt_out_cap_ = out_tot;
+        }
+        {
+            bool any_raw = false;
+            for (int b = 0; b < B; b++) any_raw = any_raw || pb[b].tgt_raw != nullptr;
+            if (any_raw && (size_t)tgt_tot * 24 > bt_raw_bytes_) {
+                free_dev(bt_raw_);
+                HIP_TRY(hipMalloc(&bt_raw_, (size_t)std::max<int64_t>(tgt_tot, 1) * 24));
+                bt_raw_bytes_ = (size_t)tgt_tot * 24;
+            }
         }
         if (tgt_tot > bt_tgt_cap_) {
             free_dev(bt_tgt_); free_dev(bt_sorted_); free_dev(bt_cell_of_);
@@ -1039,9 +1052,16 @@ public:
             if (f64 && q.ns > 0 && q.src_share < 0)
                 HIP_TRY(hipMemcpyAsync((Pt64 *)bt_src64_ + d.src_off, q.src64, sizeof(Pt64) * q.ns, hipMemcpyHostToDevice, stream_));
             if (q.grid_share >= 0) continue;
-            if (q.nt > 0) HIP_TRY(hipMemcpyAsync((float4 *)bt_tgt_ + d.sorted_off, q.tgt_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
-            if (f64 && q.nt > 0)
-                HIP_TRY(hipMemcpyAsync((Pt64 *)bt_tgt64_ + d.sorted_off, q.tgt64, sizeof(Pt64) * q.nt, hipMemcpyHostToDevice, stream_));
+            if (q.nt > 0 && q.tgt_raw) {
+                double *raw = (double *)bt_raw_ + 3 * d.sorted_off;
+                HIP_TRY(hipMemcpyAsync(raw, q.tgt_raw, sizeof(double) * 3 * q.nt, hipMemcpyHostToDevice, stream_));
+                HIP_TRY(launch_expand_f64(raw, q.nt, q.centre, (float4 *)bt_tgt_ + d.sorted_off,
+                                          f64 ? (Pt64 *)bt_tgt64_ + d.sorted_off : nullptr, stream_));
+            } else if (q.nt > 0) {
+                HIP_TRY(hipMemcpyAsync((float4 *)bt_tgt_ + d.sorted_off, q.tgt_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
+                if (f64)
+                    HIP_TRY(hipMemcpyAsync((Pt64 *)bt_tgt64_ + d.sorted_off, q.tgt64, sizeof(Pt64) * q.nt, hipMemcpyHostToDevice, stream_));
+            }
             if (lp.plane && q.nt > 0) {
                 if (f64) HIP_TRY(hipMemcpyAsync((Pt64 *)bt_nrm64_ + d.sorted_off, q.nrm64, sizeof(Pt64) * q.nt, hipMemcpyHostToDevice, stream_));
                 else HIP_TRY(hipMemcpyAsync((float4 *)bt_nrm_ + d.sorted_off, q.nrm_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
@@ -1609,6 +1629,8 @@ private:
     void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
     void *bt_src64_ = nullptr, *bt_tgt64_ = nullptr, *bt_sorted64_ = nullptr;
     int64_t bt_src64_cap_ = 0, bt_tgt64_cap_ = 0;
+    void *bt_raw_ = nullptr;                               // targets as uploaded (caller's f64 values)
+    size_t bt_raw_bytes_ = 0;
     void *bt_nrm_ = nullptr, *bt_nrm64_ = nullptr;         // point-to-plane batches: target normals
     int64_t bt_nrm_cap_ = 0, bt_nrm64_cap_ = 0;
     void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
@@ -2601,6 +2623,7 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
             }
         }
         std::vector<std::array<double, 3>> cen((size_t)n);
+        std::vector<std::array<float, 6>> tbox((size_t)n);
         // double-precision search for the whole batch when every problem qualifies
         const bool want64 = ctx->search_precision != 0;
         std::vector<std::vector<Pt64>> s8((size_t)n), t8((size_t)n), n8((size_t)n);
@@ -2623,13 +2646,17 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
                 double c[3];
                 centroid_f64(q.tgt_xyz, q.nt, 3, c, false);       // the same value as set_clouds_f64 computes
                 for (int a = 0; a < 3; a++) cen[i][a] = c[a];
-                pack_f64(q.tgt_xyz, q.nt, 3, c, tbuf[i]);
-                if (want64) {
-                    t8[i].resize((size_t)std::max<int64_t>(q.nt, 1));
-                    for (int64_t j = 0; j < q.nt; j++)
-                        t8[i][(size_t)j] = Pt64{q.tgt_xyz[3 * j] - c[0], q.tgt_xyz[3 * j + 1] - c[1],
-                                               q.tgt_xyz[3 * j + 2] - c[2], (unsigned long long)j};
-                }
+                // the target itself is uploaded as it is and expanded on the device; the host only needs the
+                // bounding box of its fp32 copy: the rounding (float)(x - c) is monotone, so the box of the
+                // f64 values, rounded the same way, is the box of the rounded values
+                double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                for (int64_t j = 0; j < q.nt; j++)
+                    for (int a = 0; a < 3; a++) {
+                        const double v = q.tgt_xyz[3 * j + a];
+                        if (j == 0 || v < lo[a]) lo[a] = v;
+                        if (j == 0 || v > hi[a]) hi[a] = v;
+                    }
+                for (int a = 0; a < 3; a++) { tbox[i][a] = (float)(lo[a] - c[a]); tbox[i][3 + a] = (float)(hi[a] - c[a]); }
             });
         if (ok)
             parallel_for(n, 1, [&](int64_t i) {
@@ -2650,11 +2677,13 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
                 }
                 Engine::BatchProblem &b = pb[i];
                 b.src64 = (want64 && sshare[i] < 0) ? s8[i].data() : nullptr;
-                b.tgt64 = want64 ? t8[t].data() : nullptr;
+                b.tgt64 = nullptr;
+                b.tgt_raw = probs[t].tgt_xyz;
+                b.tgt_f64 = want64;
                 b.nrm64 = (plane && want64) ? n8[t].data() : nullptr;
                 b.nrm_xyzw = (plane && !want64) ? nbuf[t].data() : nullptr;
                 b.src_xyzw = sshare[i] < 0 ? sbuf[i].data() : nullptr; b.ns = q.ns;
-                b.tgt_xyzw = tbuf[t].data(); b.nt = q.nt;
+                b.tgt_xyzw = nullptr; b.nt = q.nt;
                 b.src_share = sshare[i];
                 b.grid_share = gshare[i];
                 b.Tc0 = to_centred(Mat4::from(q.init), c);
@@ -2662,12 +2691,8 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
                 b.max_dist = q.max_dist;
                 for (int a = 0; a < 3; a++) { b.bb_min[a] = 0.f; b.bb_max[a] = 0.f; }
                 if (gshare[i] >= 0) return;                        // the grid (and its box) is reused
-                for (int64_t j = 0; j < q.nt; j++)
-                    for (int a = 0; a < 3; a++) {
-                        const float v = tbuf[t][4 * j + a];
-                        if (j == 0 || v < b.bb_min[a]) b.bb_min[a] = v;
-                        if (j == 0 || v > b.bb_max[a]) b.bb_max[a] = v;
-                    }
+                if (q.nt > 0)
+                    for (int a = 0; a < 3; a++) { b.bb_min[a] = tbox[t][a]; b.bb_max[a] = tbox[t][3 + a]; }
             });
         if (ok) {
             Engine::LoopParams lp;
