@@ -1663,7 +1663,10 @@ private:
         // (lanes per query, loads in flight per lane), encoded G + 100*U
         if (f64_src() && exact_)   // exact search (re-measured with the branch-free insertion: tools/lanes_probe.py,
                                    // bench.py --workload c5: sweeps of ~200 k queries 801 309 k it/s, 402 295 k, 802 274 k)
-            return q <= 32768 ? 408 : (nprob > 1 ? (q <= 98304 ? 402 : 801) : (q <= 131072 ? 802 : 801));
+            // single problems (also the source shards of 2 / 4 / 8 ranks against a 4 M-point target, tools/lanes_probe.py
+            // 32768 / 65536 / 131072 x 4194304: 804 31.6 us vs 408 34.0; 802 34.0; 1201 41.5 vs 801 43.0, 802 47.6)
+            return nprob > 1 ? (q <= 32768 ? 408 : (q <= 98304 ? 402 : 801))
+                             : (q <= 32768 ? 804 : (q <= 98304 ? 802 : (q <= 196608 ? 1201 : 801)));
         if (f64_src())   // 32-byte candidates: fewer in flight per lane (measured 5k: 408 15.8 us vs 804 18.1)
             return q <= 32768 ? 408 : (nprob > 1 ? 402 : (q <= 131072 ? 802 : 801));
         if (nprob > 1) return q <= 32768 ? 804 : 402;          // sweeps: many queries per launch
