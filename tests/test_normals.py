@@ -115,6 +115,17 @@ def test_gpu_large_cloud_properties(lib):
 
 
 @pytest.mark.gpu
+def test_gpu_longest_neighbour_list(lib, oracle):
+    """knn = 170, the longest list the LDS holds (64 threads x 170 entries)."""
+    pts = synth.surface_points(2500, 31) + np.random.default_rng(31).normal(size=(2500, 3)) * 1e-3
+    ctx = _lib.Context(0)
+    for kw in (dict(knn=170), dict(knn=170, radius=0.5)):
+        want = oracle.estimate_normals(pts, **kw)
+        got = ctx.estimate_normals(pts, **kw)
+        assert np.abs(got - want).max() < 1e-9, kw
+
+
+@pytest.mark.gpu
 def test_gpu_argument_errors(lib):
     ctx = _lib.Context(0)
     pts = np.random.default_rng(0).normal(size=(100, 3))
