@@ -382,6 +382,14 @@ def run_c4(R, args):
     T, last, elapsed, tm, setup = timed_iterations(R, ctx, radius, args.warmup, args.steps, args.nn, prof_every)
     mode = "grid" if ctx.nn_mode_used() == _lib.NN_GRID else "brute"
     search = ctx.search_mode_used()
+    # every rank solved from the same all-reduced statistics: their transforms must agree to the bit
+    ranks_agree = True
+    if R.dist is not None:
+        tt = R.torch.tensor(np.asarray(T, np.float64).ravel(), dtype=R.torch.float64, device=R.tdev)
+        hi, lo = tt.clone(), tt.clone()
+        R.dist.all_reduce(hi, op=R.dist.ReduceOp.MAX)
+        R.dist.all_reduce(lo, op=R.dist.ReduceOp.MIN)
+        ranks_agree = bool(R.torch.equal(hi, lo))
     nl = max(tm["nn_launches"], 1)
     nn_ms = R.reduce_max(tm["nn_ms"] / nl)
     cand, cand27 = tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl
@@ -468,7 +476,7 @@ def run_c4(R, args):
             "candidates_evaluated_per_sec": cand * R.world * args.steps / elapsed if mode == "grid" else float(ns) * nt * args.steps / elapsed,
             "equivalent_bruteforce_mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
             "matched_corr_per_sec": last.num_correspondences * args.steps / elapsed,
-            "fitness": last.fitness_, "inlier_rmse": last.inlier_rmse_,
+            "fitness": last.fitness_, "inlier_rmse": last.inlier_rmse_, "ranks_hold_identical_transforms": ranks_agree,
             "err_vs_T_gt": synth.rel_frobenius(T, T_gt),
             "setup_ms": {"grid_build_kernels": setup["aux_ms"]},
             "roofline": roofline,

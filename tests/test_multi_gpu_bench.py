@@ -41,7 +41,7 @@ def test_two_ranks_match_one(lib, shard, comm):
         pytest.skip("needs two GPUs")
     one = _bench([], {}, 1)
     two = _bench(["--shard", shard, "--no-weak"], {"VISMA_BENCH_COMM": comm}, 2)
-    assert two["n_gpus"] == 2
+    assert two["n_gpus"] == 2 and two["ranks_hold_identical_transforms"] is True
     want = {"ipc": "hipipc", "rccl": "rccl"}[comm]
     assert want in two["config"]["parallelism"].lower(), two["config"]["parallelism"]
     # the same registration: same fitness, same distance to the ground-truth motion
