@@ -294,13 +294,14 @@ def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
 def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, cand27_per_launch, traffic, exact):
     # ALGORITHMIC bytes of ONE grid launch on one rank.  Per query: the source point (32 B f64 in the exact
     # search, 16 B fp32 otherwise) + 9 x 16 B cell-run lookups + 8 B (index, d2) out (+ 32 B: the winner in
-    # f64), plus 16 B per candidate target point EXAMINED (counted by the kernel; rows of cells that provably
-    # cannot hold a better candidate are skipped, so this is less than the full 3x3x3 neighbourhood, whose
-    # byte count is given for reference).
+    # f64), plus 12 B (exact search: packed x,y,z) or 16 B per candidate target point EXAMINED (counted by the
+    # kernel; rows of cells that provably cannot hold a better candidate are skipped, so this is less than the
+    # full 3x3x3 neighbourhood, whose byte count is given for reference).
     per_query = (32.0 + 144.0 + 8.0 + 32.0) if exact else (16.0 + 144.0 + 8.0)
-    b_alg = queries * per_query + 16.0 * cand_per_launch
-    b_27 = queries * per_query + 16.0 * cand27_per_launch
-    comp = nt_total * 16.0 + queries * (per_query - 144.0)
+    cand_bytes = 12.0 if exact else 16.0
+    b_alg = queries * per_query + cand_bytes * cand_per_launch
+    b_27 = queries * per_query + cand_bytes * cand27_per_launch
+    comp = nt_total * cand_bytes + queries * (per_query - 144.0)
     nn_ms = max(nn_ms, 1e-9)
     gbps = b_alg / (nn_ms * 1e-3) / 1e9
     return {
@@ -316,8 +317,8 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, cand27_per_launch, 
         "compulsory_bytes": comp,
         "frac_on_compulsory_bytes": comp / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
         "note": "one launch per iteration: transform + grid NN + f64 re-rank + Jacobian/residual reduction + fold. "
-                "Bound in practice by per-lane gathers (one L1 line access per 16-B candidate) alternating with "
-                "VALU phases, not by HBM: see DESIGN.md 4.1b",
+                "Bound in practice by the chain of dependent gathers of a wave (source, row bounds, ~10 batch trips, "
+                "winner, fold), not by HBM streaming: see DESIGN.md 4.1b",
     }
 
 
@@ -695,8 +696,8 @@ def run_c5(R, args):
             tm = ctx.get_timing(reset=True)
             nl = tm["nn_launches"]
             q = sum(len(cads[c]) for s, c in chunk) * level
-            b_alg += nl * q * (32.0 + 144.0 + 8.0 + 32.0) + 16.0 * tm["grid_candidates"]
-            b_comp += nl * (sum(len(scenes[s]) for s, c in chunk) * 16.0 + q * 72.0)
+            b_alg += nl * q * (32.0 + 144.0 + 8.0 + 32.0) + 12.0 * tm["grid_candidates"]
+            b_comp += nl * (sum(len(scenes[s]) for s, c in chunk) * 12.0 + q * 72.0)
             ms += tm["nn_ms"]
             launches += nl
         ctx.set_profiling(0)

@@ -225,7 +225,7 @@ public:
         if (comm_) g_rccl.CommDestroy(comm_);
         for (int r = 0; r < ipc_n_; r++)
             if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
-        free_dev(d_mbox_); free_dev(d_ipc_flag_); free_dev(d_raw_);
+        free_dev(d_mbox_); free_dev(d_ipc_flag_); free_dev(d_raw_); free_dev(d_sorted12_); free_dev(bt_sorted12_);
         free_dev(d_pend_count_); free_dev(d_pend_q32_); free_dev(d_pend_q64_); free_dev(d_pend_best_); free_dev(d_pend_idx_);
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
@@ -344,6 +344,12 @@ public:
     }
     void *d_raw_ = nullptr;
     size_t raw_bytes_ = 0;
+    void *d_sorted12_ = nullptr;                           // packed (x,y,z) copy of d_sorted_ for the exact search
+    const float4 *search_sorted() const                    // what launch_nn_grid_reduce gets as `sorted`
+    {
+        if (exact_ && d_src64_ && d_sorted64_ && d_sorted12_) return (const float4 *)d_sorted12_;
+        return (const float4 *)d_sorted_;
+    }
     int set_clouds64(const Pt64 *src, const Pt64 *tgt) override
     {
         HIP_TRY(hipSetDevice(device_));
@@ -585,7 +591,7 @@ public:
                 if (ipc) { add_ipc(&fa); ipc_done = true; }
             }
             if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-            HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
+            HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, grid_blocks(),
@@ -686,7 +692,7 @@ public:
             // nn_pass without a reduction: run the fused kernel for its index output
             const Xform64 T64 = T64_last_;
             int nblocks = 1;
-            HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
+            HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
@@ -806,7 +812,7 @@ public:
                         if (rc) return rc;
                         if (ipc_n_ > 1) add_ipc(&fa);      // (one problem per rank: ipc needs nprob == 1)
                     }
-                    HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, (const float4 *)d_sorted_,
+                    HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
                                                   (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                                   T32_, T64, nullptr, r2f_, plane, (int32_t *)d_idx_,
                                                   (float *)d_d2_, (double *)d_partials_,
@@ -1073,6 +1079,15 @@ public:
                                       f64 ? (const Pt64 *)bt_tgt64_ + d.sorted_off : nullptr,
                                       f64 ? (Pt64 *)bt_sorted64_ + d.sorted_off : nullptr));
         }
+        const bool packed = f64 && exact_;                   // the exact search ranks on packed (x,y,z) triples
+        if (packed) {
+            if (tgt_tot > bt_sorted12_cap_) {
+                free_dev(bt_sorted12_);
+                HIP_TRY(hipMalloc(&bt_sorted12_, sizeof(float) * 3 * (size_t)(std::max<int64_t>(tgt_tot, 1) + kSortedSlack)));
+                bt_sorted12_cap_ = tgt_tot;
+            }
+            HIP_TRY(launch_pack12((const float4 *)bt_sorted_, (float *)bt_sorted12_, tgt_tot, stream_));
+        }
         HIP_TRY(hipMemcpyAsync(bt_descs_, descs.data(), sizeof(ProbDesc) * B, hipMemcpyHostToDevice, stream_));
         for (int b = 0; b < B; b++) {
             DevIcpState &h = h_state_[b];
@@ -1111,7 +1126,7 @@ public:
             const int n = std::min(chunk, lp.passes - done);
             for (int j = 0; j < n; j++) {
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-                HIP_TRY(launch_nn_grid_reduce_batch((const float4 *)bt_src_, (const float4 *)bt_sorted_,
+                HIP_TRY(launch_nn_grid_reduce_batch((const float4 *)bt_src_, packed ? (const float4 *)bt_sorted12_ : (const float4 *)bt_sorted_,
                                                     (const unsigned *)bt_start_, (const ProbDesc *)bt_descs_, B,
                                                     total_blocks, (int32_t *)bt_idx_, (float *)bt_d2_,
                                                     (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_,
@@ -1525,6 +1540,13 @@ private:
                                   (unsigned *)d_count_, (unsigned *)d_bsum_, (unsigned *)d_start_,
                                   (float4 *)d_sorted_, stream_, d_sorted64_ ? (const Pt64 *)d_tgt64_ : nullptr,
                                   (Pt64 *)d_sorted64_));
+        // the exact search ranks on a packed copy: 12 bytes per candidate (grid.hip: P12)
+        free_dev(d_sorted12_);
+        if (d_sorted64_) {
+            int prc = pool_alloc(&d_sorted12_, sizeof(float) * 3 * (size_t)(nt_ + kSortedSlack));
+            if (prc) return prc;
+            HIP_TRY(launch_pack12((const float4 *)d_sorted_, (float *)d_sorted12_, nt_, stream_));
+        }
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
         grid_valid_ = true;
         grid_radius_ = max_dist;
@@ -1629,6 +1651,8 @@ private:
     void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
     void *bt_src64_ = nullptr, *bt_tgt64_ = nullptr, *bt_sorted64_ = nullptr;
     int64_t bt_src64_cap_ = 0, bt_tgt64_cap_ = 0;
+    void *bt_sorted12_ = nullptr;                          // packed copy of bt_sorted_ (exact search)
+    int64_t bt_sorted12_cap_ = 0;
     void *bt_raw_ = nullptr;                               // targets as uploaded (caller's f64 values)
     size_t bt_raw_bytes_ = 0;
     void *bt_nrm_ = nullptr, *bt_nrm64_ = nullptr;         // point-to-plane batches: target normals

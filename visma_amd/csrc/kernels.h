@@ -232,6 +232,7 @@ hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStrea
 hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream);
 
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
+hipError_t launch_pack12(const float4 *src, float *dst, int64_t n, hipStream_t stream);   // (x,y,z,w) -> packed (x,y,z)
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
 GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells, int max_sub = 1);
 int grid_scan_blocks(int64_t ncell);
