@@ -208,3 +208,43 @@ def test_target_sharded_ranks_reproduce_the_reference_fuzz_cases(lib):
         for res in out:
             assert res.num_correspondences == int(G["ref_k"][i]), i
             assert synth.rel_frobenius(res.transformation_, G["ref_T"][i]) < 1e-9, i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("plane", [False, True])
+def test_target_shard_device_loop_through_rccl(lib, plane):
+    """A target-sharded rank in the device loop: keys, the two MIN all-reduces, the owners' moments, the sum
+    and the solve all on the stream (RCCL), the host reads the state back every 8 passes.  One rank holding the
+    whole target (a 1-rank communicator is what one GPU can run) must reproduce the unsharded run; the host
+    loop through the same communicator too."""
+    try:
+        uid = _lib.comm_unique_id()
+    except _lib.IcpError as e:                       # pragma: no cover
+        pytest.skip("RCCL not loadable here: %s" % e)
+    src, tgt, T_gt, radius = synth.make_pair(12000, 50000, motion="radius")
+    tgt = np.concatenate([tgt, tgt[:300]])                 # exact ties
+    nrm = tgt / np.linalg.norm(tgt, axis=1, keepdims=True)
+
+    def run(ctx):
+        return ctx.run_point_to_plane(None, radius, 10, 1e-9, 1e-9) if plane else ctx.run(None, radius, 10, 1e-9, 1e-9)
+
+    ref = _lib.Context(0)
+    ref.set_clouds_f64(src, tgt)
+    if plane:
+        ref.set_target_normals_f64(nrm)
+    want = run(ref)
+    want_idx = ref.correspondence_index()
+    for device_loop in (False, True):
+        ctx = _lib.Context(0)
+        ctx.set_target_shard(0, len(tgt), tgt.mean(0))
+        ctx.comm_init(0, 1, uid if not device_loop else _lib.comm_unique_id())
+        ctx.set_device_loop(device_loop)
+        ctx.set_clouds_f64(src, tgt)
+        if plane:
+            ctx.set_target_normals_f64(nrm)
+        got = run(ctx)
+        assert ctx.search_mode_used() == "exact"
+        assert got.num_correspondences == want.num_correspondences and got.iterations == want.iterations
+        assert synth.rel_frobenius(got.transformation_, want.transformation_) < (1e-7 if plane else 1e-12)
+        assert np.array_equal(ctx.correspondence_index(), want_idx)
+        ctx.close()

@@ -175,6 +175,7 @@ public:
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
     virtual bool has_device_allreduce() const { return false; }
+    virtual bool shard_loop_on_device() const { return false; }
     // aux entry points (voxel / mesh steps) run on THIS context's device and stream
     virtual int bind_device() { return VISMA_ICP_OK; }
     virtual hipStream_t aux_stream() { return nullptr; }
@@ -741,6 +742,10 @@ public:
             err_ = "batched loop needs the grid search on a single GPU";
             return VISMA_ICP_ERR_STATE;
         }
+        if (tshard_ && !(shard_loop_on_device() && use_grid_)) {
+            err_ = "the device loop of a target shard needs the library's RCCL communicator, f64 clouds and the grid search";
+            return VISMA_ICP_ERR_STATE;
+        }
         const int64_t ns_rounded = ((ns_ + kBlock - 1) / kBlock) * kBlock;
         view_offset_ = 0;
         loop_out_stride_ = ns_rounded;
@@ -805,7 +810,7 @@ public:
                 if (use_grid_) {
                     // fold inside the search launch: the statistics land in the problems' device state
                     FoldArgs fa{};
-                    fused = fused_fold_ != 0;
+                    fused = fused_fold_ != 0 && !tshard_;       // (target shards fold after their exchange)
                     if (fused) {
                         rc = make_fold(grid_launch_blocks(ns_, grid_lanes(nprob), reduce_max_blocks()), nprob,
                                        st->stats, (long long)(sizeof(DevIcpState) / sizeof(double)), nullptr, 0, &fa);
@@ -819,7 +824,13 @@ public:
                                                   reduce_max_blocks(), &nblocks, grid_lanes(nprob),
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
                                                   nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                                  exact_ ? 1 : 0, fused ? &fa : nullptr));
+                                                  exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr));
+                    if (tshard_) {
+                        // the shards' winners compared on the stream (two MIN all-reduces), the owners' moments
+                        // into the partial rows: everything stream-ordered, the host is not involved
+                        rc = shard_exchange_on_stream(st, plane, &nblocks);
+                        if (rc) return rc;
+                    }
                 } else {
                     HIP_TRY(launch_nn_brute((const float4 *)d_src_, ns_, (const float4 *)d_tgt_, nt_pad_,
                                             T32_, r2f_, (unsigned long long *)d_keys_, ns_pad_, plan_, st,
@@ -1248,6 +1259,42 @@ public:
                                         T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_, (float *)d_d2_,
                                         (double *)d_partials_, reduce_max_blocks(), &nblocks, stream_));
         HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0, (double *)d_stats_, stream_, pub, seq));
+        return VISMA_ICP_OK;
+    }
+
+    // Target shards in the device loop: the f64 protocol of shard_exchange with RCCL's stream-ordered
+    // all-reduces; the kernels read transform / frame / radius from the state.
+    bool shard_loop_on_device() const override { return tshard_ && comm_ != nullptr && shard_f64_protocol(); }
+    int shard_exchange_on_stream(const DevIcpState *st, int plane, int *nblocks)
+    {
+        if (tgt_offset_ + nt_ > tgt_global_) { err_ = "target shard exceeds the global target"; return VISMA_ICP_ERR_INVALID; }
+        if (ns_ > gkeys_cap_) {
+            free_dev(d_gkeys_); free_dev(d_claim_);
+            HIP_TRY(hipMalloc(&d_gkeys_, sizeof(unsigned long long) * std::max<int64_t>(ns_, 1)));
+            HIP_TRY(hipMalloc(&d_claim_, sizeof(unsigned long long) * std::max<int64_t>(ns_, 1)));
+            gkeys_cap_ = ns_;
+        }
+        auto min_reduce = [&](void *keys) -> int {
+            int rc = g_rccl.AllReduce(keys, keys, (size_t)ns_, kNcclUint64, kNcclMin, comm_, stream_);
+            if (rc != 0) {
+                err_ = std::string("ncclAllReduce(min): ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+                return VISMA_ICP_ERR_RCCL;
+            }
+            return VISMA_ICP_OK;
+        };
+        HIP_TRY(launch_shard_keys64((const int32_t *)d_idx_, (const double *)d_d64_, ns_, (unsigned long long *)d_gkeys_, stream_));
+        int rc = min_reduce(d_gkeys_);
+        if (rc) return rc;
+        HIP_TRY(launch_shard_claim64((const int32_t *)d_idx_, (const double *)d_d64_, (const unsigned long long *)d_gkeys_,
+                                     ns_, (unsigned)tgt_offset_, (unsigned long long *)d_claim_, stream_));
+        rc = min_reduce(d_claim_);
+        if (rc) return rc;
+        const Xform64 T64{};
+        HIP_TRY(launch_shard_accumulate64((const Pt64 *)d_src64_, ns_, (const unsigned long long *)d_gkeys_,
+                                          (const unsigned long long *)d_claim_, (const Pt64 *)d_tgt64_, nt_,
+                                          (unsigned)tgt_offset_, (const float4 *)d_nrm_, (const Pt64 *)d_nrm64_, T64,
+                                          nullptr, r2d_, plane, (int32_t *)d_idx_, (float *)d_d2_,
+                                          (double *)d_partials_, reduce_max_blocks(), nblocks, stream_, st));
         return VISMA_ICP_OK;
     }
 
@@ -1933,7 +1980,10 @@ struct visma_icp_ctx {
     // measured 46 vs 68 us per iteration at 5k x 20k), device loop for sweeps of
     // many transforms (their solves run in parallel and nothing syncs per pass)
     int loop_mode = 2;
-    bool device_loop_possible() const { return eng->supports_device_loop() && !host_allreduce && !target_sharded; }
+    bool device_loop_possible() const
+    {
+        return eng->supports_device_loop() && !host_allreduce && (!target_sharded || eng->shard_loop_on_device());
+    }
     bool use_device_loop() const { return loop_mode == 1 && device_loop_possible(); }
     bool use_device_loop_batched() const { return loop_mode != 0 && device_loop_possible(); }
     static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }

@@ -147,7 +147,8 @@ hipError_t launch_shard_accumulate64(const Pt64 *src64, int64_t ns, const unsign
                                      unsigned offset, const float4 *tgt_normals, const Pt64 *nrm64,
                                      const Xform64 &T64, const double frame_offset[3], double r2d,
                                      int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
-                                     int max_partial_blocks, int *nblocks_out, hipStream_t stream);
+                                     int max_partial_blocks, int *nblocks_out, hipStream_t stream,
+                                     const DevIcpState *st = nullptr);
 // stats (device) -> host_out[0..37] (mapped host memory), then host_out[38] = seq (u64 bits)
 hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned long long seq,
                                 hipStream_t stream);

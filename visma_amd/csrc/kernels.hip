@@ -573,9 +573,16 @@ __global__ __launch_bounds__(kBlock) void shard_accumulate64_kernel(
     const Pt64 *__restrict__ src64, int ns, const unsigned long long *__restrict__ gkeys,
     const unsigned long long *__restrict__ claim, const Pt64 *__restrict__ tgt64, long long nt_local, unsigned offset,
     const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, double r2d,
-    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials)
+    int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ partials,
+    const DevIcpState *__restrict__ st)
 {
     constexpr int NACC = Acc<PLANE>::N;
+    if (st) {                                              // device loop: transform, frame and radius from the state
+        Xform32 t32;
+        float r2f = 0.f;
+        if (!load_loop_state(st, t32, T64, off, r2f)) return;
+        r2d = (double)r2f;
+    }
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -622,7 +629,8 @@ hipError_t launch_shard_accumulate64(const Pt64 *src64, int64_t ns, const unsign
                                      unsigned offset, const float4 *tgt_normals, const Pt64 *nrm64,
                                      const Xform64 &T64, const double frame_offset[3], double r2d,
                                      int point_to_plane, int32_t *idx_out, float *d2_out, double *partials,
-                                     int max_partial_blocks, int *nblocks_out, hipStream_t stream)
+                                     int max_partial_blocks, int *nblocks_out, hipStream_t stream,
+                                     const DevIcpState *st)
 {
     Offset64 off;
     for (int a = 0; a < 3; a++) off.v[a] = frame_offset ? frame_offset[a] : 0.0;
@@ -632,11 +640,11 @@ hipError_t launch_shard_accumulate64(const Pt64 *src64, int64_t ns, const unsign
     if (point_to_plane)
         hipLaunchKernelGGL(shard_accumulate64_kernel<true>, dim3(nblocks), dim3(kBlock), 0, stream, src64, (int)ns,
                            gkeys, claim, tgt64, (long long)nt_local, offset, tgt_normals, nrm64, T64, off, r2d, idx_out,
-                           d2_out, partials);
+                           d2_out, partials, st);
     else
         hipLaunchKernelGGL(shard_accumulate64_kernel<false>, dim3(nblocks), dim3(kBlock), 0, stream, src64, (int)ns,
                            gkeys, claim, tgt64, (long long)nt_local, offset, tgt_normals, nrm64, T64, off, r2d, idx_out,
-                           d2_out, partials);
+                           d2_out, partials, st);
     if (nblocks_out) *nblocks_out = nblocks;
     return hipGetLastError();
 }
