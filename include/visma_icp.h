@@ -115,6 +115,8 @@ VISMA_ICP_API int visma_icp_destroy(visma_icp_ctx *ctx);
 /* Message of the last failure on ctx (or of the last failed create if NULL). */
 VISMA_ICP_API const char *visma_icp_last_error(const visma_icp_ctx *ctx);
 VISMA_ICP_API const char *visma_icp_version(void);
+/* Number of HIP devices this process sees (0 without a GPU or a driver); no context needed. */
+VISMA_ICP_API int visma_icp_device_count(void);
 
 /* ---- clouds ------------------------------------------------------------ */
 

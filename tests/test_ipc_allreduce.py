@@ -17,11 +17,7 @@ def _run(world, device_loop):
     import ipc_worker
     from visma_amd import _lib, synth
     ndev = int(os.environ.get("VISMA_TEST_NDEV", "0")) or 1
-    try:
-        import torch
-        ndev = max(ndev, torch.cuda.device_count())
-    except Exception:       # noqa: BLE001
-        pass
+    ndev = max(ndev, _lib.device_count())
     mpc = mp.get_context("spawn")
     pipes, procs = [], []
     for rank in range(world):

@@ -13,11 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _ngpu():
-    try:
-        import torch
-        return torch.cuda.device_count()
-    except Exception:       # noqa: BLE001
-        return 0
+    from visma_amd import _lib
+    return _lib.device_count()
 
 
 def _bench(extra, env_extra, gpus):

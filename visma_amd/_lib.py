@@ -514,6 +514,12 @@ class Context:
         self._chk(self.L.visma_icp_set_global_source_count(self._h, int(n)))
 
 
+def device_count():
+    """HIP devices visible to this process, asked through the library (no torch import: its bundled ROCm
+    libraries, RCCL among them, must not be what a later dlopen in this process resolves to)."""
+    return int(load().visma_icp_device_count())
+
+
 def comm_unique_id():
     L = load()
     buf = C.create_string_buffer(UNIQUE_ID_BYTES)

@@ -2213,6 +2213,13 @@ extern "C" {
 
 const char *visma_icp_version(void) { return "visma-icp-mi355x 0.1 (gfx950)"; }
 
+int visma_icp_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 int visma_icp_create(visma_icp_ctx **out, int device)
 {
     if (!out) { g_create_error = "out is NULL"; return VISMA_ICP_ERR_INVALID; }
