@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -189,6 +190,9 @@ public:
     // want64, the f64 copy {x - c, index}.  set_source64 then completes the pair of f64 clouds.
     virtual int set_target_f64(const double *, int64_t, int, const double *, bool) { return VISMA_ICP_ERR_STATE; }
     virtual int set_source64(const Pt64 *) { return VISMA_ICP_ERR_STATE; }
+    // The source likewise: raw f64 up, then expanded, Morton-ordered and gathered on the device (order.hip);
+    // `order` receives the original index of the point at every position.
+    virtual int set_source_f64(const double *, int64_t, int, const double *, bool, std::vector<int32_t> &) { return VISMA_ICP_ERR_STATE; }
     virtual bool search_is_f64() const { return false; }
     virtual bool search_is_exact() const { return false; }
     virtual void set_exact(bool) {}
@@ -330,6 +334,54 @@ public:
             HIP_TRY(launch_expand_f64((const double *)d_raw_, nt, c, (float4 *)d_tgt_, (Pt64 *)d_tgt64_, stream_));
         }
         HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
+                       std::vector<int32_t> &order) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_source(ns);
+        if (rc) return rc;
+        free_dev(d_sorted64_); free_dev(d_nrm64_);
+        grid_valid_ = false;
+        order.resize((size_t)std::max<int64_t>(ns, 0));
+        if (want64) {
+            if (!d_tgt64_) { err_ = "set_source_f64 without an f64 target"; return VISMA_ICP_ERR_STATE; }
+            rc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns, 1));
+            if (rc) return rc;
+        }
+        if (ns > 0) {
+            if ((size_t)ns * 24 > raw_bytes_) {
+                free_dev(d_raw_);
+                rc = pool_alloc(&d_raw_, (size_t)ns * 24);
+                if (rc) return rc;
+                raw_bytes_ = (size_t)ns * 24;
+            }
+            double *pin = reinterpret_cast<double *>(staging(3, (size_t)ns * 6));
+            parallel_for((ns + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
+                const int64_t a = ch * kHostChunk, b = std::min(ns, a + kHostChunk);
+                if (stride == 3) std::memcpy(pin + 3 * a, xyz + 3 * a, sizeof(double) * 3 * (size_t)(b - a));
+                else
+                    for (int64_t j = a; j < b; j++) {
+                        const double *q = xyz + (size_t)j * stride;
+                        pin[3 * j] = q[0]; pin[3 * j + 1] = q[1]; pin[3 * j + 2] = q[2];
+                    }
+            });
+            HIP_TRY(hipMemcpyAsync(d_raw_, pin, sizeof(double) * 3 * (size_t)ns, hipMemcpyHostToDevice, stream_));
+            void *scratch = nullptr, *d_order = nullptr;
+            const size_t sb = order_source_scratch_bytes(ns);
+            rc = pool_alloc(&scratch, sb);
+            if (rc) return rc;
+            rc = pool_alloc(&d_order, sizeof(int32_t) * (size_t)ns);
+            if (rc) { free_dev(scratch); return rc; }
+            hipError_t e = order_source_device((const double *)d_raw_, ns, c, (float4 *)d_src_, (Pt64 *)d_src64_,
+                                               (int32_t *)d_order, scratch, sb, stream_);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(order.data(), d_order, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, stream_);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+            free_dev(scratch); free_dev(d_order);
+            if (e != hipSuccess) { err_ = std::string("source ordering: ") + hipGetErrorString(e); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
+        }
         return VISMA_ICP_OK;
     }
     int set_source64(const Pt64 *src) override
@@ -2273,9 +2325,13 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad cloud arguments");
     // centre on the target centroid: sequential f64 sum in index order
     // centre on the target centroid (fixed chunked f64 sum: thread-count independent)
+    auto t_now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    static const bool trace = std::getenv("VISMA_ICP_UPLOAD_TRACE") != nullptr;
+    double tm[8]; int ti = 0; tm[ti++] = t_now();
     double c[3] = {0, 0, 0};
     if (ctx->fixed_centre) std::memcpy(c, ctx->centre, sizeof(c));
     else centroid_f64(tgt, nt, tstride, c, true);
+    tm[ti++] = t_now();   // centroid
     const bool want64 = ctx->search_precision != 0;     // (target-sharded ranks too: they compare shards in f64)
     // the target goes up as the caller's f64 values and is expanded on the device (HIP engine); otherwise it
     // is packed on a few host threads straight into the engine's (pinned) staging memory
@@ -2293,15 +2349,35 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
         rc = ctx->eng->set_target(tb, nt);
         if (rc) return ctx->eng_fail(rc);
     }
-    float *sb = ctx->eng->staging(1, (size_t)std::max<int64_t>(ns, 1) * 4);
-    pack_f64_to(src, ns, sstride, c, sb, true);
-    morton_order_ptr(sb, ns, ctx->src_order, true);
-    rc = ctx->eng->set_source(sb, ns);
-    if (rc) return ctx->eng_fail(rc);
+    tm[ti++] = t_now();   // target
+    // the source too goes up raw and is Morton-ordered on the device (HIP engine with a raw target)
+    bool raw_source = false;
+    if (raw_target) {
+        rc = ctx->eng->set_source_f64(src, ns, sstride, c, want64 && ctx->eng->supports_device_loop(), ctx->src_order);
+        raw_source = rc == VISMA_ICP_OK;
+        if (!raw_source && rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);
+    }
+    float *sb = nullptr;
+    if (!raw_source) {
+        sb = ctx->eng->staging(1, (size_t)std::max<int64_t>(ns, 1) * 4);
+        pack_f64_to(src, ns, sstride, c, sb, true);
+    }
+    tm[ti++] = t_now();   // source pack
+    if (!raw_source) morton_order_ptr(sb, ns, ctx->src_order, true);
+    tm[ti++] = t_now();   // morton
+    if (!raw_source) {
+        rc = ctx->eng->set_source(sb, ns);
+        if (rc) return ctx->eng_fail(rc);
+    }
     // double-precision search: the caller's own f64 coordinates (centred in f64) go along
     // (the size-keyed policy of round 1 is gone: the exact search costs the same as the fp32 one)
     ctx->eng->set_exact(ctx->search_precision == 1);
-    if (want64 && ctx->eng->supports_device_loop()) {
+    if (raw_source) {
+        if (!(want64 && ctx->eng->supports_device_loop())) {
+            rc = ctx->eng->set_clouds64(nullptr, nullptr);
+            if (rc) return ctx->eng_fail(rc);
+        }
+    } else if (want64 && ctx->eng->supports_device_loop()) {
         // (Pt64 = 8 floats of staging; pinned on the HIP engine)
         Pt64 *t8 = raw_target ? nullptr : reinterpret_cast<Pt64 *>(ctx->eng->staging(2, (size_t)std::max<int64_t>(nt, 1) * 8));
         Pt64 *s8 = reinterpret_cast<Pt64 *>(ctx->eng->staging(3, (size_t)std::max<int64_t>(ns, 1) * 8));
@@ -2325,6 +2401,9 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
         rc = ctx->eng->set_clouds64(nullptr, nullptr);
         if (rc) return ctx->eng_fail(rc);
     }
+    tm[ti++] = t_now();   // source upload + f64
+    if (trace) std::fprintf(stderr, "upload trace: centroid %.2f target %.2f src-pack %.2f morton %.2f src-upload+f64 %.2f ms\n",
+                            tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4]);
     std::memcpy(ctx->centre, c, sizeof(c));
     ctx->have_src = ctx->have_tgt = true;
     ctx->centred_upload = true;

@@ -229,6 +229,10 @@ hipError_t launch_nn_tile_reduce(const TileArgs &a, int point_to_plane, int conf
                                  hipStream_t stream);
 // float4 (x, y, z, .) -> Pt64 (x, y, z, index): f64 view of clouds uploaded as fp32
 hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStream_t stream);
+// order.hip: the source cloud (caller's f64 points, already on the device) into Morton order
+size_t order_source_scratch_bytes(int64_t n);
+hipError_t order_source_device(const double *d_xyz, int64_t n, const double c[3], float4 *d_src, Pt64 *d_src64,
+                               int32_t *d_order, void *scratch, size_t scratch_bytes, hipStream_t stream);
 // raw f64 xyz (3 doubles per point) -> f4[j] = ((float)(x - c), .., 0) and, when p8 != NULL, p8[j] = {x - c, .., j}
 hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream);
 
