@@ -55,12 +55,21 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float4 *__restrict__ pt
             mx[a] = fmaxf(mx[a], __shfl_down(mx[a], off, 64));
         }
     }
+    // one set of six atomics per WORKGROUP (they all hit the same six words: 8192 waves issuing their own
+    // took 0.57 ms for 4 M points, twenty times the read of the points)
+    __shared__ float wmn[4][3], wmx[4][3];
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            atomicMin(&box[a], f2ord(mn[a]));
-            atomicMax(&box[3 + a], f2ord(mx[a]));
-        }
+        for (int a = 0; a < 3; a++) { wmn[w][a] = mn[a]; wmx[w][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float lo = fminf(fminf(wmn[0][a], wmn[1][a]), fminf(wmn[2][a], wmn[3][a]));
+        const float hi = fmaxf(fmaxf(wmx[0][a], wmx[1][a]), fmaxf(wmx[2][a], wmx[3][a]));
+        atomicMin(&box[a], f2ord(lo));
+        atomicMax(&box[3 + a], f2ord(hi));
     }
 }
 
@@ -195,7 +204,7 @@ hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipSt
     hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, stream, box6);
     if (nt > 0) {
         int blocks = (int)((nt + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(bbox_kernel, dim3(blocks), dim3(256), 0, stream, tgt, (int)nt, box6);
     }
     return hipGetLastError();
