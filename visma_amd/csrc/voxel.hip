@@ -48,11 +48,22 @@ __global__ __launch_bounds__(256) void vox_bbox_kernel(const double *__restrict_
             if (o2 > mx[a]) mx[a] = o2;
         }
     }
+    // six atomics per workgroup, not per wave (they all hit the same six words)
+    __shared__ double wmn[4][3], wmx[4][3];
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0)
-        for (int a = 0; a < 3; a++) {
-            atomicMin(&box[a], d2ord(mn[a]));
-            atomicMax(&box[3 + a], d2ord(mx[a]));
+        for (int a = 0; a < 3; a++) { wmn[w][a] = mn[a]; wmx[w][a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        double lo = wmn[0][a], hi = wmx[0][a];
+        for (int k = 1; k < 4; k++) {                       // same comparisons as above: NaN never replaces
+            if (wmn[k][a] < lo) lo = wmn[k][a];
+            if (wmx[k][a] > hi) hi = wmx[k][a];
         }
+        atomicMin(&box[a], d2ord(lo));
+        atomicMax(&box[3 + a], d2ord(hi));
+    }
 }
 
 struct VoxParams {
@@ -166,7 +177,7 @@ hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, co
     if (h_col) { VOX_TRY(hipMalloc(&d_col, sizeof(double) * 3 * n)); VOX_TRY(hipMemcpyAsync(d_col, h_col, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream)); }
     VOX_TRY(hipMalloc(&d_box, sizeof(unsigned long long) * 8));
     hipLaunchKernelGGL(vox_bbox_init_kernel, dim3(1), dim3(64), 0, stream, d_box);
-    hipLaunchKernelGGL(vox_bbox_kernel, dim3(pb > 2048 ? 2048 : pb), dim3(256), 0, stream, d_xyz, (long long)n, d_box);
+    hipLaunchKernelGGL(vox_bbox_kernel, dim3(pb > 1024 ? 1024 : pb), dim3(256), 0, stream, d_xyz, (long long)n, d_box);
     VOX_TRY(hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, stream));
     VOX_TRY(hipStreamSynchronize(stream));
     for (int a = 0; a < 3; a++) { mn[a] = ord2d(box[a]); mx[a] = ord2d(box[3 + a]); }
