@@ -80,10 +80,22 @@ __global__ __launch_bounds__(kSolveThreads) void finalize_solve_kernel(const dou
 }
 
 // one workgroup per problem: the statistics are already in st->stats (fused fold / all-reduce)
-__global__ void solve_state_kernel(DevIcpState *st)
+__global__ __launch_bounds__(64) void solve_state_kernel(DevIcpState *st)
 {
+    // the whole wave brings the state into LDS (one round trip instead of one per field read by the
+    // solving thread), thread 0 solves there, the wave writes it back
+    static_assert(sizeof(DevIcpState) % 8 == 0, "state copied as 8-byte words");
+    constexpr int kWords = (int)(sizeof(DevIcpState) / 8);
+    __shared__ unsigned long long sst[kWords];
     st += blockIdx.x;
-    if (threadIdx.x == 0 && st->active) advance_state(st);
+    if (!st->active) return;
+    const unsigned long long *g = reinterpret_cast<const unsigned long long *>(st);
+    for (int k = threadIdx.x; k < kWords; k += 64) sst[k] = g[k];
+    __syncthreads();
+    if (threadIdx.x == 0) advance_state(reinterpret_cast<DevIcpState *>(sst));
+    __syncthreads();
+    unsigned long long *o = reinterpret_cast<unsigned long long *>(st);
+    for (int k = threadIdx.x; k < kWords; k += 64) o[k] = sst[k];
 }
 
 // `plane` is a host copy of st->plane (chooses the accumulator layout)
