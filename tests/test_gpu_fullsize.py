@@ -18,6 +18,16 @@ def c4():
     return synth.make_pair(NS, NT, motion="radius")
 
 
+@pytest.fixture(params=["f32", "exact"])
+def gpu_ctx_auto(request, lib, _gpu_ctx_session, _gpu_ctx_exact_session):
+    """Both flavours at full size: the fp32-specification kernels AND the default exact search
+    (the instantiation bench.py times).  Overrides conftest's f32-only fixture for this module."""
+    ctx = _gpu_ctx_session if request.param == "f32" else _gpu_ctx_exact_session
+    ctx.set_nn_mode(lib.NN_AUTO)
+    ctx.flavour = request.param
+    return ctx
+
+
 def test_c4_statistics_are_additive_over_source_shards(gpu_ctx_auto, c4):
     """The reduction is a sum over correspondences: the statistics of the whole
     source equal the sum over disjoint shards (this is what the multi-GPU
@@ -27,6 +37,7 @@ def test_c4_statistics_are_additive_over_source_shards(gpu_ctx_auto, c4):
     ctx.set_clouds_f64(src, tgt)
     ctx.nn_pass(np.eye(4), r)
     whole = ctx.reduce()
+    assert ctx.search_mode_used() == ctx.flavour
     idx_whole = ctx.correspondence_index()
     parts = np.zeros(38)
     idx_parts = []
