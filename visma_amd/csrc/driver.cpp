@@ -237,11 +237,11 @@ public:
         free_dev(d_claim_); free_dev(d_d64_);
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
-        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_partials_); free_dev(d_stats_);
+        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_partials_); free_dev(d_stats_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
-        free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_tgt_); free_dev(bt_sorted_);
+        free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_pos_); free_dev(bt_tgt_); free_dev(bt_sorted_);
         free_dev(bt_nrm_); free_dev(bt_nrm64_); free_dev(bt_raw_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
@@ -283,6 +283,7 @@ public:
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
         HIP_TRY(hipMalloc(&d_cand_, 2 * 4096 * sizeof(unsigned long long)));
         HIP_TRY(hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long)));
+        if (const char *e = std::getenv("VISMA_ICP_COOP")) coop_enabled_ = std::atoi(e) != 0;
         if (const char *e = std::getenv("VISMA_ICP_GRID_LANES")) {
             const int v = std::atoi(e);
             if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
@@ -389,6 +390,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         free_dev(d_src64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         grid_valid_ = false;
+        { int irc = invalidate_pos(); if (irc) return irc; }
         if (!src || !d_tgt64_) { err_ = "set_source64 without an f64 target"; return VISMA_ICP_ERR_STATE; }
         { int prc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns_, 1)); if (prc) return prc; }
         if (ns_ > 0) HIP_TRY(hipMemcpyAsync(d_src64_, src, sizeof(Pt64) * ns_, hipMemcpyHostToDevice, stream_));
@@ -408,6 +410,7 @@ public:
         HIP_TRY(hipSetDevice(device_));
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         grid_valid_ = false;                                     // the sorted f64 copy is built with the grid
+        { int irc = invalidate_pos(); if (irc) return irc; }
         if (!src || !tgt) return VISMA_ICP_OK;
         { int prc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns_, 1)); if (prc) return prc; }
         { int prc = pool_alloc(&d_tgt64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt_, 1)); if (prc) return prc; }
@@ -635,10 +638,11 @@ public:
             int nblocks = 1;
             // the fold of the partial rows runs inside the search launch (no second kernel)
             const bool fused = fused_fold_ && !tshard_;
+            const int lanes = pass_lanes();
             FoldArgs fa{};
             if (fused) {
                 // (peer-to-peer mailboxes: the folding workgroup exchanges with the peers and publishes itself)
-                int rc = make_fold(grid_launch_blocks(ns_, grid_lanes(), grid_blocks()), 1, (double *)d_stats_, 0,
+                int rc = make_fold(grid_launch_blocks(ns_, lanes, grid_blocks()), 1, (double *)d_stats_, 0,
                                    ipc ? h_stats_dev_ : pub, seq, &fa);
                 if (rc) return rc;
                 if (ipc) { add_ipc(&fa); ipc_done = true; }
@@ -648,10 +652,11 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, grid_blocks(),
-                                          &nblocks, grid_lanes(),
+                                          &nblocks, lanes,
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                          exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64()));
+                                          exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (float4 *)d_pos_, 1));
+            pos_fresh_ = d_pos_ != nullptr;
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (!tshard_ && !fused) {
                 if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -749,8 +754,10 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, grid_lanes(), nullptr, nullptr, 1, 0, stream_,
-                                          f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0));
+                                          &nblocks, pass_lanes(), nullptr, nullptr, 1, 0, stream_,
+                                          f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0,
+                                          nullptr, nullptr, (float4 *)d_pos_, 1));
+            pos_fresh_ = d_pos_ != nullptr;
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -863,8 +870,9 @@ public:
                     // fold inside the search launch: the statistics land in the problems' device state
                     FoldArgs fa{};
                     fused = fused_fold_ != 0 && !tshard_;       // (target shards fold after their exchange)
+                    const int lanes = pass_lanes(nprob);
                     if (fused) {
-                        rc = make_fold(grid_launch_blocks(ns_, grid_lanes(nprob), reduce_max_blocks()), nprob,
+                        rc = make_fold(grid_launch_blocks(ns_, lanes, reduce_max_blocks()), nprob,
                                        st->stats, (long long)(sizeof(DevIcpState) / sizeof(double)), nullptr, 0, &fa);
                         if (rc) return rc;
                         if (ipc_n_ > 1) add_ipc(&fa);      // (one problem per rank: ipc needs nprob == 1)
@@ -873,10 +881,12 @@ public:
                                                   (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                                   T32_, T64, nullptr, r2f_, plane, (int32_t *)d_idx_,
                                                   (float *)d_d2_, (double *)d_partials_,
-                                                  reduce_max_blocks(), &nblocks, grid_lanes(nprob),
+                                                  reduce_max_blocks(), &nblocks, lanes,
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
                                                   nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                                  exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr));
+                                                  exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr,
+                                                  (float4 *)d_pos_, 1));
+                    pos_fresh_ = d_pos_ != nullptr;
                     if (tshard_) {
                         // the shards' winners compared on the stream (two MIN all-reduces), the owners' moments
                         // into the partial rows: everything stream-ordered, the host is not involved
@@ -1060,11 +1070,14 @@ public:
             }
         }
         if (out_tot > bt_out_cap_) {
-            free_dev(bt_idx_); free_dev(bt_d2_);
+            free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_pos_);
             HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(out_tot, 1)));
             HIP_TRY(hipMalloc(&bt_d2_, sizeof(float) * std::max<int64_t>(out_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_pos_, sizeof(float4) * std::max<int64_t>(out_tot, 1)));
             bt_out_cap_ = out_tot;
         }
+        // (new problems: no previous winners)
+        HIP_TRY(hipMemsetAsync(bt_pos_, 0xFF, sizeof(float4) * (size_t)std::max<int64_t>(out_tot, 1), stream_));
         {
             bool any_raw = false;
             for (int b = 0; b < B; b++) any_raw = any_raw || pb[b].tgt_raw != nullptr;
@@ -1185,6 +1198,9 @@ public:
         }
         const int chunk = lp.check_stop ? 8 : lp.passes;
         int done = 0;
+        // the first pass prunes progressively (lane-serial kernel), the later ones start from its winners
+        const bool coop = coop_enabled_ && packed && std::getenv("VISMA_ICP_BATCH_LANES") == nullptr;
+        bool fresh = false;
         while (done < lp.passes) {
             const int n = std::min(chunk, lp.passes - done);
             for (int j = 0; j < n; j++) {
@@ -1192,13 +1208,15 @@ public:
                 HIP_TRY(launch_nn_grid_reduce_batch((const float4 *)bt_src_, packed ? (const float4 *)bt_sorted12_ : (const float4 *)bt_sorted_,
                                                     (const unsigned *)bt_start_, (const ProbDesc *)bt_descs_, B,
                                                     total_blocks, (int32_t *)bt_idx_, (float *)bt_d2_,
-                                                    (double *)d_partials_, lanes, one_per_lane ? 1 : 0, st, stream_,
+                                                    (double *)d_partials_, (coop && fresh) ? kCoopLanes : lanes, one_per_lane ? 1 : 0, st, stream_,
                                                     f64 ? (const Pt64 *)bt_src64_ : nullptr,
                                                     f64 ? (const Pt64 *)bt_sorted64_ : nullptr, exact_ ? 1 : 0,
                                                     fused_fold_ ? &bfa : nullptr,
                                                     profiling_ ? (unsigned long long *)d_cand_ : nullptr,
                                                     (lp.plane && !f64) ? (const float4 *)bt_nrm_ : nullptr,
-                                                    (lp.plane && f64) ? (const Pt64 *)bt_nrm64_ : nullptr));
+                                                    (lp.plane && f64) ? (const Pt64 *)bt_nrm64_ : nullptr,
+                                                    (float4 *)bt_pos_, 1));
+                fresh = true;
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
                 if (fused_fold_) HIP_TRY(launch_solve_state(st, B, stream_));
@@ -1553,7 +1571,7 @@ private:
         ns_ = ns;
         have_pass_ = false;
         free_dev(d_src64_);                                      // belongs to the previous source
-        return VISMA_ICP_OK;
+        return invalidate_pos();
     }
     int ensure_target(int64_t nt)
     {
@@ -1574,10 +1592,12 @@ private:
     int ensure_aux(int64_t ns_pad)
     {
         if (ns_pad > aux_cap_) {
-            free_dev(d_idx_); free_dev(d_d2_);
+            free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_);
             HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * (ns_pad > 0 ? ns_pad : 1)));
             HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * (ns_pad > 0 ? ns_pad : 1)));
+            HIP_TRY(hipMalloc(&d_pos_, sizeof(float4) * (ns_pad > 0 ? ns_pad : 1)));
             aux_cap_ = ns_pad;
+            return invalidate_pos();
         }
         return VISMA_ICP_OK;
     }
@@ -1649,7 +1669,7 @@ private:
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
         grid_valid_ = true;
         grid_radius_ = max_dist;
-        return VISMA_ICP_OK;
+        return invalidate_pos();                                 // the slots of the old sorted order mean nothing now
     }
     int next_event_pair()
     {
@@ -1747,7 +1767,7 @@ private:
     int state_cap_ = 0;
     size_t partial_rows_ = 0;
     // batch of problems with their own clouds (concatenated arrays)
-    void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
+    void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_pos_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
     void *bt_src64_ = nullptr, *bt_tgt64_ = nullptr, *bt_sorted64_ = nullptr;
     int64_t bt_src64_cap_ = 0, bt_tgt64_cap_ = 0;
     void *bt_sorted12_ = nullptr;                          // packed copy of bt_sorted_ (exact search)
@@ -1776,6 +1796,32 @@ private:
         if (grid_blocks_env_ > 0) return grid_blocks_env_;
         if (ns_ <= 262144) return 1024;
         return (int)std::min<int64_t>(kGridMaxBlocks, (ns_ + kBlock - 1) / kBlock);
+    }
+    // ---- warm start (grid_coop.hip): every query's winner as the candidate array holds it (fp32 point),
+    // written by every exact grid search.  The array is kept CONSISTENT with the current source order and
+    // target -- every entry is NaN (all bits set) or a point of the current target (reset whenever either
+    // changes) -- so any pass may read it; pos_fresh_ only says that some pass has filled it since (policy:
+    // the first pass of a registration runs the lane-serial kernel, which prunes progressively; the later ones
+    // the warm-started kernel).
+    void *d_pos_ = nullptr;
+    bool pos_fresh_ = false;
+    int coop_enabled_ = 1;       // VISMA_ICP_COOP=0: every pass on the lane-serial kernel
+    int invalidate_pos()
+    {
+        pos_fresh_ = false;
+        if (d_pos_ && aux_cap_ > 0) HIP_TRY(hipMemsetAsync(d_pos_, 0xFF, sizeof(float4) * (size_t)aux_cap_, stream_));
+        return VISMA_ICP_OK;
+    }
+    bool coop_ok() const
+    {
+        return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1;
+    }
+    // lanes code of the next grid pass over `nprob` problems sharing the clouds
+    int pass_lanes(int nprob = 1) const
+    {
+        if (grid_lanes_ > 0) return grid_lanes_;
+        if (coop_ok() && pos_fresh_) return kCoopLanes;
+        return grid_lanes(nprob);
     }
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes(int nprob = 1) const

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const DevIcpState *__restrict__ st, int bpp, long long out_stride,
     const ProbDesc *__restrict__ descs, int nprob, const Pt64 *__restrict__ src64 = nullptr,
     const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0, const Pt64 *__restrict__ nrm64 = nullptr,
-    const FoldArgs fold = FoldArgs{}, double *__restrict__ d64_out = nullptr)
+    const FoldArgs fold = FoldArgs{}, double *__restrict__ d64_out = nullptr,
+    float4 *__restrict__ prevq_out = nullptr)
 {
     static_assert(!(F64 && HYB), "F64 and HYB are different searches");
     // The exact search only ranks with the fp32 copy (the winner's index comes from the f64 copy), so it
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         out_stride = 0;
         idx_out += d.out_off;
         d2_out += d.out_off;
+        if (prevq_out) prevq_out += d.out_off;
     } else {
         // `bpp` workgroups per problem: problem b = blockIdx.x / bpp shares the
         // clouds and the grid with the others but has its own transform / state
@@ -483,6 +485,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     if constexpr (S64) r2d = (double)r2f;                  // (double)(float)(r*r), also when the radius comes from the state
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
+    if (prevq_out) prevq_out += (long long)prob * out_stride;   // the winners: the warm start of the next pass (grid_coop.hip)
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -871,6 +874,13 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             }
         }
         if (sub == 0) {
+            if constexpr (HYB) {
+                if (prevq_out) {
+                    float4 w4 = make_float4(NAN, NAN, NAN, 0.f);
+                    if (bpos != 0xFFFFFFFFu) { const P12 t = s12[bpos]; w4 = make_float4(t.x, t.y, t.z, 0.f); }
+                    prevq_out[i] = w4;
+                }
+            }
             if constexpr (S64) {
 #ifdef VISMA_GRID_DEBUG_TRIPS   /* measurement build: trips of this query | of its wave | of its wave's matched queries */
                 {
@@ -924,7 +934,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
                           double *partials, unsigned long long *cand, const DevIcpState *st,
                           int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d,
-                          const Pt64 *nrm64, int exact, const FoldArgs &fold, double *d64_out)
+                          const Pt64 *nrm64, int exact, const FoldArgs &fold, double *d64_out, float4 *prevq_out)
 {
     // one query per lane? (see ONE above)
     const long long total_groups = (long long)nblocks * (kBlock / G);
@@ -933,7 +943,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
     hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, ONE_, F64_, HYB_>), dim3(nblocks * nprob),             \
                        dim3(kBlock), 0, stream, src, ns, sorted, start, g, nrm, T32, T64, off, r2f, idx_out,      \
                        d2_out, partials, cand, st, nblocks, out_stride, (const ProbDesc *)nullptr, nprob, src64,  \
-                       sorted64, r2d, nrm64, fold, d64_out)
+                       sorted64, r2d, nrm64, fold, d64_out, prevq_out)
     if (src64 && exact) {
         if (one) VISMA_GRID_LAUNCH(true, false, true); else VISMA_GRID_LAUNCH(false, false, true);
     } else if (src64) {
@@ -953,7 +963,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
                                  const Pt64 *sorted64, double r2d, const Pt64 *nrm64, int exact,
-                                 const FoldArgs *fold, double *d64_out)
+                                 const FoldArgs *fold, double *d64_out, float4 *prevq_io, int warm)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     Offset64 off;
@@ -965,16 +975,29 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     int64_t want = (ns * G + kBlock - 1) / kBlock;
     int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
     if (nblocks < 1) nblocks = 1;
+    if (lanes_per_query == kCoopLanes) {
+        if (src64 && exact && g.sub == 1 && prevq_io) {
+            // the flattened exact search (grid_coop.hip): `sorted` is the packed 12-byte copy
+            const bool one = (ns + (int64_t)nblocks * kBlock - 1) / ((int64_t)nblocks * kBlock) <= 1;
+            hipError_t e = launch_nn_coop(nblocks * nprob, nblocks, nprob, nullptr, (int)ns, (const float *)sorted, start, g,
+                                          tgt_normals, nrm64, T64, off, r2f, point_to_plane, one ? 1 : 0, idx_out, d2_out,
+                                          partials, cand_count, st, (long long)out_stride, src64, sorted64, fa, d64_out,
+                                          prevq_io, warm, stream);
+            if (nblocks_out) *nblocks_out = nblocks;
+            return e;
+        }
+        U = 8;                                             // not the exact search: the lane-serial kernel
+    }
 #define VISMA_GRID_CASE(GG, UU)                                                                    \
     if (G == GG && U == UU) {                                                                      \
         if (point_to_plane)                                                                        \
             launch_grid_t<true, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,           \
                                         tgt_normals, T32, T64, off, r2f, idx_out, d2_out,          \
-                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa, d64_out);   \
+                                        partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa, d64_out, prevq_io);   \
         else                                                                                       \
             launch_grid_t<false, GG, UU>(nblocks, stream, src, (int)ns, sorted, start, g,          \
                                          tgt_normals, T32, T64, off, r2f, idx_out, d2_out,         \
-                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa, d64_out);  \
+                                         partials, cand_count, st, nprob, (long long)out_stride, src64, sorted64, r2d, nrm64, exact, fa, d64_out, prevq_io);  \
         launched = true;                                                                           \
     }
     bool launched = false;
@@ -993,7 +1016,8 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
                                 const float4 *sorted, const unsigned *start, const ProbDesc *descs,
                                 int nprob, int *idx_out, float *d2_out, double *partials,
                                 const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64, const FoldArgs &fold,
-                                unsigned long long *cand, const float4 *nrm = nullptr, const Pt64 *nrm64 = nullptr)
+                                unsigned long long *cand, const float4 *nrm = nullptr, const Pt64 *nrm64 = nullptr,
+                                float4 *prevq_out = nullptr)
 {
     const Xform32 T32{};
     const Xform64 T64{};
@@ -1002,7 +1026,7 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
     hipLaunchKernelGGL((nn_grid_reduce_kernel<PLANE, G, U, ONE, F64, HYB>), dim3(total_blocks), dim3(kBlock), 0, stream,
                        src, 0, sorted, start, g, nrm, T32, T64, off, 0.f, idx_out,
                        d2_out, partials, cand, st, 1, 0ll, descs, nprob, src64, sorted64, 0.0,
-                       nrm64, fold);
+                       nrm64, fold, (double *)nullptr, prevq_out);
 }
 
 // lanes_per_query = G + 100 * U; one_per_lane: every problem has at most G queries per lane group;
@@ -1014,39 +1038,52 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64, int exact,
                                        const FoldArgs *fold, unsigned long long *cand_count,
-                                       const float4 *nrm, const Pt64 *nrm64)
+                                       const float4 *nrm, const Pt64 *nrm64, float4 *prevq_io, int warm)
 {
     if (!st || !descs || (src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     const bool plane = nrm != nullptr || nrm64 != nullptr;
     if (plane && src64 && !exact) return hipErrorInvalidValue;      // point-to-plane batches: exact or fp32 search
     const FoldArgs fa = fold ? *fold : FoldArgs{};
-    const int G = lanes_per_query % 100, U = lanes_per_query / 100;
+    const int G = lanes_per_query % 100;
+    int U = lanes_per_query / 100;
+    if (lanes_per_query == kCoopLanes) {
+        if (src64 && exact && prevq_io) {
+            // (batches never use half-pitch rows: grid_plan(..., max_sub = 1))
+            const Xform64 T64{};
+            const Offset64 off{};
+            const GridParams g{};
+            return launch_nn_coop(total_blocks, 1, nprob, descs, 0, (const float *)sorted, start, g, nrm, nrm64, T64, off,
+                                  0.f, plane ? 1 : 0, one_per_lane, idx_out, d2_out, partials, cand_count, st, 0ll, src64,
+                                  sorted64, fa, nullptr, prevq_io, warm, stream);
+        }
+        U = 8;
+    }
     bool launched = false;
 #define VISMA_BATCH_ARGS total_blocks, stream, src, sorted, start, descs, nprob, idx_out, d2_out, partials, st
 #define VISMA_BATCH_CASE(GG, UU)                                                                              \
     if (G == GG && U == UU && plane) {                                                                        \
         if (src64 && one_per_lane)                                                                            \
-            launch_grid_batch_t<GG, UU, true, false, true, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nrm, nrm64);   \
+            launch_grid_batch_t<GG, UU, true, false, true, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nrm, nrm64, prevq_io);   \
         else if (src64)                                                                                       \
-            launch_grid_batch_t<GG, UU, false, false, true, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nrm, nrm64);  \
+            launch_grid_batch_t<GG, UU, false, false, true, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nrm, nrm64, prevq_io);  \
         else if (one_per_lane)                                                                                \
-            launch_grid_batch_t<GG, UU, true, false, false, true>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nrm, nrm64); \
+            launch_grid_batch_t<GG, UU, true, false, false, true>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nrm, nrm64, prevq_io); \
         else                                                                                                  \
-            launch_grid_batch_t<GG, UU, false, false, false, true>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nrm, nrm64); \
+            launch_grid_batch_t<GG, UU, false, false, false, true>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nrm, nrm64, prevq_io); \
         launched = true;                                                                                      \
     } else if (G == GG && U == UU) {                                                                          \
         if (src64 && exact && one_per_lane)                                                                   \
-            launch_grid_batch_t<GG, UU, true, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);            \
+            launch_grid_batch_t<GG, UU, true, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nullptr, nullptr, prevq_io);            \
         else if (src64 && exact)                                                                              \
-            launch_grid_batch_t<GG, UU, false, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);           \
+            launch_grid_batch_t<GG, UU, false, false, true>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nullptr, nullptr, prevq_io);           \
         else if (src64 && one_per_lane)                                                                       \
-            launch_grid_batch_t<GG, UU, true, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);            \
+            launch_grid_batch_t<GG, UU, true, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nullptr, nullptr, prevq_io);            \
         else if (src64)                                                                                       \
-            launch_grid_batch_t<GG, UU, false, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count);           \
+            launch_grid_batch_t<GG, UU, false, true, false>(VISMA_BATCH_ARGS, src64, sorted64, fa, cand_count, nullptr, nullptr, prevq_io);           \
         else if (one_per_lane)                                                                                \
-            launch_grid_batch_t<GG, UU, true, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count);          \
+            launch_grid_batch_t<GG, UU, true, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nullptr, nullptr, prevq_io);          \
         else                                                                                                  \
-            launch_grid_batch_t<GG, UU, false, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count);         \
+            launch_grid_batch_t<GG, UU, false, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nullptr, nullptr, prevq_io);         \
         launched = true;                                                                                      \
     }
     VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
