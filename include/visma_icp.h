@@ -332,7 +332,10 @@ VISMA_ICP_API int visma_icp_comm_init(visma_icp_ctx *ctx, int rank, int nranks,
  * nranks <= 16; ranks may share a device (tests).  comm_ipc_init is COLLECTIVE: it ends with a
  * handshake (one all-reduce of known values, every rank must enter within tens of seconds) and
  * fails with VISMA_ICP_ERR_HIP when a peer's stores do not arrive -- fall back to
- * visma_icp_comm_init on every rank then. */
+ * visma_icp_comm_init on every rank then.  comm_ipc_export starts a NEW session: it drops the mappings
+ * of an earlier one, clears the mailbox and restarts the exchange count (which lives in device memory and
+ * advances only when an exchange runs), so a retry after a failed handshake begins with export on every
+ * rank again. */
 #define VISMA_ICP_IPC_HANDLE_BYTES 64
 VISMA_ICP_API int visma_icp_comm_ipc_export(visma_icp_ctx *ctx, void *out_handle /* 64 bytes */);
 VISMA_ICP_API int visma_icp_comm_ipc_init(visma_icp_ctx *ctx, int rank, int nranks,

@@ -19,8 +19,15 @@ def main(rank, world, conn, device, device_loop):
     handles = conn.recv()
     ctx.comm_ipc_init(rank, world, handles)
     res = ctx.run(None, r, 12, 0.0, 0.0)
+    # registrations that STOP EARLY (loose stop test), again and again: in the device loop the launches
+    # queued after convergence return without exchanging -- they must not use up exchange numbers, or the
+    # next registration's first exchange lands in the mailbox half a slow peer is still reading
+    early = []
+    for k in range(5):
+        e = ctx.run(None, r, 3 + 2 * k, 3e-2, 3e-2)
+        early.append((int(e.iterations), int(e.num_correspondences), np.asarray(e.transformation_)))
     T2, last = ctx.iterate(np.eye(4), r, 5)
     conn.send((np.asarray(res.transformation_), int(res.num_correspondences), float(res.fitness_),
-               float(res.inlier_rmse_), np.asarray(T2)))
+               float(res.inlier_rmse_), np.asarray(T2), early))
     conn.recv()                                   # keep the mailbox alive until every rank is done
     ctx.close()

@@ -48,6 +48,7 @@ def _run(world, device_loop):
     one = _lib.Context(0)
     one.set_clouds_f64(src, tgt)
     w = one.run(None, r, 12, 0.0, 0.0)
+    w.early = [one.run(None, r, 3 + 2 * k, 3e-2, 3e-2) for k in range(5)]
     return outs, w
 
 
@@ -57,10 +58,16 @@ def _run(world, device_loop):
 def test_ranks_in_processes_hold_the_single_gpu_result(lib, world, device_loop):
     from visma_amd import synth
     outs, w = _run(world, device_loop)
-    for T, k, fit, rmse, T2 in outs:
+    for T, k, fit, rmse, T2, early in outs:
         assert k == w.num_correspondences
         assert synth.rel_frobenius(T, w.transformation_) < 1e-12
         assert abs(fit - w.fitness_) < 1e-15
-    for T, k, fit, rmse, T2 in outs[1:]:
+        assert any(it < 3 + 2 * j for j, (it, _, _) in enumerate(early))      # some did stop early
+        for (it, kk, Te), ref in zip(early, w.early):
+            assert it == ref.iterations and kk == ref.num_correspondences
+            assert synth.rel_frobenius(Te, ref.transformation_) < 1e-12
+    for T, k, fit, rmse, T2, early in outs[1:]:
         assert np.array_equal(T, outs[0][0])          # rank-ordered sums: bit-identical on every rank
         assert np.array_equal(T2, outs[0][4])
+        for a, b in zip(early, outs[0][5]):
+            assert np.array_equal(a[2], b[2])

@@ -487,12 +487,18 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
     if (f.ipc_n > 1) {
         // source-sharded ranks: this workgroup's first wave exchanges the statistics with the peers
         // (remote stores over xGMI, rank-ordered sum) before anything is published
-        if (tid == 0) f_flag[0] = 0;
+        // the number of THIS exchange: kept in device memory, advanced by the one workgroup that exchanges
+        __shared__ unsigned long long f_seq;
+        if (tid == 0) {
+            f_flag[0] = 0;
+            f_seq = __hip_atomic_load(f.ipc_seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+            __hip_atomic_store(f.ipc_seq_dev, f_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();                                   // stats[] was written by thread 0
         if (tid < 64) {
             bool late = false;
             const double sum = ipc_exchange(tid, tid < kNStats ? stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n,
-                                            f.ipc_seq, f.ipc_flag, f.ipc_spins, late);
+                                            f_seq, f.ipc_flag, f.ipc_spins, late);
             if (tid < kNStats) stats[tid] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
             if (late) f_flag[0] = 1;
         }

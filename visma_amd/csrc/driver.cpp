@@ -60,9 +60,13 @@ struct Rccl {
     bool load()
     {
         if (handle) return true;
-        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // The system's RCCL by its full path first, bound to ITSELF (RTLD_LOCAL | RTLD_DEEPBIND): a host program
+        // that has imported PyTorch already carries PyTorch's bundled copy under the same soname, and neither
+        // copy's symbols may resolve into the other.  VISMA_ICP_RCCL_PATH overrides.
+        const char *env = getenv("VISMA_ICP_RCCL_PATH");
+        const char *names[] = {env ? env : "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so", "librccl.so.1", "librccl.so"};
         for (const char *n : names) {
-            handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
             if (handle) break;
         }
         if (!handle) { error = std::string("dlopen(librccl): ") + dlerror(); return false; }
@@ -687,7 +691,7 @@ public:
             // ONE exchange of the 38 f64 accumulators per ICP iteration: remote stores into the peers'
             // mailboxes over xGMI, rank-ordered sum, publication to the host -- one tiny launch
             HIP_TRY(launch_ipc_allreduce((const double *)d_stats_, (double *)d_stats_, peers_, ipc_rank_, ipc_n_,
-                                         ++ipc_seq_, h_stats_dev_, seq, (int *)d_ipc_flag_, stream_));
+                                         ipc_seq_dev(), h_stats_dev_, seq, (int *)d_ipc_flag_, stream_));
         } else if (comm_) {
             // ONE all-reduce of the 38 f64 accumulators per ICP iteration
             int rc = g_rccl.AllReduce(d_stats_, d_stats_, kNStats, kNcclFloat64, kNcclSum, comm_, stream_);
@@ -911,7 +915,7 @@ public:
                 if (ipc_n_ > 1) {
                     if (!fused) HIP_TRY(launch_finalize_state((const double *)d_partials_, nblocks, st, plane, stream_));
                     if (!(fused && use_grid_))               // (fused: the folding workgroup exchanged already)
-                        HIP_TRY(launch_ipc_allreduce(st->stats, st->stats, peers_, ipc_rank_, ipc_n_, ++ipc_seq_, nullptr, 0,
+                        HIP_TRY(launch_ipc_allreduce(st->stats, st->stats, peers_, ipc_rank_, ipc_n_, ipc_seq_dev(), nullptr, 0,
                                                      (int *)d_ipc_flag_, stream_));
                     HIP_TRY(launch_solve_state(st, 1, stream_));
                 } else if (comm_) {
@@ -1397,8 +1401,8 @@ public:
             HIP_TRY(hipExtMallocWithFlags(&d_mbox_, bytes, hipDeviceMallocFinegrained));
         }
         HIP_TRY(hipMemset(d_mbox_, 0, bytes));
-        HIP_TRY(hipMalloc(&d_ipc_flag_, sizeof(int)));
-        HIP_TRY(hipMemset(d_ipc_flag_, 0, sizeof(int)));
+        HIP_TRY(hipMalloc(&d_ipc_flag_, 16));                    // {int timeout flag, pad, u64 exchange counter}
+        HIP_TRY(hipMemset(d_ipc_flag_, 0, 16));
         return VISMA_ICP_OK;
     }
     int ipc_export(void *out) override
@@ -1406,6 +1410,17 @@ public:
         HIP_TRY(hipSetDevice(device_));
         int rc = ensure_mailbox();
         if (rc) return rc;
+        // Exporting starts a NEW session: peers only learn the handle after this call, so nothing can be on its
+        // way into the mailbox yet -- drop the mappings of an earlier session, clear the granules it left (a
+        // retry after a failed handshake must not read them as this session's) and restart the count.
+        HIP_TRY(hipStreamSynchronize(stream_));
+        for (int r = 0; r < kIpcMaxRanks; r++) {
+            if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
+            peers_.box[r] = nullptr;
+        }
+        ipc_n_ = 0;
+        HIP_TRY(hipMemset(d_mbox_, 0, sizeof(double) * 2 * kNStats * kIpcMaxRanks * 2));
+        HIP_TRY(hipMemset(d_ipc_flag_, 0, 16));
         hipIpcMemHandle_t h;
         HIP_TRY(hipIpcGetMemHandle(&h, d_mbox_));
         static_assert(sizeof(h) <= VISMA_ICP_IPC_HANDLE_BYTES, "handle size");
@@ -1436,7 +1451,6 @@ public:
         }
         ipc_rank_ = rank;
         ipc_n_ = nranks;
-        ipc_seq_ = 0;
         // Handshake (the call is collective): one all-reduce of known values proves that every peer's
         // stores arrive in this rank's mailbox and the other way round -- a mapping that opens but does
         // not carry traffic (no peer access between two devices) must fail HERE, not in the first iteration.
@@ -1448,7 +1462,7 @@ public:
             hipError_t e = hipMemcpyAsync(d_hs, hs.data(), sizeof(double) * kNStats, hipMemcpyHostToDevice, stream_);
             if (e == hipSuccess) e = hipMemsetAsync(d_ipc_flag_, 0, sizeof(int), stream_);
             if (e == hipSuccess)
-                e = launch_ipc_allreduce(d_hs, d_hs, peers_, ipc_rank_, ipc_n_, ++ipc_seq_, nullptr, 0, (int *)d_ipc_flag_,
+                e = launch_ipc_allreduce(d_hs, d_hs, peers_, ipc_rank_, ipc_n_, ipc_seq_dev(), nullptr, 0, (int *)d_ipc_flag_,
                                          stream_, kIpcHandshakeSpins);
             int flag = 0;
             if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), d_hs, sizeof(double) * kNStats, hipMemcpyDeviceToHost, stream_);
@@ -1732,7 +1746,8 @@ private:
     void *d_mbox_ = nullptr, *d_ipc_flag_ = nullptr;      // peer-to-peer all-reduce: own mailbox, timeout flag
     IpcPeers peers_{};
     int ipc_rank_ = 0, ipc_n_ = 0;
-    unsigned long long ipc_seq_ = 0;
+    // (the exchange counter lives next to the timeout flag in device memory: d_ipc_flag_ + 8 bytes)
+    unsigned long long *ipc_seq_dev() const { return reinterpret_cast<unsigned long long *>((char *)d_ipc_flag_ + 8); }
     bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
     int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
     void *d_gkeys_ = nullptr, *d_claim_ = nullptr, *d_d64_ = nullptr;   // shard exchange: keys, index claims, local f64 d2
@@ -1932,7 +1947,7 @@ private:
         fa->peers = peers_;
         fa->ipc_rank = ipc_rank_;
         fa->ipc_n = ipc_n_;
-        fa->ipc_seq = ++ipc_seq_;
+        fa->ipc_seq_dev = ipc_seq_dev();
         fa->ipc_flag = (int *)d_ipc_flag_;
         fa->ipc_spins = kIpcSpinLimit;
     }

@@ -61,7 +61,9 @@ struct FoldArgs {
     // statistics with the peers itself before it publishes (no separate all-reduce launch)
     IpcPeers peers;
     int ipc_rank, ipc_n;
-    unsigned long long ipc_seq;
+    unsigned long long *ipc_seq_dev;   // exchanges performed so far, in DEVICE memory: it advances only when an
+                                       // exchange really runs (a launch that returns because its loop has ended
+                                       // must not burn a number: the two mailbox halves alternate by it)
     int *ipc_flag;
     long long ipc_spins;
 };
@@ -124,7 +126,7 @@ constexpr int kSortedSlack = 64;   // entries allocated past the end of a cell-s
                                    // search loads whole batches (<= U*G slots) from a run's first slot
 // one-shot all-reduce of the 38 statistics through IPC-mapped mailboxes (kernels.hip)
 hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
-                                int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
+                                int nranks, unsigned long long *seq_dev, double *host_out, unsigned long long host_seq,
                                 int *timeout_flag, hipStream_t stream, long long max_spins = kIpcSpinLimit);
 // target-sharded ranks: keys of the local winners / moments of the global winners owned here
 hipError_t launch_shard_keys(const int32_t *idx, const float *d2, int64_t ns, unsigned offset,

@@ -724,12 +724,20 @@ hipError_t launch_publish_stats(const double *stats, double *host_out, unsigned 
 // reading call k, so a granule is never overwritten before its reader has seen it.
 __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_in, double *stats_out,
                                                            IpcPeers peers, int rank, int nranks,
-                                                           unsigned long long seq, double *host_out,
+                                                           unsigned long long *seq_dev, double *host_out,
                                                            unsigned long long host_seq, int *timeout_flag,
                                                            long long max_spins)
 {
     const int a = threadIdx.x;
     bool late = false;
+    // the number of this exchange lives in device memory (see FoldArgs::ipc_seq_dev): one wave, lane 0 advances it
+    unsigned long long seq = 0ull;
+    if (a == 0) {
+        seq = __hip_atomic_load(seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+        __hip_atomic_store(seq_dev, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    seq = ((unsigned long long)(unsigned)__shfl((int)(unsigned)(seq >> 32), 0, 64) << 32) |
+          (unsigned long long)(unsigned)__shfl((int)(unsigned)seq, 0, 64);
     const double sum = ipc_exchange(a, a < kNStats ? stats_in[a] : 0.0, peers, rank, nranks, seq, timeout_flag,
                                     max_spins, late);
     // (a sum with a missing term is never handed on: NaN stops the device loop's solve)
@@ -739,11 +747,11 @@ __global__ __launch_bounds__(64) void ipc_allreduce_kernel(const double *stats_i
 }
 
 hipError_t launch_ipc_allreduce(const double *stats_in, double *stats_out, const IpcPeers &peers, int rank,
-                                int nranks, unsigned long long seq, double *host_out, unsigned long long host_seq,
+                                int nranks, unsigned long long *seq_dev, double *host_out, unsigned long long host_seq,
                                 int *timeout_flag, hipStream_t stream, long long max_spins)
 {
     hipLaunchKernelGGL(ipc_allreduce_kernel, dim3(1), dim3(64), 0, stream, stats_in, stats_out, peers, rank, nranks,
-                       seq, host_out, host_seq, timeout_flag, max_spins);
+                       seq_dev, host_out, host_seq, timeout_flag, max_spins);
     return hipGetLastError();
 }
 
