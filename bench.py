@@ -32,7 +32,18 @@ steps are always run after the timed region and reported under `brute_force`.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with the extra objects
 `roofline` (dominant kernel = NN correspondence) and `cpu_baseline` (the reference itself,
-oracle/_ref, timed on this host).
+oracle/_ref, timed on this host).  c4 also carries: `blocks` (the K-step block is timed 7 times, each between a
+barrier + synchronize pair; `value` is the MEDIAN block, min / max beside it), `from_initial_pose` (iterations
+1..K of a fresh registration: first pass cold, the rest warm-started), `end_to_end` (host arrays in ->
+transformation out: upload, grid build, 31 passes; the PCIe-inclusive rate -- never `value`),
+`roofline_saturated` (the same kernel and target with 1 M and 4 M queries per launch: the chip refilled many
+times over, no single-round latency chain) and `scaling_workloads` (what N = 1, 2, 4, 8 runs of this command
+can be divided by each other: C4 strong with the grid, C4 strong with north_star's brute-force kernel -- 115 ms
+of pair evaluations per iteration that shard linearly --, C4 weak, C5 replicas).
+
+Ranks meet over torch.distributed's GLOO backend (handles, unique ids, barriers, MAX of the elapsed times): PyTorch's
+own NCCL/RCCL backend is never initialised, the library brings up its own transport (peer-to-peer mailboxes over
+xGMI, else its own RCCL communicator, else the gloo callback) -- VISMA_BENCH_BACKEND=nccl restores the old rendezvous.
 """
 import argparse
 import json
@@ -42,6 +53,9 @@ import socket
 import subprocess
 import sys
 import time
+
+# the CPU baseline's OpenMP runtime reads this when it is loaded (all cores, threads pinned close)
+os.environ.setdefault("OMP_PROC_BIND", "close")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -71,8 +85,11 @@ def parse():
     ap.add_argument("--f32-steps", type=int, default=10)
     ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling line of c4 at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--cpu-repeats", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=7, help="how many times the K-step block is timed (value = median)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="c4: skip from_initial_pose / end_to_end / roofline_saturated / scaling_workloads")
     return ap.parse_args()
 
 
@@ -112,7 +129,8 @@ class Ranks:
             import torch
             import torch.distributed as dist
             # VISMA_BENCH_BACKEND=gloo: dry run of the multi-rank logic on a box with fewer GPUs than ranks
-            self.backend = os.environ.get("VISMA_BENCH_BACKEND", "nccl")
+            # (gloo: the rendezvous moves a few hundred bytes; PyTorch's bundled RCCL stays out of the process's way)
+            self.backend = os.environ.get("VISMA_BENCH_BACKEND", "gloo")
             self.local_rank = self.local_rank % max(torch.cuda.device_count(), 1)
             torch.cuda.set_device(self.local_rank)
             if self.backend == "nccl":
@@ -179,7 +197,9 @@ def attach_comm(R, ctx, make_ctx, args):
             if int(flag.item()):
                 return ctx, "peer-to-peer mailboxes over xGMI (hipIpc, %d ranks; one launch per iteration)" % R.world
             ctx = make_ctx()                                  # some ranks mapped, some did not: start clean
-    ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or R.backend != "nccl" or want == "torch") else 1
+    # the library's own RCCL communicator needs one device per rank (RCCL refuses two ranks on one GPU)
+    distinct = torch.cuda.device_count() >= R.world or os.environ.get("VISMA_BENCH_RCCL_SHARED_GPU") == "1"
+    ok = 0 if (os.environ.get("VISMA_BENCH_FORCE_TORCH_COMM") == "1" or want == "torch" or not distinct) else 1
     uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
     if R.rank == 0 and ok:
         try:
@@ -202,15 +222,22 @@ def attach_comm(R, ctx, make_ctx, args):
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()):
         return ctx, "rccl (ncclAllReduce inside the library, saw %d ranks)" % R.world
-    if args.shard == "target" and not (R.world == 1 and not R.force_comm):
-        raise SystemExit("bench: the target-sharded mode needs the library's own RCCL communicator")
     ctx = make_ctx()                                          # a context without the half-made communicator
 
     def torch_allreduce(a):
         t = torch.from_numpy(a.copy()).to(R.tdev)
         dist.all_reduce(t)
         a[:] = t.cpu().numpy()
+
+    def torch_minreduce(a):
+        # element-wise MIN of unsigned 64-bit keys: flip the top bit, compare as signed, flip back
+        top = np.uint64(1 << 63)
+        t = torch.from_numpy((a ^ top).view(np.int64).copy()).to(R.tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        a[:] = t.cpu().numpy().view(np.uint64) ^ top
     ctx.set_allreduce(torch_allreduce, R.rank, R.world)
+    if args.shard == "target":
+        ctx.set_minreduce(torch_minreduce)                    # (host loop: two MIN exchanges + the sum per pass)
     return ctx, "torch.distributed callback (%s, %d ranks)" % (R.backend, R.world)
 
 
@@ -219,11 +246,11 @@ def attach_comm(R, ctx, make_ctx, args):
 # ------------------------------------------------------------------------------------------
 def cpu_registration():
     from oracle.oracle import Oracle, Ref
-    if Ref.available():
-        r = Ref()
-        return "reference", (os.cpu_count() or 1), lambda s, t, rad, m, init=None: r.registration_icp(
-            s, t, rad, init=init, max_iter=m, rel_fitness=0.0, rel_rmse=0.0)
     o = Oracle()
+    if Ref.available():
+        r = Ref()                   # (same OpenMP runtime in this process: omp_get_max_threads() of the port's library)
+        return "reference", o.num_threads(), lambda s, t, rad, m, init=None: r.registration_icp(
+            s, t, rad, init=init, max_iter=m, rel_fitness=0.0, rel_rmse=0.0)
     return "port", o.num_threads(), lambda s, t, rad, m, init=None: o.registration_icp(
         s, t, rad, init=init, max_iter=m, rel_fitness=0.0, rel_rmse=0.0, grid=True)
 
@@ -246,9 +273,9 @@ def cpu_baseline_c4(src, tgt, radius, iters, repeats):
     return {
         "value": float(np.median(rates)), "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
         "sample": "same clouds %d->%d, r=%.4g: %d steady-state iterations (t[%d its]-t[1 it]), median of %d; "
-                  "KD-tree build + 2 passes %.2fs; OMP_PROC_BIND=%s" % (
-                      len(src), len(tgt), radius, iters, iters + 1, repeats, float(np.median(t1s)),
-                      os.environ.get("OMP_PROC_BIND", "unset")),
+                  "KD-tree build + 2 passes %.2fs; %d OpenMP threads of %d logical CPUs, OMP_PROC_BIND=%s" % (
+                      len(src), len(tgt), radius, iters, iters + 1, repeats, float(np.median(t1s)), int(threads),
+                      os.cpu_count() or 0, os.environ.get("OMP_PROC_BIND", "unset")),
         "runs": [float(x) for x in rates], "ms_per_iter": 1e3 / float(np.median(rates)),
         "setup_plus_first_iter_s": float(np.median(t1s)), "T": np.asarray(res.T).tolist(),
     }
@@ -291,34 +318,45 @@ def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
     }
 
 
-def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, cand27_per_launch, traffic, exact):
-    # ALGORITHMIC bytes of ONE grid launch on one rank.  Per query: the source point (32 B f64 in the exact
-    # search, 16 B fp32 otherwise) + 9 x 16 B cell-run lookups + 8 B (index, d2) out (+ 32 B: the winner in
-    # f64), plus 12 B (exact search: packed x,y,z) or 16 B per candidate target point EXAMINED (counted by the
-    # kernel; rows of cells that provably cannot hold a better candidate are skipped, so this is less than the
-    # full 3x3x3 neighbourhood, whose byte count is given for reference).
-    per_query = (32.0 + 144.0 + 8.0 + 32.0) if exact else (16.0 + 144.0 + 8.0)
-    cand_bytes = 12.0 if exact else 16.0
-    b_alg = queries * per_query + cand_bytes * cand_per_launch
-    b_27 = queries * per_query + cand_bytes * cand27_per_launch
-    comp = nt_total * cand_bytes + queries * (per_query - 144.0)
+def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, traffic, exact, kernel="serial"):
+    """ALGORITHMIC (examined) bytes of ONE grid launch on one rank.  Per query: the source point (32 B f64 in the
+    exact search, 16 B fp32 otherwise) + 8 B (index, d2) out, and in the exact search 32 B x 1.05 (the winner and
+    the near-ties in f64) + 16 B (the winner written for the next pass) + 16 B (the previous winner read, warm
+    kernel); plus 16 B per cell-table row LOOKED UP (counted by the kernel: all 9 in the lane-serial kernel, the
+    1.9 the previous winner's distance cannot exclude in the warm-started one) and 12 B (exact: packed x,y,z) or
+    16 B per candidate EXAMINED / LISTED (counted by the kernel).
+    `compulsory` = every source and target point once.  The fraction on examined bytes falls when the search gets
+    smarter (fewer bytes AND less time); the fraction on compulsory bytes and `traffic_frac` (fabric bytes of the
+    PMC passes) do not have that defect."""
+    if exact:
+        per_query = 32.0 + 8.0 + 33.6 + 16.0 + (16.0 if kernel == "warm" else 0.0)
+        cand_bytes = 12.0
+    else:
+        per_query, cand_bytes = 16.0 + 8.0, 16.0
+    b_alg = queries * per_query + 16.0 * rows_per_launch + cand_bytes * cand_per_launch
+    comp = nt_total * cand_bytes + queries * (32.0 + 8.0 if exact else 24.0)
     nn_ms = max(nn_ms, 1e-9)
     gbps = b_alg / (nn_ms * 1e-3) / 1e9
     return {
-        "kernel": "nn_grid_reduce_kernel" + (" (exact: fp32 ranking + f64 re-rank of the rounding band; fold fused)"
-                                             if exact else ""),
+        "kernel": {"warm": "nn_coop_kernel (warm-started wave-cooperative exact search: previous winner bounds the query, "
+                           "reachable cells listed, chunks flattened over the wave; f64 re-rank; fold fused)",
+                   "serial": "nn_grid_reduce_kernel" + (" (exact: fp32 ranking + f64 re-rank of the rounding band; fold fused)"
+                                                        if exact else "")}[kernel],
         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
         "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
-        "traffic_source": "profiles/traffic.json (PMC passes of a profiled run, not this run)",
+        "traffic_source": "profiles/traffic.json (PMC passes of a profiled run of this command, not this run)",
+        "traffic_frac": (traffic / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS) if traffic else None,
         "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_alg,
         "candidates_per_query": cand_per_launch / max(queries, 1),
-        "full_27cell": {"bytes_per_launch": b_27, "gbps": b_27 / (nn_ms * 1e-3) / 1e9,
-                        "candidates_per_query": cand27_per_launch / max(queries, 1)},
+        "cell_table_rows_per_query": rows_per_launch / max(queries, 1),
         "compulsory_bytes": comp,
         "frac_on_compulsory_bytes": comp / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-        "note": "one launch per iteration: transform + grid NN + f64 re-rank + Jacobian/residual reduction + fold. "
-                "Bound in practice by the chain of dependent gathers of a wave (source, row bounds, ~10 batch trips, "
-                "winner, fold), not by HBM streaming: see DESIGN.md 4.1b",
+        "note": "one launch per iteration: transform + exact NN + Jacobian/residual reduction + fold.  `frac` is on the "
+                "bytes the search EXAMINES (it falls when pruning improves: fewer bytes and less time); "
+                "`frac_on_compulsory_bytes` prices the same launch on every point once; `traffic_frac` on the fabric "
+                "bytes the PMC counters saw.  At 262,144 queries the chip holds every wave at once: the launch lasts "
+                "as long as one wave's chain of dependent phases (DESIGN.md 4.1c); `roofline_saturated` shows the "
+                "same kernel with the chip refilled.",
     }
 
 
@@ -341,8 +379,18 @@ def c4_context(R, args, src, tgt, ns, nt, prec="exact"):
     return ctx, ns, hi - lo
 
 
-def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every):
-    """W untimed + K timed ICP iterations, barrier + synchronize on both sides, max over ranks."""
+def timed_block(R, ctx, T, radius, steps):
+    """K ICP iterations continuing from T, between two barrier + synchronize pairs; the MAX over ranks."""
+    R.barrier_sync()
+    t0 = time.perf_counter()
+    T, last = ctx.iterate(T, radius, steps)          # every step ends with the statistics on the host
+    R.barrier_sync()
+    return T, last, R.reduce_max(time.perf_counter() - t0)
+
+
+def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=1):
+    """W untimed iterations, then `blocks` blocks of K timed iterations each (the pose carries on from block to
+    block).  Returns the elapsed time of every block."""
     from visma_amd import _lib
     ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID, "brute": _lib.NN_BRUTE}[nn_mode])
     ctx.set_profiling(prof_every)
@@ -351,11 +399,10 @@ def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every):
     if warmup > 0:
         T, _ = ctx.iterate(T, radius, warmup)       # also builds the grid (one-off)
     setup = ctx.get_timing(reset=True)
-    R.barrier_sync()
-    t0 = time.perf_counter()
-    T, last = ctx.iterate(T, radius, steps)          # every step ends with the statistics on the host
-    R.barrier_sync()
-    elapsed = R.reduce_max(time.perf_counter() - t0)
+    elapsed, last = [], None
+    for _ in range(max(blocks, 1)):
+        T, last, el = timed_block(R, ctx, T, radius, steps)
+        elapsed.append(el)
     tm = ctx.get_timing(reset=True)
     if tm["nn_launches"] == 0:
         # too few steps for the sparse event timing to have seen a launch: time three more passes (outside
@@ -367,6 +414,67 @@ def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every):
     return T, last, elapsed, tm, setup
 
 
+def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None):
+    """roofline object of the search kernel the context's last passes ran, from its event / candidate counters"""
+    nl = max(tm["nn_launches"], 1)
+    kind = ctx.search_kernel_used()
+    key = {"warm": "grid_warm", "serial": "grid"}.get(kind, "grid")
+    return grid_roofline(ns_local, nt_local, tm["nn_ms"] / nl, tm["grid_candidates"] / nl,
+                         tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
+                         ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial")
+
+
+def c4_end_to_end(device, src, tgt, radius, iters=30, repeats=5):
+    """What `RegistrationICP(source, target, ...)` costs its caller (src/evaluation.cpp:248-271): host arrays
+    in, transformation out, on a context whose buffers exist (the second registration of a process)."""
+    from visma_amd import _lib
+    c = _lib.Context(device)
+    c.set_clouds_f64(src, tgt)
+    c.run(None, radius, iters, 0.0, 0.0)
+    up, run = [], []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        c.set_clouds_f64(src, tgt)
+        t1 = time.perf_counter()
+        res = c.run(None, radius, iters, 0.0, 0.0)
+        t2 = time.perf_counter()
+        up.append(t1 - t0)
+        run.append(t2 - t1)
+    c.close()
+    u, r = float(np.median(up)), float(np.median(run))
+    return {"ns": len(src), "nt": len(tgt), "iterations": iters, "nn_passes": iters + 1,
+            "upload_ms": u * 1e3, "grid_build_and_loop_ms": r * 1e3, "total_ms": (u + r) * 1e3,
+            "pcie_inclusive_iterations_per_sec": iters / (u + r), "median_of": repeats,
+            "fitness": res.fitness_, "K": res.num_correspondences}
+
+
+def c4_saturated(device, tgt, nt, radius, ns_list=(1048576, 4194304), steps=5):
+    """The kernel of the timed region with the chip refilled many times: same 4 M-point target and radius,
+    1 M and 4 M queries per launch (measured after the timed region, HIP events on the context's stream)."""
+    from visma_amd import _lib, synth
+    out = []
+    for ns_s in ns_list:
+        src_s = synth.make_source(ns_s, nt, seed_s=5678 + ns_s % 9973)
+        c = _lib.Context(device)
+        c.set_clouds_f64(src_s, tgt)
+        c.set_nn_mode(_lib.NN_GRID)
+        T, _ = c.iterate(np.eye(4), radius, 4)
+        c.set_profiling(1)
+        c.get_timing(reset=True)
+        t0 = time.perf_counter()
+        T, last = c.iterate(T, radius, steps)
+        dt = time.perf_counter() - t0
+        tm = c.get_timing(reset=True)
+        c.set_profiling(0)
+        r = kernel_roofline(c, ns_s, nt, tm, traffic_kind="none")
+        r.update(ns=ns_s, nt=nt, steps=steps, ms_per_step=dt / steps * 1e3, launches_timed=tm["nn_launches"],
+                 query_iterations_per_sec=float(ns_s) * steps / dt, fitness=last.fitness_)
+        r.pop("note", None)
+        out.append(r)
+        c.close()
+    return out
+
+
 def run_c4(R, args):
     from visma_amd import _lib, synth
     ns, nt = args.ns, args.nt
@@ -376,13 +484,16 @@ def run_c4(R, args):
     if R.dist is not None:
         ctx, comm_kind = attach_comm(R, ctx, lambda: c4_context(R, args, src, tgt, ns, nt)[0], args)
     # HIP-event timing of the kernels: every launch with brute force (117 ms each), every 4th ICP pass with
-    # the grid (two event records cost ~7 us of a ~60 us iteration)
+    # the grid (two event records cost ~7 us of a ~50 us iteration)
     # (with fewer than 8 steps nothing is timed inside the timed region: timed_iterations measures the
     #  kernel on three extra passes afterwards)
     prof_every = 1 if args.nn == "brute" else (4 if args.steps >= 8 else 0)
-    T, last, elapsed, tm, setup = timed_iterations(R, ctx, radius, args.warmup, args.steps, args.nn, prof_every)
+    blocks = 1 if args.nn == "brute" else max(args.blocks, 1)
+    T, last, elapsed_all, tm, setup = timed_iterations(R, ctx, radius, args.warmup, args.steps, args.nn, prof_every, blocks)
+    elapsed = float(np.median(elapsed_all))
     mode = "grid" if ctx.nn_mode_used() == _lib.NN_GRID else "brute"
     search = ctx.search_mode_used()
+    kernel_kind = ctx.search_kernel_used()
     # every rank solved from the same all-reduced statistics: their transforms must agree to the bit
     ranks_agree = True
     if R.dist is not None:
@@ -393,18 +504,32 @@ def run_c4(R, args):
         ranks_agree = bool(R.torch.equal(hi, lo))
     nl = max(tm["nn_launches"], 1)
     nn_ms = R.reduce_max(tm["nn_ms"] / nl)
-    cand, cand27 = tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl
+    cand = tm["grid_candidates"] / nl
 
-    # a few brute-force steps (outside the timed region) for the north_star kernel's own numbers
+    # iterations 1..K of a FRESH registration (what the winners of the passes so far would not be there for):
+    # first pass on the lane-serial kernel, the rest warm-started while the pose still moves
+    initial = None
+    if mode == "grid" and not args.no_extras:
+        ctx.forget_winners()
+        ctx.iterate(np.eye(4), radius, args.steps)                  # throw-away
+        els = []
+        for _ in range(3):
+            ctx.forget_winners()
+            _, li, el = timed_block(R, ctx, np.eye(4), radius, args.steps)
+            els.append(el)
+        initial = {"steps": args.steps, "ms_per_step": float(np.median(els)) / args.steps * 1e3,
+                   "icp_iterations_per_sec": args.steps / float(np.median(els)), "median_of": 3,
+                   "note": "identity start, nothing remembered from earlier passes; `value` above times iterations "
+                           "%d..%d continuing at the converged pose" % (args.warmup + 1, args.warmup + args.steps * blocks)}
+
+    # north_star's brute-force kernel on the same (sharded) problem, outside the timed region: collective timing
     brute = None
     if mode != "brute" and args.brute_steps > 0:
         ctx.set_nn_mode(_lib.NN_BRUTE)
         ctx.set_profiling(1)
         ctx.iterate(T, radius, 1)
         ctx.get_timing(reset=True)
-        tb0 = time.perf_counter()
-        Tb, _ = ctx.iterate(np.eye(4), radius, args.brute_steps)
-        tb = time.perf_counter() - tb0
+        Tb, _, tb = timed_block(R, ctx, np.eye(4), radius, args.brute_steps)
         tmb = ctx.get_timing(reset=True)
         ctx.set_profiling(0)
         Tg, _ = (ctx.set_nn_mode(_lib.NN_GRID), ctx.iterate(np.eye(4), radius, args.brute_steps))[1]
@@ -427,7 +552,7 @@ def run_c4(R, args):
         Tex, _ = ctx.iterate(np.eye(4), radius, args.f32_steps)
         f32_extra = {"steps": args.f32_steps, "iterations_per_sec": args.f32_steps / tf,
                      "rel_frobenius_vs_exact_search": synth.rel_frobenius(T32, Tex),
-                     "note": "fp32 ranking only (round-1 kernel): may decide near-ties / radius cases "
+                     "note": "fp32 ranking only (round-1 kernel, lane-serial): may decide near-ties / radius cases "
                              "differently from the reference"}
         c32.close()
 
@@ -436,25 +561,39 @@ def run_c4(R, args):
     weak = None
     if R.world > 1 and not args.no_weak and args.shard == "source":
         wns, wnt = ns * R.world, nt
-        wsrc, wtgt, _, wr = synth.make_pair(wns, wnt, motion="radius")
-        wctx, wns_local, _ = c4_context(R, args, wsrc, wtgt, wns, wnt)
-        wctx, _ = attach_comm(R, wctx, lambda: c4_context(R, args, wsrc, wtgt, wns, wnt)[0], args)
-        _, wlast, welapsed, wtm, _ = timed_iterations(R, wctx, wr, args.warmup, args.steps, args.nn, 4)
-        weak = {"ns": wns, "nt": wnt, "radius": wr, "ms_per_step": welapsed / args.steps * 1e3,
+        wsrc = synth.make_source(wns, wnt)
+        wctx, wns_local, _ = c4_context(R, args, wsrc, tgt, wns, wnt)
+        wctx, _ = attach_comm(R, wctx, lambda: c4_context(R, args, wsrc, tgt, wns, wnt)[0], args)
+        _, wlast, wel, wtm, _ = timed_iterations(R, wctx, radius, args.warmup, args.steps, args.nn, 4, 3)
+        welapsed = float(np.median(wel))
+        weak = {"ns": wns, "nt": wnt, "radius": radius, "ms_per_step": welapsed / args.steps * 1e3,
                 "icp_iterations_per_sec": args.steps / welapsed,
                 "point_iterations_per_sec": float(wns) * args.steps / welapsed,
                 "nn_kernel_ms": R.reduce_max(wtm["nn_ms"] / max(wtm["nn_launches"], 1)),
-                "fitness": wlast.fitness_,
+                "fitness": wlast.fitness_, "median_of_blocks": 3,
                 "note": "per-rank work fixed (262,144 queries per rank against the same target and radius as at N = 1): "
                         "ideal weak scaling keeps icp_iterations_per_sec at the N = 1 value of this line's `value`"}
         wctx.close()
+
+    # configuration 5 (replicas only) for a few passes, so that the N = 1, 2, 4, 8 lines of this same command
+    # also carry a workload that shards without any exchange
+    c5 = None
+    if not args.no_extras and args.nn != "brute":
+        sub = argparse.Namespace(**vars(args))
+        sub.steps, sub.warmup, sub.no_cpu_baseline = 2, 1, True
+        c5r = run_c5(R, sub, tag="sw")
+        if c5r is not None:
+            c5 = {"icp_iterations_per_sec": c5r["value"], "registrations_per_sec": c5r["registrations_per_sec"],
+                  "ms_per_pass": c5r["ms_per_step"], "passes": 2, "parallelism": c5r["config"]["parallelism"]}
 
     out = None
     if R.rank == 0:
         tile = _lib.tile_config()
         exact = search != "f32"
         if mode == "grid":
-            roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, cand27, load_traffic("grid", ns_local, nt_local), exact)
+            roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, tm["grid_candidates_27cell"] / nl,
+                                     load_traffic("grid_warm" if kernel_kind == "warm" else "grid", ns_local, nt_local),
+                                     exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial")
         else:
             roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
         roofline["launches_timed"] = tm["nn_launches"]
@@ -463,6 +602,8 @@ def run_c4(R, args):
         par = ("source-sharded x%d, 1 all-reduce(38 f64)/iter via %s" % (R.world, comm_kind)
                if args.shard == "source" else
                "target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter via %s" % (R.world, ns, comm_kind))
+        if R.dist is not None:
+            par += "; ranks meet over torch.distributed/%s" % R.backend
         out = {
             "metric": "icp_iterations_per_sec", "value": args.steps / elapsed,
             "unit": "ICP iterations/s", "n_gpus": R.world, "steps": args.steps,
@@ -472,8 +613,12 @@ def run_c4(R, args):
             "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, nn=%s, "
                                    "search=%s" % (ns, nt, args.steps, mode, search),
                        "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode, "search": search,
+                       "search_kernel": kernel_kind,
                        "arithmetic": "fp32 candidate ranking, f64 re-rank of the rounding band, f64 statistics",
                        "parallelism": par},
+            "blocks": {"timed": len(elapsed_all), "steps_each": args.steps, "value_is": "median block",
+                       "iterations_per_sec": [args.steps / e for e in elapsed_all],
+                       "min": args.steps / max(elapsed_all), "max": args.steps / min(elapsed_all)},
             "candidates_evaluated_per_sec": cand * R.world * args.steps / elapsed if mode == "grid" else float(ns) * nt * args.steps / elapsed,
             "equivalent_bruteforce_mpairs_per_sec": float(ns) * nt * args.steps / elapsed / 1e6,
             "matched_corr_per_sec": last.num_correspondences * args.steps / elapsed,
@@ -482,6 +627,8 @@ def run_c4(R, args):
             "setup_ms": {"grid_build_kernels": setup["aux_ms"]},
             "roofline": roofline,
         }
+        if initial is not None:
+            out["from_initial_pose"] = initial
         if brute is not None:
             b = brute_roofline(ns_local, nt_local, brute["nn_ms"], tile, load_traffic("brute", ns_local, nt_local))
             b.update(steps=brute["steps"], ms_per_step=brute["ms_per_step"],
@@ -493,6 +640,28 @@ def run_c4(R, args):
             out["f32_search"] = f32_extra
         if weak is not None:
             out["weak_scaling"] = weak
+        if not args.no_extras:
+            sw = {"c4_grid_strong": {"icp_iterations_per_sec": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                                     "expectation": "one launch of ~45 us whose duration is a chain of dependent phases, not "
+                                                    "work: halving the queries per rank does not halve it (DESIGN.md 5: "
+                                                    "<= 1.4x / 1.7x / 1.9x at 2 / 4 / 8 GPUs before the exchange costs anything)"}}
+            if brute is not None:
+                sw["c4_brute_strong"] = {"icp_iterations_per_sec": 1e3 / brute["ms_per_step"], "ms_per_step": brute["ms_per_step"],
+                                         "expectation": "north_star's kernel: NS/N x NT pair evaluations per rank and "
+                                                        "iteration, 608 bytes exchanged: shards linearly"}
+            sw["c4_weak"] = ({"icp_iterations_per_sec": weak["icp_iterations_per_sec"], "ms_per_step": weak["ms_per_step"],
+                              "source_points": weak["ns"]} if weak is not None else
+                             {"icp_iterations_per_sec": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                              "source_points": ns})
+            if c5 is not None:
+                sw["c5_replicas"] = c5
+            out["scaling_workloads"] = sw
+        if R.world == 1 and not args.no_extras and mode == "grid":
+            out["end_to_end"] = {"c4": c4_end_to_end(R.local_rank, src, tgt, radius),
+                                 "c2_5k_20k": c4_end_to_end(R.local_rank, *synth.make_pair(5000, 20000)[:2], 0.075, iters=20),
+                                 "note": "host arrays in -> transformation out on a context whose buffers exist: both "
+                                         "clouds cross PCIe as the caller's f64 values; never `value`"}
+            out["roofline_saturated"] = c4_saturated(R.local_rank, tgt, nt, radius)
         if R.world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline_c4(src, tgt, radius, args.cpu_iters, args.cpu_repeats)
             Tg = ctx.run(None, radius, 1 + args.cpu_iters, 0.0, 0.0)       # parity on this workload, same iteration count
@@ -553,7 +722,8 @@ def run_c3(R, args):
     if R.rank == 0:
         queries = my_queries
         nt_total = sum(len(objs[i][1]) for i in mine)
-        roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True)
+        roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True,
+                                 "warm" if ctx.search_kernel_used() == "warm" else "serial")
         roofline["launches_timed"] = tm["nn_launches"]
         out = {
             "metric": "icp_iterations_per_sec", "value": total_its / elapsed, "unit": "ICP iterations/s",
@@ -634,7 +804,7 @@ def c5_pick(results, level):
     return out
 
 
-def run_c5(R, args):
+def run_c5(R, args, tag=""):
     from visma_amd import _lib
     scenes, cads, items = c5_corpus()
     radius, level, iters = 0.05, 24, 30
@@ -650,7 +820,7 @@ def run_c5(R, args):
                 yield items[i:i + C5_CHUNK]
             return
         while True:
-            i = store.add("c5_next_%d" % step, C5_CHUNK) - C5_CHUNK
+            i = store.add("c5%s_next_%d" % (tag, step), C5_CHUNK) - C5_CHUNK
             if i >= len(items):
                 return
             yield items[i:i + C5_CHUNK]
@@ -696,14 +866,14 @@ def run_c5(R, args):
             tm = ctx.get_timing(reset=True)
             nl = tm["nn_launches"]
             q = sum(len(cads[c]) for s, c in chunk) * level
-            b_alg += nl * q * (32.0 + 144.0 + 8.0 + 32.0) + 12.0 * tm["grid_candidates"]
+            b_alg += nl * q * (32.0 + 8.0 + 33.6 + 16.0 + 16.0) + 16.0 * tm["grid_candidates_27cell"] + 12.0 * tm["grid_candidates"]
             b_comp += nl * (sum(len(scenes[s]) for s, c in chunk) * 12.0 + q * 72.0)
             ms += tm["nn_ms"]
             launches += nl
         ctx.set_profiling(0)
         if ms > 0:
             gbps = b_alg / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "nn_grid_reduce_kernel (%d problems per launch: %d items x 24 starts, exact search, fold fused)" % (
+            roofline = {"kernel": "nn_coop_kernel after each batch's first pass (%d problems per launch: %d items x 24 starts, exact search, fold fused)" % (
                             C5_CHUNK * level, C5_CHUNK),
                         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                         "traffic": None, "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": b_alg / max(launches, 1),

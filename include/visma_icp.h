@@ -288,6 +288,15 @@ VISMA_ICP_API int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode);
 VISMA_ICP_API int visma_icp_get_search_precision_used(visma_icp_ctx *ctx, int *is_f64);
 /* Which search the last nn_pass used (VISMA_ICP_NN_BRUTE or VISMA_ICP_NN_GRID). */
 VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
+/* Which kernel the last grid pass ran: 0 brute force, 1 the lane-serial grid search (first pass of a
+ * registration: progressive pruning, nothing known about the queries), 2 the warm-started wave-cooperative
+ * search (visma_amd/csrc/grid_coop.hip: every later pass; each query starts from its previous winner, which
+ * bounds it before anything is gathered).  Same results, bit for bit.
+ * visma_icp_forget_winners drops what the passes so far remembered (the library does so itself whenever the
+ * source, the target or the radius changes): the next pass then runs like the first of a new registration.
+ * Replaces nothing in the reference (KDTreeFlann keeps no state between searches, KDTreeFlann.cpp:164-189). */
+VISMA_ICP_API int visma_icp_get_search_kernel_used(visma_icp_ctx *ctx, int *kernel);
+VISMA_ICP_API int visma_icp_forget_winners(visma_icp_ctx *ctx);
 /* Where the ICP loop runs.  1: ON THE DEVICE (per-iteration solve, compose and
  * stop test in a one-thread kernel epilogue, the host reads the state back
  * every 8 passes); 0: on the host (statistics published to mapped host memory,

@@ -1,7 +1,11 @@
-"""bench.py on two real GPUs, one process each: both shardings, through the peer-to-peer mailbox
-all-reduce and through RCCL (the MIN all-reduce of the target-sharded mode included).  Skips on a
-box with one GPU (the driver's multi-GPU run and the gloo dry runs of test_distributed_gloo.py cover
-the same code there)."""
+"""bench.py with two ranks, one process each.
+On two real GPUs: both shardings, through the peer-to-peer mailbox all-reduce and through RCCL (the MIN
+all-reduce of the target-sharded mode included) -- skipped on a box with one GPU.
+On ONE GPU (the box the suite normally runs on): the same command with both ranks on device 0 -- the whole
+N > 1 path of the bench (gloo rendezvous, handle exchange, collective bring-up with fall-backs, barriers,
+MAX-over-ranks timing, the weak-scaling line, scaling_workloads incl. the corpus counter) executes before the
+driver's multi-GPU run does: source-sharded over the hipIpc mailboxes and over the host callback,
+target-sharded over the host callbacks."""
 import json
 import os
 import subprocess
@@ -45,3 +49,40 @@ def test_two_ranks_match_one(lib, shard, comm):
     assert abs(two["fitness"] - one["fitness"]) < 1e-12
     assert abs(two["err_vs_T_gt"] - one["err_vs_T_gt"]) < 1e-9
     assert abs(two["inlier_rmse"] - one["inlier_rmse"]) < 1e-12
+
+
+def _same_registration(one, two):
+    assert two["n_gpus"] == 2 and two["ranks_hold_identical_transforms"] is True
+    assert abs(two["fitness"] - one["fitness"]) < 1e-12
+    assert abs(two["err_vs_T_gt"] - one["err_vs_T_gt"]) < 1e-9
+    assert abs(two["inlier_rmse"] - one["inlier_rmse"]) < 1e-12
+
+
+@pytest.fixture(scope="module")
+def one_rank(lib):
+    return _bench(["--no-extras"], {}, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("comm,want", [("ipc", "hipipc"), ("torch", "callback")])
+def test_two_source_sharded_ranks_on_one_gpu(lib, one_rank, comm, want):
+    two = _bench(["--shard", "source"], {"VISMA_BENCH_COMM": comm, "VISMA_TEST_SHARE_GPU": "1"}, 2)
+    _same_registration(one_rank, two)
+    par = two["config"]["parallelism"].lower()
+    assert want in par and "x2" in par and "gloo" in par, par
+    assert two["weak_scaling"]["ns"] == 2 * 65536 and two["weak_scaling"]["fitness"] > 0.99
+    sw = two["scaling_workloads"]
+    assert set(sw) >= {"c4_grid_strong", "c4_weak", "c5_replicas"}
+    assert sw["c5_replicas"]["icp_iterations_per_sec"] > 0 and "2 rank" in sw["c5_replicas"]["parallelism"]
+    assert len(two["blocks"]["iterations_per_sec"]) == 7
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_two_target_sharded_ranks_on_one_gpu(lib, one_rank):
+    """north_star's decomposition: each rank holds half of the target; per pass a MIN exchange of the f64
+    distances, a MIN exchange of the claimed indices, then the 38-double sum (host callbacks on one GPU)."""
+    two = _bench(["--shard", "target", "--no-weak", "--no-extras"], {"VISMA_BENCH_COMM": "torch", "VISMA_TEST_SHARE_GPU": "1"}, 2)
+    _same_registration(one_rank, two)
+    assert "target-sharded x2" in two["config"]["parallelism"]

@@ -93,6 +93,8 @@ def load():
     L.visma_icp_set_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.visma_icp_set_source_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.visma_icp_set_target_normals_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int]
+    L.visma_icp_get_search_kernel_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.visma_icp_forget_winners.argtypes = [C.c_void_p]
     L.visma_icp_nn_pass.argtypes = [C.c_void_p, _dp, C.c_double]
     L.visma_icp_reduce.argtypes = [C.c_void_p, _dp]
     L.visma_icp_get_correspondences.argtypes = [C.c_void_p, _ip, _ip, _fp, C.POINTER(C.c_int64)]
@@ -439,6 +441,16 @@ class Context:
         m = C.c_int(0)
         self._chk(self.L.visma_icp_get_nn_mode_used(self._h, C.byref(m)))
         return m.value
+
+    def search_kernel_used(self):
+        """'brute' | 'serial' (lane-serial grid search) | 'warm' (warm-started wave-cooperative grid search)."""
+        v = C.c_int(0)
+        self._chk(self.L.visma_icp_get_search_kernel_used(self._h, C.byref(v)))
+        return {0: "brute", 1: "serial", 2: "warm"}[v.value]
+
+    def forget_winners(self):
+        """The next pass runs like the first of a new registration (no warm start)."""
+        self._chk(self.L.visma_icp_forget_winners(self._h))
 
     def set_device_loop(self, on=True):
         """True: on-device loop, False: host loop, None: automatic (default)."""

@@ -176,6 +176,8 @@ public:
     }
     virtual int set_nn_mode(int mode) { return mode == VISMA_ICP_NN_AUTO ? VISMA_ICP_OK : VISMA_ICP_ERR_STATE; }
     virtual int nn_mode_used() const { return VISMA_ICP_NN_AUTO; }
+    virtual int search_kernel_used() const { return 0; }
+    virtual int forget_winners() { return VISMA_ICP_OK; }
     virtual void set_profiling(int) {}
     virtual void get_timing(visma_icp_timing *t, bool) { std::memset(t, 0, sizeof(*t)); }
     virtual void launch_config(int *tiles, int *splits) { *tiles = 0; *splits = 0; }
@@ -660,6 +662,7 @@ public:
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
                                           exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (float4 *)d_pos_, 1));
+            last_kernel_ = pass_kernel(lanes);
             pos_fresh_ = d_pos_ != nullptr;
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (!tshard_ && !fused) {
@@ -758,7 +761,7 @@ public:
                                           (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                           T32_, T64, nullptr, r2f_, 0, (int32_t *)d_idx_,
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
-                                          &nblocks, pass_lanes(), nullptr, nullptr, 1, 0, stream_,
+                                          &nblocks, (last_kernel_ = pass_kernel(pass_lanes()), pass_lanes()), nullptr, nullptr, 1, 0, stream_,
                                           f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0,
                                           nullptr, nullptr, (float4 *)d_pos_, 1));
             pos_fresh_ = d_pos_ != nullptr;
@@ -890,6 +893,7 @@ public:
                                                   nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
                                                   exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr,
                                                   (float4 *)d_pos_, 1));
+                    last_kernel_ = pass_kernel(lanes);
                     pos_fresh_ = d_pos_ != nullptr;
                     if (tshard_) {
                         // the shards' winners compared on the stream (two MIN all-reduces), the owners' moments
@@ -1220,6 +1224,7 @@ public:
                                                     (lp.plane && !f64) ? (const float4 *)bt_nrm_ : nullptr,
                                                     (lp.plane && f64) ? (const Pt64 *)bt_nrm64_ : nullptr,
                                                     (float4 *)bt_pos_, 1));
+                last_kernel_ = (coop && fresh) ? 2 : 1;
                 fresh = true;
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
                 if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -1257,6 +1262,8 @@ public:
         return VISMA_ICP_OK;
     }
     int nn_mode_used() const override { return use_grid_ ? VISMA_ICP_NN_GRID : VISMA_ICP_NN_BRUTE; }
+    int search_kernel_used() const override { return use_grid_ ? last_kernel_ : 0; }
+    int forget_winners() override { HIP_TRY(hipSetDevice(device_)); return invalidate_pos(); }
 
     int set_target_shard(int64_t offset, int64_t global_nt) override
     {
@@ -1820,6 +1827,7 @@ private:
     // the warm-started kernel).
     void *d_pos_ = nullptr;
     bool pos_fresh_ = false;
+    int last_kernel_ = 0;        // what the last pass ran: 0 brute force, 1 lane-serial grid, 2 warm-started cooperative grid
     int coop_enabled_ = 1;       // VISMA_ICP_COOP=0: every pass on the lane-serial kernel
     int invalidate_pos()
     {
@@ -1831,6 +1839,8 @@ private:
     {
         return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1;
     }
+    // which kernel a lanes code selects (see launch_nn_grid_reduce)
+    int pass_kernel(int lanes) const { return (lanes == kCoopLanes && coop_ok()) ? 2 : 1; }
     // lanes code of the next grid pass over `nprob` problems sharing the clouds
     int pass_lanes(int nprob = 1) const
     {
@@ -2990,6 +3000,22 @@ int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode)
     CTX_CHECK();
     if (!nn_mode) return ctx->fail(VISMA_ICP_ERR_INVALID, "nn_mode is NULL");
     *nn_mode = ctx->eng->nn_mode_used();
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_search_kernel_used(visma_icp_ctx *ctx, int *kernel)
+{
+    CTX_CHECK();
+    if (!kernel) return ctx->fail(VISMA_ICP_ERR_INVALID, "kernel is NULL");
+    *kernel = ctx->eng->search_kernel_used();
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_forget_winners(visma_icp_ctx *ctx)
+{
+    CTX_CHECK();
+    int rc = ctx->eng->forget_winners();
+    if (rc) return ctx->eng_fail(rc);
     return VISMA_ICP_OK;
 }
 

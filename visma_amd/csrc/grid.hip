@@ -732,11 +732,11 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 row_b[kk - 1][threadIdx.x] = rb[k];
                 row_e[kk - 1][threadIdx.x] = re[k];
                 row_bound[kk - 1][threadIdx.x] = row_bound_of(k % 3 - 1, k / 3 - 1);
-                if (cand_count && sub == 0) ncand_all += re[k] - rb[k];
+                if (cand_count && sub == 0) ncand_all += 1u;       // profiling: cell-table rows looked up
             }
             base = rb[4];
             e = re[4];                                           // centre row: never pruned
-            if (cand_count && sub == 0) { ncand_all += e - base; ncand += e - base; }
+            if (cand_count && sub == 0) { ncand_all += 1u; ncand += e - base; }
             walk();
         }
         if (g.sub == 2) {
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     row_b[k][threadIdx.x] = rb[k];
                     row_e[k][threadIdx.x] = re[k];
                     row_bound[k][threadIdx.x] = bd[k];
-                    if (cand_count && sub == 0) ncand_all += re[k] - rb[k];
+                    if (cand_count && sub == 0) ncand_all += 1u;
                 }
                 base = e = 0;
                 walk();

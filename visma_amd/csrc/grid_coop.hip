@@ -197,6 +197,7 @@ __device__ __forceinline__ void coop_body(
         auto load_row = [&](int k, bool want) {
             const int z = cz + (k / 3 - 1), y = cy + (k % 3 - 1);
             const bool ok = want && span > 0 && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+            if (cand_count && ok) ncand_all++;               // profiling: cell-table rows looked up
             u4a v = {0u, 0u, 0u, 0u};
             if (ok) v = *reinterpret_cast<const u4a *>(start + ((long long)z * g.dim[1] + y) * g.dim[0] + x0);
             return v;
@@ -262,7 +263,6 @@ __device__ __forceinline__ void coop_body(
             xe[k] = e;
             if (cand_count) ncand += e - b;
         }
-        if (cand_count) ncand_all = ncand;                   // (the 27-cell population is not looked up any more)
 #ifdef VISMA_COOP_DEBUG_PHASES
         asm volatile("" ::"v"(xb[0]), "v"(xe[8]), "v"(xb[4]));
 #endif

@@ -139,6 +139,16 @@ def make_pair(ns, nt, seed_t=1234, seed_s=5678, noise=1e-3, offset=None, motion=
     return src, tgt, T, default_radius(nt)
 
 
+def make_source(ns, nt, seed_s=5678, motion="radius"):
+    """The source cloud make_pair(ns, nt, seed_s=seed_s, motion=motion) returns, without generating the target
+    again (the ground-truth motion depends on nt through the radius only)."""
+    src = surface_points(ns, seed_s)
+    T = T_gt() if motion == "fixed" else T_gt_scaled(default_radius(nt))
+    Ti = np.linalg.inv(T)
+    src = src @ Ti[:3, :3].T + Ti[:3, 3]
+    return src.astype(np.float32).astype(np.float64)
+
+
 def rel_frobenius(A, B):
     """||A - B||_F / ||B||_F on 4x4 transforms (the parity metric)."""
     A = np.asarray(A, dtype=np.float64)
