@@ -805,47 +805,47 @@ def c5_pick(results, level):
 
 
 def run_c5(R, args, tag=""):
+    """The corpus through the library's NATIVE work queue (visma_icp_run_corpus): this process is one rank with
+    one context; with several ranks (one process per GPU) the counter lives in shared memory and every rank's
+    host thread pulls chunks from it with atomic adds."""
+    import ctypes
+    from multiprocessing import shared_memory
     from visma_amd import _lib
     scenes, cads, items = c5_corpus()
     radius, level, iters = 0.05, 24, 30
     ctx = _lib.Context(R.local_rank)
-    store = None
+    corpus = _lib.Corpus([(cads[c], scenes[s]) for s, c in items], level=level, max_dist=radius, max_iter=iters,
+                         rel_fitness=1e-6, rel_rmse=1e-6, chunk=C5_CHUNK)
+    nwarm = max(args.warmup, 1)
+    nslots = nwarm + args.steps
+    shm = None
     if R.dist is not None:
-        store = R.torch.distributed.distributed_c10d._get_default_store()
+        # one counter per pass (a rank may start the next pass while another still works on this one)
+        name = "visma_c5_%s_%s" % (os.environ.get("MASTER_PORT", "0"), tag or "w")
+        if R.rank == 0:
+            try:
+                shared_memory.SharedMemory(name=name).unlink()            # left behind by a killed run
+            except Exception:      # noqa: BLE001
+                pass
+            shm = shared_memory.SharedMemory(name=name, create=True, size=8 * nslots)
+            shm.buf[:8 * nslots] = bytes(8 * nslots)
+        R.dist.barrier()
+        if R.rank != 0:
+            shm = shared_memory.SharedMemory(name=name)
+        base = ctypes.addressof(ctypes.c_char.from_buffer(shm.buf))
 
-    def pull(step):
-        """next chunk of work items of this pass: a shared counter when there are several ranks"""
-        if store is None:
-            for i in range(0, len(items), C5_CHUNK):
-                yield items[i:i + C5_CHUNK]
-            return
-        while True:
-            i = store.add("c5%s_next_%d" % (tag, step), C5_CHUNK) - C5_CHUNK
-            if i >= len(items):
-                return
-            yield items[i:i + C5_CHUNK]
+    def one_pass(slot):
+        res = corpus.run([ctx], (base + 8 * slot) if shm is not None else None)
+        mine = [r for r in res if r[2] >= 0]
+        return sum(r[3] for r in mine), len(mine)
 
-    prepared = {}                               # chunk -> the C array of its problems (the corpus is static)
-
-    def one_pass(step):
-        its, done = 0, 0
-        for chunk in pull(step):
-            key = tuple(chunk)
-            if key not in prepared:
-                prepared[key] = ctx.make_batch(c5_chunk_problems(scenes, cads, chunk, radius, level))
-            res = ctx.run_batch(prepared[key], max_iter=iters)
-            c5_pick(res, level)
-            its += sum(p.iterations for p in res)
-            done += len(chunk)
-        return its, done
-
-    for w in range(max(args.warmup, 1)):
-        one_pass(-1 - w)
+    for w in range(nwarm):
+        one_pass(w)
     R.barrier_sync()
     t0 = time.perf_counter()
     its = done = 0
     for step in range(args.steps):
-        a, b = one_pass(step)
+        a, b = one_pass(nwarm + step)
         its += a
         done += b
     R.barrier_sync()
@@ -853,6 +853,12 @@ def run_c5(R, args, tag=""):
     total_its = R.reduce_sum(float(its))
     per_rank_items = done
     total_items = int(round(R.reduce_sum(float(done))))
+    if shm is not None:
+        del base
+        R.dist.barrier()
+        shm.close()
+        if R.rank == 0:
+            shm.unlink()
     # roofline of the batch kernel: one profiled pass over the first chunks (after the timed region)
     roofline = None
     if R.rank == 0:
@@ -890,7 +896,9 @@ def run_c5(R, args, tag=""):
                                    "(24 yaw starts each, <= %d iterations, r=%.3g) per pass" % (
                                        len(scenes), len(cads), len(items), iters, radius),
                        "items": len(items), "search": ctx.search_mode_used(),
-                       "parallelism": "replicas only: %d rank(s) pull chunks of %d work items from a shared counter, no collective" % (R.world, C5_CHUNK)},
+                       "parallelism": "replicas only: %d rank(s) pull chunks of %d work items from one atomic counter%s "
+                                      "(visma_icp_run_corpus: native work queue, one host thread per GPU), no collective" % (
+                                          R.world, C5_CHUNK, " in shared memory" if R.world > 1 else "")},
             "registrations_per_sec": len(items) * args.steps / elapsed,
             "items_done_by_rank0": per_rank_items, "items_done_by_all_ranks": total_items,
             "roofline": roofline,

@@ -255,6 +255,39 @@ VISMA_ICP_API int visma_icp_run_batch_point_to_plane(visma_icp_ctx *ctx, const v
                                                      int max_iter, double rel_fitness, double rel_rmse,
                                                      visma_icp_result *out);
 
+/* ---- the corpus: every (scene, CAD candidate) pair, one orientation-constrained registration each --------
+ * The per-object loop of AnnotationTool (src/annotation.cpp:103-168: for each entry of objects.json ->
+ * RegisterModelToScene(model, scan, config["ICP"])) over a whole corpus, as a native work queue: ONE HOST
+ * THREAD PER CONTEXT (= per GPU) pulls chunks of `chunk` items from a counter, runs their `level` yaw starts
+ * (src/annotation.cpp:35-39) as one batch (visma_icp_run_batch: clouds passed by several problems are uploaded
+ * and gridded once) and keeps, per item, the first start with strictly the most correspondences
+ * (src/annotation.cpp:59-61).  No collective, no exchange: replicas only.
+ * `counter` (may be NULL: a private one) is advanced with atomic adds: ranks in OTHER processes can pull from
+ * the same queue when it lives in shared memory (bench.py --workload c5 --gpus N: one process per GPU); it must
+ * be 0 when the pass starts.  results[i].device is the index of the context that registered item i, -1 when
+ * another process took it.  Returns the first error of any thread (message in errbuf). */
+typedef struct {
+    const double *model_xyz; int64_t n_model;   /* source: the sampled CAD model (AoS f64, stride 3) */
+    const double *scene_xyz; int64_t n_scene;   /* target: the scan */
+} visma_icp_corpus_item;
+typedef struct {
+    int level;               /* rotation_level (cfg/tool.json:17): yaw starts R_y(2 pi k / level) */
+    double max_dist;         /* distance_threshold */
+    int max_iter;            /* ICPConvergenceCriteria: 30 */
+    double rel_fitness, rel_rmse;
+    int solver;              /* VISMA_ICP_SOLVER_KABSCH = the reference's estimator */
+    int chunk;               /* items per pull (<= 0: 8 -> 8 x 24 = 192 registrations in flight per launch) */
+} visma_icp_corpus_params;
+typedef struct {
+    visma_icp_result best;   /* RegisterModelToScene's choice (transformation_ = what it returns) */
+    int32_t best_level;      /* which start it was; -1: no start found a correspondence (best = identity) */
+    int32_t device;          /* index into ctxs of the context that did it; -1: not done by this call */
+    int64_t iterations_all_starts;   /* ICP iterations summed over the item's `level` registrations */
+} visma_icp_corpus_result;
+VISMA_ICP_API int visma_icp_run_corpus(visma_icp_ctx *const *ctxs, int n_ctx, const visma_icp_corpus_item *items,
+                                       int64_t n_items, const visma_icp_corpus_params *params, int64_t *counter,
+                                       visma_icp_corpus_result *results, char *errbuf, size_t errbuf_len);
+
 /* ---- options / measurement --------------------------------------------- */
 /* AUTO (default) uses the radius-cell grid whenever the target/radius make it
  * worthwhile and the LDS-tiled brute-force kernel otherwise; BRUTE / GRID force

@@ -367,6 +367,58 @@ inline Eigen::Matrix4d RegisterModelToScene(const PointCloud &model, const Point
     return best.transformation_;
 }
 
+// The per-object loop of feh::AnnotationTool (src/annotation.cpp:103-168) for MANY (model, scan) pairs at
+// once: what the loop body hands to RegisterModelToScene, collected first, registered together by the
+// library's native work queue (visma_icp_run_corpus: one host thread per GPU pulls chunks of pairs, each
+// chunk's rotation_level yaw starts run as one batch), the loop's T3 per pair returned in order.
+// `devices`: GPUs to use (empty = device 0).  Point-to-point estimator (ICP.point_to_plane = false).
+inline std::vector<Eigen::Matrix4d> RegisterModelsToScenes(
+    const std::vector<std::pair<std::shared_ptr<PointCloud>, std::shared_ptr<PointCloud>>> &model_scan_pairs,
+    int rotation_level, double distance_threshold, const std::vector<int> &devices = std::vector<int>(),
+    std::vector<RegistrationResult> *best_out = nullptr)
+{
+    const size_t n = model_scan_pairs.size();
+    std::vector<Eigen::Matrix4d> T(n, Eigen::Matrix4d::Identity());
+    if (best_out) best_out->assign(n, RegistrationResult());
+    if (n == 0 || rotation_level <= 0 || !(distance_threshold > 0.0)) return T;
+    std::vector<visma_icp_corpus_item> items(n);
+    for (size_t i = 0; i < n; i++) {
+        const PointCloud &m = *model_scan_pairs[i].first, &sc = *model_scan_pairs[i].second;
+        // std::vector<Eigen::Vector3d> is AoS f64 with stride 3 (static_assert in detail::upload)
+        items[i].model_xyz = m.points_.empty() ? nullptr : m.points_[0].data();
+        items[i].n_model = (int64_t)m.points_.size();
+        items[i].scene_xyz = sc.points_.empty() ? nullptr : sc.points_[0].data();
+        items[i].n_scene = (int64_t)sc.points_.size();
+    }
+    std::vector<visma_icp_ctx *> ctxs;
+    const std::vector<int> devs = devices.empty() ? std::vector<int>(1, 0) : devices;
+    auto destroy_all = [&]() { for (visma_icp_ctx *c : ctxs) visma_icp_destroy(c); };
+    for (int d : devs) {
+        visma_icp_ctx *c = nullptr;
+        if (visma_icp_create(&c, d) != VISMA_ICP_OK) { destroy_all(); throw std::runtime_error("visma_icp_create failed (no gfx950 GPU?)"); }
+        ctxs.push_back(c);
+    }
+    const ICPConvergenceCriteria crit;
+    visma_icp_corpus_params p;
+    p.level = rotation_level; p.max_dist = distance_threshold; p.max_iter = crit.max_iteration_;
+    p.rel_fitness = crit.relative_fitness_; p.rel_rmse = crit.relative_rmse_; p.solver = VISMA_ICP_SOLVER_KABSCH; p.chunk = 0;
+    std::vector<visma_icp_corpus_result> res(n);
+    char err[512];
+    const int rc = visma_icp_run_corpus(ctxs.data(), (int)ctxs.size(), items.data(), (int64_t)n, &p, nullptr, res.data(), err, sizeof(err));
+    destroy_all();
+    if (rc != VISMA_ICP_OK) throw std::runtime_error(std::string("visma_icp_run_corpus: ") + err);
+    for (size_t i = 0; i < n; i++) {
+        T[i] = detail::from_rowmajor(res[i].best.transformation);
+        if (best_out) {
+            RegistrationResult &b = (*best_out)[i];
+            b.transformation_ = T[i];
+            b.fitness_ = res[i].best.fitness;
+            b.inlier_rmse_ = res[i].best.inlier_rmse;
+        }
+    }
+    return T;
+}
+
 // open3d::VoxelDownSample (O3D/Core/Geometry/DownSample.cpp:179-220) on the GPU:
 // same points / normals / colours, bit for bit; voxels come out in ascending
 // (ix,iy,iz) order instead of the reference's hash-map iteration order.

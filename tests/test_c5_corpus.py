@@ -59,3 +59,50 @@ def test_two_ranks_pull_the_corpus_from_one_counter(lib):
     assert d["items_done_by_all_ranks"] == 2 * 192          # two timed passes: every item exactly once per pass
     assert 0 < d["items_done_by_rank0"] < 2 * 192          # ... shared between the ranks
     assert d["registrations_per_sec"] > 0 and np.isfinite(d["value"])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_native_work_queue_registers_every_item_once_and_like_the_sweep(lib, oracle):
+    """visma_icp_run_corpus with TWO contexts (two host threads pulling from one counter; they share GPU 0 on a
+    one-GPU box): every item done exactly once, by either thread; each item's choice is what a single
+    orientation-constrained sweep of the library gives, and for a sampled item what the oracle's
+    RegisterModelToScene restatement gives."""
+    scenes, cads, items = c5_corpus()
+    sub = items[:40]
+    corpus = _lib.Corpus([(cads[c], scenes[s]) for s, c in sub], level=24, max_dist=0.05, max_iter=30, chunk=4)
+    a, b = _lib.Context(0), _lib.Context(0)
+    res = corpus.run([a, b])
+    assert len(res) == len(sub)
+    assert all(r[2] in (0, 1) for r in res)
+    assert {r[2] for r in res} == {0, 1}                      # both threads took work
+    one = _lib.Context(0)
+    for i in (0, 7, 23, 39):
+        s, c = sub[i]
+        one.set_clouds_f64(cads[c], scenes[s])
+        best, level, per = one.run_yaw_sweep(24, 0.05, 30)
+        got, lvl, dev, its = res[i]
+        assert lvl == level and got.num_correspondences == best.num_correspondences
+        assert synth.rel_frobenius(got.transformation_, best.transformation_) < 1e-10
+        assert its == sum(p.iterations for p in per)
+    cost = [len(cads[c]) * np.log(len(scenes[s])) for s, c in sub]
+    i = int(np.argmin(cost))
+    s, c = sub[i]
+    want = oracle.register_model_to_scene(cads[c], scenes[s], 24, 0.05, max_iter=30)
+    assert res[i][1] == want.best_level and res[i][0].num_correspondences == want.k
+    assert synth.rel_frobenius(res[i][0].transformation_, want.T) < 1e-9
+    # a second pass over a shared counter that another "process" has already advanced: those items are not ours
+    import ctypes
+    cnt = ctypes.c_int64(16)
+    res2 = corpus.run([a], ctypes.addressof(cnt))
+    assert [r[2] for r in res2[:16]] == [-1] * 16 and all(r[2] == 0 for r in res2[16:])
+    assert cnt.value >= len(sub)
+    for x in (a, b, one):
+        x.close()
+
+
+def test_corpus_arguments_are_checked(lib):
+    L = _lib.load()
+    err = _lib.C.create_string_buffer(256)
+    assert L.visma_icp_run_corpus(None, 0, None, 0, None, None, None, err, 256) == 1
+    assert b"bad corpus" in err.value

@@ -8,14 +8,14 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.json"), ("bench_c5.json", "%s_bench_c5.json"),
          ("bench_c4_under_rocprof.json", "%s_bench_c4_under_rocprof.json"),
          ("stats_c4/c4_kernel_stats.csv", "%s_bench_c4_kernel_stats.csv"), ("stats_c3/c3_kernel_stats.csv", "%s_bench_c3_kernel_stats.csv"),
          ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv"),
-         ("pmc_kernel_summary.csv", "%s_c4_exact_gather_kernel_pmc_summary.csv")]
+         ("pmc_kernel_summary.csv", "%s_c4_kernel_pmc_summary.csv")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p):
@@ -23,22 +23,25 @@ for a, b in pairs:
         print("copied", b % tag)
     else:
         print("missing", p)
-# traffic of the default C4 kernel: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md, HBM) + WRITE_SIZE, KiB -> bytes
-vals = {}
+# traffic of the C4 kernels: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md, HBM) + WRITE_SIZE, KiB -> bytes.
+# tools/run_c4_iterations.py runs one cold pass (lane-serial kernel) and five warm-started ones.
 p = os.path.join(src, "pmc_traffic_summary.csv")
-if os.path.exists(p):
-    for r in csv.DictReader(open(p)):
-        if "nn_grid_reduce_kernel" in r["kernel"]:
-            vals[r["counter"]] = float(r["mean_per_dispatch"])
-if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-    tj_path = os.path.join(dst, "traffic.json")
-    tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-    tj["grid:262144x4194304"] = {
-        "hbm_bytes_per_nn_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-        "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
-        "correction": "FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE "
-                      "uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB" % (vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
-        "kernel": "nn_grid_reduce_kernel<false,1,8,true,false,true> (exact search, fold fused)",
-        "source": "profiles/%s_c4_traffic_pmc_summary.csv (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % tag}
-    json.dump(tj, open(tj_path, "w"), indent=1)
-    print("traffic.json: %.1f MB per launch" % (tj["grid:262144x4194304"]["hbm_bytes_per_nn_launch"] / 1e6))
+tj_path = os.path.join(dst, "traffic.json")
+tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+for key, match, label in (("grid:262144x4194304", "nn_grid_reduce_kernel", "nn_grid_reduce_kernel<false,1,8,true,false,true> (lane-serial exact search: first pass of a registration; fold fused)"),
+                          ("grid_warm:262144x4194304", "nn_coop_kernel", "nn_coop_kernel_one<false> (warm-started wave-cooperative exact search: every later pass; fold fused)")):
+    vals = {}
+    if os.path.exists(p):
+        for r in csv.DictReader(open(p)):
+            if match in r["kernel"]:
+                vals[r["counter"]] = float(r["mean_per_dispatch"])
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        tj[key] = {
+            "hbm_bytes_per_nn_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+            "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+            "correction": "FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE "
+                          "uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB" % (vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
+            "kernel": label,
+            "source": "profiles/%s_c4_traffic_pmc_summary.csv (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % tag}
+        print("traffic.json %s: %.1f MB per launch" % (key, tj[key]["hbm_bytes_per_nn_launch"] / 1e6))
+json.dump(tj, open(tj_path, "w"), indent=1)

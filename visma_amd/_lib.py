@@ -61,6 +61,20 @@ ENG_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, _dp, C.c_int, _dp)
 ENG_CORR = C.CFUNCTYPE(C.c_int, C.c_void_p, _ip, _fp)
 
 
+class CCorpusItem(C.Structure):
+    _fields_ = [("model_xyz", C.POINTER(C.c_double)), ("n_model", C.c_int64),
+                ("scene_xyz", C.POINTER(C.c_double)), ("n_scene", C.c_int64)]
+
+
+class CCorpusParams(C.Structure):
+    _fields_ = [("level", C.c_int), ("max_dist", C.c_double), ("max_iter", C.c_int), ("rel_fitness", C.c_double),
+                ("rel_rmse", C.c_double), ("solver", C.c_int), ("chunk", C.c_int)]
+
+
+class CCorpusResult(C.Structure):
+    _fields_ = [("best", CResult), ("best_level", C.c_int32), ("device", C.c_int32), ("iterations_all_starts", C.c_int64)]
+
+
 class CEngine(C.Structure):
     _fields_ = [("set_source", ENG_SET), ("set_target", ENG_SET),
                 ("set_target_normals", ENG_SET), ("nn_pass", ENG_NN),
@@ -95,6 +109,9 @@ def load():
     L.visma_icp_set_target_normals_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int]
     L.visma_icp_get_search_kernel_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_forget_winners.argtypes = [C.c_void_p]
+    L.visma_icp_run_corpus.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CCorpusItem), C.c_int64,
+                                       C.POINTER(CCorpusParams), C.POINTER(C.c_int64), C.POINTER(CCorpusResult),
+                                       C.c_char_p, C.c_size_t]
     L.visma_icp_nn_pass.argtypes = [C.c_void_p, _dp, C.c_double]
     L.visma_icp_reduce.argtypes = [C.c_void_p, _dp]
     L.visma_icp_get_correspondences.argtypes = [C.c_void_p, _ip, _ip, _fp, C.POINTER(C.c_int64)]
@@ -524,6 +541,35 @@ class Context:
 
     def set_global_source_count(self, n):
         self._chk(self.L.visma_icp_set_global_source_count(self._h, int(n)))
+
+
+class Corpus:
+    """visma_icp_run_corpus: items = [(model_xyz, scene_xyz), ...] (arrays kept alive here), one host thread per
+    context pulls chunks from a counter.  `counter_address`: address of an int64 in shared memory when ranks in
+    other processes pull from the same queue (else a private counter)."""
+
+    def __init__(self, items, level=24, max_dist=0.05, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6,
+                 solver=SOLVER_KABSCH, chunk=8):
+        self.L = load()
+        self._keep = [(_f64(m, (-1, 3)), _f64(s, (-1, 3))) for m, s in items]
+        self.n = len(self._keep)
+        self.items = (CCorpusItem * max(self.n, 1))()
+        for i, (m, s) in enumerate(self._keep):
+            self.items[i] = CCorpusItem(_p(m, _dp), len(m), _p(s, _dp), len(s))
+        self.params = CCorpusParams(int(level), float(max_dist), int(max_iter), float(rel_fitness), float(rel_rmse),
+                                    int(solver), int(chunk))
+        self.results = (CCorpusResult * max(self.n, 1))()
+
+    def run(self, ctxs, counter_address=None):
+        """-> list of (Result best, best_level, device, iterations_all_starts) per item (device -1: another process's)."""
+        arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+        err = C.create_string_buffer(512)
+        cnt = C.cast(C.c_void_p(counter_address), C.POINTER(C.c_int64)) if counter_address else None
+        rc = self.L.visma_icp_run_corpus(arr, len(ctxs), self.items, self.n, C.byref(self.params), cnt, self.results, err, 512)
+        if rc != 0:
+            raise IcpError(rc, err.value.decode(errors="replace"))
+        return [(Result(self.results[i].best), int(self.results[i].best_level), int(self.results[i].device),
+                 int(self.results[i].iterations_all_starts)) for i in range(self.n)]
 
 
 def device_count():
