@@ -17,6 +17,7 @@
 #ifndef VISMA_ICP_H
 #define VISMA_ICP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
