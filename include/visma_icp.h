@@ -496,33 +496,20 @@ VISMA_ICP_API int visma_icp_selftest_so3_jac(const double *w, int n, double *R, 
  *   matrix_derivatives   dAB_dA, dAB_dB (:87-141), dAt_dA (:58-69), dhat (:17-35), dvee (:43-56);
  *                        any output may be NULL.
  * Jacobian arguments may be NULL. */
+/* SE3Type of core/se3.h:79-169 as plain functions on g = [R | t], row-major 3x4: composition (:96-100),
+ * action on a point (:103-106: what every search kernel applies to a source point), inverse (:108-110).
+ * Host functions; visma_icp_selftest_se3 runs the same code on the GPU for n elements. */
+VISMA_ICP_API int visma_se3_compose(const double a[12], const double b[12], double out[12]);
+VISMA_ICP_API int visma_se3_act(const double g[12], const double v[3], double out[3]);
+VISMA_ICP_API int visma_se3_inv(const double g[12], double out[12]);
+VISMA_ICP_API int visma_icp_selftest_se3(const double *g, const double *h, const double *v, int n,
+                                         double *gh, double *gv, double *g_inv);
 VISMA_ICP_API int visma_so3_rodrigues(const double w[3], double R[9], double dR_dw[27]);
 VISMA_ICP_API int visma_so3_invrodrigues(const double R[9], double w[3], double dw_dR[27]);
 VISMA_ICP_API int visma_so3_project(const double A[9], double R[9]);
 VISMA_ICP_API int visma_so3_matrix_derivatives(const double A[9], const double B[9],
                                                double dAB_dA[81], double dAB_dB[81],
                                                double dAt_dA[81], double dhat[27], double dvee[27]);
-
-/* ---- engine injection (test seam) --------------------------------------- */
-
-/* The driver (centring, loop, solve, stop test, sharding) runs over an
- * "engine" that owns the clouds and produces statistics.  visma_icp_create
- * installs the HIP engine, the only one the product ships.  This entry point
- * lets the CPU test-suite drive the same host logic with an engine of its
- * own; the product never calls it. */
-typedef struct {
-    int (*set_source)(void *user, const float *xyzw, int64_t ns);
-    int (*set_target)(void *user, const float *xyzw, int64_t nt);
-    int (*set_target_normals)(void *user, const float *nxyzw, int64_t nt);
-    int (*nn_pass)(void *user, const double T_centred[16], double max_dist);
-    /* statistics of p + frame_offset, q + frame_offset (0 = centred frame) */
-    int (*reduce)(void *user, const double T_centred[16], const double frame_offset[3],
-                  int point_to_plane, double stats[VISMA_ICP_NSTATS]);
-    int (*get_correspondences)(void *user, int32_t *tgt_idx_per_src, float *d2);
-} visma_icp_engine;
-VISMA_ICP_API int visma_icp_create_with_engine(visma_icp_ctx **out,
-                                               const visma_icp_engine *engine,
-                                               void *user);
 
 #ifdef __cplusplus
 }

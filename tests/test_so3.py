@@ -138,3 +138,65 @@ def test_device_versions_match_the_reference_goldens(lib):
         Rh = np.empty(9)
         assert L.visma_so3_project(p(np.ascontiguousarray(A)), p(Rh)) == 0
         assert np.max(np.abs(Rh - proj[i])) < 1e-13
+
+
+# ---- SE(3): core/se3.h:79-169 (SE3Type) -- compose / act / inverse ---------------------------------------
+def _se3_lib():
+    import ctypes as C
+    from visma_amd import _lib
+    L = _lib.load()
+    dp = C.POINTER(C.c_double)
+    return L, lambda a: a.ctypes.data_as(dp)
+
+
+def _rand_g(rng, n):
+    from scipy.spatial.transform import Rotation
+    g = np.zeros((n, 3, 4))
+    g[:, :, :3] = Rotation.random(n, random_state=int(rng.integers(1 << 30))).as_matrix()
+    g[:, :, 3] = rng.standard_normal((n, 3)) * 3
+    return g.reshape(n, 12)
+
+
+def test_se3_host_functions_equal_the_oracle_restatement_and_form_a_group(lib, oracle):
+    """The reference header does not compile with this g++ (core/se3.h:142), so the pins are the oracle's
+    line-by-line restatement (oracle/icp_oracle.c: vo_se3_*) and the group axioms."""
+    L, P = _se3_lib()
+    rng = np.random.default_rng(4)
+    G, H, K = _rand_g(rng, 50), _rand_g(rng, 50), _rand_g(rng, 50)
+    V = rng.standard_normal((50, 3))
+    I = np.hstack([np.eye(3), np.zeros((3, 1))]).ravel()
+    for g, h, k, v in zip(G, H, K, V):
+        gh, gv, gi, t = np.empty(12), np.empty(3), np.empty(12), np.empty(12)
+        assert L.visma_se3_compose(P(g), P(h), P(gh)) == 0 and L.visma_se3_act(P(g), P(v), P(gv)) == 0
+        assert L.visma_se3_inv(P(g), P(gi)) == 0
+        Rg, tg, Rh, th = g.reshape(3, 4)[:, :3], g.reshape(3, 4)[:, 3], h.reshape(3, 4)[:, :3], h.reshape(3, 4)[:, 3]
+        Ro, to = oracle.se3_compose(Rg, tg, Rh, th)
+        assert np.allclose(gh.reshape(3, 4)[:, :3], Ro, atol=1e-15) and np.allclose(gh.reshape(3, 4)[:, 3], to, atol=1e-14)
+        assert np.allclose(gv, oracle.se3_act(Rg, tg, v), atol=1e-15)
+        Ri, ti = oracle.se3_inv(Rg, tg)
+        assert np.allclose(gi.reshape(3, 4)[:, :3], Ri, atol=0) and np.allclose(gi.reshape(3, 4)[:, 3], ti, atol=1e-15)
+        # axioms: g g^-1 = e, (g h) k = g (h k), (g h)(v) = g(h(v))
+        L.visma_se3_compose(P(g), P(gi), P(t))
+        assert np.allclose(t, I, atol=1e-14)
+        a, b, hk = np.empty(12), np.empty(12), np.empty(12)
+        L.visma_se3_compose(P(gh), P(k), P(a)); L.visma_se3_compose(P(h), P(k), P(hk)); L.visma_se3_compose(P(g), P(hk), P(b))
+        assert np.allclose(a, b, atol=1e-13)
+        hv, ghv, w = np.empty(3), np.empty(3), np.empty(3)
+        L.visma_se3_act(P(h), P(v), P(hv)); L.visma_se3_act(P(g), P(hv), P(ghv)); L.visma_se3_act(P(gh), P(v), P(w))
+        assert np.allclose(w, ghv, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_se3_on_the_device_is_the_host_code_bit_for_bit(lib):
+    """The kernels transform every source point with se3_act: the device build of so3.h must agree with the
+    host build to the last bit (-ffp-contract=off on both sides)."""
+    L, P = _se3_lib()
+    rng = np.random.default_rng(6)
+    n = 1000
+    G, H, V = _rand_g(rng, n), _rand_g(rng, n), rng.standard_normal((n, 3))
+    gh, gv, gi = np.empty((n, 12)), np.empty((n, 3)), np.empty((n, 12))
+    assert L.visma_icp_selftest_se3(P(G), P(H), P(V), n, P(gh), P(gv), P(gi)) == 0
+    for i in range(0, n, 37):
+        a, b, c = np.empty(12), np.empty(3), np.empty(12)
+        L.visma_se3_compose(P(G[i]), P(H[i]), P(a)); L.visma_se3_act(P(G[i]), P(V[i]), P(b)); L.visma_se3_inv(P(G[i]), P(c))
+        assert np.array_equal(a, gh[i]) and np.array_equal(b, gv[i]) and np.array_equal(c, gi[i])

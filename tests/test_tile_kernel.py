@@ -4,9 +4,29 @@ It must return what the default (per-lane gather) exact search returns: same cor
 statistics -- in every geometry (2 / 4 / 1 lanes per query), when a footprint has to be split, and
 when it cannot be tiled at all (searched from global memory)."""
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
+
+# The kernel lost (2.4-3x slower than the gather kernels, DESIGN.md 4.1b) and is not part of libvisma_icp.so any
+# more: it lives in the side build (-DVISMA_WITH_TILE, visma_amd.build.build_experiments), which this module
+# loads INSTEAD of the product library -- in a process of its own, so that the rest of the suite keeps the product.
+CHILD = os.environ.get("VISMA_TILE_TEST_CHILD") == "1"
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+@pytest.mark.skipif(CHILD, reason="this is the child")
+def test_streamed_search_in_the_side_build():
+    from visma_amd import build
+    lib = build.build_experiments()
+    env = dict(os.environ, VISMA_TILE_TEST_CHILD="1", VISMA_ICP_LIB=lib)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=1700)
+    assert p.returncode == 0 and " passed" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
+
 
 from visma_amd import _lib, synth
 
@@ -31,6 +51,7 @@ VARIANTS = [{"VISMA_ICP_TILE_CONFIG": "0"}, {"VISMA_ICP_TILE_CONFIG": "1"}, {"VI
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not CHILD, reason="runs in a child process against the side build (test_streamed_search_in_the_side_build)")
 @pytest.mark.parametrize("ns,nt,radius,offset", CASES)
 def test_streamed_search_equals_the_default_exact_search(lib, ns, nt, radius, offset):
     src, tgt, T_gt, r = synth.make_pair(ns, nt, seed_t=ns + 1, seed_s=nt + 2, offset=offset, motion="radius")

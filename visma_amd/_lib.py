@@ -84,6 +84,19 @@ class CEngine(C.Structure):
 _lib = None
 
 
+_seams = None
+
+
+def load_seams():
+    """The side build with the test seam visma_icp_create_with_engine (and the experiments that lost): what the
+    CPU suite drives the host loop through.  Never the product library."""
+    global _seams
+    if _seams is None:
+        from . import build
+        _seams = _bind(C.CDLL(build.build_experiments()))
+    return _seams
+
+
 def load():
     """Load libvisma_icp.so (raises if it has not been built)."""
     global _lib
@@ -94,12 +107,17 @@ def load():
         raise ImportError(
             "%s is missing: build it with `python -m visma_amd.build` (hipcc, gfx950). "
             "visma_amd has no non-HIP implementation." % lib_path)
-    L = C.CDLL(lib_path)
+    _lib = _bind(C.CDLL(lib_path))
+    return _lib
+
+
+def _bind(L):
     L.visma_icp_last_error.restype = C.c_char_p
     L.visma_icp_last_error.argtypes = [C.c_void_p]
     L.visma_icp_version.restype = C.c_char_p
     L.visma_icp_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
-    L.visma_icp_create_with_engine.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CEngine), C.c_void_p]
+    if hasattr(L, "visma_icp_create_with_engine"):
+        L.visma_icp_create_with_engine.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CEngine), C.c_void_p]
     L.visma_icp_destroy.argtypes = [C.c_void_p]
     L.visma_icp_set_clouds_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int]
     L.visma_icp_set_target.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
@@ -166,7 +184,6 @@ def load():
     L.visma_icp_comm_ipc_export.argtypes = [C.c_void_p, C.c_void_p]
     L.visma_icp_comm_ipc_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     L.visma_icp_set_global_source_count.argtypes = [C.c_void_p, C.c_int64]
-    _lib = L
     return L
 
 
@@ -200,7 +217,7 @@ class Context:
     """One ICP context = one HIP stream on one GPU (visma_icp_ctx)."""
 
     def __init__(self, device=0, engine=None):
-        self.L = load()
+        self.L = load() if engine is None else load_seams()
         self._h = C.c_void_p()
         self._keep = []
         if engine is None:

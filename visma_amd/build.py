@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvisma_icp.so")
-SOURCES = ["kernels.hip", "grid.hip", "grid_coop.hip", "tile.hip", "icp_loop.hip", "voxel.hip", "order.hip", "normals.hip", "mesh.hip", "driver.cpp", "corpus.cpp", "io.cpp"]
-HEADERS = ["kernels.h", "device_common.h", "so3.h", "host_math.hpp", os.path.join("..", "..", "include", "visma_icp.h")]
+SOURCES = ["kernels.hip", "grid.hip", "grid_coop.hip", "icp_loop.hip", "voxel.hip", "order.hip", "normals.hip", "mesh.hip", "hip_engine.cpp", "driver.cpp", "aux_api.cpp", "corpus.cpp", "io.cpp"]
+HEADERS = ["kernels.h", "device_common.h", "so3.h", "host_math.hpp", "engine.hpp", "driver_ctx.hpp", os.path.join("..", "..", "include", "visma_icp.h")]
 
 
 def hipcc():
@@ -38,7 +38,8 @@ def build_lib(force=False, verbose=False, defines=(), out=None):
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
     flags += ["-D" + d for d in defines]
     procs, objs = [], []
-    for src in SOURCES:
+    sources = list(SOURCES) + (["tile.hip"] if "VISMA_WITH_TILE" in defines else [])
+    for src in sources:
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         cmd = [hipcc()] + flags + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
@@ -54,6 +55,23 @@ def build_lib(force=False, verbose=False, defines=(), out=None):
     subprocess.check_call(link)
     shutil.rmtree(obj_dir, ignore_errors=True)
     return lib_path
+
+
+EXPERIMENTS_LIB = os.path.join(LIB_DIR, "libvisma_icp_experiments.so")
+
+
+def build_experiments(force=False):
+    """The side build with the experiments that lost (tile.hip: -DVISMA_WITH_TILE) and the test seam
+    visma_icp_create_with_engine (-DVISMA_TEST_SEAMS): what tests load through VISMA_ICP_LIB, never the product."""
+    if force or not os.path.exists(EXPERIMENTS_LIB) or is_stale_against(EXPERIMENTS_LIB):
+        build_lib(force=True, defines=("VISMA_WITH_TILE", "VISMA_TEST_SEAMS"), out=EXPERIMENTS_LIB)
+    return EXPERIMENTS_LIB
+
+
+def is_stale_against(path):
+    t = os.path.getmtime(path)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + ["tile.hip"] + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
 if __name__ == "__main__":

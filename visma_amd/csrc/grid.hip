@@ -476,12 +476,6 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     }
     if (st) st += prob;
     if (!load_loop_state(st, T32, T64, off, r2f)) return;
-#ifdef VISMA_GRID_EXPERIMENT_STAGGER   /* timing experiment: workgroups of one CU start their chains at different times */
-    {
-        const int cls = (VISMA_GRID_EXPERIMENT_STAGGER >= 100) ? (int)(threadIdx.x >> 6) : (int)((blockIdx.x >> 8) & 3);
-        for (int k = 0; k < cls * (VISMA_GRID_EXPERIMENT_STAGGER % 100); k++) __builtin_amdgcn_s_sleep(32);
-    }
-#endif
     if constexpr (S64) r2d = (double)r2f;                  // (double)(float)(r*r), also when the radius comes from the state
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
@@ -663,13 +657,6 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 const P12 *qp = s12 + b0;                          // 12 bytes per candidate (see P12)
 #pragma unroll
                 for (int u = 0; u < U; u++) { const P12 t = qp[u * G]; q[u] = make_float4(t.x, t.y, t.z, 0.f); }
-#ifdef VISMA_GRID_EXPERIMENT_EXTRA_LOADS  /* timing experiment only: one more gather per slot (a nearby line), result unused */
-                float dummy[U];
-#pragma unroll
-                for (int u = 0; u < U; u++) dummy[u] = qp[u * G + 4 + U * G].z;
-#pragma unroll
-                for (int u = 0; u < U; u++) asm volatile("" ::"v"(dummy[u]));
-#endif
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     float d = sqdist_f32(q[u], px, py, pz);

@@ -179,9 +179,13 @@ __device__ __forceinline__ void coop_body(
             s8 = src64[i];
             if (warm) qprev = prevq_io[i];
         }
-        const double pxd = T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0;
-        const double pyd = T64.m[4] * s8.x + T64.m[5] * s8.y + T64.m[6] * s8.z + T64.m[7] * 1.0;
-        const double pzd = T64.m[8] * s8.x + T64.m[9] * s8.y + T64.m[10] * s8.z + T64.m[11] * 1.0;
+        // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
+        double pd[3];
+        {
+            const double sv[3] = {s8.x, s8.y, s8.z};
+            se3_act(T64.m, sv, pd);
+        }
+        const double pxd = pd[0], pyd = pd[1], pzd = pd[2];
         const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
 #ifdef VISMA_COOP_DEBUG_PHASES
         asm volatile("" ::"v"(px), "v"(qprev.x));

@@ -193,6 +193,7 @@ struct ProbDesc {
     GridParams g;
 };
 
+#ifdef VISMA_WITH_TILE   /* experiment, side build only (see HipEngine::use_tile) */
 // ---- streamed radius-cell search with exact (f64) tie-breaks and fused fold (tile.hip) ------
 struct TileArgs {
     const Pt64 *src64;            // source, f64 (centred), Morton order
@@ -229,6 +230,7 @@ int tile_threads(int config);
 // total_blocks = sum over problems of ceil(ns / tile_threads(config))
 hipError_t launch_nn_tile_reduce(const TileArgs &a, int point_to_plane, int config, int total_blocks,
                                  hipStream_t stream);
+#endif
 // float4 (x, y, z, .) -> Pt64 (x, y, z, index): f64 view of clouds uploaded as fp32
 hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStream_t stream);
 // order.hip: the source cloud (caller's f64 points, already on the device) into Morton order
@@ -324,6 +326,8 @@ hipError_t launch_pack_float4(const float *src, int stride, float4 *dst, int64_t
 // SO(3) self-test kernel: R = rodrigues(w), w2 = invrodrigues(R), v2 = g*v
 hipError_t launch_so3_selftest(const double *w, double *R, double *w2, int n,
                                hipStream_t stream);
+hipError_t launch_se3_selftest(const double *g, const double *h, const double *v, int n, double *gh, double *gv,
+                               double *gi, hipStream_t stream);
 hipError_t launch_so3_selftest_jac(const double *w, int n, double *R, double *dR, double *w2, double *dw, double *proj,
                                    hipStream_t stream);
 

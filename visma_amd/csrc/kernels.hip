@@ -898,6 +898,31 @@ hipError_t launch_so3_selftest_jac(const double *w, int n, double *R, double *dR
     return hipGetLastError();
 }
 
+// SE(3) on the device (so3.h: se3_compose / se3_act / se3_inv, the restatement of core/se3.h:96-110):
+// gh = g * h, gv = g(v), gi = g^-1 for n elements (g, h: row-major 3x4)
+__global__ void se3_selftest_kernel(const double *g, const double *h, const double *v, int n, double *gh, double *gv,
+                                    double *gi)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a[12], b[12], o[12], p[3], q[3];
+    for (int k = 0; k < 12; k++) { a[k] = g[12 * i + k]; b[k] = h[12 * i + k]; }
+    for (int k = 0; k < 3; k++) p[k] = v[3 * i + k];
+    se3_compose(a, b, o);
+    for (int k = 0; k < 12; k++) gh[12 * i + k] = o[k];
+    se3_act(a, p, q);
+    for (int k = 0; k < 3; k++) gv[3 * i + k] = q[k];
+    se3_inv(a, o);
+    for (int k = 0; k < 12; k++) gi[12 * i + k] = o[k];
+}
+
+hipError_t launch_se3_selftest(const double *g, const double *h, const double *v, int n, double *gh, double *gv,
+                               double *gi, hipStream_t stream)
+{
+    hipLaunchKernelGGL(se3_selftest_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, g, h, v, n, gh, gv, gi);
+    return hipGetLastError();
+}
+
 hipError_t launch_so3_selftest(const double *w, double *R, double *w2, int n,
                                hipStream_t stream)
 {

@@ -710,44 +710,6 @@ __global__ __launch_bounds__(NTH, 3) void nn_tile_reduce_kernel(const TileArgs a
     if (a.host_out) publish_tagged_stats(stats, a.host_out, a.seq);
 }
 
-__global__ void promote_pt64_kernel(const float4 *__restrict__ src, Pt64 *__restrict__ dst, long long n)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 q = src[i];
-    Pt64 o;
-    o.x = (double)q.x; o.y = (double)q.y; o.z = (double)q.z;
-    o.w = (unsigned long long)i;
-    dst[i] = o;
-}
-
-__global__ void expand_f64_kernel(const double *__restrict__ xyz, long long n, double cx, double cy, double cz,
-                                  float4 *__restrict__ f4, Pt64 *__restrict__ p8)
-{
-    const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    // the same f64 subtraction and rounding as the host packing (pack_f64_to / set_clouds_f64)
-    const double x = xyz[3 * j] - cx, y = xyz[3 * j + 1] - cy, z = xyz[3 * j + 2] - cz;
-    f4[j] = make_float4((float)x, (float)y, (float)z, 0.f);
-    if (p8) p8[j] = Pt64{x, y, z, (unsigned long long)j};
-}
-
-hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream)
-{
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xyz, (long long)n,
-                       c[0], c[1], c[2], f4, p8);
-    return hipGetLastError();
-}
-
-hipError_t launch_promote_pt64(const float4 *src, Pt64 *dst, int64_t n, hipStream_t stream)
-{
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(promote_pt64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst,
-                       (long long)n);
-    return hipGetLastError();
-}
-
 // ---- launch ------------------------------------------------------------------------------
 template <bool PLANE, int NTH, int G, int CAP, int MAXR, bool PRUNE, bool STAMPS = false>
 static hipError_t launch_tile_t(const TileArgs &a, int total_blocks, hipStream_t stream)
