@@ -445,7 +445,9 @@ VISMA_ICP_API int visma_icp_sample_mesh(visma_icp_ctx *ctx, const double *V, int
  *               1  KDTreeSearchParamRadius(radius)      every point with d2 < (double)(float)(radius^2)
  *               2  KDTreeSearchParamHybrid(radius, knn) the knn nearest of those
  * -- fewer than 3 neighbours: (0,0,1); normals_in (may be NULL) are the cloud's existing normals, whose
- * sign is kept (EstimateNormals.cpp:133-146).  n x 3 f64 in, n x 3 f64 out.  knn / max_nn <= 170. */
+ * sign is kept (EstimateNormals.cpp:133-146).  n x 3 f64 in, n x 3 f64 out.  Any knn /
+ * max_nn: lists of up to 170 entries live in LDS, longer ones (and dense Radius searches) in a heap per point in
+ * global memory; Radius results are summed in the order of the reference's result list too. */
 VISMA_ICP_API int visma_icp_estimate_normals(visma_icp_ctx *ctx, const double *xyz, int64_t n,
                                              const double *normals_in, int search_type, int knn,
                                              double radius, double *normals_out);

@@ -56,7 +56,7 @@ def test_ply_semantics_spelled_out(io):
 
 
 @pytest.mark.parametrize("name", ["bad_truncated.ply", "bad_novertex.ply", "does_not_exist.ply", "tri.obj",
-                                  "bad_hugecount.ply", "bad_hugecount_ascii.ply"])
+                                  "bad_hugecount.ply", "bad_hugecount_ascii.ply", "bad_ny_only.ply", "bad_green_only.ply"])
 def test_ply_failures_are_reported(io, gold, name):
     key = name.replace(".", "_") + "_ok"
     if key in gold and name.endswith(".ply"):
@@ -135,7 +135,7 @@ def test_pcd_nan_rule_is_the_references(io):
 
 
 @pytest.mark.parametrize("name", ["bad_truncated.pcd", "bad_nofields.pcd", "bad_nopoints.pcd", "bad_sizecount.pcd",
-                                  "bad_lzf.pcd", "does_not_exist.pcd", "tri.obj"])
+                                  "bad_lzf.pcd", "does_not_exist.pcd", "tri.obj", "bad_hugepoints.pcd", "bad_count0.pcd"])
 def test_pcd_failures_are_reported(io, name):
     key = name.replace(".", "_") + "_ok"
     if key in PCD_GOLD:

@@ -87,12 +87,8 @@ def test_gpu_equals_oracle_on_other_clouds_and_offsets(lib, oracle):
             # the covariance is E[xx] - E[x]E[x]: its rounding grows with the square of the offset
             tol = 1e-9 * max(1.0, off * off) * 10
             err = np.abs(got - want).max(1)
-            if kw.get("knn") is None:
-                # Radius: the moments are summed in scan order, not by distance; where two eigenvalues nearly
-                # coincide (an edge between two faces) that rounding difference is amplified
-                assert np.quantile(err, 0.995) < tol and err.max() < 1e-4, (seed, kw, err.max())
-            else:
-                assert err.max() < tol, (seed, kw, err.max())
+            # (Radius searches too: the moments are summed in the order of the reference's result list)
+            assert err.max() < tol, (seed, kw, err.max())
 
 
 @pytest.mark.gpu
@@ -126,11 +122,29 @@ def test_gpu_longest_neighbour_list(lib, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_lists_longer_than_the_lds_holds(lib, oracle):
+    """knn / max_nn above 170 and dense radius searches: the result list is a heap per point in global memory,
+    heap-sorted into the reference's list order before the moments are summed."""
+    pts = synth.surface_points(4000, 41) + np.random.default_rng(41).normal(size=(4000, 3)) * 1e-3
+    ctx = _lib.Context(0)
+    for kw in (dict(knn=171), dict(knn=400), dict(knn=600, radius=0.45), dict(knn=None, radius=0.4), dict(knn=4000)):
+        want = oracle.estimate_normals(pts, **kw)
+        got = ctx.estimate_normals(pts, **kw)
+        assert np.abs(got - want).max() < 1e-9, kw
+    far = pts + np.array([120.0, -80.0, 40.0])              # 150 m from the origin: binning is relative to the cloud
+    want = oracle.estimate_normals(far, knn=None, radius=0.02)
+    got = ctx.estimate_normals(far, knn=None, radius=0.02)
+    fb = (want == [0.0, 0.0, 1.0]).all(1)
+    assert np.array_equal(got[fb], want[fb])                 # same neighbour COUNTS (< 3 -> the fall-back normal)
+    assert np.abs(got - want).max() < 1e-3                   # (the covariance itself loses digits at this offset)
+
+
+@pytest.mark.gpu
 def test_gpu_argument_errors(lib):
     ctx = _lib.Context(0)
     pts = np.random.default_rng(0).normal(size=(100, 3))
-    with pytest.raises(_lib.IcpError):
-        ctx.estimate_normals(pts, knn=500)                   # list above the LDS capacity
+    assert ctx.L.visma_icp_estimate_normals(ctx._h, None, 5, None, 0, 30, 0.0, None) != 0      # NULL arrays
     out = ctx.estimate_normals(pts, knn=None, radius=0.0)    # no neighbours anywhere
     assert np.array_equal(out, np.tile([0.0, 0.0, 1.0], (100, 1)))
     assert ctx.estimate_normals(np.empty((0, 3)), knn=30).shape == (0, 3)

@@ -30,8 +30,6 @@ int visma_icp_estimate_normals(visma_icp_ctx *ctx, const double *xyz, int64_t n,
     if (n < 0 || (n > 0 && (!xyz || !normals_out)) || search_type < 0 || search_type > 2)
         return ctx->fail(VISMA_ICP_ERR_INVALID, "bad estimate_normals arguments");
     if (n > 0x7fffffff) return ctx->fail(VISMA_ICP_ERR_INVALID, "too many points for 32-bit indices");
-    if (search_type != 1 && knn > kNormalsMaxList)
-        return ctx->fail(VISMA_ICP_ERR_INVALID, "knn / max_nn above 170: the neighbour list would not fit the LDS");
     if (!ctx->eng->supports_device_loop()) return ctx->fail(VISMA_ICP_ERR_STATE, "estimate_normals needs the HIP engine");
     if (int rc = ctx->eng->bind_device()) return ctx->eng_fail(rc);
     hipError_t e = estimate_normals_device(xyz, n, normals_in, search_type, knn, radius, normals_out,

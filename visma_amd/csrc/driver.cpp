@@ -347,6 +347,7 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
 int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt, int stride)
 {
     CTX_CHECK();
+    ctx->eng->set_exact(ctx->search_precision == 1);     // (the search precision applies from an upload on)
     if (nt < 0 || stride < 3 || (nt > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad target arguments");
     float *buf = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
     pack_f32_to(xyz, nt, stride, buf);
@@ -360,6 +361,7 @@ int visma_icp_set_target(visma_icp_ctx *ctx, const float *xyz, int64_t nt, int s
 int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns, int stride)
 {
     CTX_CHECK();
+    ctx->eng->set_exact(ctx->search_precision == 1);     // (the search precision applies from an upload on)
     if (ns < 0 || stride < 3 || (ns > 0 && !xyz)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
     float *buf = ctx->eng->staging(1, (size_t)std::max<int64_t>(ns, 1) * 4);
     pack_f32_to(xyz, ns, stride, buf);
@@ -374,6 +376,7 @@ int visma_icp_set_source(visma_icp_ctx *ctx, const float *xyz, int64_t ns, int s
 int visma_icp_set_target_device(visma_icp_ctx *ctx, const void *d, int64_t nt)
 {
     CTX_CHECK();
+    ctx->eng->set_exact(ctx->search_precision == 1);     // (the search precision applies from an upload on)
     if (nt < 0 || (nt > 0 && !d)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad target arguments");
     int rc = ctx->eng->set_target_device(d, nt);
     if (rc) return ctx->eng_fail(rc);
@@ -385,6 +388,7 @@ int visma_icp_set_target_device(visma_icp_ctx *ctx, const void *d, int64_t nt)
 int visma_icp_set_source_device(visma_icp_ctx *ctx, const void *d, int64_t ns)
 {
     CTX_CHECK();
+    ctx->eng->set_exact(ctx->search_precision == 1);     // (the search precision applies from an upload on)
     if (ns < 0 || (ns > 0 && !d)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad source arguments");
     int rc = ctx->eng->set_source_device(d, ns);
     if (rc) return ctx->eng_fail(rc);
@@ -681,6 +685,7 @@ static int yaw_sweep(visma_icp_ctx *ctx, int level, double max_dist, int max_ite
 static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, const double *const *normals, int n,
                           int max_iter, double rel_fitness, double rel_rmse, int solver, visma_icp_result *out)
 {
+    ctx->eng->set_exact(ctx->search_precision == 1);     // (a batch uploads its own clouds)
     const bool plane = normals != nullptr;
     bool all_normals = plane;
     for (int i = 0; plane && i < n; i++)
@@ -979,8 +984,10 @@ int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode)
 {
     CTX_CHECK();
     if (mode < 0 || mode > 2) return ctx->fail(VISMA_ICP_ERR_INVALID, "search precision must be 0, 1 or 2");
+    // takes effect at the next cloud upload (the header's contract): the clouds resident now were laid out
+    // for the mode they were uploaded under (fp32 only / fp32 + f64 copies), and switching the flag alone would
+    // run a third kernel (mode 0 over f64 copies = the all-f64 search), not the one asked for
     ctx->search_precision = mode;
-    ctx->eng->set_exact(mode == 1);
     return VISMA_ICP_OK;
 }
 

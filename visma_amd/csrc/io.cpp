@@ -274,6 +274,11 @@ int visma_io_read_ply(const char *path, visma_io_cloud *out)
                 want[k] = e.find(names[k]);
                 if (want[k] >= 0 && e.props[want[k]].list) want[k] = -1;
             }
+            // FilePLY.cpp:228-236,77-79: the normal / colour arrays are sized by `nx` / `red` alone, while `ny`, `nz`,
+            // `green`, `blue` get their callbacks regardless: a file with one of those but not the sizing property
+            // makes the callback return 0 on the first vertex and ply_read fail ("unable to read file").
+            if (e.count > 0 && ((want[3] < 0 && (want[4] >= 0 || want[5] >= 0)) || (want[6] < 0 && (want[7] >= 0 || want[8] >= 0))))
+                return bail("unable to read file: normal / colour components without nx / red");
             c.n = e.count;
             c.n_normals = want[3] >= 0 ? e.count : 0;
             c.n_colors = want[6] >= 0 ? e.count : 0;
@@ -585,35 +590,45 @@ extern "C" int visma_io_read_pcd(const char *path, visma_io_cloud *out)
             pointsize = (int)(4 * fields.size());
         } else if (t.compare(0, 4, "SIZE") == 0) {
             if (nch != st.size() - 1) { bad = true; break; }
-            int offset = 0, v = 0;
+            long long offset = 0;
+            int v = 0;
             for (size_t i = 0; i < nch; i++) {
                 v = stream_int(st, i + 1, v);
+                if (v < 0 || v > 1024 || offset > (1ll << 30)) { bad = true; break; }
                 fields[i].size = v;
-                fields[i].offset = offset;
+                fields[i].offset = (int)offset;
                 offset += v;
             }
-            pointsize = offset;
+            if (bad || offset > (1ll << 30)) { bad = true; break; }
+            pointsize = (int)offset;
         } else if (t.compare(0, 4, "TYPE") == 0) {
             if (nch != st.size() - 1) { bad = true; break; }
             for (size_t i = 0; i < nch; i++) fields[i].type = st[i + 1][0];
         } else if (t.compare(0, 5, "COUNT") == 0) {
             if (nch != st.size() - 1) { bad = true; break; }
-            int co = 0, offset = 0, v = 0;
+            long long co = 0, offset = 0;
+            int v = 0;
             for (size_t i = 0; i < nch; i++) {
                 v = stream_int(st, i + 1, v);
+                if (v < 0 || v > (1 << 20) || co > (1ll << 30) || offset > (1ll << 30)) { bad = true; break; }
                 fields[i].count = v;
-                fields[i].count_offset = co;
-                fields[i].offset = offset;
+                fields[i].count_offset = (int)co;
+                fields[i].offset = (int)offset;
                 co += v;
-                offset += v * fields[i].size;
+                offset += (long long)v * fields[i].size;
             }
-            elementnum = co;
-            pointsize = offset;
+            if (bad || co > (1ll << 30) || offset > (1ll << 30)) { bad = true; break; }
+            elementnum = (int)co;
+            pointsize = (int)offset;
         } else if (t.compare(0, 5, "WIDTH") == 0) {
             width = stream_int(st, 1, width);
         } else if (t.compare(0, 6, "HEIGHT") == 0) {
             height = stream_int(st, 1, height);
-            points = (int)((long long)width * height);
+            {
+                const long long wh = (long long)width * height;
+                if (width < 0 || height < 0 || wh > 0x7fffffffll) { bad = true; break; }
+                points = (int)wh;
+            }
         } else if (t.compare(0, 9, "VIEWPOINT") == 0) {
         } else if (t.compare(0, 6, "POINTS") == 0) {
             points = stream_int(st, 1, points);
@@ -640,6 +655,28 @@ extern "C" int visma_io_read_pcd(const char *path, visma_io_cloud *out)
         if (fd.size < 0 || fd.count < 0 || fd.offset < 0) return fail(VISMA_IO_ERR_FORMAT, "Read PCD failed: unable to parse header.");
     const bool has_n = fnx >= 0 && fny >= 0 && fnz >= 0, has_c = fc >= 0;
     const int64_t n = points;
+    // A field that is READ must hold at least one element (COUNT 0 would make the ascii branch index one token
+    // past the line, the binary ones read a neighbour's bytes) ...
+    {
+        const int read[7] = {fx, fy, fz, has_n ? fnx : -1, has_n ? fny : -1, has_n ? fnz : -1, fc};
+        for (int k = 0; k < 7; k++)
+            if (read[k] >= 0 && (fields[(size_t)read[k]].count < 1 || fields[(size_t)read[k]].size < 1))
+                return fail(VISMA_IO_ERR_FORMAT, "Read PCD failed: unable to parse header.");
+    }
+    // ... and the header's point count is checked against what the file can hold BEFORE anything is allocated
+    // (a 100-byte file announcing 2^31 points must not cost 3 x 48 GB of zeroed memory).
+    {
+        const uint64_t left = (uint64_t)(end - p);
+        bool fits = true;
+        if (datatype == 0) fits = (uint64_t)n <= left / 2 + 1;                   // >= 2 bytes per ascii record
+        else if (datatype == 1) fits = (uint64_t)n <= left / (uint64_t)pointsize;
+        else {
+            uint32_t usz = 0;
+            if (left >= 8) std::memcpy(&usz, p + 4, 4);
+            fits = left >= 8 && (uint64_t)n * (uint64_t)pointsize <= (uint64_t)usz && (uint64_t)usz <= (1ull << 32) - 2;
+        }
+        if (!fits) return fail(VISMA_IO_ERR_FORMAT, "Read PCD failed: unable to read data.");
+    }
 
     visma_io_cloud c;
     std::memset(&c, 0, sizeof(c));

@@ -261,7 +261,7 @@ hipError_t surface_distances_device(const double *h_Vs, int64_t nvs, const int32
 
 // ---- normal estimation (normals.hip): host arrays in, host arrays out ----------
 // open3d::EstimateNormals; search_type 0 KNN(knn) | 1 Radius(radius) | 2 Hybrid(radius, max_nn = knn)
-constexpr int kNormalsMaxList = 170;     // knn / max_nn above it: hipErrorInvalidValue (the list is in LDS)
+constexpr int kNormalsMaxList = 170;     // longer result lists live in global memory (a heap per point) instead of LDS
 hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double *h_nrm_in, int search_type,
                                    int knn, double radius, double *h_out, hipStream_t stream);
 

@@ -16,9 +16,11 @@
 // 27 cells cover the radius), or of about the distance to the knn-th neighbour (KNN: rings of cells
 // are added until the knn-th distance is covered -- exact for any cell size).  One thread per
 // point, in cell order; the result list (d2, index) lives in LDS, sorted by (d2, index) -- the
-// reference's order up to exactly equal distances, which flann orders by tree traversal.
-// Radius searches have no list: the moments are summed in scan order (same values up to the
-// rounding of a different summation order).
+// reference's order up to exactly equal distances, which flann orders by tree traversal.  Lists longer than
+// kNormalsMaxList entries (the LDS capacity at 64 threads) live in global memory as a max-heap per point that is
+// heap-sorted at the end: any knn / max_nn.  Radius searches (no bound on the list) first COUNT every point's
+// neighbours, then run as a Hybrid search whose max_nn is the largest count: the moments are summed in list order
+// like the reference's (round 2 summed them in scan order: 3e-7 off where two eigenvalues nearly coincide).
 #include "device_common.h"
 
 #include <math.h>
@@ -42,6 +44,10 @@ struct NormalArgs {
     int cap;                     // list capacity (knn / max_nn); unused for Radius
     double r2d;                  // (double)(float)(r * r); unused for KNN
     unsigned long long *n27;     // (sampling pass) sum of 27-cell populations, queries counted
+    int *count_out;              // (counting pass) neighbours within the radius, per point in cell order
+    double *spill_d2;            // (spilled lists) [cap][q_count] squared distances ...
+    int *spill_id;               // ... and indices, one max-heap per query of the slab
+    int q_begin, q_count;        // the slab of queries (cell order) this launch works on
 };
 
 __device__ __forceinline__ double sqr(double x) { return x * x; }
@@ -92,16 +98,22 @@ __device__ bool fast_eigen_3x3(const double A[3][3], double out[3])
     return true;
 }
 
-// TYPE: 0 KNN, 1 Radius, 2 Hybrid.  SAMPLE: only count the 27-cell population of every 64th point.
-template <int TYPE, int NTH, bool SAMPLE>
+// TYPE: 0 KNN, 1 Radius (counting pass only), 2 Hybrid.  MODE 1: only count the 27-cell population of every
+// 64th point (cell-size tuning); MODE 2: only count the neighbours within the radius.  SPILL: the list is a
+// max-heap in global memory instead of a sorted array in LDS.
+template <int TYPE, int NTH, int MODE, bool SPILL>
 __global__ __launch_bounds__(NTH) void estimate_normals_kernel(NormalArgs a)
 {
+    constexpr bool SAMPLE = MODE == 1, COUNT = MODE == 2;
     extern __shared__ double lds_raw[];
-    double *ld2 = lds_raw;                                        // [cap][NTH]
-    int *lid = reinterpret_cast<int *>(lds_raw + (size_t)a.cap * NTH);   // [cap][NTH]
     const int tid = threadIdx.x;
-    const long long t = (long long)blockIdx.x * NTH + tid;
-    if (t >= a.n) return;
+    const long long u = (long long)blockIdx.x * NTH + tid;          // query of the slab
+    if (u >= a.q_count) return;
+    const long long t = a.q_begin + u;
+    // element j of this thread's list: LDS [cap][NTH] or global [cap][q_count] (coalesced across threads)
+    double *ld2 = SPILL ? a.spill_d2 + u : lds_raw + tid;
+    int *lid = SPILL ? a.spill_id + u : reinterpret_cast<int *>(lds_raw + (size_t)a.cap * NTH) + tid;
+    const size_t lstride = SPILL ? (size_t)a.q_count : (size_t)NTH;
     const Pt64 q = a.sorted64[t];                                 // queries in cell order
     const float4 qf = a.sorted[t];
     const GridParams g = a.g;
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(NTH) void estimate_normals_kernel(NormalArgs a)
         return;
     }
     int cnt = 0;
-    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};                      // Radius: moments in scan order
+    double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto moments = [&](const double x, const double y, const double z) {
         // EstimateNormals.cpp:95-105
         c[0] += x; c[1] += y; c[2] += z;
@@ -132,8 +144,22 @@ __global__ __launch_bounds__(NTH) void estimate_normals_kernel(NormalArgs a)
         c[6] += y * y; c[7] += y * z; c[8] += z * z;
     };
     auto less = [&](double d, int id, int j) {
-        const double dj = ld2[(size_t)j * NTH + tid];
-        return d < dj || (d == dj && id < lid[(size_t)j * NTH + tid]);
+        const double dj = ld2[(size_t)j * lstride];
+        return d < dj || (d == dj && id < lid[(size_t)j * lstride]);
+    };
+    // (SPILL) max-heap on (d2, index): the root is the entry a nearer candidate replaces
+    auto sift_down = [&](int pos, int len, double d, int id) {
+        for (;;) {
+            int ch = 2 * pos + 1;
+            if (ch >= len) break;
+            if (ch + 1 < len && less(ld2[(size_t)ch * lstride], lid[(size_t)ch * lstride], ch + 1)) ch++;
+            if (!less(d, id, ch)) break;
+            ld2[(size_t)pos * lstride] = ld2[(size_t)ch * lstride];
+            lid[(size_t)pos * lstride] = lid[(size_t)ch * lstride];
+            pos = ch;
+        }
+        ld2[(size_t)pos * lstride] = d;
+        lid[(size_t)pos * lstride] = id;
     };
     auto consider = [&](const Pt64 &p) {
         // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
@@ -142,19 +168,39 @@ __global__ __launch_bounds__(NTH) void estimate_normals_kernel(NormalArgs a)
         d += dy * dy;
         d += dz * dz;
         if (TYPE != 0 && !(d < a.r2d)) return;
-        if (TYPE == 1) { moments(p.x, p.y, p.z); cnt++; return; }
+        if (COUNT) { cnt++; return; }
         const int id = (int)p.w;
+        if (SPILL) {
+            if (cnt < a.cap) {
+                // sift up: parents smaller than the new entry move down
+                int pos = cnt++;
+                while (pos > 0) {
+                    const int par = (pos - 1) >> 1;
+                    const double dp = ld2[(size_t)par * lstride];
+                    const int ip = lid[(size_t)par * lstride];
+                    if (!(dp < d || (dp == d && ip < id))) break;
+                    ld2[(size_t)pos * lstride] = dp;
+                    lid[(size_t)pos * lstride] = ip;
+                    pos = par;
+                }
+                ld2[(size_t)pos * lstride] = d;
+                lid[(size_t)pos * lstride] = id;
+            } else if (less(d, id, 0)) {
+                sift_down(0, a.cap, d, id);
+            }
+            return;
+        }
         int pos;
         if (cnt < a.cap) pos = cnt++;
         else if (less(d, id, a.cap - 1)) pos = a.cap - 1;
         else return;
         while (pos > 0 && less(d, id, pos - 1)) {
-            ld2[(size_t)pos * NTH + tid] = ld2[(size_t)(pos - 1) * NTH + tid];
-            lid[(size_t)pos * NTH + tid] = lid[(size_t)(pos - 1) * NTH + tid];
+            ld2[(size_t)pos * lstride] = ld2[(size_t)(pos - 1) * lstride];
+            lid[(size_t)pos * lstride] = lid[(size_t)(pos - 1) * lstride];
             pos--;
         }
-        ld2[(size_t)pos * NTH + tid] = d;
-        lid[(size_t)pos * NTH + tid] = id;
+        ld2[(size_t)pos * lstride] = d;
+        lid[(size_t)pos * lstride] = id;
     };
     auto scan_cells = [&](int z, int y, int xa, int xb) {              // cells xa..xb of row (y, z), clipped
         if (z < 0 || z >= g.dim[2] || y < 0 || y >= g.dim[1]) return;
@@ -176,20 +222,31 @@ __global__ __launch_bounds__(NTH) void estimate_normals_kernel(NormalArgs a)
         // every point nearer than R cell edges has been seen (0.1 % slack for the fp32 binning)
         if (cnt == a.cap && R >= 1) {
             const double cover = (double)R * (double)g.h * 0.999;
-            if (ld2[(size_t)(a.cap - 1) * NTH + tid] <= cover * cover) break;
+            const double farthest = ld2[(size_t)(SPILL ? 0 : a.cap - 1) * lstride];      // heap root / end of the sorted list
+            if (farthest <= cover * cover) break;
         }
         if (cx - R <= 0 && cy - R <= 0 && cz - R <= 0 && cx + R >= g.dim[0] - 1 && cy + R >= g.dim[1] - 1 &&
             cz + R >= g.dim[2] - 1)
             break;                                                  // the whole grid has been scanned
     }
+    if (COUNT) { a.count_out[t] = cnt; return; }
     const int me = (int)q.w;
     double nrm[3] = {0.0, 0.0, 1.0};                                // fewer than 3 neighbours (:147-149)
     if (cnt >= 3) {
-        if (TYPE != 1)
-            for (int j = 0; j < cnt; j++) {
-                const Pt64 p = a.pts[lid[(size_t)j * NTH + tid]];
-                moments(p.x, p.y, p.z);
+        if (SPILL) {
+            // heap sort in place: ascending (d2, index) = the order of the reference's result list
+            for (int end = cnt - 1; end > 0; end--) {
+                const double dl = ld2[(size_t)end * lstride];
+                const int il = lid[(size_t)end * lstride];
+                ld2[(size_t)end * lstride] = ld2[0];
+                lid[(size_t)end * lstride] = lid[0];
+                sift_down(0, end, dl, il);
             }
+        }
+        for (int j = 0; j < cnt; j++) {
+            const Pt64 p = a.pts[lid[(size_t)j * lstride]];
+            moments(p.x, p.y, p.z);
+        }
         const double inv = (double)cnt;
         for (int k = 0; k < 9; k++) c[k] /= inv;
         double A[3][3];
@@ -214,13 +271,17 @@ __global__ __launch_bounds__(NTH) void estimate_normals_kernel(NormalArgs a)
     a.nrm_out[3ll * me + 2] = nrm[2];
 }
 
-__global__ void pack_points_kernel(const double *__restrict__ xyz, long long n, float4 *__restrict__ f4,
-                                   Pt64 *__restrict__ p8)
+// The fp32 copy is used for BINNING only and is taken relative to a point of the cloud (subtracted in f64): its
+// rounding error then scales with the cloud's extent, not with its distance from the origin -- a scan 100 m from
+// the origin with a 5 mm radius would otherwise put neighbours one cell off (0.1 % slack between cell and radius).
+// Distances and moments use the caller's f64 coordinates, so the results do not depend on the shift.
+__global__ void pack_points_kernel(const double *__restrict__ xyz, long long n, double cx, double cy, double cz,
+                                   float4 *__restrict__ f4, Pt64 *__restrict__ p8)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-    f4[i] = make_float4((float)x, (float)y, (float)z, __uint_as_float((unsigned)i));
+    f4[i] = make_float4((float)(x - cx), (float)(y - cy), (float)(z - cz), __uint_as_float((unsigned)i));
     p8[i] = Pt64{x, y, z, (unsigned long long)i};
 }
 
@@ -239,23 +300,24 @@ struct DevBufs {
     }
 };
 
-template <int TYPE, bool SAMPLE>
+template <int TYPE, int MODE, bool SPILL>
 hipError_t launch_normals(const NormalArgs &a, hipStream_t stream)
 {
-    // list bytes per thread: cap * 12; keep a workgroup's list within 128 KiB of LDS
-    const size_t per_thread = TYPE == 1 || SAMPLE ? 0 : (size_t)a.cap * 12;
+    // list bytes per thread: cap * 12 (LDS lists only); keep a workgroup's list within 128 KiB of LDS
+    const size_t per_thread = (MODE != 0 || SPILL) ? 0 : (size_t)a.cap * 12;
     int nth = 256;
     while (nth > 64 && per_thread * nth > 60 * 1024) nth >>= 1;      // (64 threads: up to 128 KiB of the 160)
     const size_t lds = per_thread * nth + 64;
-    const unsigned blocks = (unsigned)((a.n + nth - 1) / nth);
+    const unsigned blocks = (unsigned)((a.q_count + nth - 1) / nth);
+    if (a.q_count <= 0) return hipSuccess;
 #define VISMA_NRM_LAUNCH(NTH_)                                                                                  \
     do {                                                                                                        \
         if (lds > 48 * 1024) {                                                                                  \
-            hipError_t e = hipFuncSetAttribute((const void *)estimate_normals_kernel<TYPE, NTH_, SAMPLE>,       \
+            hipError_t e = hipFuncSetAttribute((const void *)estimate_normals_kernel<TYPE, NTH_, MODE, SPILL>,  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
             if (e != hipSuccess) return e;                                                                      \
         }                                                                                                       \
-        hipLaunchKernelGGL((estimate_normals_kernel<TYPE, NTH_, SAMPLE>), dim3(blocks), dim3(NTH_), lds, stream, a); \
+        hipLaunchKernelGGL((estimate_normals_kernel<TYPE, NTH_, MODE, SPILL>), dim3(blocks), dim3(NTH_), lds, stream, a); \
     } while (0)
     if (nth == 256) VISMA_NRM_LAUNCH(256);
     else if (nth == 128) VISMA_NRM_LAUNCH(128);
@@ -281,8 +343,7 @@ hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double 
         for (int64_t i = 0; i < n; i++) { h_out[3 * i] = 0.0; h_out[3 * i + 1] = 0.0; h_out[3 * i + 2] = 1.0; }
         return hipSuccess;
     }
-    const int cap = search_type == 1 ? 1 : (int)std::min<int64_t>(knn, n);
-    if (cap > kNormalsMaxList) return hipErrorInvalidValue;                   // the result list lives in LDS
+    int cap = search_type == 1 ? 1 : (int)std::min<int64_t>(knn, n);           // (Radius: set from the counting pass)
     DevBufs B;
     double *d_xyz = nullptr, *d_nin = nullptr, *d_out = nullptr;
     float4 *d_f4 = nullptr, *d_sorted = nullptr;
@@ -303,8 +364,17 @@ hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double 
         NRM_TRY(hipMemcpyAsync(d_nin, h_nrm_in, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream));
     }
     NRM_TRY(hipMemcpyAsync(d_xyz, h_xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(pack_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_xyz,
-                       (long long)n, d_f4, d_p8);
+    {
+        // a finite point of the cloud as the binning origin
+        double c0[3] = {0.0, 0.0, 0.0};
+        for (int64_t i = 0; i < n; i++)
+            if (std::isfinite(h_xyz[3 * i]) && std::isfinite(h_xyz[3 * i + 1]) && std::isfinite(h_xyz[3 * i + 2])) {
+                c0[0] = h_xyz[3 * i]; c0[1] = h_xyz[3 * i + 1]; c0[2] = h_xyz[3 * i + 2];
+                break;
+            }
+        hipLaunchKernelGGL(pack_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_xyz,
+                           (long long)n, c0[0], c0[1], c0[2], d_f4, d_p8);
+    }
     NRM_TRY(launch_grid_bbox(d_f4, n, d_box, stream));
     unsigned box[6];
     NRM_TRY(hipMemcpyAsync(box, d_box, sizeof(box), hipMemcpyDeviceToHost, stream));
@@ -333,13 +403,14 @@ hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double 
         NRM_TRY(launch_grid_build(d_f4, n, g, d_cell_of, d_count, d_bsum, d_start, d_sorted, stream, d_p8, d_sorted64));
         a.sorted = d_sorted; a.sorted64 = d_sorted64; a.start = d_start; a.g = g; a.pts = d_p8;
         a.nrm_in = d_nin; a.nrm_out = d_out; a.n = (int)n; a.cap = cap;
+        a.q_begin = 0; a.q_count = (int)n;
         const float r2f = (float)(radius * radius);
         a.r2d = (double)r2f;
         a.n27 = d_n27;
         if (use_r || attempt >= 3) break;
         // KNN: aim at 2.5 knn points in the 27 cells (one ring is then enough for most points)
         NRM_TRY(hipMemsetAsync(d_n27, 0, 2 * sizeof(unsigned long long), stream));
-        NRM_TRY((launch_normals<0, true>(a, stream)));
+        NRM_TRY((launch_normals<0, 1, false>(a, stream)));
         unsigned long long h27[2];
         NRM_TRY(hipMemcpyAsync(h27, d_n27, sizeof(h27), hipMemcpyDeviceToHost, stream));
         NRM_TRY(hipStreamSynchronize(stream));
@@ -350,9 +421,40 @@ hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double 
         if (g.h > (float)(cell * 1.01) && next < cell) break;              // the cell cap already enlarged the cells
         cell = next;
     }
-    if (search_type == 0) NRM_TRY((launch_normals<0, false>(a, stream)));
-    else if (search_type == 1) NRM_TRY((launch_normals<1, false>(a, stream)));
-    else NRM_TRY((launch_normals<2, false>(a, stream)));
+    int type = search_type;
+    if (search_type == 1) {
+        // Radius: count every point's neighbours, then run as a Hybrid search that keeps them all
+        int *d_cnt = nullptr;
+        NRM_TRY(B.alloc(&d_cnt, (size_t)n));
+        a.count_out = d_cnt;
+        NRM_TRY((launch_normals<1, 2, false>(a, stream)));
+        std::vector<int> cnt((size_t)n);
+        NRM_TRY(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        NRM_TRY(hipStreamSynchronize(stream));
+        cap = std::max(1, *std::max_element(cnt.begin(), cnt.end()));
+        a.cap = cap;
+        type = 2;
+    }
+    if (cap <= kNormalsMaxList) {
+        if (type == 0) NRM_TRY((launch_normals<0, 0, false>(a, stream)));
+        else NRM_TRY((launch_normals<2, 0, false>(a, stream)));
+    } else {
+        // lists longer than the LDS holds: one max-heap per query in global memory, a slab of queries at a time
+        const size_t budget = (size_t)1 << 30;
+        int64_t slab = (int64_t)std::max<size_t>(1024, budget / ((size_t)cap * 12));
+        slab = std::min<int64_t>(slab, n);
+        double *d_sd = nullptr;
+        int *d_si = nullptr;
+        NRM_TRY(B.alloc(&d_sd, (size_t)cap * (size_t)slab));
+        NRM_TRY(B.alloc(&d_si, (size_t)cap * (size_t)slab));
+        a.spill_d2 = d_sd; a.spill_id = d_si;
+        for (int64_t q0 = 0; q0 < n; q0 += slab) {
+            a.q_begin = (int)q0;
+            a.q_count = (int)std::min<int64_t>(slab, n - q0);
+            if (type == 0) NRM_TRY((launch_normals<0, 0, true>(a, stream)));
+            else NRM_TRY((launch_normals<2, 0, true>(a, stream)));
+        }
+    }
     NRM_TRY(hipMemcpyAsync(h_out, d_out, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, stream));
     NRM_TRY(hipStreamSynchronize(stream));
     return hipSuccess;
