@@ -33,6 +33,7 @@ def lib():
     """The product library; built on demand (hipcc cross-compiles without a GPU)."""
     from visma_amd import build
     build.build_lib()
+    build.build_experiments()          # the side build (test seam, experiments): built once, before any worker process
     from visma_amd import _lib
     _lib.load()
     return _lib

@@ -63,8 +63,14 @@ EXPERIMENTS_LIB = os.path.join(LIB_DIR, "libvisma_icp_experiments.so")
 def build_experiments(force=False):
     """The side build with the experiments that lost (tile.hip: -DVISMA_WITH_TILE) and the test seam
     visma_icp_create_with_engine (-DVISMA_TEST_SEAMS): what tests load through VISMA_ICP_LIB, never the product."""
-    if force or not os.path.exists(EXPERIMENTS_LIB) or is_stale_against(EXPERIMENTS_LIB):
-        build_lib(force=True, defines=("VISMA_WITH_TILE", "VISMA_TEST_SEAMS"), out=EXPERIMENTS_LIB)
+    import fcntl
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".experiments.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)                 # (several test processes may get here together)
+        if force or not os.path.exists(EXPERIMENTS_LIB) or is_stale_against(EXPERIMENTS_LIB):
+            tmp = EXPERIMENTS_LIB + ".tmp.so"
+            build_lib(force=True, defines=("VISMA_WITH_TILE", "VISMA_TEST_SEAMS"), out=tmp)
+            os.replace(tmp, EXPERIMENTS_LIB)
     return EXPERIMENTS_LIB
 
 
