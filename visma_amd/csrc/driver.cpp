@@ -263,9 +263,10 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
     static const bool trace = std::getenv("VISMA_ICP_UPLOAD_TRACE") != nullptr;
     double tm[8]; int ti = 0; tm[ti++] = t_now();
     double c[3] = {0, 0, 0};
+    // (the HIP engine sums the centroid while it stages the target: one pass over the caller's memory instead
+    //  of two; engines without a raw upload get it from centroid_f64 -- the same chunk sums, the same value)
     if (ctx->fixed_centre) std::memcpy(c, ctx->centre, sizeof(c));
-    else centroid_f64(tgt, nt, tstride, c, true);
-    tm[ti++] = t_now();   // centroid
+    tm[ti++] = t_now();   // (centroid: inside the target upload)
     const bool want64 = ctx->search_precision != 0;     // (target-sharded ranks too: they compare shards in f64)
     // the target goes up as the caller's f64 values and is expanded on the device (HIP engine); otherwise it
     // is packed on a few host threads straight into the engine's (pinned) staging memory
@@ -273,11 +274,12 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
         const char *e = std::getenv("VISMA_ICP_RAW_UPLOAD_MIN");
         return e ? (int64_t)std::atoll(e) : (int64_t)0;
     }();
-    int rc = nt >= raw_min ? ctx->eng->set_target_f64(tgt, nt, tstride, c, want64 && ctx->eng->supports_device_loop())
+    int rc = nt >= raw_min ? ctx->eng->set_target_f64(tgt, nt, tstride, c, !ctx->fixed_centre, want64 && ctx->eng->supports_device_loop())
                            : (int)VISMA_ICP_ERR_STATE;
     const bool raw_target = rc == VISMA_ICP_OK;
     if (!raw_target) {
         if (rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);
+        if (!ctx->fixed_centre) centroid_f64(tgt, nt, tstride, c, true);
         float *tb = ctx->eng->staging(0, (size_t)std::max<int64_t>(nt, 1) * 4);
         pack_f64_to(tgt, nt, tstride, c, tb, true);
         rc = ctx->eng->set_target(tb, nt);

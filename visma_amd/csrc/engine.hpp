@@ -27,7 +27,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -95,15 +98,90 @@ constexpr int kNcclMin = 3;      // ncclMin
 constexpr int kNcclUint64 = 5;   // ncclUint64
 
 // ---- engines --------------------------------------------------------------------
+// Host threads for the passes over the caller's clouds (staging, packing, ordering).  Starting a std::thread
+// costs ~30 us and a C4 upload runs five such passes: the workers are started ONCE per process and parked on a
+// condition variable.  One pass at a time uses them; a caller that finds them busy (another context's upload on
+// another host thread -- the corpus workers) starts threads of its own, as every pass did before.
+class HostPool {
+public:
+    static HostPool &instance() { static HostPool *p = new HostPool(); return *p; }      // (never destroyed: its
+                                                                                         //  threads are parked)
+    int size() const { return (int)workers_; }
+    // fn(i) for i in [0, n) on up to `threads` threads including the caller's; false: busy, nothing was run
+    template <typename F>
+    bool run(int64_t n, int threads, F &fn)
+    {
+        std::unique_lock<std::mutex> busy(run_mu_, std::try_to_lock);
+        if (!busy.owns_lock()) return false;
+        struct Job { F *fn; std::atomic<int64_t> next; int64_t n; } job{&fn, {0}, n};
+        auto body = [](void *j) {
+            Job *jb = static_cast<Job *>(j);
+            for (;;) {
+                const int64_t i = jb->next.fetch_add(1, std::memory_order_relaxed);
+                if (i >= jb->n) break;
+                (*jb->fn)(i);
+            }
+        };
+        const int helpers = std::min(threads - 1, (int)workers_);
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            job_ = &job; body_ = body; wanted_ = helpers; pending_ = helpers; gen_++;
+        }
+        for (int w = 0; w < helpers; w++) cv_work_[w].notify_one();       // (only the workers this pass uses wake up)
+        body(&job);
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        job_ = nullptr;
+        return true;
+    }
+
+private:
+    HostPool()
+    {
+        int hc = (int)std::thread::hardware_concurrency();
+        workers_ = (size_t)std::max(0, std::min(hc, 32) - 1);
+        cv_work_.reset(new std::condition_variable[workers_ ? workers_ : 1]);
+        for (size_t w = 0; w < workers_; w++) std::thread([this, w] { loop((int)w); }).detach();
+    }
+    void loop(int w)
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            void *job; void (*body)(void *);
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_[w].wait(lk, [&] { return gen_ != seen && w < wanted_; });
+                seen = gen_;
+                job = job_; body = body_;
+            }
+            body(job);
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                if (--pending_ == 0) cv_done_.notify_one();
+            }
+        }
+    }
+    std::mutex run_mu_, mu_;
+    std::unique_ptr<std::condition_variable[]> cv_work_;       // one per worker
+    std::condition_variable cv_done_;
+    void *job_ = nullptr;
+    void (*body_)(void *) = nullptr;
+    int wanted_ = 0, pending_ = 0;
+    unsigned long long gen_ = 0;
+    size_t workers_ = 0;
+};
+
 // Run fn(i) for i in [0, n) on a few host threads (packing / ordering of clouds).
 template <typename F>
 void parallel_for(int64_t n, int64_t min_per_thread, F fn)
 {
     int64_t nt = (int64_t)std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
+    if (nt > 32) nt = 32;
     if (nt < 1) nt = 1;
     if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
     if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    if (HostPool::instance().run(n, (int)nt, fn)) return;
+    if (nt > 16) nt = 16;
     std::vector<std::thread> th;
     std::atomic<int64_t> next(0);
     for (int64_t t = 0; t < nt; t++)
@@ -201,7 +279,7 @@ public:
     // The target straight from the caller's f64 array (stride doubles per point): uploaded as it is (24 bytes
     // per point instead of 16 + 32) and expanded on the device into the fp32 copy (float)(x - c) and, with
     // want64, the f64 copy {x - c, index}.  set_source64 then completes the pair of f64 clouds.
-    virtual int set_target_f64(const double *, int64_t, int, const double *, bool) { return VISMA_ICP_ERR_STATE; }
+    virtual int set_target_f64(const double *, int64_t, int, double * /* centre: in, or out when computed */, bool /* compute */, bool) { return VISMA_ICP_ERR_STATE; }
     virtual int set_source64(const Pt64 *) { return VISMA_ICP_ERR_STATE; }
     // The source likewise: raw f64 up, then expanded, Morton-ordered and gathered on the device (order.hip);
     // `order` receives the original index of the point at every position.

@@ -90,7 +90,16 @@ public:
         return VISMA_ICP_OK;
     }
 
-    int set_target_f64(const double *xyz, int64_t nt, int stride, const double *c, bool want64) override
+    // The target as the caller holds it (f64 AoS) -> device, in 1 M-point pieces whose DMA runs while the next
+    // piece is staged.  Staging does three things in ONE pass over the caller's memory:
+    //  * the centroid's chunk sums (centre_out != NULL: the fixed 16 k-point chunks of centroid_f64, combined in
+    //    chunk order afterwards -- the same value, bit for bit, as a separate pass would give),
+    //  * the copy into pinned memory,
+    //  * and, while every value so far is exactly representable in fp32 (scans read from float PLY / PCD files,
+    //    depth maps: the common case), the copy is the fp32 value -- half the bytes to stage and to send; the
+    //    device widens it back to the identical double.  The first piece that holds a value fp32 cannot hold is
+    //    re-staged as f64 and the rest of the upload stays f64.
+    int set_target_f64(const double *xyz, int64_t nt, int stride, double *c, bool compute_centre, bool want64) override
     {
         HIP_TRY(hipSetDevice(device_));
         int rc = ensure_target(nt);
@@ -103,29 +112,82 @@ public:
                 if (rc) return rc;
                 raw_bytes_ = (size_t)nt * 24;
             }
-            // caller's array -> pinned staging on a few host threads, chunk by chunk, each chunk's DMA
-            // running while the next one is copied
             double *pin = reinterpret_cast<double *>(staging(2, (size_t)nt * 6));
-            const int64_t chunk = 1 << 20;                       // (a parallel_for starts its threads anew)
-            for (int64_t lo = 0; lo < nt; lo += chunk) {
-                const int64_t hi = std::min(nt, lo + chunk);
-                parallel_for((hi - lo + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
-                    const int64_t a = lo + ch * kHostChunk, b = std::min(hi, a + kHostChunk);
-                    if (stride == 3) std::memcpy(pin + 3 * a, xyz + 3 * a, sizeof(double) * 3 * (size_t)(b - a));
-                    else
-                        for (int64_t j = a; j < b; j++) {
-                            const double *q = xyz + (size_t)j * stride;
-                            pin[3 * j] = q[0]; pin[3 * j + 1] = q[1]; pin[3 * j + 2] = q[2];
+            const int64_t nch_all = (nt + kHostChunk - 1) / kHostChunk;
+            std::vector<double> part(compute_centre ? (size_t)nch_all * 3 : 0, 0.0);
+            const int64_t piece = 1 << 20;                       // (a parallel_for starts its threads anew)
+            struct Piece { int64_t lo, hi; bool f32; };
+            std::vector<Piece> pieces;
+            bool try32 = true;
+            for (int64_t lo = 0; lo < nt; lo += piece) {
+                const int64_t hi = std::min(nt, lo + piece);
+                const int64_t nch = (hi - lo + kHostChunk - 1) / kHostChunk;      // (piece is a multiple of kHostChunk)
+                std::atomic<bool> exact(true);
+                bool as32 = try32;
+                for (int pass = 0; pass < 2; pass++) {
+                    parallel_for(nch, 1, [&](int64_t ch) {
+                        const int64_t a = lo + ch * kHostChunk, b = std::min(hi, a + kHostChunk);
+                        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                        if (as32) {
+                            // the piece's fp32 copy lives at the start of its own f64 area of the staging buffer
+                            float *f = reinterpret_cast<float *>(pin + 3 * lo) + 3 * (a - lo);
+                            bool ok = true;
+                            for (int64_t j = a; j < b; j++, f += 3) {
+                                const double *q = xyz + (size_t)j * stride;
+                                const float x = (float)q[0], y = (float)q[1], z = (float)q[2];
+                                ok = ok && (double)x == q[0] && (double)y == q[1] && (double)z == q[2];
+                                f[0] = x; f[1] = y; f[2] = z;
+                                s0 += q[0]; s1 += q[1]; s2 += q[2];
+                            }
+                            if (!ok) exact.store(false, std::memory_order_relaxed);
+                        } else {
+                            for (int64_t j = a; j < b; j++) {
+                                const double *q = xyz + (size_t)j * stride;
+                                pin[3 * j] = q[0]; pin[3 * j + 1] = q[1]; pin[3 * j + 2] = q[2];
+                                s0 += q[0]; s1 += q[1]; s2 += q[2];
+                            }
                         }
-                });
-                HIP_TRY(hipMemcpyAsync((double *)d_raw_ + 3 * lo, pin + 3 * lo, sizeof(double) * 3 * (size_t)(hi - lo),
-                                       hipMemcpyHostToDevice, stream_));
+                        if (compute_centre) {
+                            const int64_t g = a / kHostChunk;
+                            part[3 * g] = s0; part[3 * g + 1] = s1; part[3 * g + 2] = s2;
+                        }
+                    });
+                    if (!as32 || exact.load()) break;
+                    as32 = false;                                // a value fp32 cannot hold: this piece again, as f64
+                    try32 = false;
+                }
+                // (an fp32 piece of a LATER upload may still be in flight from this area: the stream is in order,
+                //  and the previous upload ended with a synchronise)
+                if (as32)
+                    HIP_TRY(hipMemcpyAsync((char *)d_raw_ + (size_t)lo * 24, pin + 3 * lo, sizeof(float) * 3 * (size_t)(hi - lo),
+                                           hipMemcpyHostToDevice, stream_));
+                else
+                    HIP_TRY(hipMemcpyAsync((double *)d_raw_ + 3 * lo, pin + 3 * lo, sizeof(double) * 3 * (size_t)(hi - lo),
+                                           hipMemcpyHostToDevice, stream_));
+                pieces.push_back({lo, hi, as32});
             }
-            HIP_TRY(launch_expand_f64((const double *)d_raw_, nt, c, (float4 *)d_tgt_, (Pt64 *)d_tgt64_, stream_));
+            if (compute_centre) {
+                c[0] = c[1] = c[2] = 0.0;
+                for (int64_t ch = 0; ch < nch_all; ch++)
+                    for (int k = 0; k < 3; k++) c[k] += part[3 * ch + k];
+                for (int k = 0; k < 3; k++) c[k] /= (double)nt;
+            }
+            for (const Piece &pc : pieces) {
+                if (pc.f32)
+                    HIP_TRY(launch_expand_f32(reinterpret_cast<const float *>((const char *)d_raw_ + (size_t)pc.lo * 24), pc.hi - pc.lo,
+                                              pc.lo, c, (float4 *)d_tgt_ + pc.lo, d_tgt64_ ? (Pt64 *)d_tgt64_ + pc.lo : nullptr, stream_));
+                else
+                    HIP_TRY(launch_expand_f64((const double *)d_raw_ + 3 * pc.lo, pc.hi - pc.lo, c, (float4 *)d_tgt_ + pc.lo,
+                                              d_tgt64_ ? (Pt64 *)d_tgt64_ + pc.lo : nullptr, stream_, pc.lo));
+            }
+            last_upload_f32_ = !pieces.empty() && pieces.back().f32;
+        } else if (compute_centre) {
+            c[0] = c[1] = c[2] = 0.0;
         }
         HIP_TRY(hipStreamSynchronize(stream_));
         return VISMA_ICP_OK;
     }
+    bool last_upload_f32_ = false;   // (reported by VISMA_ICP_UPLOAD_TRACE)
     int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
                        std::vector<int32_t> &order) override
     {

@@ -238,7 +238,11 @@ size_t order_source_scratch_bytes(int64_t n);
 hipError_t order_source_device(const double *d_xyz, int64_t n, const double c[3], float4 *d_src, Pt64 *d_src64,
                                int32_t *d_order, void *scratch, size_t scratch_bytes, hipStream_t stream);
 // raw f64 xyz (3 doubles per point) -> f4[j] = ((float)(x - c), .., 0) and, when p8 != NULL, p8[j] = {x - c, .., j}
-hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream);
+hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream,
+                             int64_t index0 = 0);
+// ... the same from values fp32 holds exactly (3 floats per point): p8[j].w = index0 + j
+hipError_t launch_expand_f32(const float *xyz, int64_t n, int64_t index0, const double c[3], float4 *f4, Pt64 *p8,
+                             hipStream_t stream);
 
 hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipStream_t stream);
 hipError_t launch_pack12(const float4 *src, float *dst, int64_t n, hipStream_t stream);   // (x,y,z,w) -> packed (x,y,z)

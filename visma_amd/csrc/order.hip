@@ -129,22 +129,34 @@ __global__ void promote_pt64_kernel(const float4 *__restrict__ src, Pt64 *__rest
     dst[i] = o;
 }
 
-__global__ void expand_f64_kernel(const double *__restrict__ xyz, long long n, double cx, double cy, double cz,
+// RAW = double: the caller's f64 values; RAW = float: values that fp32 holds exactly, widened back first
+template <typename RAW>
+__global__ void expand_raw_kernel(const RAW *__restrict__ xyz, long long n, long long index0, double cx, double cy, double cz,
                                   float4 *__restrict__ f4, Pt64 *__restrict__ p8)
 {
     const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     // the same f64 subtraction and rounding as the host packing (pack_f64_to / set_clouds_f64)
-    const double x = xyz[3 * j] - cx, y = xyz[3 * j + 1] - cy, z = xyz[3 * j + 2] - cz;
+    const double x = (double)xyz[3 * j] - cx, y = (double)xyz[3 * j + 1] - cy, z = (double)xyz[3 * j + 2] - cz;
     f4[j] = make_float4((float)x, (float)y, (float)z, 0.f);
-    if (p8) p8[j] = Pt64{x, y, z, (unsigned long long)j};
+    if (p8) p8[j] = Pt64{x, y, z, (unsigned long long)(index0 + j)};
 }
 
-hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream)
+hipError_t launch_expand_f64(const double *xyz, int64_t n, const double c[3], float4 *f4, Pt64 *p8, hipStream_t stream,
+                             int64_t index0)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(expand_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xyz, (long long)n,
-                       c[0], c[1], c[2], f4, p8);
+    hipLaunchKernelGGL(expand_raw_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xyz, (long long)n,
+                       (long long)index0, c[0], c[1], c[2], f4, p8);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_f32(const float *xyz, int64_t n, int64_t index0, const double c[3], float4 *f4, Pt64 *p8,
+                             hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(expand_raw_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xyz, (long long)n,
+                       (long long)index0, c[0], c[1], c[2], f4, p8);
     return hipGetLastError();
 }
 
