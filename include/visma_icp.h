@@ -131,6 +131,18 @@ VISMA_ICP_API int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src
                                            int64_t ns, int src_stride,
                                            const double *tgt_xyz, int64_t nt,
                                            int tgt_stride);
+/* The same with target = open3d::VoxelDownSample(scene, voxel_size) (O3D/Core/Geometry/DownSample.cpp:179-220):
+ * the step both callers run on the scene right before RegistrationICP (src/evaluation.cpp:258-271,
+ * src/annotation.cpp:112), fused with the target upload.  The scene crosses PCIe once, is down-sampled on the
+ * device (the reference's point values bit for bit; voxels in ascending voxel-index order instead of the
+ * reference's hash-map iteration order) and becomes the target where it lies; *nt_out = its point count.
+ * Target indices of the results refer to that order; visma_icp_get_voxel_target copies the down-sampled points
+ * out (nt x 3 f64) for a caller that wants them too.  The registration that follows equals, bit for bit, the one
+ * after visma_icp_voxel_down_sample + visma_icp_set_clouds_f64. */
+VISMA_ICP_API int visma_icp_set_clouds_f64_voxel_target(visma_icp_ctx *ctx, const double *src_xyz, int64_t ns,
+                                                        int src_stride, const double *scene_xyz, int64_t n_scene,
+                                                        int scene_stride, double voxel_size, int64_t *nt_out);
+VISMA_ICP_API int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out, int64_t nt);
 /* fp32 uploads, no centring (the caller's coordinates are used as they are; the exact search
  * takes the fp32 values as its f64 coordinates).  FRAME RULE: visma_icp_set_clouds_f64 centres
  * BOTH clouds on one point; these setters (and the _device ones) upload in the caller's frame.

@@ -561,6 +561,27 @@ inline RegistrationResult ICPRefinement(const PointCloud &scene_raw, const Point
                                         const Eigen::Matrix4d &T_scene_src, double voxel_size,
                                         double max_distance, bool use_point_to_plane)
 {
+    if (!use_point_to_plane && voxel_size > 0.0 && max_distance > 0.0 && !scene_raw.points_.empty() &&
+        !scene_est.points_.empty()) {
+        // the scene goes up once, is down-sampled on the device and becomes the target where it lies
+        // (visma_icp_set_clouds_f64_voxel_target): the down-sampled cloud never crosses PCIe.  The result is the
+        // one of the two separate steps below; its correspondence_set_ indexes the voxels in ascending order.
+        visma_icp_ctx *ctx = detail::ThreadContext::instance().get();
+        int64_t nt = 0;
+        detail::check(ctx, visma_icp_set_clouds_f64_voxel_target(ctx, detail::xyz(scene_est.points_), (int64_t)scene_est.points_.size(), 3,
+                                                                 detail::xyz(scene_raw.points_), (int64_t)scene_raw.points_.size(), 3,
+                                                                 voxel_size, &nt),
+                      "visma_icp_set_clouds_f64_voxel_target");
+        const ICPConvergenceCriteria c;
+        double T[16];
+        detail::to_rowmajor(T_scene_src, T);
+        visma_icp_result r;
+        detail::check(ctx, visma_icp_run(ctx, T, max_distance, c.max_iteration_, c.relative_fitness_, c.relative_rmse_,
+                                         VISMA_ICP_SOLVER_KABSCH, 0, &r), "visma_icp_run");
+        RegistrationResult result(T_scene_src);
+        detail::fill_result(ctx, r, scene_est.points_.size(), result);
+        return result;
+    }
     const std::shared_ptr<PointCloud> scene = cicp::VoxelDownSample(scene_raw, voxel_size);
     if (use_point_to_plane)
         return cicp::RegistrationICP(scene_est, *scene, max_distance, T_scene_src,

@@ -71,3 +71,30 @@ def test_gpu_matches_reference_outputs(gpu_ctx_auto, oracle):
     a = ctx.voxel_down_sample(big, 0.01)[0]
     b = oracle.voxel_down_sample(big, 0.01)[0]
     assert same(a, b)
+
+
+@pytest.mark.gpu
+def test_voxel_grid_target_made_on_the_device_equals_the_two_steps(lib):
+    """visma_icp_set_clouds_f64_voxel_target: the scene is down-sampled and installed as the ICP target without
+    leaving the device.  Same points as visma_icp_voxel_down_sample, and the registration that follows is the
+    one after the two separate calls, bit for bit (the centroid is summed on the device in the host's order)."""
+    from visma_amd import _lib, synth
+    for ns, n_scene, voxel, off in ((8000, 300000, 0.02, 0.0), (3000, 40000, 0.05, 2.5), (20000, 1200000, 0.01, -1.0)):
+        src, scene, T_gt, _ = synth.make_pair(ns, n_scene, seed_t=n_scene, seed_s=ns, offset=[off, 0.5 * off, -off])
+        scene = scene + np.random.default_rng(ns).normal(size=scene.shape) * 1e-4          # (not fp32-representable)
+        a, b = _lib.Context(0), _lib.Context(0)
+        down, _, _ = a.voxel_down_sample(scene, voxel)
+        a.set_clouds_f64(src, down)
+        ra = a.run(None, 0.06, 20, 1e-6, 1e-6)
+        nt = b.set_clouds_f64_voxel_target(src, scene, voxel)
+        assert nt == len(down)
+        assert np.array_equal(b.get_voxel_target(nt), down)
+        rb = b.run(None, 0.06, 20, 1e-6, 1e-6)
+        assert ra.num_correspondences == rb.num_correspondences and ra.iterations == rb.iterations
+        assert np.array_equal(ra.transformation_, rb.transformation_)
+        assert np.array_equal(a.correspondence_index(), b.correspondence_index())
+        a.close(); b.close()
+    c = _lib.Context(0)
+    with pytest.raises(_lib.IcpError):
+        c.set_clouds_f64_voxel_target(src, scene, 0.0)
+    c.close()

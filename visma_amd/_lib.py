@@ -120,6 +120,9 @@ def _bind(L):
         L.visma_icp_create_with_engine.argtypes = [C.POINTER(C.c_void_p), C.POINTER(CEngine), C.c_void_p]
     L.visma_icp_destroy.argtypes = [C.c_void_p]
     L.visma_icp_set_clouds_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int]
+    L.visma_icp_set_clouds_f64_voxel_target.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int,
+                                                        C.c_double, C.POINTER(C.c_int64)]
+    L.visma_icp_get_voxel_target.argtypes = [C.c_void_p, _dp, C.c_int64]
     L.visma_icp_set_target.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
     L.visma_icp_set_source.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
     L.visma_icp_set_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -257,6 +260,20 @@ class Context:
         self._chk(self.L.visma_icp_set_clouds_f64(self._h, _p(src, _dp), len(src), 3,
                                                   _p(tgt, _dp), len(tgt), 3))
         self.ns, self.nt = len(src), len(tgt)
+
+    def set_clouds_f64_voxel_target(self, src, scene, voxel_size):
+        """target = VoxelDownSample(scene, voxel_size), made and installed on the device -> its point count."""
+        s = _f64(src, (-1, 3)); t = _f64(scene, (-1, 3))
+        nt = C.c_int64(0)
+        self._chk(self.L.visma_icp_set_clouds_f64_voxel_target(self._h, _p(s, _dp), len(s), 3, _p(t, _dp), len(t), 3,
+                                                               float(voxel_size), C.byref(nt)))
+        self.ns, self.nt = len(s), int(nt.value)
+        return int(nt.value)
+
+    def get_voxel_target(self, nt):
+        out = np.empty((max(nt, 1), 3))
+        self._chk(self.L.visma_icp_get_voxel_target(self._h, _p(out, _dp), int(nt)))
+        return out[:nt].copy()
 
     def set_target(self, xyz):
         a = np.ascontiguousarray(xyz, dtype=np.float32)

@@ -251,8 +251,35 @@ const char *visma_icp_last_error(const visma_icp_ctx *ctx)
 }
 
 
+static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride, const double *tgt,
+                               int64_t nt, int tstride, double voxel, int64_t *nt_out);
+
 int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride,
                              const double *tgt, int64_t nt, int tstride)
+{
+    return set_clouds_f64_impl(ctx, src, ns, sstride, tgt, nt, tstride, 0.0, nullptr);
+}
+
+int visma_icp_set_clouds_f64_voxel_target(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride,
+                                          const double *scene, int64_t n_scene, int tstride, double voxel_size,
+                                          int64_t *nt_out)
+{
+    if (ctx && (!nt_out || !(voxel_size > 0.0))) return ctx->fail(VISMA_ICP_ERR_INVALID, "voxel_size must be positive, nt_out not NULL");
+    return set_clouds_f64_impl(ctx, src, ns, sstride, scene, n_scene, tstride, voxel_size, nt_out);
+}
+
+int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out, int64_t nt)
+{
+    CTX_CHECK();
+    if (nt < 0 || (nt > 0 && !xyz_out)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad arguments");
+    int rc = ctx->eng->get_voxel_target(xyz_out, nt);
+    if (rc) return ctx->eng_fail(rc);
+    return VISMA_ICP_OK;
+}
+
+// voxel > 0: the target is VoxelDownSample(tgt, voxel), made and installed on the device (*nt_out = its size)
+static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride, const double *tgt,
+                               int64_t nt, int tstride, double voxel, int64_t *nt_out)
 {
     CTX_CHECK();
     if (ns < 0 || nt < 0 || sstride < 3 || tstride < 3 || (ns > 0 && !src) || (nt > 0 && !tgt))
@@ -274,8 +301,16 @@ int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, 
         const char *e = std::getenv("VISMA_ICP_RAW_UPLOAD_MIN");
         return e ? (int64_t)std::atoll(e) : (int64_t)0;
     }();
-    int rc = nt >= raw_min ? ctx->eng->set_target_f64(tgt, nt, tstride, c, !ctx->fixed_centre, want64 && ctx->eng->supports_device_loop())
+    int rc;
+    if (voxel > 0.0) {
+        rc = ctx->eng->set_target_voxel_f64(tgt, nt, tstride, voxel, c, !ctx->fixed_centre, want64 && ctx->eng->supports_device_loop(), nt_out);
+        if (rc == VISMA_ICP_ERR_STATE) return ctx->fail(VISMA_ICP_ERR_STATE, "the voxel-grid target needs the HIP engine");
+        if (rc) return ctx->eng_fail(rc);
+        nt = *nt_out;                                            // (what follows only needs the count)
+    } else {
+        rc = nt >= raw_min ? ctx->eng->set_target_f64(tgt, nt, tstride, c, !ctx->fixed_centre, want64 && ctx->eng->supports_device_loop())
                            : (int)VISMA_ICP_ERR_STATE;
+    }
     const bool raw_target = rc == VISMA_ICP_OK;
     if (!raw_target) {
         if (rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);

@@ -280,6 +280,9 @@ public:
     // per point instead of 16 + 32) and expanded on the device into the fp32 copy (float)(x - c) and, with
     // want64, the f64 copy {x - c, index}.  set_source64 then completes the pair of f64 clouds.
     virtual int set_target_f64(const double *, int64_t, int, double * /* centre: in, or out when computed */, bool /* compute */, bool) { return VISMA_ICP_ERR_STATE; }
+    // the target = VoxelDownSample(scene, voxel), down-sampled and installed without leaving the device
+    virtual int set_target_voxel_f64(const double *, int64_t, int, double /* voxel */, double * /* centre */, bool, bool, int64_t * /* nt */) { return VISMA_ICP_ERR_STATE; }
+    virtual int get_voxel_target(double *, int64_t) { return VISMA_ICP_ERR_STATE; }
     virtual int set_source64(const Pt64 *) { return VISMA_ICP_ERR_STATE; }
     // The source likewise: raw f64 up, then expanded, Morton-ordered and gathered on the device (order.hip);
     // `order` receives the original index of the point at every position.

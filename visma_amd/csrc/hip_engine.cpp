@@ -27,6 +27,7 @@ public:
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_partials_); free_dev(d_stats_);
+        if (d_vox_out_) (void)hipFree(d_vox_out_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
@@ -188,6 +189,84 @@ public:
         return VISMA_ICP_OK;
     }
     bool last_upload_f32_ = false;   // (reported by VISMA_ICP_UPLOAD_TRACE)
+
+    // open3d::VoxelDownSample(scene, voxel) (O3D/Core/Geometry/DownSample.cpp:179-220) + the target upload of
+    // RegistrationICP as ONE step (src/evaluation.cpp:258-271, src/annotation.cpp:112): the scene goes up once, is
+    // down-sampled on the device (voxel.hip: the reference's values bit for bit, voxels in ascending index order)
+    // and the result becomes the target where it lies -- the down-sampled cloud never crosses PCIe.  The centroid
+    // is summed on the device in the host's order (centroid_f64), so the registration that follows is the one a
+    // caller gets from the two separate calls, bit for bit.
+    int set_target_voxel_f64(const double *xyz, int64_t n, int stride, double voxel, double *c, bool compute_centre,
+                             bool want64, int64_t *nt_out) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        *nt_out = 0;
+        if (n < 0 || n > 0x7fffffff - 4096) { err_ = "scene too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
+        void *d_in = nullptr;
+        if (n > 0) {
+            int rc = pool_alloc(&d_in, (size_t)n * 24);
+            if (rc) return rc;
+            double *pin = reinterpret_cast<double *>(staging(2, (size_t)n * 6));
+            const int64_t piece = 1 << 20;
+            for (int64_t lo = 0; lo < n; lo += piece) {
+                const int64_t hi = std::min(n, lo + piece);
+                parallel_for((hi - lo + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
+                    const int64_t a = lo + ch * kHostChunk, b = std::min(hi, a + kHostChunk);
+                    if (stride == 3) std::memcpy(pin + 3 * a, xyz + 3 * a, sizeof(double) * 3 * (size_t)(b - a));
+                    else
+                        for (int64_t j = a; j < b; j++) {
+                            const double *q = xyz + (size_t)j * stride;
+                            pin[3 * j] = q[0]; pin[3 * j + 1] = q[1]; pin[3 * j + 2] = q[2];
+                        }
+                });
+                HIP_TRY(hipMemcpyAsync((double *)d_in + 3 * lo, pin + 3 * lo, sizeof(double) * 3 * (size_t)(hi - lo),
+                                       hipMemcpyHostToDevice, stream_));
+            }
+        }
+        double *d_o = nullptr;
+        int64_t nvox = 0;
+        int too_fine = 0;
+        hipError_t e = voxel_down_sample_core((const double *)d_in, nullptr, nullptr, n, voxel, &d_o, nullptr, nullptr, &nvox,
+                                              &too_fine, stream_);
+        free_dev(d_in);
+        if (e != hipSuccess) { err_ = std::string("voxel_down_sample: ") + hipGetErrorString(e); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
+        if (too_fine) { (void)hipFree(d_o); err_ = "voxel grid too fine to key in 62 bits"; return VISMA_ICP_ERR_INVALID; }
+        if (d_vox_out_) (void)hipFree(d_vox_out_);
+        d_vox_out_ = d_o;
+        vox_out_n_ = nvox;
+        int rc = ensure_target(nvox);
+        if (rc) return rc;
+        if (want64) { rc = pool_alloc(&d_tgt64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nvox, 1)); if (rc) return rc; }
+        if (nvox > 0) {
+            if (compute_centre) {
+                const int64_t nch = (nvox + kHostChunk - 1) / kHostChunk;
+                double *d_part = nullptr;
+                HIP_TRY(hipMalloc((void **)&d_part, sizeof(double) * (size_t)(3 * nch + 3)));
+                hipError_t e2 = centroid_device(d_o, nvox, kHostChunk, d_part, d_part + 3 * nch, stream_);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(c, d_part + 3 * nch, sizeof(double) * 3, hipMemcpyDeviceToHost, stream_);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream_);
+                (void)hipFree(d_part);
+                if (e2 != hipSuccess) { err_ = std::string("centroid: ") + hipGetErrorString(e2); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
+            }
+            HIP_TRY(launch_expand_f64(d_o, nvox, c, (float4 *)d_tgt_, (Pt64 *)d_tgt64_, stream_));
+        } else if (compute_centre) {
+            c[0] = c[1] = c[2] = 0.0;
+        }
+        HIP_TRY(hipStreamSynchronize(stream_));
+        *nt_out = nvox;
+        return VISMA_ICP_OK;
+    }
+    // the down-sampled cloud of the last set_target_voxel_f64 (kept on the device until the next one), for callers
+    // that want the points as well
+    int get_voxel_target(double *out, int64_t n) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (n != vox_out_n_) { err_ = "no down-sampled target of that size"; return VISMA_ICP_ERR_STATE; }
+        if (n > 0) HIP_TRY(hipMemcpy(out, d_vox_out_, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+        return VISMA_ICP_OK;
+    }
+    double *d_vox_out_ = nullptr;
+    int64_t vox_out_n_ = -1;
     int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
                        std::vector<int32_t> &order) override
     {

@@ -274,6 +274,12 @@ hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, co
                                     int64_t n, double voxel, double *h_out_xyz, double *h_out_nrm,
                                     double *h_out_col, int64_t *n_out, int *too_fine,
                                     hipStream_t stream);
+// ... the device part alone (resident input, hipMalloc'ed resident output that the caller frees), and the centroid
+// of resident points with the host's summation order (centroid_f64): what the device-resident caller pipeline uses
+hipError_t voxel_down_sample_core(const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double voxel,
+                                  double **d_oxyz_out, double **d_onrm_out, double **d_ocol_out, int64_t *n_out,
+                                  int *too_fine, hipStream_t stream);
+hipError_t centroid_device(const double *d_xyz, int64_t n, int64_t chunk, double *d_part, double *d_out, hipStream_t stream);
 // counting sort of the target by cell: start[ncell+1], sorted[nt] = (x,y,z, bits(orig index))
 // tgt64 / sorted64 (both or neither): the f64 copy of the target is scattered in the same order
 hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,

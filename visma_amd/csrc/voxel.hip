@@ -147,18 +147,20 @@ hipError_t launch_exclusive_scan_u32(const unsigned *in, long long n, unsigned *
 
 #define VOX_TRY(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rc = e__; goto done; } } while (0)
 
-// Returns hipSuccess and *n_out (0 when the reference would return an empty cloud);
-// *too_fine is set when the voxel grid cannot be keyed in 62 bits.
-hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, const double *h_col,
-                                    int64_t n, double voxel, double *h_out_xyz, double *h_out_nrm,
-                                    double *h_out_col, int64_t *n_out, int *too_fine,
-                                    hipStream_t stream)
+// The device part: d_xyz (+ d_nrm, d_col or NULL), n points resident -> *d_oxyz (+ *d_onrm, *d_ocol) hipMalloc'ed
+// here with *n_out voxels (NULL / 0 when the reference would return an empty cloud); the caller frees them.
+hipError_t voxel_down_sample_core(const double *d_xyz, const double *d_nrm, const double *d_col, int64_t n, double voxel,
+                                  double **d_oxyz_out, double **d_onrm_out, double **d_ocol_out, int64_t *n_out,
+                                  int *too_fine, hipStream_t stream)
 {
     *n_out = 0;
     *too_fine = 0;
+    *d_oxyz_out = nullptr;
+    if (d_onrm_out) *d_onrm_out = nullptr;
+    if (d_ocol_out) *d_ocol_out = nullptr;
     if (!(voxel > 0.0) || n <= 0) return hipSuccess;       // DownSample.cpp:183-186
     hipError_t rc = hipSuccess;
-    double *d_xyz = nullptr, *d_nrm = nullptr, *d_col = nullptr, *d_oxyz = nullptr, *d_onrm = nullptr, *d_ocol = nullptr;
+    double *d_oxyz = nullptr, *d_onrm = nullptr, *d_ocol = nullptr;
     unsigned long long *d_box = nullptr, *d_key = nullptr, *d_key2 = nullptr;
     unsigned *d_val = nullptr, *d_val2 = nullptr, *d_head = nullptr, *d_vid = nullptr, *d_bsum = nullptr, *d_vstart = nullptr;
     void *d_tmp = nullptr;
@@ -170,11 +172,8 @@ hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, co
     unsigned last_vid = 0, last_head = 0;
     int64_t nvox = 0;
     int end_bit = 64;
+    bool keep = false;
 
-    VOX_TRY(hipMalloc(&d_xyz, sizeof(double) * 3 * n));
-    VOX_TRY(hipMemcpyAsync(d_xyz, h_xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream));
-    if (h_nrm) { VOX_TRY(hipMalloc(&d_nrm, sizeof(double) * 3 * n)); VOX_TRY(hipMemcpyAsync(d_nrm, h_nrm, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream)); }
-    if (h_col) { VOX_TRY(hipMalloc(&d_col, sizeof(double) * 3 * n)); VOX_TRY(hipMemcpyAsync(d_col, h_col, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream)); }
     VOX_TRY(hipMalloc(&d_box, sizeof(unsigned long long) * 8));
     hipLaunchKernelGGL(vox_bbox_init_kernel, dim3(1), dim3(64), 0, stream, d_box);
     hipLaunchKernelGGL(vox_bbox_kernel, dim3(pb > 1024 ? 1024 : pb), dim3(256), 0, stream, d_xyz, (long long)n, d_box);
@@ -218,22 +217,85 @@ hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, co
     VOX_TRY(hipMalloc(&d_vstart, sizeof(unsigned) * (nvox + 1)));
     hipLaunchKernelGGL(vox_starts_kernel, dim3(pb), dim3(256), 0, stream, d_head, d_vid, (long long)n, d_vstart);
     VOX_TRY(hipMalloc(&d_oxyz, sizeof(double) * 3 * nvox));
-    if (h_nrm) VOX_TRY(hipMalloc(&d_onrm, sizeof(double) * 3 * nvox));
-    if (h_col) VOX_TRY(hipMalloc(&d_ocol, sizeof(double) * 3 * nvox));
+    if (d_nrm && d_onrm_out) VOX_TRY(hipMalloc(&d_onrm, sizeof(double) * 3 * nvox));
+    if (d_col && d_ocol_out) VOX_TRY(hipMalloc(&d_ocol, sizeof(double) * 3 * nvox));
     hipLaunchKernelGGL(vox_reduce_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, stream, d_xyz,
-                       d_nrm, d_col, d_val2, d_vstart, (long long)nvox, (long long)n, d_oxyz, d_onrm, d_ocol);
+                       d_onrm ? d_nrm : nullptr, d_ocol ? d_col : nullptr, d_val2, d_vstart, (long long)nvox, (long long)n,
+                       d_oxyz, d_onrm, d_ocol);
     VOX_TRY(hipGetLastError());
-    VOX_TRY(hipMemcpyAsync(h_out_xyz, d_oxyz, sizeof(double) * 3 * nvox, hipMemcpyDeviceToHost, stream));
-    if (h_nrm && h_out_nrm) VOX_TRY(hipMemcpyAsync(h_out_nrm, d_onrm, sizeof(double) * 3 * nvox, hipMemcpyDeviceToHost, stream));
-    if (h_col && h_out_col) VOX_TRY(hipMemcpyAsync(h_out_col, d_ocol, sizeof(double) * 3 * nvox, hipMemcpyDeviceToHost, stream));
-    VOX_TRY(hipStreamSynchronize(stream));
+    VOX_TRY(hipStreamSynchronize(stream));                     // (the scratch below is freed on return)
     *n_out = nvox;
+    *d_oxyz_out = d_oxyz;
+    if (d_onrm_out) *d_onrm_out = d_onrm;
+    if (d_ocol_out) *d_ocol_out = d_ocol;
+    keep = true;
 done:
-    (void)hipFree(d_xyz); (void)hipFree(d_nrm); (void)hipFree(d_col); (void)hipFree(d_oxyz); (void)hipFree(d_onrm);
-    (void)hipFree(d_ocol); (void)hipFree(d_box); (void)hipFree(d_key); (void)hipFree(d_key2); (void)hipFree(d_val);
+    if (!keep) { (void)hipFree(d_oxyz); (void)hipFree(d_onrm); (void)hipFree(d_ocol); }
+    (void)hipFree(d_box); (void)hipFree(d_key); (void)hipFree(d_key2); (void)hipFree(d_val);
     (void)hipFree(d_val2); (void)hipFree(d_head); (void)hipFree(d_vid); (void)hipFree(d_bsum); (void)hipFree(d_vstart);
     (void)hipFree(d_tmp);
     return rc;
+}
+
+// Host arrays in, host arrays out.  Returns hipSuccess and *n_out (0 when the reference would return an empty
+// cloud); *too_fine is set when the voxel grid cannot be keyed in 62 bits.
+hipError_t voxel_down_sample_device(const double *h_xyz, const double *h_nrm, const double *h_col,
+                                    int64_t n, double voxel, double *h_out_xyz, double *h_out_nrm,
+                                    double *h_out_col, int64_t *n_out, int *too_fine,
+                                    hipStream_t stream)
+{
+    *n_out = 0;
+    *too_fine = 0;
+    if (!(voxel > 0.0) || n <= 0) return hipSuccess;       // DownSample.cpp:183-186
+    hipError_t rc = hipSuccess;
+    double *d_xyz = nullptr, *d_nrm = nullptr, *d_col = nullptr, *d_oxyz = nullptr, *d_onrm = nullptr, *d_ocol = nullptr;
+    int64_t nvox = 0;
+    VOX_TRY(hipMalloc(&d_xyz, sizeof(double) * 3 * n));
+    VOX_TRY(hipMemcpyAsync(d_xyz, h_xyz, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream));
+    if (h_nrm) { VOX_TRY(hipMalloc(&d_nrm, sizeof(double) * 3 * n)); VOX_TRY(hipMemcpyAsync(d_nrm, h_nrm, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream)); }
+    if (h_col) { VOX_TRY(hipMalloc(&d_col, sizeof(double) * 3 * n)); VOX_TRY(hipMemcpyAsync(d_col, h_col, sizeof(double) * 3 * n, hipMemcpyHostToDevice, stream)); }
+    VOX_TRY(voxel_down_sample_core(d_xyz, d_nrm, d_col, n, voxel, &d_oxyz, &d_onrm, &d_ocol, &nvox, too_fine, stream));
+    if (nvox > 0) {
+        VOX_TRY(hipMemcpyAsync(h_out_xyz, d_oxyz, sizeof(double) * 3 * nvox, hipMemcpyDeviceToHost, stream));
+        if (h_nrm && h_out_nrm) VOX_TRY(hipMemcpyAsync(h_out_nrm, d_onrm, sizeof(double) * 3 * nvox, hipMemcpyDeviceToHost, stream));
+        if (h_col && h_out_col) VOX_TRY(hipMemcpyAsync(h_out_col, d_ocol, sizeof(double) * 3 * nvox, hipMemcpyDeviceToHost, stream));
+        VOX_TRY(hipStreamSynchronize(stream));
+    }
+    *n_out = nvox;
+done:
+    (void)hipFree(d_xyz); (void)hipFree(d_nrm); (void)hipFree(d_col); (void)hipFree(d_oxyz); (void)hipFree(d_onrm);
+    (void)hipFree(d_ocol);
+    return rc;
+}
+
+// The centroid of n device-resident points as centroid_f64 (driver.cpp) computes it on the host: sequential f64
+// sums over fixed chunks of `chunk` points, the chunk sums added in chunk order, divided by n -- the same value,
+// bit for bit (no contraction on either side).  part: ceil(n / chunk) * 3 doubles of scratch; out: 3 doubles.
+__global__ void centroid_chunks_kernel(const double *__restrict__ xyz, long long n, long long chunk, double *__restrict__ part)
+{
+    const long long ch = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long lo = ch * chunk;
+    if (lo >= n) return;
+    const long long hi = lo + chunk < n ? lo + chunk : n;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (long long i = lo; i < hi; i++) { s0 += xyz[3 * i]; s1 += xyz[3 * i + 1]; s2 += xyz[3 * i + 2]; }
+    part[3 * ch] = s0; part[3 * ch + 1] = s1; part[3 * ch + 2] = s2;
+}
+__global__ void centroid_combine_kernel(const double *__restrict__ part, long long nch, long long n, double *__restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+    for (long long ch = 0; ch < nch; ch++) { c0 += part[3 * ch]; c1 += part[3 * ch + 1]; c2 += part[3 * ch + 2]; }
+    out[0] = c0 / (double)n; out[1] = c1 / (double)n; out[2] = c2 / (double)n;
+}
+hipError_t centroid_device(const double *d_xyz, int64_t n, int64_t chunk, double *d_part, double *d_out, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const long long nch = (n + chunk - 1) / chunk;
+    hipLaunchKernelGGL(centroid_chunks_kernel, dim3((unsigned)((nch + 63) / 64)), dim3(64), 0, stream, d_xyz, (long long)n,
+                       (long long)chunk, d_part);
+    hipLaunchKernelGGL(centroid_combine_kernel, dim3(1), dim3(64), 0, stream, d_part, nch, (long long)n, d_out);
+    return hipGetLastError();
 }
 
 }  // namespace visma
