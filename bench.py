@@ -466,7 +466,7 @@ def c4_saturated(device, tgt, nt, radius, ns_list=(1048576, 4194304), steps=5):
         dt = time.perf_counter() - t0
         tm = c.get_timing(reset=True)
         c.set_profiling(0)
-        r = kernel_roofline(c, ns_s, nt, tm, traffic_kind="none")
+        r = kernel_roofline(c, ns_s, nt, tm)
         r.update(ns=ns_s, nt=nt, steps=steps, ms_per_step=dt / steps * 1e3, launches_timed=tm["nn_launches"],
                  query_iterations_per_sec=float(ns_s) * steps / dt, fitness=last.fitness_)
         r.pop("note", None)

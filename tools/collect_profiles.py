@@ -15,6 +15,7 @@ pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.j
          ("bench_c4_under_rocprof.json", "%s_bench_c4_under_rocprof.json"),
          ("stats_c4/c4_kernel_stats.csv", "%s_bench_c4_kernel_stats.csv"), ("stats_c3/c3_kernel_stats.csv", "%s_bench_c3_kernel_stats.csv"),
          ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv"),
+         ("pmc_traffic_saturated_summary.csv", "%s_4m_queries_traffic_pmc_summary.csv"),
          ("pmc_kernel_summary.csv", "%s_c4_kernel_pmc_summary.csv")]
 for a, b in pairs:
     p = os.path.join(src, a)
@@ -44,4 +45,19 @@ for key, match, label in (("grid:262144x4194304", "nn_grid_reduce_kernel", "nn_g
             "kernel": label,
             "source": "profiles/%s_c4_traffic_pmc_summary.csv (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % tag}
         print("traffic.json %s: %.1f MB per launch" % (key, tj[key]["hbm_bytes_per_nn_launch"] / 1e6))
+# ... and with 4 M queries per launch
+p = os.path.join(src, "pmc_traffic_saturated_summary.csv")
+vals = {}
+if os.path.exists(p):
+    for r in csv.DictReader(open(p)):
+        if "nn_coop_kernel" in r["kernel"]:
+            vals[r["counter"]] = float(r["mean_per_dispatch"])
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    tj["grid_warm:4194304x4194304"] = {
+        "hbm_bytes_per_nn_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+        "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+        "correction": "as above; cross-check TCC_MISS_sum x 128 B = %.1f MB" % (vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
+        "kernel": "nn_coop_kernel_one<false>, 4,194,304 queries per launch",
+        "source": "profiles/%s_4m_queries_traffic_pmc_summary.csv" % tag}
+    print("traffic.json grid_warm 4M: %.1f MB per launch" % (tj["grid_warm:4194304x4194304"]["hbm_bytes_per_nn_launch"] / 1e6))
 json.dump(tj, open(tj_path, "w"), indent=1)

@@ -16,6 +16,12 @@ for g in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   ( cd /tmp && timeout 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out/pmc -o $t -- python /root/repo/tools/run_c4_iterations.py > $out/pmc_$t.log 2>&1 )
 done
 python tools/pmc_summarize.py $out/pmc nn_ > $out/pmc_traffic_summary.csv
+# the same counters with 4 M queries per launch (bench.py: roofline_saturated)
+for g in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  t=$(echo "$g" | tr ' ' '_' | cut -c1-16)
+  ( cd /tmp && VISMA_NS=4194304 timeout 240 rocprofv3 --pmc $g --kernel-trace --output-format csv -d $out/pmc_sat -o $t -- python /root/repo/tools/run_c4_iterations.py > $out/pmc_sat_$t.log 2>&1 )
+done
+python tools/pmc_summarize.py $out/pmc_sat nn_ > $out/pmc_traffic_saturated_summary.csv
 # instruction mix / L1 / wait counters of the default kernel (every pass under its own timeout)
 tools/pmc_quick.sh $out/pmc_kernel > $out/pmc_kernel_summary.txt 2>&1
 python tools/pmc_summarize.py $out/pmc_kernel nn_ > $out/pmc_kernel_summary.csv

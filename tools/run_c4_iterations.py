@@ -1,8 +1,16 @@
+"""What the PMC passes profile: one cold pass (lane-serial kernel) + five warm-started ones at C4
+(VISMA_NS overrides the source size: the saturated launches of bench.py's roofline_saturated)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from visma_amd import _lib, synth
-src, tgt, T_gt, r = synth.make_pair(262144, 4194304, motion="radius")
+ns = int(os.environ.get("VISMA_NS", "262144"))
+nt = 4194304
+if ns == 262144:
+    src, tgt, T_gt, r = synth.make_pair(ns, nt, motion="radius")
+else:
+    _, tgt, T_gt, r = synth.make_pair(1024, nt, motion="radius")
+    src = synth.make_source(ns, nt, seed_s=5678 + ns % 9973)
 c = _lib.Context(0); c.set_clouds_f64(src, tgt); c.set_nn_mode(_lib.NN_GRID)
 c.iterate(np.eye(4), r, 6)
 c.close()

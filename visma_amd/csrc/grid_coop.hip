@@ -166,7 +166,8 @@ __device__ __forceinline__ void coop_body(
     const long long i_end = i_begin + per_group < ns ? i_begin + per_group : ns;
 
     __shared__ float4 s_qp[kBlock];                         // (px, py, pz, W) of the query of each lane
-    __shared__ uint2 s_item[kBlock / 64][kCoopCap];         // chunk descriptors, overwritten by chunk results
+    __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, overwritten by chunk results (+ 64 null
+                                                            // descriptors behind the last one: the list is read unguarded)
     uint2 *items = s_item[wave];
     const float4 *qp = s_qp + wave * 64;
 
@@ -198,12 +199,15 @@ __device__ __forceinline__ void coop_body(
         const int span = x1 + 1 - x0;                        // cells of a row that exist: <= 0, 1, 2 or 3
         // ---- starts of the cells x0 .. x0+3 of a row: one 16-byte load (absent row / lane: zeros = empty)
         typedef unsigned u4a __attribute__((ext_vector_type(4), aligned(4)));
+        // (cell indices fit 32 bits: kGridMaxCells; which of the three y / z rows exist is tested once per axis)
+        const bool yok[3] = {cy - 1 >= 0 && cy - 1 < g.dim[1], cy >= 0 && cy < g.dim[1], cy + 1 >= 0 && cy + 1 < g.dim[1]};
+        const bool zok[3] = {cz - 1 >= 0 && cz - 1 < g.dim[2], cz >= 0 && cz < g.dim[2], cz + 1 >= 0 && cz + 1 < g.dim[2]};
+        const int row_c = (cz * g.dim[1] + cy) * g.dim[0] + x0, pitch_y = g.dim[0], pitch_z = g.dim[1] * g.dim[0];
         auto load_row = [&](int k, bool want) {
-            const int z = cz + (k / 3 - 1), y = cy + (k % 3 - 1);
-            const bool ok = want && span > 0 && z >= 0 && z < g.dim[2] && y >= 0 && y < g.dim[1];
+            const bool ok = want && span > 0 && zok[k / 3] && yok[k % 3];
             if (cand_count && ok) ncand_all++;               // profiling: cell-table rows looked up
             u4a v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u4a *>(start + ((long long)z * g.dim[1] + y) * g.dim[0] + x0);
+            if (ok) v = *reinterpret_cast<const u4a *>(start + (row_c + (k / 3 - 1) * pitch_z + (k % 3 - 1) * pitch_y));
             return v;
         };
         // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
@@ -231,12 +235,11 @@ __device__ __forceinline__ void coop_body(
             const float ex = xi == cx ? 0.f : (xi < cx ? lo_x + (float)(cx - xi - 1) : hi_x + (float)(xi - cx - 1));
             exq[j] = ex * ex * h2;
         }
-        auto row_bound_of = [&](int k) {
-            const int dy = k % 3 - 1, dz = k / 3 - 1;
-            const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y : hi_y);
-            const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z : hi_z);
-            return (ey * ey + ez * ez) * h2;
-        };
+        const float ey2[3] = {lo_y * lo_y, 0.f, hi_y * hi_y}, ez2[3] = {lo_z * lo_z, 0.f, hi_z * hi_z};
+        float rowB[9];                                       // squared slab bound of row k = (dy, dz)
+#pragma unroll
+        for (int k = 0; k < 9; k++) rowB[k] = (ey2[k % 3] + ez2[k / 3]) * h2;
+        auto row_bound_of = [&](int k) { return rowB[k]; };
         // what nothing nearer than can be missed by: the previous winner's distance now, or the radius
         float bound0 = L;
         {
@@ -305,34 +308,33 @@ __device__ __forceinline__ void coop_body(
                         }
                     }
                 }
+                const unsigned Mw = min(M - w0, (unsigned)kCoopCap);
+                items[Mw + lane] = make_uint2(0u, 0u);       // null descriptors (count 0) for the last, partial trip
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 COOP_STAMP(2);                               // chunk list written
-                const unsigned Mw = min(M - w0, (unsigned)kCoopCap);
                 for (unsigned t = 0; t < Mw; t += 8u * kCoopDepth) {
                     // kCoopDepth chunks per lane octet in flight: every load of the list is independent
                     P12 c4[kCoopDepth];
+                    unsigned meta[kCoopDepth];
 #pragma unroll
                     for (int u = 0; u < kCoopDepth; u++) {
-                        const unsigned j = t + u * 8 + oct;
-                        unsigned b = 0u;
-                        if (j < Mw) b = items[j].x;
-                        c4[u] = s12[b + l8];                 // (the array carries kSortedSlack entries of slack)
+                        const uint2 dsc = items[t + u * 8 + oct];
+                        meta[u] = dsc.y;
+                        c4[u] = s12[dsc.x + l8];             // (the array carries kSortedSlack entries of slack)
                     }
 #pragma unroll
                     for (int u = 0; u < kCoopDepth; u++) {
-                        const unsigned j = t + u * 8 + oct;
-                        unsigned meta = 0u;
-                        if (j < Mw) meta = items[j].y;
-                        const unsigned cnt = meta >> 8;
-                        const float4 p = qp[meta & 63u];
+                        const unsigned cnt = meta[u] >> 8;
+                        const float4 p = qp[meta[u] & 63u];
                         float d = sqdist_f32(make_float4(c4[u].x, c4[u].y, c4[u].z, 0.f), p.x, p.y, p.z);
-                        const bool mine = (unsigned)l8 < cnt;
-                        d = mine ? d : INFINITY;
+                        d = (unsigned)l8 < cnt ? d : INFINITY;
                         const float m = octet_min(d);
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(mine && d <= m + p.w);
+                        // (a lane past the chunk's end holds +inf: never within m + W of a finite minimum; a null
+                        //  descriptor's flags are not stored)
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(d <= m + p.w);
                         const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
-                        if (l8 == 0 && cnt) items[j] = make_uint2(__float_as_uint(m), flags);
+                        if (l8 == 0 && cnt) items[t + u * 8 + oct] = make_uint2(__float_as_uint(m), flags);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

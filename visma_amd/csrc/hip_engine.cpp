@@ -1732,7 +1732,7 @@ private:
     int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0, bt_out_cap_ = 0;
     int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
-    static constexpr int kGridMaxBlocks = 8192;
+    static constexpr int kGridMaxBlocks = 32768;   // (8 M queries at one per lane: the warm kernel keeps 4 waves per SIMD only there)
     double r2d_ = 0.0;
     const Pt64 *f64_src() const { return d_sorted64_ ? (const Pt64 *)d_src64_ : nullptr; }
     const Pt64 *f64_sorted() const { return d_src64_ ? (const Pt64 *)d_sorted64_ : nullptr; }
