@@ -24,6 +24,24 @@ for a, b in pairs:
         print("copied", b % tag)
     else:
         print("missing", p)
+# The default bench command launches the search kernels at several sizes (C4, the saturated sizes, the C5 batches,
+# the 5k -> 20k end-to-end case): rocprofv3's --stats averages them together, so the per-kernel durations are also
+# tabulated by launch size from the kernel trace (262,144 threads = the C4 launches the roofline object times).
+import collections
+import statistics
+kt = os.path.join(src, "stats_c4", "c4_kernel_trace.csv")
+if os.path.exists(kt):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        n = r["Kernel_Name"]
+        if "nn_coop" in n or "nn_grid_reduce" in n or "nn_brute" in n:
+            acc[(n.split("(")[0][:60], int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    rows = [("kernel", "grid_threads", "launches", "avg_ns", "median_ns", "min_ns", "max_ns")]
+    for (n, g), v in sorted(acc.items(), key=lambda kv: -len(kv[1])):
+        rows.append((n, g, len(v), round(sum(v) / len(v), 1), statistics.median(v), min(v), max(v)))
+    csv.writer(open(os.path.join(dst, "%s_bench_c4_search_kernels_by_launch_size.csv" % tag), "w")).writerows(rows)
+    print("wrote %s_bench_c4_search_kernels_by_launch_size.csv" % tag)
+
 # traffic of the C4 kernels: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md, HBM) + WRITE_SIZE, KiB -> bytes.
 # tools/run_c4_iterations.py runs one cold pass (lane-serial kernel) and five warm-started ones.
 p = os.path.join(src, "pmc_traffic_summary.csv")
