@@ -11,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from visma_amd import build  # noqa: E402
 
-SIDE = os.path.join(ROOT, "visma_amd", "lib", "libvisma_icp_phases.so")
+SIDE = os.path.join(ROOT, "visma_amd", "lib", "libvisma_icp_spans.so" if "--spans" in sys.argv else "libvisma_icp_phases.so")
 if not os.path.exists(SIDE) or "--rebuild" in sys.argv:
-    build.build_lib(force=True, defines=("VISMA_COOP_DEBUG_PHASES",), out=SIDE)
+    build.build_lib(force=True, defines=("VISMA_COOP_DEBUG_PHASES=2" if "--spans" in sys.argv else "VISMA_COOP_DEBUG_PHASES=1",), out=SIDE)
 os.environ["VISMA_ICP_LIB"] = SIDE
 from visma_amd import _lib, synth  # noqa: E402
 
@@ -40,6 +40,26 @@ def main():
     for k in range(9):
         print("  %-22s %9.1f ticks = %6.2f us  %5.1f%%" % (NAMES[k], out[k] / nwg, out[k] / nwg / 100.0, 100.0 * out[k] / max(tot, 1)))
     print("  total %.2f us" % (tot / nwg / 100.0))
+    # when the waves of the LAST launch started and reached the block reduction (100 MHz clock)
+    nw = min((ns + 255) // 256, 2048) * 4
+    sp = (C.c_ulonglong * (2 * nw))()
+    L.visma_debug_coop_spans(sp, 2 * nw)
+    a = np.array(sp[:], dtype=np.int64).reshape(nw, 2)
+    t0 = a[:, 0].min()
+    st, en = (a[:, 0] - t0) / 100.0, (a[:, 1] - t0) / 100.0
+    q = [0, 10, 50, 90, 99, 100]
+    print("  wave start  us, percentiles %s: %s" % (q, np.percentile(st, q).round(2).tolist()))
+    print("  wave done   us, percentiles %s: %s" % (q, np.percentile(en, q).round(2).tolist()))
+    print("  wave length us, percentiles %s: %s" % (q, np.percentile(en - st, q).round(2).tolist()))
+    ln = en - st
+    blk = np.arange(nw) // 4
+    print("  mean / max wave length by XCD (block & 7): " + ", ".join("%d: %.1f/%.1f" % (x, ln[(blk & 7) == x].mean(), ln[(blk & 7) == x].max()) for x in range(8)))
+    seq = blk >> 3
+    nb = max(int(seq.max()) + 1, 1)
+    print("  mean wave length by dispatch order within the XCD (eighths): " + ", ".join("%.1f" % ln[(seq * 8 // nb) == e].mean() for e in range(8)))
+    print("  XCD 6, by sixteenths of its query range: " + ", ".join("%.1f" % ln[((blk & 7) == 6) & ((seq * 16 // nb) == e)].mean() for e in range(16)))
+    late = np.argsort(en)[-8:]
+    print("  last waves: " + ", ".join("w%d %.2f-%.2f" % (w, st[w], en[w]) for w in late))
 
 
 if __name__ == "__main__":

@@ -470,7 +470,18 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
         const double *g2 = f.partials2 + (long long)prob * f.ticket_stride * kReduceAcc;
         double v = 0.0;
         if (sa < NACC)
-            for (int r = sg; r < ngroups; r += NG) v += load_agent_f64(g2 + (long long)r * kReduceAcc + sa);
+            // rows sg, sg + NG, ...: all loads of a thread in flight (a dependent round trip per row cost 2 us at
+            // 1024 workgroups), added in row order
+            for (int r0 = sg; r0 < ngroups; r0 += 8 * NG) {
+                double w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int r = r0 + u * NG;
+                    w[u] = r < ngroups ? load_agent_f64(g2 + (long long)r * kReduceAcc + sa) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += w[u];
+            }
         f_part[sg][sa] = v;
     }
     __syncthreads();
@@ -482,8 +493,12 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
     }
     }
     __syncthreads();
+    // the statistics are expanded into LDS and go out from there (device copy, exchange, host granules): reading
+    // them back from global memory put a store -> load round trip into the tail of every launch
     double *stats = f.stats_out + (long long)prob * f.stats_stride;
-    if (tid == 0) expand_moments<PLANE>(f_tot, stats);
+    __shared__ double f_stats[kNStats + 2];
+    if (tid == 0) expand_moments<PLANE>(f_tot, f_stats);
+    __syncthreads();
     if (f.ipc_n > 1) {
         // source-sharded ranks: this workgroup's first wave exchanges the statistics with the peers
         // (remote stores over xGMI, rank-ordered sum) before anything is published
@@ -494,18 +509,31 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
             f_seq = __hip_atomic_load(f.ipc_seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
             __hip_atomic_store(f.ipc_seq_dev, f_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();                                   // stats[] was written by thread 0
+        __syncthreads();
         if (tid < 64) {
             bool late = false;
-            const double sum = ipc_exchange(tid, tid < kNStats ? stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n,
+            const double sum = ipc_exchange(tid, tid < kNStats ? f_stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n,
                                             f_seq, f.ipc_flag, f.ipc_spins, late);
-            if (tid < kNStats) stats[tid] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
+            if (tid < kNStats) f_stats[tid] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
             if (late) f_flag[0] = 1;
         }
         __syncthreads();
-        if (f_flag[0]) return;                             // a peer was lost: nothing is published
+        if (f_flag[0]) {                                   // a peer was lost: nothing is published
+            if (tid < kNStats) stats[tid] = f_stats[tid];
+            return;
+        }
     }
-    if (f.host_out) publish_tagged_stats(stats, f.host_out, f.seq);
+    if (tid < kNStats) {
+        const double sv = f_stats[tid];
+        stats[tid] = sv;
+        if (f.host_out) {
+            const unsigned long long v = (unsigned long long)__double_as_longlong(sv);
+            u4_t g;
+            g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
+            g.z = (unsigned)f.seq; g.w = (unsigned)(f.seq >> 32);
+            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(f.host_out) + tid);
+        }
+    }
 }
 
 }  // namespace visma

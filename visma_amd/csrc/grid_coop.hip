@@ -80,14 +80,25 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int lane)
 
 #ifdef VISMA_COOP_DEBUG_PHASES   /* measurement build: cycles of wave 0 of every workgroup between the phases */
 __device__ unsigned long long g_coop_phase[16];
+__device__ unsigned long long g_coop_span[4 * 8192];        // per wave of the last launch: first and last clock
+#if VISMA_COOP_DEBUG_PHASES == 2   /* only the per-wave clocks (the phase counters perturb the launch) */
+#define COOP_STAMP(k) do { } while (0)
+#else
 #define COOP_STAMP(k)                                                                              \
     do {                                                                                           \
         const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                              \
         if (threadIdx.x == 0) atomicAdd(&g_coop_phase[k], now_ - stamp_);                          \
         stamp_ = now_;                                                                             \
     } while (0)
+#endif
 #else
 #define COOP_STAMP(k) do { } while (0)
+#endif
+#ifndef VISMA_COOP_STOP_AFTER    /* measurement build: a query's work ends after phase k (tools/truncate_probe.py) */
+#define VISMA_COOP_STOP_AFTER 99
+#endif
+#ifdef VISMA_COOP_STAGGER        /* measurement build: some workgroups start late (tools/stagger_probe.py) */
+__device__ int g_coop_stagger[4];
 #endif
 
 }  // namespace
@@ -143,8 +154,24 @@ __device__ __forceinline__ void coop_body(
         if (!load_loop_state(st, T32_unused, T64, off, r2f)) return;
     }
     const double r2d = (double)r2f;                         // (double)(float)(r*r): KDTreeFlann.cpp:184-185
+#ifdef VISMA_COOP_STAGGER
+    {
+        const int mode = g_coop_stagger[0], n = g_coop_stagger[1];
+        const unsigned s = blockIdx.x >> 3;
+        bool late = false;
+        if (mode == 1) late = s & 1u;
+        else if (mode == 2) late = (s >> 5) & 1u;
+        else if (mode == 3) late = ((s * 2654435761u) >> 16) & 1u;
+        else if (mode == 4) late = (threadIdx.x >> 6) & 1u;
+        else if (mode == 5) late = (s >> 1) & 1u;
+        else if (mode == 6) late = (s >> 6) & 1u;
+        if (late)
+            for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #ifdef VISMA_COOP_DEBUG_PHASES
     unsigned long long stamp_ = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long stamp0_ = stamp_;
 #endif
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
@@ -169,11 +196,11 @@ __device__ __forceinline__ void coop_body(
     __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, overwritten by chunk results (+ 64 null
                                                             // descriptors behind the last one: the list is read unguarded)
     uint2 *items = s_item[wave];
-    const float4 *qp = s_qp + wave * 64;
 
     // one query (or none: the lanes past the end still work on the others' chunks)
     auto query = [&](long long i, bool active) {
         // ---- the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
+        if (VISMA_COOP_STOP_AFTER == -1) return;
         Pt64 s8 = Pt64{0.0, 0.0, 0.0, 0ull};
         float4 qprev = make_float4(NAN, NAN, NAN, 0.f);     // the previous pass's winner (fp32 view), NaN = none
         if (active) {
@@ -188,10 +215,11 @@ __device__ __forceinline__ void coop_body(
         }
         const double pxd = pd[0], pyd = pd[1], pzd = pd[2];
         const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
-#ifdef VISMA_COOP_DEBUG_PHASES
+#if defined(VISMA_COOP_DEBUG_PHASES) && VISMA_COOP_DEBUG_PHASES != 2
         asm volatile("" ::"v"(px), "v"(qprev.x));
 #endif
         COOP_STAMP(0);                                       // source + previous winner arrived
+        if (VISMA_COOP_STOP_AFTER == 0) { if (active) d2_out[i] = px + py + pz + qprev.x + qprev.y + qprev.z; return; }
         const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(py, g.mn[1], g.inv_hs, g.dim[1]);
         const int cz = cell_coord(pz, g.mn[2], g.inv_hs, g.dim[2]);
@@ -207,7 +235,7 @@ __device__ __forceinline__ void coop_body(
             const bool ok = want && span > 0 && zok[k / 3] && yok[k % 3];
             if (cand_count && ok) ncand_all++;               // profiling: cell-table rows looked up
             u4a v = {0u, 0u, 0u, 0u};
-            if (ok) v = *reinterpret_cast<const u4a *>(start + (row_c + (k / 3 - 1) * pitch_z + (k % 3 - 1) * pitch_y));
+            if (ok) v = *reinterpret_cast<const u4a *>(reinterpret_cast<const char *>(start) + (unsigned)(row_c + (k / 3 - 1) * pitch_z + (k % 3 - 1) * pitch_y) * 4u);
             return v;
         };
         // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
@@ -270,10 +298,17 @@ __device__ __forceinline__ void coop_body(
             xe[k] = e;
             if (cand_count) ncand += e - b;
         }
-#ifdef VISMA_COOP_DEBUG_PHASES
+#if defined(VISMA_COOP_DEBUG_PHASES) && VISMA_COOP_DEBUG_PHASES != 2
         asm volatile("" ::"v"(xb[0]), "v"(xe[8]), "v"(xb[4]));
 #endif
         COOP_STAMP(1);                                       // row bounds + previous winner arrived, rows pruned
+        if (VISMA_COOP_STOP_AFTER == 1) {
+            unsigned a = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) a += xb[k] ^ xe[k];
+            if (active) idx_out[i] = (int)a;
+            return;
+        }
         // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
         float gh0 = L, gh1 = L, gh2 = L;
         unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
@@ -302,7 +337,9 @@ __device__ __forceinline__ void coop_body(
                         unsigned b = xb[k];
                         while (b < xe[k]) {
                             const unsigned c = min(xe[k] - b, 8u);
-                            if (j < (unsigned)kCoopCap) items[j] = make_uint2(b, (unsigned)lane | (c << 8));
+                            // (byte offset of the chunk's first candidate -- the launcher keeps 12 * slots below 2^32 --
+                            //  and where the owner's query lies in LDS | candidates << 16)
+                            if (j < (unsigned)kCoopCap) items[j] = make_uint2(b * 12u, ((unsigned)tid << 4) | (c << 16));
                             j++;
                             b += 8u;
                         }
@@ -313,6 +350,7 @@ __device__ __forceinline__ void coop_body(
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 COOP_STAMP(2);                               // chunk list written
+                if (VISMA_COOP_STOP_AFTER == 2) { if (active) idx_out[i] = (int)items[(lane * 7) & 255].x; return; }
                 for (unsigned t = 0; t < Mw; t += 8u * kCoopDepth) {
                     // kCoopDepth chunks per lane octet in flight: every load of the list is independent
                     P12 c4[kCoopDepth];
@@ -321,12 +359,13 @@ __device__ __forceinline__ void coop_body(
                     for (int u = 0; u < kCoopDepth; u++) {
                         const uint2 dsc = items[t + u * 8 + oct];
                         meta[u] = dsc.y;
-                        c4[u] = s12[dsc.x + l8];             // (the array carries kSortedSlack entries of slack)
+                        // scalar base + 32-bit byte offset (the array carries kSortedSlack entries of slack)
+                        c4[u] = *reinterpret_cast<const P12 *>(reinterpret_cast<const char *>(s12) + (dsc.x + (unsigned)l8 * 12u));
                     }
 #pragma unroll
                     for (int u = 0; u < kCoopDepth; u++) {
-                        const unsigned cnt = meta[u] >> 8;
-                        const float4 p = qp[meta[u] & 63u];
+                        const unsigned cnt = meta[u] >> 16;
+                        const float4 p = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_qp) + (meta[u] & 0xFFF0u));
                         float d = sqdist_f32(make_float4(c4[u].x, c4[u].y, c4[u].z, 0.f), p.x, p.y, p.z);
                         d = (unsigned)l8 < cnt ? d : INFINITY;
                         const float m = octet_min(d);
@@ -340,6 +379,7 @@ __device__ __forceinline__ void coop_body(
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 COOP_STAMP(3);                               // chunks worked off
+                if (VISMA_COOP_STOP_AFTER == 3) { if (active) idx_out[i] = (int)items[(lane * 7) & 255].x; return; }
                 {
                     unsigned j = off_q - w0;
 #pragma unroll
@@ -360,6 +400,7 @@ __device__ __forceinline__ void coop_body(
             }
         }
         COOP_STAMP(4);                                       // chunk results merged per query
+        if (VISMA_COOP_STOP_AFTER == 4) { if (active) { idx_out[i] = (int)(gb0 + gb1 + gm0 + gm1); d2_out[i] = gh0 + gh1 + gh2; } return; }
         // ---- the f64 decision: flagged candidates of the kept chunks inside g + W
         double bd = r2d;                                     // best d2 so far (strictly below r2d once set)
         unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
@@ -377,11 +418,12 @@ __device__ __forceinline__ void coop_body(
             bpos = lt ? pos : bpos;
             bq.x = lt ? c8.x : bq.x; bq.y = lt ? c8.y : bq.y; bq.z = lt ? c8.z : bq.z; bq.w = lt ? c8.w : bq.w;
         };
+        bool slow = false;                                   // needs every listed candidate ranked in f64
         if (active && gb0 != 0xFFFFFFFFu) {
             const float thr = gh0 + W;
             unsigned c[4] = {0u, 0u, 0u, 0u};
             int n = 0;
-            bool slow = gh2 <= thr;                          // a third chunk reaches into the band
+            slow = gh2 <= thr;                               // a third chunk reaches into the band
             auto add = [&](unsigned b, unsigned flags) {
                 while (flags) {
                     const unsigned pos = b + (unsigned)__builtin_ctz(flags);
@@ -401,28 +443,107 @@ __device__ __forceinline__ void coop_body(
             if (n > 1) rank(c8b, c[1]);
             if (n > 2) rank(sorted64[c[2]], c[2]);
             if (n > 3) rank(sorted64[c[3]], c[3]);
-            if (slow) {
-                // every candidate of the 27 cells that the fp32 filter cannot exclude, in f64
-                const float sl = fminf(sqrtf(gh0), rup) + 2.0f * E;
-                const float Ls = sl * sl * (1.0f + 6e-7f);
-#pragma unroll 1
-                for (int k = 0; k < 9; k++) {
-                    const int z = cz + (k / 3 - 1), y = cy + (k % 3 - 1);
-                    if (span <= 0 || z < 0 || z >= g.dim[2] || y < 0 || y >= g.dim[1]) continue;
-                    const unsigned *row = start + ((long long)z * g.dim[1] + y) * g.dim[0] + x0;
-                    const unsigned rb = row[0], re = row[span];
-#pragma unroll 1
-                    for (unsigned j = rb; j < re; j++) {
-                        const P12 t = s12[j];
-                        if (sqdist_f32(make_float4(t.x, t.y, t.z, 0.f), px, py, pz) <= Ls) rank(sorted64[j], j);
+        }
+#ifdef VISMA_COOP_NO_SLOW   /* measurement build: the re-scan skipped (rare queries may be wrong) */
+        slow = false;
+#endif
+        // ---- the re-scan, by the WHOLE WAVE for one such query at a time (a few per launch at C4, and the launch
+        // lasts as long as its slowest wave: one lane walking its 27 cells alone -- ~90 dependent loads -- put 6 us
+        // on the tail of every launch).  The query's listed slot ranges (everything that can win or tie lies in
+        // them, see the pruning above) are flattened over the lanes: one fp32 filter load, one f64 load, a
+        // butterfly over (d2, original index), the winner's coordinates handed to the owner lane.
+        for (unsigned long long rem = __builtin_amdgcn_ballot_w64(slow); rem; rem &= rem - 1ull) {
+            const int q = (int)__builtin_ctzll(rem);         // wave-uniform
+            auto bcast_u = [&](unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, q); };
+            auto bcast_f = [&](float v) { return __uint_as_float(bcast_u(__float_as_uint(v))); };
+            auto bcast_d = [&](double v) {
+                const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+                return __longlong_as_double((long long)(((unsigned long long)bcast_u((unsigned)(u >> 32)) << 32) | bcast_u((unsigned)u)));
+            };
+            const float qx = bcast_f(px), qy = bcast_f(py), qz = bcast_f(pz);
+            const double qxd = bcast_d(pxd), qyd = bcast_d(pyd), qzd = bcast_d(pzd);
+            const float qrup = rup, qE = bcast_f(E);
+            const float sl = fminf(sqrtf(bcast_f(gh0)), qrup) + 2.0f * qE;
+            const float Ls = sl * sl * (1.0f + 6e-7f);       // fp32 distances beyond it cannot win or tie in f64
+            unsigned qb[9], pre[10];
+            pre[0] = 0u;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                qb[k] = bcast_u(xb[k]);
+                pre[k + 1] = pre[k] + (bcast_u(xe[k]) - qb[k]);
+            }
+            double ld = r2d;
+            unsigned lid = 0xFFFFFFFFu, lpos = 0xFFFFFFFFu;
+            Pt64 lq = Pt64{0.0, 0.0, 0.0, 0ull};
+            for (unsigned f0 = 0; f0 < pre[9]; f0 += 128u) {  // (one trip unless the rows are very dense)
+                unsigned j[2];
+                bool in[2];
+                P12 t[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const unsigned f = f0 + (unsigned)u * 64u + (unsigned)lane;
+                    in[u] = f < pre[9];
+                    unsigned jj = 0u;
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        if (f >= pre[k] && f < pre[k + 1]) jj = qb[k] + (f - pre[k]);
+                    j[u] = jj;
+                    t[u] = P12{0.f, 0.f, 0.f};
+                    if (in[u]) t[u] = s12[jj];
+                }
+                Pt64 c8[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    in[u] = in[u] && sqdist_f32(make_float4(t[u].x, t[u].y, t[u].z, 0.f), qx, qy, qz) <= Ls;
+                    c8[u] = Pt64{0.0, 0.0, 0.0, 0ull};
+                    if (in[u]) c8[u] = sorted64[j[u]];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++)
+                    if (in[u]) {
+                        // flann L2 (dist.h:159-176), as rank() above
+                        const double dx = c8[u].x - qxd, dy = c8[u].y - qyd, dz = c8[u].z - qzd;
+                        double d = dx * dx;
+                        d += dy * dy;
+                        d += dz * dz;
+                        const unsigned id = (unsigned)c8[u].w;
+                        const bool lt = d < ld || (d == ld && id < lid && lid != 0xFFFFFFFFu);
+                        if (lt) { ld = d; lid = id; lpos = j[u]; lq = c8[u]; }
                     }
+            }
+            // minimum over the lanes by (d2, original index); lanes without a candidate hold (r2d, none)
+            double rd = ld;
+            unsigned rid = lid;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double od = __shfl_xor(rd, o, 64);
+                const unsigned oid = (unsigned)__shfl_xor((int)rid, o, 64);
+                const bool lt = oid != 0xFFFFFFFFu && (od < rd || (od == rd && oid < rid));
+                rd = lt ? od : rd;
+                rid = lt ? oid : rid;
+            }
+            if (rid != 0xFFFFFFFFu) {                        // (wave-uniform)
+                const unsigned long long holders = __builtin_amdgcn_ballot_w64(lid == rid && ld == rd);
+                const int wl = (int)__builtin_ctzll(holders);
+                auto from_w = [&](unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, wl); };
+                auto from_w64 = [&](unsigned long long u) { return ((unsigned long long)from_w((unsigned)(u >> 32)) << 32) | from_w((unsigned)u); };
+                Pt64 w8;
+                w8.x = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.x)));
+                w8.y = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.y)));
+                w8.z = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.z)));
+                w8.w = from_w64(lq.w);
+                const unsigned wpos = from_w(lpos);
+                if (lane == q) {
+                    const bool lt = rd < bd || (rd == bd && rid < bidx && bidx != 0xFFFFFFFFu);
+                    if (lt) { bd = rd; bidx = rid; bpos = wpos; bq = w8; }
                 }
             }
         }
-#ifdef VISMA_COOP_DEBUG_PHASES
+#if defined(VISMA_COOP_DEBUG_PHASES) && VISMA_COOP_DEBUG_PHASES != 2
         asm volatile("" ::"v"(bd));
 #endif
         COOP_STAMP(5);                                       // f64 winner arrived and ranked
+        if (VISMA_COOP_STOP_AFTER == 5) { if (active) { idx_out[i] = (int)bidx; d2_out[i] = (float)(bd + bq.x); } return; }
         if (active) {
             idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
             d2_out[i] = (float)bd;
@@ -445,6 +566,13 @@ __device__ __forceinline__ void coop_body(
         for (int it = 0; it < per_group; it++) query(i_begin + it, i_begin + it < i_end);   // wave-uniform trip count
     }
     COOP_STAMP(6);                                           // outputs + moments
+#ifdef VISMA_COOP_DEBUG_PHASES
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
+        const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);
+        g_coop_span[2 * w_] = stamp0_;
+        g_coop_span[2 * w_ + 1] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
     COOP_STAMP(7);                                           // workgroup's partial row stored
     if (cand_count) {
@@ -493,6 +621,10 @@ __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 #undef VISMA_COOP_ARGS
 
 #ifdef VISMA_COOP_DEBUG_PHASES
+extern "C" __attribute__((visibility("default"))) int visma_debug_coop_spans(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_span), sizeof(unsigned long long) * n) != hipSuccess;
+}
 extern "C" __attribute__((visibility("default"))) int visma_debug_coop_phases(unsigned long long *out16, int reset)
 {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coop_phase), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
@@ -501,6 +633,14 @@ extern "C" __attribute__((visibility("default"))) int visma_debug_coop_phases(un
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_phase), z, sizeof(z)) != hipSuccess) return 1;
     }
     return 0;
+}
+#endif
+
+#ifdef VISMA_COOP_STAGGER
+extern "C" __attribute__((visibility("default"))) int visma_debug_coop_stagger(int mode, int n)
+{
+    const int v[4] = {mode, n, 0, 0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stagger), v, sizeof(v)) != hipSuccess;
 }
 #endif
 

@@ -1137,7 +1137,8 @@ public:
         const int chunk = lp.check_stop ? 8 : lp.passes;
         int done = 0;
         // the first pass prunes progressively (lane-serial kernel), the later ones start from its winners
-        const bool coop = coop_enabled_ && packed && std::getenv("VISMA_ICP_BATCH_LANES") == nullptr;
+        const bool coop = coop_enabled_ && packed && std::getenv("VISMA_ICP_BATCH_LANES") == nullptr &&
+                          (tgt_tot + kSortedSlack) * 12 < (1ll << 32);
         bool fresh = false;
         while (done < lp.passes) {
             const int n = std::min(chunk, lp.passes - done);
@@ -1767,7 +1768,9 @@ private:
     }
     bool coop_ok() const
     {
-        return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1;
+        // (the kernel addresses the candidate array with 32-bit byte offsets: 12 bytes per slot)
+        return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1 &&
+               (nt_ + kSortedSlack) * 12 < (1ll << 32);
     }
     // which kernel a lanes code selects (see launch_nn_grid_reduce)
     int pass_kernel(int lanes) const { return (lanes == kCoopLanes && coop_ok()) ? 2 : 1; }
