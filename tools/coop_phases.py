@@ -58,6 +58,18 @@ def main():
     nb = max(int(seq.max()) + 1, 1)
     print("  mean wave length by dispatch order within the XCD (eighths): " + ", ".join("%.1f" % ln[(seq * 8 // nb) == e].mean() for e in range(8)))
     print("  XCD 6, by sixteenths of its query range: " + ", ".join("%.1f" % ln[((blk & 7) == 6) & ((seq * 16 // nb) == e)].mean() for e in range(16)))
+    if "--spans" in sys.argv:
+        mk = (C.c_ulonglong * (16 * nw))()
+        L.visma_debug_coop_marks(mk, 16 * nw)
+        m = np.array(mk[:], dtype=np.int64).reshape(nw, 16)[:, :7]
+        prev = a[:, 0]
+        first, last = (seq * 8 // nb) < 2, (seq * 8 // nb) >= 6
+        print("  phase durations per wave, us: median all | first-dispatched quarter | last-dispatched quarter | max")
+        for k in range(7):
+            d = (m[:, k] - prev) / 100.0
+            ok = m[:, k] > 0
+            print("    %-22s %6.2f | %6.2f | %6.2f | %6.2f" % (NAMES[k], np.median(d[ok]), np.median(d[ok & first]), np.median(d[ok & last]), d[ok].max()))
+            prev = np.where(ok, m[:, k], prev)
     late = np.argsort(en)[-8:]
     print("  last waves: " + ", ".join("w%d %.2f-%.2f" % (w, st[w], en[w]) for w in late))
 

@@ -46,7 +46,7 @@ namespace {
 struct P12 { float x, y, z; };                // fp32 rounding of a cell-sorted f64 target point
 constexpr int kCoopCap = 512;                 // chunk descriptors per wave and list window (4 KiB)
 #ifndef VISMA_COOP_DEPTH
-#define VISMA_COOP_DEPTH 8
+#define VISMA_COOP_DEPTH 7
 #endif
 constexpr int kCoopDepth = VISMA_COOP_DEPTH;  // chunks per lane octet in flight
 
@@ -81,8 +81,13 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int lane)
 #ifdef VISMA_COOP_DEBUG_PHASES   /* measurement build: cycles of wave 0 of every workgroup between the phases */
 __device__ unsigned long long g_coop_phase[16];
 __device__ unsigned long long g_coop_span[4 * 8192];        // per wave of the last launch: first and last clock
-#if VISMA_COOP_DEBUG_PHASES == 2   /* only the per-wave clocks (the phase counters perturb the launch) */
-#define COOP_STAMP(k) do { } while (0)
+#if VISMA_COOP_DEBUG_PHASES == 2   /* per-wave clocks at the phase borders, one store each (the shared counters perturb the launch) */
+__device__ unsigned long long g_coop_marks[16 * 8192];
+#define COOP_STAMP(k)                                                                              \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                          \
+            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 #else
 #define COOP_STAMP(k)                                                                              \
     do {                                                                                           \
@@ -193,7 +198,7 @@ __device__ __forceinline__ void coop_body(
     const long long i_end = i_begin + per_group < ns ? i_begin + per_group : ns;
 
     __shared__ float4 s_qp[kBlock];                         // (px, py, pz, W) of the query of each lane
-    __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, overwritten by chunk results (+ 64 null
+    __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, completed by chunk results (+ 64 null
                                                             // descriptors behind the last one: the list is read unguarded)
     uint2 *items = s_item[wave];
 
@@ -321,7 +326,9 @@ __device__ __forceinline__ void coop_body(
             gb1 = c1 ? gb0 : gb1; gm1 = c1 ? gm0 : gm1;
             gb0 = c1 ? b : gb0; gm0 = c1 ? flags : gm0;
         };
-        // ---- the rows, chunked and flattened over the wave
+        // ---- the rows, chunked and flattened over the wave.  A query's chunks take CONSECUTIVE list entries: the
+        // owner reads its results back as one short run (walking the rows again, one LDS round trip per chunk, took
+        // 2.5 us of every wave's 17).
         {
             unsigned nq = 0;
 #pragma unroll
@@ -329,17 +336,17 @@ __device__ __forceinline__ void coop_body(
             const unsigned incl = wave_scan_incl(nq, lane);
             const unsigned M = (unsigned)__shfl((int)incl, 63, 64);
             const unsigned off_q = incl - nq;
-            for (unsigned w0 = 0; w0 < M; w0 += kCoopCap) {             // (one window unless the cloud is very dense)
+            auto window = [&](const unsigned w0) {
                 {
-                    unsigned j = off_q - w0;
+                    // descriptor: (the chunk's first slot, owner's query in LDS | candidates << 16); a query's chunks
+                    // take CONSECUTIVE list entries, row after row
+                    const unsigned own = (unsigned)tid << 4; // where this lane's query lies in s_qp
+                    unsigned j = off_q - w0;                 // (a run that begins before the window wraps: never < cap)
 #pragma unroll
                     for (int k = 0; k < 9; k++) {
                         unsigned b = xb[k];
                         while (b < xe[k]) {
-                            const unsigned c = min(xe[k] - b, 8u);
-                            // (byte offset of the chunk's first candidate -- the launcher keeps 12 * slots below 2^32 --
-                            //  and where the owner's query lies in LDS | candidates << 16)
-                            if (j < (unsigned)kCoopCap) items[j] = make_uint2(b * 12u, ((unsigned)tid << 4) | (c << 16));
+                            if (j < (unsigned)kCoopCap) items[j] = make_uint2(b, own | (min(xe[k] - b, 8u) << 16));
                             j++;
                             b += 8u;
                         }
@@ -350,7 +357,6 @@ __device__ __forceinline__ void coop_body(
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 COOP_STAMP(2);                               // chunk list written
-                if (VISMA_COOP_STOP_AFTER == 2) { if (active) idx_out[i] = (int)items[(lane * 7) & 255].x; return; }
                 for (unsigned t = 0; t < Mw; t += 8u * kCoopDepth) {
                     // kCoopDepth chunks per lane octet in flight: every load of the list is independent
                     P12 c4[kCoopDepth];
@@ -359,8 +365,9 @@ __device__ __forceinline__ void coop_body(
                     for (int u = 0; u < kCoopDepth; u++) {
                         const uint2 dsc = items[t + u * 8 + oct];
                         meta[u] = dsc.y;
-                        // scalar base + 32-bit byte offset (the array carries kSortedSlack entries of slack)
-                        c4[u] = *reinterpret_cast<const P12 *>(reinterpret_cast<const char *>(s12) + (dsc.x + (unsigned)l8 * 12u));
+                        // scalar base + 32-bit byte offset (the launcher keeps 12 * slots below 2^32; the array carries
+                        // kSortedSlack entries of slack)
+                        c4[u] = *reinterpret_cast<const P12 *>(reinterpret_cast<const char *>(s12) + (((dsc.x * 3u) << 2) + (unsigned)l8 * 12u));
                     }
 #pragma unroll
                     for (int u = 0; u < kCoopDepth; u++) {
@@ -370,34 +377,36 @@ __device__ __forceinline__ void coop_body(
                         d = (unsigned)l8 < cnt ? d : INFINITY;
                         const float m = octet_min(d);
                         // (a lane past the chunk's end holds +inf: never within m + W of a finite minimum; a null
-                        //  descriptor's flags are not stored)
+                        //  descriptor's result is not stored)
                         const unsigned long long bal = __builtin_amdgcn_ballot_w64(d <= m + p.w);
                         const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
-                        if (l8 == 0 && cnt) items[t + u * 8 + oct] = make_uint2(__float_as_uint(m), flags);
+                        // the result takes the place of the descriptor's second word: the chunk minimum rounded DOWN to
+                        // 16 mantissa bits | the flag byte (the first word, the chunk's position, stays)
+                        if (l8 == 0 && cnt) items[t + u * 8 + oct].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 COOP_STAMP(3);                               // chunks worked off
-                if (VISMA_COOP_STOP_AFTER == 3) { if (active) idx_out[i] = (int)items[(lane * 7) & 255].x; return; }
-                {
-                    unsigned j = off_q - w0;
+                // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
+                for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
+                    uint2 r[4];
+                    bool in[4];
 #pragma unroll
-                    for (int k = 0; k < 9; k++) {
-                        unsigned b = xb[k];
-                        while (b < xe[k]) {
-                            if (j < (unsigned)kCoopCap) {
-                                const uint2 r = items[j];
-                                chunk_insert(__uint_as_float(r.x), b, r.y);
-                            }
-                            j++;
-                            b += 8u;
-                        }
+                    for (int u = 0; u < 4; u++) {
+                        const unsigned j = off_q - w0 + c0 + (unsigned)u;
+                        in[u] = c0 + (unsigned)u < nq && j < (unsigned)kCoopCap;
+                        r[u] = items[in[u] ? j : 0u];
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        chunk_insert(in[u] ? __uint_as_float(r[u].y & 0xFFFFFF00u) : INFINITY, r[u].x, r[u].y & 0xFFu);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-            }
+            };
+            // (one window unless the cloud is very dense)
+            for (unsigned w0 = 0; w0 < M; w0 += kCoopCap) window(w0);
         }
         COOP_STAMP(4);                                       // chunk results merged per query
         if (VISMA_COOP_STOP_AFTER == 4) { if (active) { idx_out[i] = (int)(gb0 + gb1 + gm0 + gm1); d2_out[i] = gh0 + gh1 + gh2; } return; }
@@ -419,8 +428,11 @@ __device__ __forceinline__ void coop_body(
             bq.x = lt ? c8.x : bq.x; bq.y = lt ? c8.y : bq.y; bq.z = lt ? c8.z : bq.z; bq.w = lt ? c8.w : bq.w;
         };
         bool slow = false;                                   // needs every listed candidate ranked in f64
+        // (the kept chunk minima were rounded down by < 2^-15 relative: g_up bounds the fp32 minimum from above, and
+        //  the tests below stay on the safe side -- a chunk or candidate more is ranked in f64, never one less)
+        const float g_up = gh0 * (1.0f + 6.2e-5f);
         if (active && gb0 != 0xFFFFFFFFu) {
-            const float thr = gh0 + W;
+            const float thr = g_up + W;
             unsigned c[4] = {0u, 0u, 0u, 0u};
             int n = 0;
             slow = gh2 <= thr;                               // a third chunk reaches into the band
@@ -463,7 +475,7 @@ __device__ __forceinline__ void coop_body(
             const float qx = bcast_f(px), qy = bcast_f(py), qz = bcast_f(pz);
             const double qxd = bcast_d(pxd), qyd = bcast_d(pyd), qzd = bcast_d(pzd);
             const float qrup = rup, qE = bcast_f(E);
-            const float sl = fminf(sqrtf(bcast_f(gh0)), qrup) + 2.0f * qE;
+            const float sl = fminf(sqrtf(bcast_f(g_up)), qrup) + 2.0f * qE;
             const float Ls = sl * sl * (1.0f + 6e-7f);       // fp32 distances beyond it cannot win or tie in f64
             unsigned qb[9], pre[10];
             pre[0] = 0u;
@@ -621,6 +633,12 @@ __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 #undef VISMA_COOP_ARGS
 
 #ifdef VISMA_COOP_DEBUG_PHASES
+#if VISMA_COOP_DEBUG_PHASES == 2
+extern "C" __attribute__((visibility("default"))) int visma_debug_coop_marks(unsigned long long *out, int n)
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_marks), sizeof(unsigned long long) * n) != hipSuccess;
+}
+#endif
 extern "C" __attribute__((visibility("default"))) int visma_debug_coop_spans(unsigned long long *out, int n)
 {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_span), sizeof(unsigned long long) * n) != hipSuccess;
