@@ -1029,7 +1029,7 @@ public:
             free_dev(bt_tgt_); free_dev(bt_sorted_); free_dev(bt_cell_of_);
             HIP_TRY(hipMalloc(&bt_tgt_, sizeof(float4) * std::max<int64_t>(tgt_tot, 1)));
             HIP_TRY(hipMalloc(&bt_sorted_, sizeof(float4) * (std::max<int64_t>(tgt_tot, 1) + kSortedSlack)));
-            HIP_TRY(hipMalloc(&bt_cell_of_, sizeof(unsigned) * std::max<int64_t>(tgt_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_cell_of_, 2 * sizeof(unsigned) * std::max<int64_t>(tgt_tot, 1)));   // (cell, rank)
             bt_tgt_cap_ = tgt_tot;
         }
         if (cell_tot > bt_cell_cap_) {
@@ -1087,7 +1087,7 @@ public:
                 else HIP_TRY(hipMemcpyAsync((float4 *)bt_nrm_ + d.sorted_off, q.nrm_xyzw, sizeof(float4) * q.nt, hipMemcpyHostToDevice, stream_));
             }
             HIP_TRY(launch_grid_build((const float4 *)bt_tgt_ + d.sorted_off, q.nt, d.g,
-                                      (unsigned *)bt_cell_of_ + d.sorted_off, (unsigned *)bt_count_ + d.start_off,
+                                      (unsigned *)bt_cell_of_ + 2 * d.sorted_off, (unsigned *)bt_count_ + d.start_off,
                                       (unsigned *)bt_bsum_, (unsigned *)bt_start_ + d.start_off,
                                       (float4 *)bt_sorted_ + d.sorted_off, stream_,
                                       f64 ? (const Pt64 *)bt_tgt64_ + d.sorted_off : nullptr,
@@ -1594,7 +1594,7 @@ private:
         if ((int64_t)nt_ > sorted_cap_) {
             free_dev(d_sorted_); free_dev(d_cell_of_);
             HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * (nt_ + kSortedSlack)));   // batches read past a run's end
-            HIP_TRY(hipMalloc(&d_cell_of_, sizeof(unsigned) * nt_));
+            HIP_TRY(hipMalloc(&d_cell_of_, 2 * sizeof(unsigned) * nt_));   // (cell, rank in the cell)
             sorted_cap_ = nt_;
         }
         if (grid_.ncell + 1 > cell_cap_) {

@@ -282,6 +282,10 @@ hipError_t voxel_down_sample_core(const double *d_xyz, const double *d_nrm, cons
 hipError_t centroid_device(const double *d_xyz, int64_t n, int64_t chunk, double *d_part, double *d_out, hipStream_t stream);
 // counting sort of the target by cell: start[ncell+1], sorted[nt] = (x,y,z, bits(orig index))
 // tgt64 / sorted64 (both or neither): the f64 copy of the target is scattered in the same order
+size_t exclusive_scan_u32_tmp_bytes(long long n);
+hipError_t launch_exclusive_scan_u32_lib(const unsigned *in, long long n, unsigned *out, void *tmp, size_t tmp_bytes,
+                                         hipStream_t stream);
+// (cell_of: 2 * nt words; bsum: grid_scan_blocks(g.ncell) + 1 words)
 hipError_t launch_grid_build(const float4 *tgt, int64_t nt, const GridParams &g,
                              unsigned *cell_of, unsigned *count, unsigned *bsum,
                              unsigned *start, float4 *sorted, hipStream_t stream,

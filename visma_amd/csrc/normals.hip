@@ -357,7 +357,7 @@ hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double 
     NRM_TRY(B.alloc(&d_p8, (size_t)n));
     NRM_TRY(B.alloc(&d_sorted64, (size_t)n));
     NRM_TRY(B.alloc(&d_box, 8));
-    NRM_TRY(B.alloc(&d_cell_of, (size_t)n));
+    NRM_TRY(B.alloc(&d_cell_of, 2 * (size_t)n));   // (cell, rank in the cell)
     NRM_TRY(B.alloc(&d_n27, 2));
     if (h_nrm_in) {
         NRM_TRY(B.alloc(&d_nin, 3 * (size_t)n));

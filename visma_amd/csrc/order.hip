@@ -117,6 +117,23 @@ hipError_t order_source_device(const double *d_xyz, int64_t n, const double c[3]
     return hipGetLastError();
 }
 
+// ---- exclusive prefix sum of n u32 values in ONE pass over the data (hipCUB, decoupled look-back) -------------
+size_t exclusive_scan_u32_tmp_bytes(long long n)
+{
+    size_t tmp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const unsigned *)nullptr, (unsigned *)nullptr,
+                                          (int)std::min<long long>(std::max<long long>(n, 1), 0x7fffffff), (hipStream_t) nullptr);
+    return tmp;
+}
+
+hipError_t launch_exclusive_scan_u32_lib(const unsigned *in, long long n, unsigned *out, void *tmp, size_t tmp_bytes,
+                                         hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    if (n > 0x7fffffff) return hipErrorInvalidValue;
+    return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, (int)n, stream);
+}
+
 // ---- the clouds as uploaded -> the fp32 / f64 copies the searches read ----------------------------------
 __global__ void promote_pt64_kernel(const float4 *__restrict__ src, Pt64 *__restrict__ dst, long long n)
 {
