@@ -733,6 +733,7 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
     if (ctx->use_device_loop_batched() && n > 1 && batch_ok) {
         // every problem in flight together: concatenated clouds, one grid per problem,
         // one NN launch + one fold/solve launch per pass for the whole batch
+        StageTrace tr("batch/driver");
         std::vector<std::vector<float>> sbuf((size_t)n), tbuf((size_t)n);
         std::vector<Engine::BatchProblem> pb((size_t)n);
         bool ok = true;
@@ -761,6 +762,7 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
                     sshare[i] = j;
             }
         }
+        tr.mark("sharing found");
         std::vector<std::array<double, 3>> cen((size_t)n);
         std::vector<std::array<float, 6>> tbox((size_t)n);
         // double-precision search for the whole batch when every problem qualifies
@@ -797,6 +799,7 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
                     }
                 for (int a = 0; a < 3; a++) { tbox[i][a] = (float)(lo[a] - c[a]); tbox[i][3 + a] = (float)(hi[a] - c[a]); }
             });
+        tr.mark("targets: centroid, box");
         if (ok)
             parallel_for(n, 1, [&](int64_t i) {
                 const visma_icp_problem &q = probs[i];
@@ -833,6 +836,7 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
                 if (q.nt > 0)
                     for (int a = 0; a < 3; a++) { b.bb_min[a] = tbox[t][a]; b.bb_max[a] = tbox[t][3 + a]; }
             });
+        tr.mark("sources: pack, order");
         if (ok) {
             Engine::LoopParams lp;
             lp.Tc0 = Mat4::identity();
@@ -844,6 +848,7 @@ static int run_batch_impl(visma_icp_ctx *ctx, const visma_icp_problem *probs, co
             lp.check_stop = true; lp.ns_total = 0;
             std::vector<Engine::LoopResult> rs((size_t)n);
             int rc = ctx->eng->run_loop_batch(lp, pb, rs.data());
+            tr.mark("engine batch loop");
             if (rc == VISMA_ICP_OK) {
                 for (int i = 0; i < n; i++) {
                     std::memset(&out[i], 0, sizeof(out[i]));

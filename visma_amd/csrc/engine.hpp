@@ -198,6 +198,26 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
 constexpr int64_t kHostChunk = 16384;   // points per work item of the host passes below
 
 
+// VISMA_ICP_BATCH_TRACE=1: wall-clock marks of the batch path's host stages on stderr (measurement aid)
+struct StageTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    const char *who;
+    explicit StageTrace(const char *w) : on(std::getenv("VISMA_ICP_BATCH_TRACE") != nullptr), who(w)
+    {
+        if (on) t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[%s] %-28s +%8.1f us  (%8.1f)\n", who, what,
+                     std::chrono::duration<double, std::micro>(now - last).count(),
+                     std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
+
 class Engine {
 public:
     virtual ~Engine() {}

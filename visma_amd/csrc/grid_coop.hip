@@ -124,12 +124,17 @@ __device__ __forceinline__ void coop_body(
     long long row0;
     if (descs) {
         // batch of problems with their own clouds (largest p with first_block <= blockIdx.x; wave-uniform)
-        int lo = 0, hi = nprob - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (warm & 2) {
+            // (the launcher put a workgroup -> problem map behind the descriptors)
+            prob = reinterpret_cast<const int *>(descs + nprob)[blockIdx.x];
+        } else {
+            int lo = 0, hi = nprob - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (descs[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+            }
+            prob = lo;
         }
-        prob = lo;
         const ProbDesc d = descs[prob];
         lb = (int)blockIdx.x - d.first_block;
         bpp = d.nblocks;
@@ -210,7 +215,7 @@ __device__ __forceinline__ void coop_body(
         float4 qprev = make_float4(NAN, NAN, NAN, 0.f);     // the previous pass's winner (fp32 view), NaN = none
         if (active) {
             s8 = src64[i];
-            if (warm) qprev = prevq_io[i];
+            if (warm & 1) qprev = prevq_io[i];
         }
         // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
         double pd[3];
@@ -669,7 +674,8 @@ extern "C" __attribute__((visibility("default"))) int visma_debug_coop_stagger(i
 
 // The warm-started, flattened exact search.  Shared clouds: `nprob` problems of `bpp` workgroups each
 // (descs == NULL); own clouds: descs[nprob], total_blocks workgroups.  `one`: at most one query per lane.
-// prevq_io (one float4 per query, laid out like idx_out): read when `warm` (the winners of the previous pass
+// warm & 2: a workgroup -> problem map (int per workgroup) follows descs[nprob].
+// prevq_io (one float4 per query, laid out like idx_out): read when `warm & 1` (the winners of the previous pass
 // over the SAME source order and target, as fp32 points of the candidate array; NaN = none), always written.
 hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *descs, int ns, const float *s12,
                           const unsigned *start, const GridParams &g, const float4 *nrm, const Pt64 *nrm64,

@@ -904,6 +904,7 @@ public:
         const int B = (int)pb.size();
         if (B < 1) return VISMA_ICP_OK;
         if (comm_) { err_ = "batched loop is single-GPU"; return VISMA_ICP_ERR_STATE; }
+        StageTrace tr("batch/engine");
         // ---- layout of the concatenated arrays
         std::vector<ProbDesc> descs((size_t)B);
         int64_t src_tot = 0, tgt_tot = 0, cell_tot = 0, max_ncell = 0, out_tot = 0;
@@ -1014,6 +1015,7 @@ public:
             HIP_TRY(hipMalloc(&bt_pos_, sizeof(float4) * std::max<int64_t>(out_tot, 1)));
             bt_out_cap_ = out_tot;
         }
+        tr.mark("layout, buffers");
         // (new problems: no previous winners)
         HIP_TRY(hipMemsetAsync(bt_pos_, 0xFF, sizeof(float4) * (size_t)std::max<int64_t>(out_tot, 1), stream_));
         {
@@ -1044,10 +1046,13 @@ public:
             bt_bsum_cap_ = grid_scan_blocks(max_ncell) + 1;
             HIP_TRY(hipMalloc(&bt_bsum_, sizeof(unsigned) * bt_bsum_cap_));
         }
-        if (B > bt_desc_cap_) {
+        // descriptors, followed by the workgroup -> problem map (one word per workgroup: the warm kernel reads its
+        // problem with one load instead of a binary search over the descriptors -- ~9 dependent scalar loads per wave)
+        const size_t desc_bytes = sizeof(ProbDesc) * (size_t)B + sizeof(int) * (size_t)std::max(total_blocks, 1);
+        if (desc_bytes > bt_desc_cap_) {
             free_dev(bt_descs_);
-            HIP_TRY(hipMalloc(&bt_descs_, sizeof(ProbDesc) * B));
-            bt_desc_cap_ = B;
+            HIP_TRY(hipMalloc(&bt_descs_, desc_bytes));
+            bt_desc_cap_ = desc_bytes;
         }
         if ((size_t)total_blocks > partial_rows_) {
             free_dev(d_partials_);
@@ -1102,7 +1107,14 @@ public:
             }
             HIP_TRY(launch_pack12((const float4 *)bt_sorted_, (float *)bt_sorted12_, tgt_tot, stream_));
         }
-        HIP_TRY(hipMemcpyAsync(bt_descs_, descs.data(), sizeof(ProbDesc) * B, hipMemcpyHostToDevice, stream_));
+        bt_desc_host_.resize(desc_bytes);
+        std::memcpy(bt_desc_host_.data(), descs.data(), sizeof(ProbDesc) * (size_t)B);
+        {
+            int *map = reinterpret_cast<int *>(bt_desc_host_.data() + sizeof(ProbDesc) * (size_t)B);
+            for (int b = 0; b < B; b++)
+                for (int k = 0; k < descs[b].nblocks; k++) map[descs[b].first_block + k] = b;
+        }
+        HIP_TRY(hipMemcpyAsync(bt_descs_, bt_desc_host_.data(), desc_bytes, hipMemcpyHostToDevice, stream_));
         for (int b = 0; b < B; b++) {
             DevIcpState &h = h_state_[b];
             std::memset(&h, 0, sizeof(h));
@@ -1117,7 +1129,9 @@ public:
         }
         HIP_TRY(hipMemcpyAsync(d_state_, h_state_, sizeof(DevIcpState) * B, hipMemcpyHostToDevice, stream_));
         // the staging memory of the caller must stay valid until the copies are done
+        tr.mark("uploads, grids enqueued");
         HIP_TRY(hipStreamSynchronize(stream_));
+        tr.mark("... and finished");
         if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
         // ---- the loop: one NN launch (search + fold) + one solve launch per pass for ALL problems
         DevIcpState *st = (DevIcpState *)d_state_;
@@ -1154,7 +1168,7 @@ public:
                                                     profiling_ ? (unsigned long long *)d_cand_ : nullptr,
                                                     (lp.plane && !f64) ? (const float4 *)bt_nrm_ : nullptr,
                                                     (lp.plane && f64) ? (const Pt64 *)bt_nrm64_ : nullptr,
-                                                    (float4 *)bt_pos_, 1));
+                                                    (float4 *)bt_pos_, 1 | 2));   // warm | workgroup map behind the descriptors
                 last_kernel_ = (coop && fresh) ? 2 : 1;
                 fresh = true;
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
@@ -1172,6 +1186,7 @@ public:
             for (int b = 0; b < B; b++) any = any || h_state_[b].active;
             if (!any) break;
         }
+        tr.mark("passes");
         for (int b = 0; b < B; b++) {
             const DevIcpState &h = h_state_[b];
             out[b].Tc = Mat4::identity();
@@ -1731,7 +1746,9 @@ private:
     int64_t bt_nrm_cap_ = 0, bt_nrm64_cap_ = 0;
     void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
     int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0, bt_out_cap_ = 0;
-    int bt_bsum_cap_ = 0, bt_desc_cap_ = 0;
+    int bt_bsum_cap_ = 0;
+    size_t bt_desc_cap_ = 0;
+    std::vector<char> bt_desc_host_;                       // (kept: the copy is asynchronous)
     int64_t view_offset_ = 0, loop_out_stride_ = 0;
     static constexpr int kGridMaxBlocks = 32768;   // (8 M queries at one per lane: the warm kernel keeps 4 waves per SIMD only there)
     double r2d_ = 0.0;
