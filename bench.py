@@ -642,10 +642,11 @@ def run_c4(R, args):
             out["weak_scaling"] = weak
         if not args.no_extras:
             sw = {"c4_grid_strong": {"icp_iterations_per_sec": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
-                                     "expectation": "one launch of ~45 us whose duration is a chain of lock-step phases, not "
-                                                    "work: halving the queries per rank does not halve it (DESIGN.md 5: "
-                                                    "1.25x / 1.36x / 1.57x at 2 / 4 / 8 GPUs measured at the per-rank sizes, "
-                                                    "before the exchange costs anything)"}}
+                                     "expectation": "one iteration of ~37 us of which ~14 us are launch, block reduction, "
+                                                    "fold and host turn-around that no shard shortens: halving the queries "
+                                                    "per rank does not halve it (DESIGN.md 5: 1.19x / 1.37x / 1.50x at "
+                                                    "2 / 4 / 8 GPUs measured at the per-rank sizes, before the exchange "
+                                                    "costs anything)"}}
             if brute is not None:
                 sw["c4_brute_strong"] = {"icp_iterations_per_sec": 1e3 / brute["ms_per_step"], "ms_per_step": brute["ms_per_step"],
                                          "expectation": "north_star's kernel: NS/N x NT pair evaluations per rank and "
