@@ -152,5 +152,77 @@ GenericErrorMetric<T> MeasureSurfaceError(const Eigen::Matrix<T, Eigen::Dynamic,
     return MeasureSurfaceError<T>(Vs, Fs, Vt, Ft, (int)options["num_samples"].asInt());
 }
 
+// feh::ICPRefinement (src/evaluation.cpp:248-271) with BOTH clouds made on the device: every model's mesh is
+// sampled (SamplePointCloudFromMesh, samples_per_model draws), moved by its model_to_scene (PointCloud::Transform)
+// and appended to the estimated scene there; the scan is voxel-down-sampled there (voxel_size <= 0: used as it is);
+// then the registration runs.  The sampled points never cross PCIe (visma_icp_set_clouds_meshes_f64).
+// `models`: anything iterable whose elements have V_, F_ (geometry.h's matrices) and model_to_scene_ -- the
+// reference's feh::Model (include/evaluation.h), or MeshModel below; an unordered_map's values work through
+// ICPRefinementMap.  Point-to-point estimator (options["use_point_to_plane"] = false, the reference's default).
+// result.correspondence_set_ indexes the concatenation in model order / the voxels in ascending order;
+// *scene_est_out (optional) receives the sampled cloud.
+struct MeshModel {
+    Eigen::Matrix<double, Eigen::Dynamic, 3> V_;
+    Eigen::Matrix<int, Eigen::Dynamic, 3> F_;
+    Eigen::Matrix4d model_to_scene_ = Eigen::Matrix4d::Identity();
+};
+
+template <typename ModelRange>
+open3d::RegistrationResult ICPRefinement(const open3d::PointCloud &scene, const ModelRange &models,
+                                         const Eigen::Matrix4d &T_scene_src, int samples_per_model, double voxel_size,
+                                         double max_distance, SamplingMode mode = SamplingMode::Surface, uint64_t seed = 0,
+                                         open3d::PointCloud *scene_est_out = nullptr)
+{
+    std::vector<std::vector<double>> vs, ts;
+    std::vector<std::vector<int32_t>> fs;
+    std::vector<visma_icp_mesh_source> ms;
+    for (const auto &m : models) {
+        vs.push_back(detail::rows3(m.V_));
+        fs.push_back(detail::faces3(m.F_));
+        ts.emplace_back(16);
+        open3d::cicp::detail::to_rowmajor(m.model_to_scene_, ts.back().data());
+    }
+    for (size_t k = 0; k < vs.size(); k++)
+        ms.push_back(visma_icp_mesh_source{vs[k].data(), (int64_t)(vs[k].size() / 3), fs[k].data(), (int64_t)(fs[k].size() / 3),
+                                           (int64_t)samples_per_model, ts[k].data()});
+    visma_icp_ctx *c = detail::ctx();
+    int64_t ns = 0, nt = 0;
+    open3d::cicp::detail::check(
+        c, visma_icp_set_clouds_meshes_f64(c, ms.data(), (int)ms.size(), mode == SamplingMode::Reference, seed,
+                                           open3d::cicp::detail::xyz(scene.points_), (int64_t)scene.points_.size(), 3,
+                                           voxel_size > 0.0 ? voxel_size : 0.0, &ns, &nt),
+        "visma_icp_set_clouds_meshes_f64");
+    if (scene_est_out) {
+        std::vector<double> p((size_t)ns * 3);
+        open3d::cicp::detail::check(c, visma_icp_get_mesh_source(c, p.data(), ns), "visma_icp_get_mesh_source");
+        scene_est_out->points_.resize((size_t)ns);
+        for (int64_t i = 0; i < ns; i++) scene_est_out->points_[(size_t)i] = Eigen::Vector3d(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    }
+    const open3d::ICPConvergenceCriteria crit;
+    double T[16];
+    open3d::cicp::detail::to_rowmajor(T_scene_src, T);
+    visma_icp_result r;
+    open3d::cicp::detail::check(c, visma_icp_run(c, T, max_distance, crit.max_iteration_, crit.relative_fitness_,
+                                                 crit.relative_rmse_, VISMA_ICP_SOLVER_KABSCH, 0, &r), "visma_icp_run");
+    open3d::RegistrationResult result(T_scene_src);
+    open3d::cicp::detail::fill_result(c, r, (size_t)ns, result);
+    return result;
+}
+
+// The reference's container: std::unordered_map<int, Model> (iterated in ITS order, as `for (const auto &kv : src)` does)
+template <typename Map>
+open3d::RegistrationResult ICPRefinementMap(const open3d::PointCloud &scene, const Map &src, const Eigen::Matrix4d &T_scene_src,
+                                            int samples_per_model, double voxel_size, double max_distance,
+                                            SamplingMode mode = SamplingMode::Surface, uint64_t seed = 0)
+{
+    std::vector<MeshModel> models;
+    for (const auto &kv : src) {
+        MeshModel m;
+        m.V_ = kv.second.V_; m.F_ = kv.second.F_; m.model_to_scene_ = kv.second.model_to_scene_;
+        models.push_back(m);
+    }
+    return ICPRefinement(scene, models, T_scene_src, samples_per_model, voxel_size, max_distance, mode, seed);
+}
+
 }  // namespace gpu
 }  // namespace feh

@@ -143,6 +143,26 @@ VISMA_ICP_API int visma_icp_set_clouds_f64_voxel_target(visma_icp_ctx *ctx, cons
                                                         int src_stride, const double *scene_xyz, int64_t n_scene,
                                                         int scene_stride, double voxel_size, int64_t *nt_out);
 VISMA_ICP_API int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out, int64_t nt);
+/* feh::ICPRefinement's clouds (src/evaluation.cpp:248-271) made on the device, source side too:
+ *   for every model: SamplePointCloudFromMesh(V, F, samples) (include/geometry.h:29-64; visma_icp_sample_mesh's
+ *   draws: mesh k uses the stream `seed + k`, reference_quirks as there), PointCloud::Transform(model_to_scene)
+ *   (O3D/Core/Geometry/PointCloud.cpp:75-80; row-major 4x4, NULL = identity), `*scene_est += *model`;
+ *   scene = VoxelDownSample(scene, voxel_size)  (voxel_size == 0: the scene as it is).
+ * The sampled points never cross PCIe: they are sampled, moved, concatenated, ordered and widened where the search
+ * reads them.  *ns_out / *nt_out = the sizes of the two clouds; source indices of the results refer to the
+ * concatenation in mesh order, visma_icp_get_mesh_source copies it (ns x 3 doubles) to the host.  Same values as
+ * visma_icp_sample_mesh + a host transform + visma_icp_set_clouds_f64[_voxel_target] (tests/test_mesh_source.py). */
+typedef struct {
+    const double *V; int64_t nv;        /* vertices, nv x 3 */
+    const int32_t *F; int64_t nf;       /* faces, nf x 3 */
+    int64_t samples;                    /* options["samples_per_model"] */
+    const double *model_to_scene;       /* 16 doubles, row-major, or NULL */
+} visma_icp_mesh_source;
+VISMA_ICP_API int visma_icp_set_clouds_meshes_f64(visma_icp_ctx *ctx, const visma_icp_mesh_source *meshes, int n_meshes,
+                                                  int reference_quirks, uint64_t seed, const double *scene_xyz,
+                                                  int64_t n_scene, int scene_stride, double voxel_size,
+                                                  int64_t *ns_out, int64_t *nt_out);
+VISMA_ICP_API int visma_icp_get_mesh_source(visma_icp_ctx *ctx, double *xyz_out, int64_t ns);
 /* fp32 uploads, no centring (the caller's coordinates are used as they are; the exact search
  * takes the fp32 values as its f64 coordinates).  FRAME RULE: visma_icp_set_clouds_f64 centres
  * BOTH clouds on one point; these setters (and the _device ones) upload in the caller's frame.

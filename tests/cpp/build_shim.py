@@ -27,9 +27,12 @@ def build():
     if e is None:
         return None
     os.makedirs(OUT, exist_ok=True)
-    src = os.path.join(HERE, "shim_driver.cpp")
     outs = []
-    for name, extra in (("shim_driver", []), ("shim_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"])):
+    for name, extra, cpp in (("shim_driver", [], "shim_driver.cpp"),
+                             ("shim_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"], "shim_driver.cpp"),
+                             ("mesh_refine_driver", [], "mesh_refine_driver.cpp"),
+                             ("mesh_refine_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"], "mesh_refine_driver.cpp")):
+        src = os.path.join(HERE, cpp)
         out = os.path.join(OUT, name)
         cmd = ["g++", "-std=c++11", "-O2", "-w"] + extra + [
             "-I" + os.path.join(ROOT, "include"), "-I" + e, src, "-o", out,

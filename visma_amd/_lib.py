@@ -61,6 +61,11 @@ ENG_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, _dp, C.c_int, _dp)
 ENG_CORR = C.CFUNCTYPE(C.c_int, C.c_void_p, _ip, _fp)
 
 
+class CMeshSource(C.Structure):
+    _fields_ = [("V", C.POINTER(C.c_double)), ("nv", C.c_int64), ("F", C.POINTER(C.c_int32)), ("nf", C.c_int64),
+                ("samples", C.c_int64), ("model_to_scene", C.POINTER(C.c_double))]
+
+
 class CCorpusItem(C.Structure):
     _fields_ = [("model_xyz", C.POINTER(C.c_double)), ("n_model", C.c_int64),
                 ("scene_xyz", C.POINTER(C.c_double)), ("n_scene", C.c_int64)]
@@ -123,6 +128,9 @@ def _bind(L):
     L.visma_icp_set_clouds_f64_voxel_target.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int, _dp, C.c_int64, C.c_int,
                                                         C.c_double, C.POINTER(C.c_int64)]
     L.visma_icp_get_voxel_target.argtypes = [C.c_void_p, _dp, C.c_int64]
+    L.visma_icp_set_clouds_meshes_f64.argtypes = [C.c_void_p, C.POINTER(CMeshSource), C.c_int, C.c_int, C.c_uint64, _dp,
+                                                  C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.visma_icp_get_mesh_source.argtypes = [C.c_void_p, _dp, C.c_int64]
     L.visma_icp_set_target.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
     L.visma_icp_set_source.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
     L.visma_icp_set_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -269,6 +277,33 @@ class Context:
                                                                float(voxel_size), C.byref(nt)))
         self.ns, self.nt = len(s), int(nt.value)
         return int(nt.value)
+
+    def set_clouds_meshes_f64(self, meshes, scene, voxel_size=0.0, reference_quirks=0, seed=0):
+        """meshes: [(V (nv,3) f64, F (nf,3) i32, samples, T (4,4) or None)]; the source is sampled, moved and
+        concatenated on the device (feh::ICPRefinement's scene_est), the scene optionally voxel-down-sampled there.
+        Returns (ns, nt)."""
+        keep = []
+        arr = (CMeshSource * max(len(meshes), 1))()
+        for k, (V, F, n, T) in enumerate(meshes):
+            V = np.ascontiguousarray(V, np.float64); F = np.ascontiguousarray(F, np.int32)
+            Tm = None if T is None else np.ascontiguousarray(T, np.float64).reshape(16)
+            keep += [V, F, Tm]
+            arr[k].V = _p(V, _dp); arr[k].nv = len(V)
+            arr[k].F = _p(F, C.POINTER(C.c_int32)); arr[k].nf = len(F)
+            arr[k].samples = int(n)
+            arr[k].model_to_scene = _p(Tm, _dp) if Tm is not None else None
+        scene = np.ascontiguousarray(scene, np.float64)
+        ns, nt = C.c_int64(0), C.c_int64(0)
+        self._chk(self.L.visma_icp_set_clouds_meshes_f64(self._h, arr, len(meshes), int(reference_quirks), int(seed),
+                                                         _p(scene, _dp), len(scene), 3, float(voxel_size),
+                                                         C.byref(ns), C.byref(nt)))
+        self.ns, self.nt = int(ns.value), int(nt.value)
+        return self.ns, self.nt
+
+    def get_mesh_source(self, ns):
+        out = np.empty((int(ns), 3), np.float64)
+        self._chk(self.L.visma_icp_get_mesh_source(self._h, _p(out, _dp), int(ns)))
+        return out
 
     def get_voxel_target(self, nt):
         out = np.empty((max(nt, 1), 3))

@@ -251,8 +251,16 @@ const char *visma_icp_last_error(const visma_icp_ctx *ctx)
 }
 
 
+struct MeshSourceSpec {                  // the source comes from meshes sampled on the device (src == NULL then)
+    const Engine::MeshSource *meshes;
+    int n;
+    int quirks;
+    unsigned long long seed;
+    int64_t *ns_out;
+};
+
 static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride, const double *tgt,
-                               int64_t nt, int tstride, double voxel, int64_t *nt_out);
+                               int64_t nt, int tstride, double voxel, int64_t *nt_out, const MeshSourceSpec *ms = nullptr);
 
 int visma_icp_set_clouds_f64(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride,
                              const double *tgt, int64_t nt, int tstride)
@@ -268,6 +276,40 @@ int visma_icp_set_clouds_f64_voxel_target(visma_icp_ctx *ctx, const double *src,
     return set_clouds_f64_impl(ctx, src, ns, sstride, scene, n_scene, tstride, voxel_size, nt_out);
 }
 
+int visma_icp_set_clouds_meshes_f64(visma_icp_ctx *ctx, const visma_icp_mesh_source *meshes, int n_meshes,
+                                    int reference_quirks, uint64_t seed, const double *scene_xyz, int64_t n_scene,
+                                    int scene_stride, double voxel_size, int64_t *ns_out, int64_t *nt_out)
+{
+    CTX_CHECK();
+    if (n_meshes < 0 || (n_meshes > 0 && !meshes) || !ns_out || !nt_out || !(voxel_size >= 0.0))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "bad mesh-source arguments");
+    *ns_out = 0;
+    *nt_out = 0;
+    std::vector<Engine::MeshSource> ms((size_t)n_meshes);
+    for (int k = 0; k < n_meshes; k++) {
+        ms[(size_t)k].V = meshes[k].V; ms[(size_t)k].nv = meshes[k].nv;
+        ms[(size_t)k].F = meshes[k].F; ms[(size_t)k].nf = meshes[k].nf;
+        ms[(size_t)k].samples = meshes[k].samples;
+        ms[(size_t)k].has_transform = meshes[k].model_to_scene != nullptr;
+        if (meshes[k].model_to_scene) std::memcpy(ms[(size_t)k].T, meshes[k].model_to_scene, sizeof(double) * 16);
+    }
+    MeshSourceSpec spec{ms.data(), n_meshes, reference_quirks, (unsigned long long)seed, ns_out};
+    int64_t nt = n_scene;
+    int rc = set_clouds_f64_impl(ctx, nullptr, 0, 3, scene_xyz, n_scene, scene_stride, voxel_size, &nt, &spec);
+    if (rc) return rc;
+    *nt_out = voxel_size > 0.0 ? nt : n_scene;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_mesh_source(visma_icp_ctx *ctx, double *xyz_out, int64_t ns)
+{
+    CTX_CHECK();
+    if (ns < 0 || (ns > 0 && !xyz_out)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad arguments");
+    int rc = ctx->eng->get_mesh_source(xyz_out, ns);
+    if (rc) return ctx->eng_fail(rc);
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out, int64_t nt)
 {
     CTX_CHECK();
@@ -279,7 +321,7 @@ int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out, int64_t nt)
 
 // voxel > 0: the target is VoxelDownSample(tgt, voxel), made and installed on the device (*nt_out = its size)
 static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns, int sstride, const double *tgt,
-                               int64_t nt, int tstride, double voxel, int64_t *nt_out)
+                               int64_t nt, int tstride, double voxel, int64_t *nt_out, const MeshSourceSpec *ms)
 {
     CTX_CHECK();
     if (ns < 0 || nt < 0 || sstride < 3 || tstride < 3 || (ns > 0 && !src) || (nt > 0 && !tgt))
@@ -323,7 +365,15 @@ static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns
     tm[ti++] = t_now();   // target
     // the source too goes up raw and is Morton-ordered on the device (HIP engine with a raw target)
     bool raw_source = false;
-    if (raw_target) {
+    if (ms) {
+        if (!raw_target) return ctx->fail(VISMA_ICP_ERR_STATE, "a mesh-sampled source needs the HIP engine");
+        rc = ctx->eng->set_source_meshes_f64(ms->meshes, ms->n, ms->quirks, ms->seed, c, want64 && ctx->eng->supports_device_loop(),
+                                             ctx->src_order, ms->ns_out);
+        if (rc == VISMA_ICP_ERR_STATE) return ctx->fail(VISMA_ICP_ERR_STATE, "a mesh-sampled source needs the HIP engine");
+        if (rc) return ctx->eng_fail(rc);
+        raw_source = true;
+        ns = *ms->ns_out;
+    } else if (raw_target) {
         rc = ctx->eng->set_source_f64(src, ns, sstride, c, want64 && ctx->eng->supports_device_loop(), ctx->src_order);
         raw_source = rc == VISMA_ICP_OK;
         if (!raw_source && rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);

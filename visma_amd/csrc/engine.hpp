@@ -303,6 +303,14 @@ public:
     // the target = VoxelDownSample(scene, voxel), down-sampled and installed without leaving the device
     virtual int set_target_voxel_f64(const double *, int64_t, int, double /* voxel */, double * /* centre */, bool, bool, int64_t * /* nt */) { return VISMA_ICP_ERR_STATE; }
     virtual int get_voxel_target(double *, int64_t) { return VISMA_ICP_ERR_STATE; }
+    // the source sampled from meshes on the device (HIP engine)
+    struct MeshSource {
+        const double *V; int64_t nv; const int32_t *F; int64_t nf; int64_t samples;
+        int has_transform; double T[16];
+    };
+    virtual int set_source_meshes_f64(const MeshSource *, int, int /* quirks */, unsigned long long /* seed */, const double * /* centre */,
+                                      bool, std::vector<int32_t> &, int64_t * /* ns */) { return VISMA_ICP_ERR_STATE; }
+    virtual int get_mesh_source(double *, int64_t) { return VISMA_ICP_ERR_STATE; }
     virtual int set_source64(const Pt64 *) { return VISMA_ICP_ERR_STATE; }
     // The source likewise: raw f64 up, then expanded, Morton-ordered and gathered on the device (order.hip);
     // `order` receives the original index of the point at every position.

@@ -103,6 +103,7 @@ public:
     int set_target_f64(const double *xyz, int64_t nt, int stride, double *c, bool compute_centre, bool want64) override
     {
         HIP_TRY(hipSetDevice(device_));
+        raw_source_points_ = 0;                              // (d_raw_ is about to be reused)
         int rc = ensure_target(nt);
         if (rc) return rc;
         if (want64) { rc = pool_alloc(&d_tgt64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt, 1)); if (rc) return rc; }
@@ -267,10 +268,9 @@ public:
     }
     double *d_vox_out_ = nullptr;
     int64_t vox_out_n_ = -1;
-    int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
-                       std::vector<int32_t> &order) override
+    // buffers of a source of ns points that arrives as raw f64 triples in d_raw_
+    int begin_raw_source(int64_t ns, bool want64, std::vector<int32_t> &order)
     {
-        HIP_TRY(hipSetDevice(device_));
         int rc = ensure_source(ns);
         if (rc) return rc;
         free_dev(d_sorted64_); free_dev(d_nrm64_);
@@ -281,13 +281,46 @@ public:
             rc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns, 1));
             if (rc) return rc;
         }
+        return VISMA_ICP_OK;
+    }
+    int ensure_raw(size_t points)
+    {
+        if (points * 24 > raw_bytes_) {
+            free_dev(d_raw_);
+            int rc = pool_alloc(&d_raw_, points * 24);
+            if (rc) return rc;
+            raw_bytes_ = points * 24;
+        }
+        return VISMA_ICP_OK;
+    }
+    // d_raw_ holds ns points (caller order): Morton order on the device, fp32 + f64 copies, the permutation back
+    int finish_raw_source(int64_t ns, const double *c, std::vector<int32_t> &order)
+    {
+        void *scratch = nullptr, *d_order = nullptr;
+        const size_t sb = order_source_scratch_bytes(ns);
+        int rc = pool_alloc(&scratch, sb);
+        if (rc) return rc;
+        rc = pool_alloc(&d_order, sizeof(int32_t) * (size_t)ns);
+        if (rc) { free_dev(scratch); return rc; }
+        hipError_t e = order_source_device((const double *)d_raw_, ns, c, (float4 *)d_src_, (Pt64 *)d_src64_,
+                                           (int32_t *)d_order, scratch, sb, stream_);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(order.data(), d_order, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, stream_);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        free_dev(scratch); free_dev(d_order);
+        if (e != hipSuccess) { err_ = std::string("source ordering: ") + hipGetErrorString(e); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
+        return VISMA_ICP_OK;
+    }
+    int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
+                       std::vector<int32_t> &order) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        raw_source_points_ = 0;
+        int rc = begin_raw_source(ns, want64, order);
+        if (rc) return rc;
         if (ns > 0) {
-            if ((size_t)ns * 24 > raw_bytes_) {
-                free_dev(d_raw_);
-                rc = pool_alloc(&d_raw_, (size_t)ns * 24);
-                if (rc) return rc;
-                raw_bytes_ = (size_t)ns * 24;
-            }
+            rc = ensure_raw((size_t)ns);
+            if (rc) return rc;
             double *pin = reinterpret_cast<double *>(staging(3, (size_t)ns * 6));
             parallel_for((ns + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
                 const int64_t a = ch * kHostChunk, b = std::min(ns, a + kHostChunk);
@@ -299,22 +332,60 @@ public:
                     }
             });
             HIP_TRY(hipMemcpyAsync(d_raw_, pin, sizeof(double) * 3 * (size_t)ns, hipMemcpyHostToDevice, stream_));
-            void *scratch = nullptr, *d_order = nullptr;
-            const size_t sb = order_source_scratch_bytes(ns);
-            rc = pool_alloc(&scratch, sb);
+            rc = finish_raw_source(ns, c, order);
             if (rc) return rc;
-            rc = pool_alloc(&d_order, sizeof(int32_t) * (size_t)ns);
-            if (rc) { free_dev(scratch); return rc; }
-            hipError_t e = order_source_device((const double *)d_raw_, ns, c, (float4 *)d_src_, (Pt64 *)d_src64_,
-                                               (int32_t *)d_order, scratch, sb, stream_);
-            if (e == hipSuccess)
-                e = hipMemcpyAsync(order.data(), d_order, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, stream_);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream_);
-            free_dev(scratch); free_dev(d_order);
-            if (e != hipSuccess) { err_ = std::string("source ordering: ") + hipGetErrorString(e); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
         }
         return VISMA_ICP_OK;
     }
+    // The source of feh::ICPRefinement (src/evaluation.cpp:252-259) made where it is used: every mesh sampled on the
+    // device (mesh.hip), moved by its model_to_scene, the clouds concatenated in d_raw_ -- which then is what an
+    // uploaded source would be.  Mesh k draws from the stream seed + k.
+    int set_source_meshes_f64(const MeshSource *meshes, int n_meshes, int quirks, unsigned long long seed, const double *c,
+                              bool want64, std::vector<int32_t> &order, int64_t *ns_out) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        raw_source_points_ = 0;
+        int64_t room = 0;
+        for (int k = 0; k < n_meshes; k++) {
+            if (meshes[k].samples < 0 || meshes[k].nv < 0 || meshes[k].nf < 0 ||
+                (meshes[k].nf > 0 && (!meshes[k].V || !meshes[k].F))) { err_ = "bad mesh source"; return VISMA_ICP_ERR_INVALID; }
+            if (meshes[k].nf > 0) room += meshes[k].samples;
+        }
+        if (room > 0x7fffffff - 4096) { err_ = "source too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
+        int rc = ensure_raw((size_t)std::max<int64_t>(room, 1));
+        if (rc) return rc;
+        int64_t ns = 0;
+        for (int k = 0; k < n_meshes; k++) {
+            int64_t m = 0;
+            hipError_t e = sample_mesh_transformed_device(meshes[k].V, meshes[k].nv, meshes[k].F, meshes[k].nf, meshes[k].samples,
+                                                          quirks, seed + (unsigned long long)k,
+                                                          meshes[k].has_transform ? meshes[k].T : nullptr,
+                                                          (double *)d_raw_ + 3 * ns, room - ns, &m, stream_);
+            if (e != hipSuccess) {
+                err_ = std::string("mesh source: ") + (e == hipErrorInvalidValue ? "face index out of range" : hipGetErrorString(e));
+                (void)hipGetLastError();
+                return e == hipErrorInvalidValue ? VISMA_ICP_ERR_INVALID : VISMA_ICP_ERR_HIP;
+            }
+            ns += m;
+        }
+        rc = begin_raw_source(ns, want64, order);
+        if (rc) return rc;
+        if (ns > 0) {
+            rc = finish_raw_source(ns, c, order);
+            if (rc) return rc;
+        }
+        raw_source_points_ = ns;
+        *ns_out = ns;
+        return VISMA_ICP_OK;
+    }
+    int get_mesh_source(double *out, int64_t ns) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (ns != raw_source_points_ || !d_raw_) { err_ = "no mesh-sampled source of that size on this context"; return VISMA_ICP_ERR_STATE; }
+        if (ns > 0) HIP_TRY(hipMemcpy(out, d_raw_, sizeof(double) * 3 * (size_t)ns, hipMemcpyDeviceToHost));
+        return VISMA_ICP_OK;
+    }
+    int64_t raw_source_points_ = 0;                        // > 0: d_raw_ holds the mesh-sampled source (caller order)
     int set_source64(const Pt64 *src) override
     {
         HIP_TRY(hipSetDevice(device_));

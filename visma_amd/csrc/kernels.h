@@ -255,6 +255,9 @@ int grid_scan_blocks(int64_t ncell);
 hipError_t point_mesh_distance_device(const double *h_P, int64_t np, const double *h_V, int64_t nv,
                                       const int32_t *h_F, int64_t nf, int method, double *h_d2, int32_t *h_face,
                                       double *h_closest, float *kernel_ms, float *build_ms, hipStream_t stream);
+hipError_t sample_mesh_transformed_device(const double *h_V, int64_t nv, const int32_t *h_F, int64_t nf, int64_t n,
+                                          int quirks, unsigned long long seed, const double *T16, double *d_out,
+                                          int64_t room, int64_t *m_out, hipStream_t stream);
 hipError_t sample_mesh_device(const double *h_V, int64_t nv, const int32_t *h_F, int64_t nf, int64_t n,
                               int quirks, unsigned long long seed, const double *h_uniforms,
                               double *h_out, int64_t *n_out, hipStream_t stream);

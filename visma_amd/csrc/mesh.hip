@@ -651,6 +651,51 @@ hipError_t sample_mesh_device(const double *h_V, int64_t nv, const int32_t *h_F,
     return hipSuccess;
 }
 
+// The source cloud of feh::ICPRefinement (src/evaluation.cpp:252-259) without a host round trip: n draws of
+// feh::SamplePointCloudFromMesh on the mesh, moved by PointCloud::Transform (PointCloud.cpp:75-80:
+// transformation * (x, y, z, 1), first three rows; T16 row-major, NULL = identity), written to d_out (device,
+// room for `room` points, 3 doubles each).  *m_out = points written (<= n; < n only with reference_quirks).
+__global__ void transform_points_kernel(const double *__restrict__ in, long long m, const double *__restrict__ T,
+                                        double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+    if (T) {
+        out[3 * i] = T[0] * x + T[1] * y + T[2] * z + T[3];
+        out[3 * i + 1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+        out[3 * i + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+    } else {
+        out[3 * i] = x; out[3 * i + 1] = y; out[3 * i + 2] = z;
+    }
+}
+
+hipError_t sample_mesh_transformed_device(const double *h_V, int64_t nv, const int32_t *h_F, int64_t nf, int64_t n,
+                                          int quirks, unsigned long long seed, const double *T16, double *d_out,
+                                          int64_t room, int64_t *m_out, hipStream_t stream)
+{
+    *m_out = 0;
+    if (nf <= 0 || n <= 0) return hipSuccess;
+    if (n > room) return hipErrorInvalidValue;
+    DevMesh mesh;
+    DBuf pts, d_T;
+    int64_t m = 0;
+    MESH_TRY(upload_mesh(h_V, nv, h_F, nf, mesh, stream));
+    MESH_TRY(sample_on_device(h_V, h_F, mesh, n, quirks, seed, nullptr, pts, &m, stream));
+    if (m > 0) {
+        if (T16) {
+            MESH_TRY(d_T.alloc(sizeof(double) * 16));
+            MESH_TRY(hipMemcpyAsync(d_T.p, T16, sizeof(double) * 16, hipMemcpyHostToDevice, stream));
+        }
+        hipLaunchKernelGGL(transform_points_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, stream,
+                           pts.as<double>(), (long long)m, T16 ? d_T.as<double>() : (const double *)nullptr, d_out);
+        MESH_TRY(hipGetLastError());
+        MESH_TRY(hipStreamSynchronize(stream));          // (pts and d_T are freed on return)
+    }
+    *m_out = m;
+    return hipSuccess;
+}
+
 // feh::MeasureSurfaceError (geometry.h:117-141) with the samples kept on the
 // device: sample the source mesh -> distance to the target mesh -> sqrt; the
 // distances come back to the host for the statistics.  h_dist holds n entries.
