@@ -44,6 +44,11 @@ def check(ns, nt, npass, seed, radius=None, offset=None, label="", dup=0):
             d1 = c.get_correspondences()[2]
             nd = int((i0 != i1).sum())
             same = np.array_equal(st.view(np.uint64), st0.view(np.uint64)) and np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+            if n == "auto" and p == 0 and not same:
+                # the first pass of `auto` runs the lane-serial kernel with the lanes-per-query policy of the cloud size
+                # (several lanes per query for small clouds): another summation tree than the reference context's 801
+                # -- same correspondences and distances, statistics equal to rounding
+                same = np.array_equal(d0.view(np.uint32), d1.view(np.uint32)) and bool(np.all(np.abs(st - st0) <= 1e-11 * (np.abs(st0) + np.abs(st0).max())))
             if nd or not same:
                 bad += 1
                 rel = float(np.max(np.abs(st - st0) / (np.abs(st0) + 1e-300 + 1e-12 * np.abs(st0).max())))
