@@ -834,6 +834,13 @@ def run_c5(R, args, tag=""):
         R.dist.barrier()
         if R.rank != 0:
             shm = shared_memory.SharedMemory(name=name)
+            try:
+                # (rank 0 owns the segment and unlinks it: keep this process's resource tracker from doing -- and
+                #  complaining about -- the same at exit)
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(shm._name, "shared_memory")
+            except Exception:      # noqa: BLE001
+                pass
         base = ctypes.addressof(ctypes.c_char.from_buffer(shm.buf))
 
     def one_pass(slot):
