@@ -34,10 +34,10 @@ def main():
     from visma_amd import build
     a = [int(x) for x in sys.argv[1:] if x.isdigit()]
     ns, nt = (a + [262144, 4194304])[:2] if len(a) >= 2 else (262144, 4194304)
-    for k in [int(x[2:]) for x in sys.argv if x.startswith("k=")] or (0, 1, 2, 3, 4, 5, 99):
+    for k in [int(x[2:]) for x in sys.argv if x.startswith("k=")] or (0, 1, 4, 5, 99):
         side = os.path.join(ROOT, "visma_amd", "lib", "libvisma_icp_stop%s.so" % str(k).replace("-", "m"))
         if not os.path.exists(side):
-            build.build_lib(force=True, defines=("VISMA_COOP_NO_SLOW",) if k == 77 else ("VISMA_COOP_STOP_AFTER=%d" % k,), out=side)
+            build.build_lib(force=True, defines=("VISMA_COOP_STOP_AFTER=%d" % k,), out=side)
         if "--build-only" in sys.argv:
             continue
         env = dict(os.environ, VISMA_ICP_LIB=side)

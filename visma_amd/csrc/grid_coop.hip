@@ -38,6 +38,7 @@
 // g + W, or more than four flagged candidates, sends the query to the f64 re-scan of its 27 cells (points
 // given several times).
 #include "device_common.h"
+#include "grid_coop_probe.h"   // COOP_PHASE / COOP_MARK: no-ops outside the measurement builds
 
 namespace visma {
 
@@ -77,34 +78,6 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int lane)
     }
     return v;
 }
-
-#ifdef VISMA_COOP_DEBUG_PHASES   /* measurement build: cycles of wave 0 of every workgroup between the phases */
-__device__ unsigned long long g_coop_phase[16];
-__device__ unsigned long long g_coop_span[4 * 8192];        // per wave of the last launch: first and last clock
-#if VISMA_COOP_DEBUG_PHASES == 2   /* per-wave clocks at the phase borders, one store each (the shared counters perturb the launch) */
-__device__ unsigned long long g_coop_marks[16 * 8192];
-#define COOP_STAMP(k)                                                                              \
-    do {                                                                                           \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                          \
-            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
-    } while (0)
-#else
-#define COOP_STAMP(k)                                                                              \
-    do {                                                                                           \
-        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                              \
-        if (threadIdx.x == 0) atomicAdd(&g_coop_phase[k], now_ - stamp_);                          \
-        stamp_ = now_;                                                                             \
-    } while (0)
-#endif
-#else
-#define COOP_STAMP(k) do { } while (0)
-#endif
-#ifndef VISMA_COOP_STOP_AFTER    /* measurement build: a query's work ends after phase k (tools/truncate_probe.py) */
-#define VISMA_COOP_STOP_AFTER 99
-#endif
-#ifdef VISMA_COOP_STAGGER        /* measurement build: some workgroups start late (tools/stagger_probe.py) */
-__device__ int g_coop_stagger[4];
-#endif
 
 }  // namespace
 
@@ -164,25 +137,7 @@ __device__ __forceinline__ void coop_body(
         if (!load_loop_state(st, T32_unused, T64, off, r2f)) return;
     }
     const double r2d = (double)r2f;                         // (double)(float)(r*r): KDTreeFlann.cpp:184-185
-#ifdef VISMA_COOP_STAGGER
-    {
-        const int mode = g_coop_stagger[0], n = g_coop_stagger[1];
-        const unsigned s = blockIdx.x >> 3;
-        bool late = false;
-        if (mode == 1) late = s & 1u;
-        else if (mode == 2) late = (s >> 5) & 1u;
-        else if (mode == 3) late = ((s * 2654435761u) >> 16) & 1u;
-        else if (mode == 4) late = (threadIdx.x >> 6) & 1u;
-        else if (mode == 5) late = (s >> 1) & 1u;
-        else if (mode == 6) late = (s >> 6) & 1u;
-        if (late)
-            for (int k = 0; k < n; k++) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
-#ifdef VISMA_COOP_DEBUG_PHASES
-    unsigned long long stamp_ = __builtin_amdgcn_s_memrealtime();
-    const unsigned long long stamp0_ = stamp_;
-#endif
+    COOP_PROBE_BEGIN();
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
     prevq_io += (long long)prob * out_stride;
@@ -210,7 +165,6 @@ __device__ __forceinline__ void coop_body(
     // one query (or none: the lanes past the end still work on the others' chunks)
     auto query = [&](long long i, bool active) {
         // ---- the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
-        if (VISMA_COOP_STOP_AFTER == -1) return;
         Pt64 s8 = Pt64{0.0, 0.0, 0.0, 0ull};
         float4 qprev = make_float4(NAN, NAN, NAN, 0.f);     // the previous pass's winner (fp32 view), NaN = none
         if (active) {
@@ -225,11 +179,7 @@ __device__ __forceinline__ void coop_body(
         }
         const double pxd = pd[0], pyd = pd[1], pzd = pd[2];
         const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
-#if defined(VISMA_COOP_DEBUG_PHASES) && VISMA_COOP_DEBUG_PHASES != 2
-        asm volatile("" ::"v"(px), "v"(qprev.x));
-#endif
-        COOP_STAMP(0);                                       // source + previous winner arrived
-        if (VISMA_COOP_STOP_AFTER == 0) { if (active) d2_out[i] = px + py + pz + qprev.x + qprev.y + qprev.z; return; }
+        COOP_PHASE(0, 0u, px + py + pz + qprev.x + qprev.y + qprev.z);   // source + previous winner arrived
         const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(py, g.mn[1], g.inv_hs, g.dim[1]);
         const int cz = cell_coord(pz, g.mn[2], g.inv_hs, g.dim[2]);
@@ -308,17 +258,7 @@ __device__ __forceinline__ void coop_body(
             xe[k] = e;
             if (cand_count) ncand += e - b;
         }
-#if defined(VISMA_COOP_DEBUG_PHASES) && VISMA_COOP_DEBUG_PHASES != 2
-        asm volatile("" ::"v"(xb[0]), "v"(xe[8]), "v"(xb[4]));
-#endif
-        COOP_STAMP(1);                                       // row bounds + previous winner arrived, rows pruned
-        if (VISMA_COOP_STOP_AFTER == 1) {
-            unsigned a = 0;
-#pragma unroll
-            for (int k = 0; k < 9; k++) a += xb[k] ^ xe[k];
-            if (active) idx_out[i] = (int)a;
-            return;
-        }
+        COOP_PHASE(1, xb[0] ^ xe[8] ^ xb[4] ^ xe[2] ^ xb[6], 0.f);            // row bounds arrived, rows pruned
         // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
         float gh0 = L, gh1 = L, gh2 = L;
         unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
@@ -361,7 +301,7 @@ __device__ __forceinline__ void coop_body(
                 items[Mw + lane] = make_uint2(0u, 0u);       // null descriptors (count 0) for the last, partial trip
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                COOP_STAMP(2);                               // chunk list written
+                COOP_MARK(2);                                // chunk list written
                 for (unsigned t = 0; t < Mw; t += 8u * kCoopDepth) {
                     // kCoopDepth chunks per lane octet in flight: every load of the list is independent
                     P12 c4[kCoopDepth];
@@ -392,7 +332,7 @@ __device__ __forceinline__ void coop_body(
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                COOP_STAMP(3);                               // chunks worked off
+                COOP_MARK(3);                                // chunks worked off
                 // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
                 for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
                     uint2 r[4];
@@ -413,8 +353,7 @@ __device__ __forceinline__ void coop_body(
             // (one window unless the cloud is very dense)
             for (unsigned w0 = 0; w0 < M; w0 += kCoopCap) window(w0);
         }
-        COOP_STAMP(4);                                       // chunk results merged per query
-        if (VISMA_COOP_STOP_AFTER == 4) { if (active) { idx_out[i] = (int)(gb0 + gb1 + gm0 + gm1); d2_out[i] = gh0 + gh1 + gh2; } return; }
+        COOP_PHASE(4, gb0 + gb1 + gm0 + gm1, gh0 + gh1 + gh2);              // chunk results merged per query
         // ---- the f64 decision: flagged candidates of the kept chunks inside g + W
         double bd = r2d;                                     // best d2 so far (strictly below r2d once set)
         unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
@@ -461,9 +400,6 @@ __device__ __forceinline__ void coop_body(
             if (n > 2) rank(sorted64[c[2]], c[2]);
             if (n > 3) rank(sorted64[c[3]], c[3]);
         }
-#ifdef VISMA_COOP_NO_SLOW   /* measurement build: the re-scan skipped (rare queries may be wrong) */
-        slow = false;
-#endif
         // ---- the re-scan, by the WHOLE WAVE for one such query at a time (a few per launch at C4, and the launch
         // lasts as long as its slowest wave: one lane walking its 27 cells alone -- ~90 dependent loads -- put 6 us
         // on the tail of every launch).  The query's listed slot ranges (everything that can win or tie lies in
@@ -556,11 +492,7 @@ __device__ __forceinline__ void coop_body(
                 }
             }
         }
-#if defined(VISMA_COOP_DEBUG_PHASES) && VISMA_COOP_DEBUG_PHASES != 2
-        asm volatile("" ::"v"(bd));
-#endif
-        COOP_STAMP(5);                                       // f64 winner arrived and ranked
-        if (VISMA_COOP_STOP_AFTER == 5) { if (active) { idx_out[i] = (int)bidx; d2_out[i] = (float)(bd + bq.x); } return; }
+        COOP_PHASE(5, bidx, (float)(bd + bq.x));                            // f64 winner arrived and ranked
         if (active) {
             idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
             d2_out[i] = (float)bd;
@@ -582,16 +514,10 @@ __device__ __forceinline__ void coop_body(
     } else {
         for (int it = 0; it < per_group; it++) query(i_begin + it, i_begin + it < i_end);   // wave-uniform trip count
     }
-    COOP_STAMP(6);                                           // outputs + moments
-#ifdef VISMA_COOP_DEBUG_PHASES
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {
-        const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);
-        g_coop_span[2 * w_] = stamp0_;
-        g_coop_span[2 * w_ + 1] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
+    COOP_MARK(6);                                            // outputs + moments
+    COOP_WAVE_DONE();
     block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
-    COOP_STAMP(7);                                           // workgroup's partial row stored
+    COOP_MARK(7);                                            // workgroup's partial row stored
     if (cand_count) {
         unsigned long long c = ncand, ca = ncand_all;
 #pragma unroll
@@ -606,7 +532,7 @@ __device__ __forceinline__ void coop_body(
         }
     }
     if (fold.tickets) fused_fold<PLANE, kBlock>(fold, partials, row0, lb, bpp, prob);
-    COOP_STAMP(8);                                           // fold (most workgroups: just the ticket)
+    COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
 }
 
 #define VISMA_COOP_PARAMS                                                                                         \
@@ -636,36 +562,6 @@ __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 }
 #undef VISMA_COOP_PARAMS
 #undef VISMA_COOP_ARGS
-
-#ifdef VISMA_COOP_DEBUG_PHASES
-#if VISMA_COOP_DEBUG_PHASES == 2
-extern "C" __attribute__((visibility("default"))) int visma_debug_coop_marks(unsigned long long *out, int n)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_marks), sizeof(unsigned long long) * n) != hipSuccess;
-}
-#endif
-extern "C" __attribute__((visibility("default"))) int visma_debug_coop_spans(unsigned long long *out, int n)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_coop_span), sizeof(unsigned long long) * n) != hipSuccess;
-}
-extern "C" __attribute__((visibility("default"))) int visma_debug_coop_phases(unsigned long long *out16, int reset)
-{
-    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_coop_phase), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
-    if (reset) {
-        const unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_coop_phase), z, sizeof(z)) != hipSuccess) return 1;
-    }
-    return 0;
-}
-#endif
-
-#ifdef VISMA_COOP_STAGGER
-extern "C" __attribute__((visibility("default"))) int visma_debug_coop_stagger(int mode, int n)
-{
-    const int v[4] = {mode, n, 0, 0};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_coop_stagger), v, sizeof(v)) != hipSuccess;
-}
-#endif
 
 #define VISMA_COOP_LAUNCH(KERNEL_)                                                                               \
     hipLaunchKernelGGL(KERNEL_, dim3(total_blocks), dim3(kBlock), 0, stream, ns, s12, start, g, nrm, T64, off,   \
