@@ -68,14 +68,16 @@ __device__ __forceinline__ float octet_min(float d)
     return r;
 }
 
-// inclusive prefix sum over the 64 lanes
-__device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int lane)
+// inclusive prefix sum over the 64 lanes: DPP row shifts inside the 16-lane rows (absent lanes read 0), then the
+// last lane of row 0 / 2 broadcast into row 1 / 3 and lane 31 into the upper half -- no LDS round trips
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned t = (unsigned)__shfl_up((int)v, o, 64);
-        if (lane >= o) v += t;
-    }
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
     return v;
 }
 
@@ -243,13 +245,16 @@ __device__ __forceinline__ void coop_body(
         // ---- the slots of each row that can hold a candidate at or within bound0: cells whose slab bound
         // (y, z and x slab distances, squared) does not exceed it.  A skipped cell holds nothing that could
         // win or tie (margins: fp32 binning + rounding band, as in the lane-serial kernel).
+        // (B + exq[j] <= bound0 tested as B <= bound0 - exq[j]: the slab bounds carry a relative margin of ~1e-3, a
+        //  rounding of the subtraction cannot drop a cell that matters; a cell that does not exist: -inf)
+        const float lim0 = span > 0 ? bound0 - exq[0] : -INFINITY;
+        const float lim1 = span > 1 ? bound0 - exq[1] : -INFINITY;
+        const float lim2 = span > 2 ? bound0 - exq[2] : -INFINITY;
         unsigned xb[9], xe[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) {
             const float B = row_bound_of(k);
-            const bool n0 = span > 0 && !(B + exq[0] > bound0);
-            const bool n1 = span > 1 && !(B + exq[1] > bound0);
-            const bool n2 = span > 2 && !(B + exq[2] > bound0);
+            const bool n0 = B <= lim0, n1 = B <= lim1, n2 = B <= lim2;
             const u4a v = cs[k];                             // (a row not looked up reads as zeros: empty)
             const unsigned b = n0 ? v.x : (n1 ? v.y : v.z);
             unsigned e = n2 ? v.w : (n1 ? v.z : (n0 ? v.y : b));
