@@ -195,7 +195,6 @@ __device__ __forceinline__ void coop_body(
         const int row_c = (cz * g.dim[1] + cy) * g.dim[0] + x0, pitch_y = g.dim[0], pitch_z = g.dim[1] * g.dim[0];
         auto load_row = [&](int k, bool want) {
             const bool ok = want && span > 0 && zok[k / 3] && yok[k % 3];
-            if (cand_count && ok) ncand_all++;               // profiling: cell-table rows looked up
             u4a v = {0u, 0u, 0u, 0u};
             if (ok) v = *reinterpret_cast<const u4a *>(reinterpret_cast<const char *>(start) + (unsigned)(row_c + (k / 3 - 1) * pitch_z + (k % 3 - 1) * pitch_y) * 4u);
             return v;
@@ -261,9 +260,16 @@ __device__ __forceinline__ void coop_body(
             if (!(n0 || n1 || n2)) e = b;
             xb[k] = b;
             xe[k] = e;
-            if (cand_count) ncand += e - b;
         }
         COOP_PHASE(1, xb[0] ^ xe[8] ^ xb[4] ^ xe[2] ^ xb[6], 0.f);            // row bounds arrived, rows pruned
+        if (cand_count) {
+            // profiling only (one uniform branch): candidates listed, cell-table rows looked up
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                ncand += xe[k] - xb[k];
+                if (active && !(row_bound_of(k) > bound0) && span > 0 && zok[k / 3] && yok[k % 3]) ncand_all++;
+            }
+        }
         // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
         float gh0 = L, gh1 = L, gh2 = L;
         unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
