@@ -1,0 +1,87 @@
+"""Randomised search for a disagreement between the warm-started wave-cooperative search (grid_coop.hip: every pass
+after the first) and the lane-serial kernel, both exact: clouds on lattices (points exactly on cell faces),
+duplicates (exact ties everywhere: the whole-wave re-scan), planes, lines, extreme radii, elongated boxes, big
+offsets; passes after no motion at all, small motions and jumps larger than the radius (previous winner useless).
+Indices, distances and the 38 statistics must be equal BIT for bit.   usage: fuzz_warm_vs_serial.py [N] [seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+from visma_amd import _lib, synth  # noqa: E402
+
+os.environ.pop("VISMA_ICP_COOP", None)
+os.environ.pop("VISMA_ICP_GRID_LANES", None)
+warm = _lib.Context(0)                                   # default policy: lane-serial first pass, then warm-started
+os.environ["VISMA_ICP_COOP"] = "0"
+os.environ["VISMA_ICP_GRID_LANES"] = "801"
+serial = _lib.Context(0)                                 # the lane-serial kernel, one query per lane, every pass
+os.environ.pop("VISMA_ICP_COOP", None)
+os.environ.pop("VISMA_ICP_GRID_LANES", None)
+for c in (warm, serial):
+    c.set_nn_mode(_lib.NN_GRID)
+bad = 0
+used = {}
+for it in range(N):
+    kind = int(rng.integers(0, 7))
+    nt = int(rng.integers(1, 60000)); ns = int(rng.integers(1, 20000))
+    scale = 10.0 ** rng.uniform(-2, 2)
+    if kind == 0:      # lattice: many points exactly on cell boundaries of a radius-sized grid
+        r = scale * 0.05
+        tgt = rng.integers(-40, 40, (nt, 3)) * r * rng.choice([0.5, 1.0, 1.001, 2.0])
+        src = rng.integers(-40, 40, (ns, 3)) * r * 0.5
+    elif kind == 1:    # duplicates
+        base = rng.standard_normal((max(nt // 8, 1), 3)) * scale
+        tgt = base[rng.integers(0, len(base), nt)]
+        src = base[rng.integers(0, len(base), ns)] + rng.standard_normal((ns, 3)) * scale * 1e-3
+        r = scale * 10.0 ** rng.uniform(-3, 0)
+    elif kind == 2:    # plane / line
+        tgt = rng.standard_normal((nt, 3)) * scale; tgt[:, rng.integers(0, 3)] = 0.0
+        if rng.random() < 0.5:
+            tgt[:, rng.integers(0, 3)] = 1.0
+        src = rng.standard_normal((ns, 3)) * scale; src[:, 2] *= 1e-3
+        r = scale * 10.0 ** rng.uniform(-2.5, 0.5)
+    elif kind == 3:    # elongated box
+        tgt = rng.random((nt, 3)) * scale * np.array([1000.0, 1.0, 1.0])
+        src = rng.random((ns, 3)) * scale * np.array([1000.0, 1.0, 1.0])
+        r = scale * 10.0 ** rng.uniform(-2, 0)
+    elif kind == 4:    # far from the origin
+        off = rng.standard_normal(3) * scale * 1e4
+        tgt = rng.standard_normal((nt, 3)) * scale + off
+        src = rng.standard_normal((ns, 3)) * scale + off
+        r = scale * 10.0 ** rng.uniform(-2, 0)
+    elif kind == 5:    # tiny / huge radius
+        tgt = rng.standard_normal((nt, 3)) * scale; src = rng.standard_normal((ns, 3)) * scale
+        r = scale * 10.0 ** rng.choice([-6, -4, 1, 3])
+    else:              # the bench's surface
+        src, tgt, _, r = synth.make_pair(ns, max(nt, 8), seed_t=int(rng.integers(1 << 30)), seed_s=int(rng.integers(1 << 30)), motion="radius")
+        r *= 10.0 ** rng.uniform(-0.5, 0.5)
+    for c in (warm, serial):
+        c.set_clouds_f64(src, tgt)
+    T = synth.make_T(synth.rot_y(rng.uniform(-0.2, 0.2)), rng.standard_normal(3) * r * 0.5)
+    motions = [0.0, 0.02, 0.3, 0.0, 3.0, 0.1]            # in radii; pass 0 is the first (lane-serial on both)
+    for p, m in enumerate([None] + motions):
+        if m is not None:
+            T = synth.make_T(synth.rot_y(rng.uniform(-1, 1) * min(m, 1.0) * 0.05), rng.standard_normal(3) * r * m) @ T
+        out = []
+        for c in (warm, serial):
+            c.nn_pass(T, r)
+            st = c.reduce()
+            out.append((c.correspondence_index(), c.get_correspondences()[2].view(np.uint32), st.view(np.uint64)))
+        k = warm.search_kernel_used()
+        used[k] = used.get(k, 0) + 1
+        same = np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        if p > 0:
+            same = same and np.array_equal(out[0][2], out[1][2])   # (pass 0 of `warm` may use several lanes per query)
+            if k != "warm":
+                print("NOTE it=%d pass %d ran kernel %s" % (it, p, k))
+        if not same:
+            bad += 1
+            d = np.flatnonzero(out[0][0] != out[1][0])
+            print("MISMATCH it=%d kind=%d pass=%d ns=%d nt=%d r=%g: %d indices differ (first %s), stats equal %s" %
+                  (it, kind, p, ns, nt, r, len(d), d[:5], np.array_equal(out[0][2], out[1][2])), flush=True)
+print("done: %d configurations x 7 passes, kernels used %s, %d mismatches" % (N, used, bad))
+sys.exit(1 if bad else 0)
