@@ -697,24 +697,47 @@ def run_c3(R, args):
     objs, probs = c3_problems()
     # static deal: objects (with their 24 yaw starts, which share clouds) sorted by size, round-robin
     order = sorted(range(len(objs)), key=lambda i: -len(objs[i][0]) * len(objs[i][1]))
-    mine = set(order[R.rank::R.world])
-    my = [p[:4] for p in probs if p[4] in mine]
-    ctx = _lib.Context(R.local_rank)
+    mine_order = order[R.rank::R.world]
+    mine = set(mine_order)
+    # workers per GPU: the rank's objects dealt (by size, round-robin) to W contexts, each with its own stream; their
+    # batches run side by side -- while one packs, uploads or runs its one-thread solves, the others' searches have the GPU
+    W = max(1, min(int(os.environ.get("VISMA_C3_WORKERS_PER_GPU", "2")), len(mine_order)))
+    ctxs = [_lib.Context(R.local_rank) for _ in range(W)]
+    ctx = ctxs[0]
     iters = 30
-    my_queries = sum(len(p[0]) for p in my)
-    my = ctx.make_batch(my)                     # the C array of problems, built once (not part of a step)
+    parts = [set(mine_order[w::W]) for w in range(W)]
+    batches, part_queries = [], []
+    for w in range(W):
+        pw = [p[:4] for p in probs if p[4] in parts[w]]
+        part_queries.append(sum(len(p[0]) for p in pw))
+        batches.append(ctxs[w].make_batch(pw))     # the C array of problems, built once (not part of a step)
+    my_queries = part_queries[0]
+
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=W)
+
+    def one_step():
+        # (ctypes releases the GIL for the duration of visma_icp_run_batch)
+        futs = [pool.submit(ctxs[w].run_batch, batches[w], iters) for w in range(1, W)]
+        res = list(ctxs[0].run_batch(batches[0], max_iter=iters))
+        for f in futs:
+            res += list(f.result())
+        return res
+
     for _ in range(max(args.warmup, 1)):
-        ctx.run_batch(my, max_iter=iters)
-    ctx.set_profiling(1)
-    ctx.get_timing(reset=True)
+        one_step()
     R.barrier_sync()
     t0 = time.perf_counter()
     its = 0
     for _ in range(args.steps):
-        res = ctx.run_batch(my, max_iter=iters)
+        res = one_step()
         its += sum(r.iterations for r in res)
     R.barrier_sync()
     elapsed = R.reduce_max(time.perf_counter() - t0)
+    # the search launches of ONE worker's batch, alone on the GPU, timed by HIP events (after the timed region)
+    ctx.set_profiling(1)
+    ctx.get_timing(reset=True)
+    ctx.run_batch(batches[0], max_iter=iters)
     tm = ctx.get_timing(reset=True)
     ctx.set_profiling(0)
     total_its = R.reduce_sum(float(its))
@@ -723,7 +746,7 @@ def run_c3(R, args):
     out = None
     if R.rank == 0:
         queries = my_queries
-        nt_total = sum(len(objs[i][1]) for i in mine)
+        nt_total = sum(len(objs[i][1]) for i in parts[0])
         roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True,
                                  "warm" if ctx.search_kernel_used() == "warm" else "serial")
         roofline["launches_timed"] = tm["nn_launches"]
@@ -736,7 +759,8 @@ def run_c3(R, args):
                                    "source 4k..40k -> target half, r=0.02, <= 30 iterations each",
                        "problems": len(probs), "source_points_per_pass": sum(len(p[0]) for p in probs),
                        "search": ctx.search_mode_used(),
-                       "parallelism": "replicas only: objects dealt round-robin by size over %d rank(s), no collective" % R.world},
+                       "parallelism": "replicas only: objects dealt round-robin by size over %d rank(s) x %d worker context(s) "
+                                      "per GPU (each its own stream, batches side by side), no collective" % (R.world, W)},
             "problems_per_sec": len(probs) * args.steps / elapsed,
             "roofline": roofline,
         }
@@ -760,7 +784,9 @@ def run_c3(R, args):
                                    "sample": "6 of the 288 problems, %d iterations each, one after another "
                                              "(KD-tree builds included)" % iters,
                                    "gpu_vs_cpu_rel_frobenius": worst}
-    ctx.close()
+    pool.shutdown()
+    for c in ctxs:
+        c.close()
     return out
 
 
@@ -816,6 +842,10 @@ def run_c5(R, args, tag=""):
     scenes, cads, items = c5_corpus()
     radius, level, iters = 0.05, 24, 30
     ctx = _lib.Context(R.local_rank)
+    # queue workers per GPU (visma_icp_run_corpus takes any number of contexts; each has its own stream): while one
+    # worker packs and uploads its next chunk -- and while its one-thread solves run -- the other's searches have the GPU
+    nctx = max(1, int(os.environ.get("VISMA_C5_WORKERS_PER_GPU", "3")))
+    ctxs = [ctx] + [_lib.Context(R.local_rank) for _ in range(nctx - 1)]
     corpus = _lib.Corpus([(cads[c], scenes[s]) for s, c in items], level=level, max_dist=radius, max_iter=iters,
                          rel_fitness=1e-6, rel_rmse=1e-6, chunk=C5_CHUNK)
     nwarm = max(args.warmup, 1)
@@ -844,7 +874,7 @@ def run_c5(R, args, tag=""):
         base = ctypes.addressof(ctypes.c_char.from_buffer(shm.buf))
 
     def one_pass(slot):
-        res = corpus.run([ctx], (base + 8 * slot) if shm is not None else None)
+        res = corpus.run(ctxs, (base + 8 * slot) if shm is not None else None)
         mine = [r for r in res if r[2] >= 0]
         return sum(r[3] for r in mine), len(mine)
 
@@ -906,8 +936,8 @@ def run_c5(R, args, tag=""):
                                        len(scenes), len(cads), len(items), iters, radius),
                        "items": len(items), "search": ctx.search_mode_used(),
                        "parallelism": "replicas only: %d rank(s) pull chunks of %d work items from one atomic counter%s "
-                                      "(visma_icp_run_corpus: native work queue, one host thread per GPU), no collective" % (
-                                          R.world, C5_CHUNK, " in shared memory" if R.world > 1 else "")},
+                                      "(visma_icp_run_corpus: native work queue, %d worker context(s) per GPU), no collective" % (
+                                          R.world, C5_CHUNK, " in shared memory" if R.world > 1 else "", nctx)},
             "registrations_per_sec": len(items) * args.steps / elapsed,
             "items_done_by_rank0": per_rank_items, "items_done_by_all_ranks": total_items,
             "roofline": roofline,
@@ -925,7 +955,8 @@ def run_c5(R, args, tag=""):
             out["cpu_baseline"] = {"value": n_it / dt, "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
                                    "sample": "8 of the %d yaw starts (4 each of two work items), %d iterations each, "
                                              "KD-tree builds included" % (len(items) * level, iters)}
-    ctx.close()
+    for c in ctxs:
+        c.close()
     return out
 
 
