@@ -104,8 +104,15 @@ constexpr int kNcclUint64 = 5;   // ncclUint64
 // another host thread -- the corpus workers) starts threads of its own, as every pass did before.
 class HostPool {
 public:
-    static HostPool &instance() { static HostPool *p = new HostPool(); return *p; }      // (never destroyed: its
-                                                                                         //  threads are parked)
+    // a few pools (never destroyed: their threads are parked): concurrent callers -- several contexts working a
+    // corpus or a scene's batches side by side -- each find one, instead of the second caller starting 16 threads of its
+    // own for every pass (pool 0: up to 31 helpers; the others 15)
+    static constexpr int kPools = 4;
+    static HostPool &instance(int k)
+    {
+        static HostPool *p[kPools] = {new HostPool(32), new HostPool(16), new HostPool(16), new HostPool(16)};
+        return *p[k];
+    }
     int size() const { return (int)workers_; }
     // fn(i) for i in [0, n) on up to `threads` threads including the caller's; false: busy, nothing was run
     template <typename F>
@@ -136,10 +143,10 @@ public:
     }
 
 private:
-    HostPool()
+    explicit HostPool(int max_threads)
     {
         int hc = (int)std::thread::hardware_concurrency();
-        workers_ = (size_t)std::max(0, std::min(hc, 32) - 1);
+        workers_ = (size_t)std::max(0, std::min(hc, max_threads) - 1);
         cv_work_.reset(new std::condition_variable[workers_ ? workers_ : 1]);
         for (size_t w = 0; w < workers_; w++) std::thread([this, w] { loop((int)w); }).detach();
     }
@@ -180,7 +187,8 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
     if (nt < 1) nt = 1;
     if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
     if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
-    if (HostPool::instance().run(n, (int)nt, fn)) return;
+    for (int k = 0; k < HostPool::kPools; k++)
+        if (HostPool::instance(k).run(n, (int)nt, fn)) return;
     if (nt > 16) nt = 16;
     std::vector<std::thread> th;
     std::atomic<int64_t> next(0);
