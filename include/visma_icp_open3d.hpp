@@ -371,7 +371,9 @@ inline Eigen::Matrix4d RegisterModelToScene(const PointCloud &model, const Point
 // once: what the loop body hands to RegisterModelToScene, collected first, registered together by the
 // library's native work queue (visma_icp_run_corpus: one host thread per GPU pulls chunks of pairs, each
 // chunk's rotation_level yaw starts run as one batch), the loop's T3 per pair returned in order.
-// `devices`: GPUs to use (empty = device 0).  Point-to-point estimator (ICP.point_to_plane = false).
+// `devices`: one queue worker (context, own stream) per entry -- the SAME GPU may be listed several times, and should:
+// while one worker packs and uploads its next chunk, the others' searches have the device (three on one GPU: ~1.5x one).
+// Empty = three workers on device 0.  Point-to-point estimator (ICP.point_to_plane = false).
 inline std::vector<Eigen::Matrix4d> RegisterModelsToScenes(
     const std::vector<std::pair<std::shared_ptr<PointCloud>, std::shared_ptr<PointCloud>>> &model_scan_pairs,
     int rotation_level, double distance_threshold, const std::vector<int> &devices = std::vector<int>(),
@@ -391,7 +393,7 @@ inline std::vector<Eigen::Matrix4d> RegisterModelsToScenes(
         items[i].n_scene = (int64_t)sc.points_.size();
     }
     std::vector<visma_icp_ctx *> ctxs;
-    const std::vector<int> devs = devices.empty() ? std::vector<int>(1, 0) : devices;
+    const std::vector<int> devs = devices.empty() ? std::vector<int>(3, 0) : devices;   // (three workers on GPU 0)
     auto destroy_all = [&]() { for (visma_icp_ctx *c : ctxs) visma_icp_destroy(c); };
     for (int d : devs) {
         visma_icp_ctx *c = nullptr;
