@@ -807,7 +807,7 @@ def c5_corpus():
     return scenes, cads, items
 
 
-C5_CHUNK = 8          # work items a rank takes from the counter at a time: 8 x 24 = 192 ICPs in flight per launch
+C5_CHUNK = int(os.environ.get("VISMA_C5_CHUNK", "8"))          # work items a rank takes from the counter at a time: 8 x 24 = 192 ICPs in flight per launch
                       # (measured on one MI355X: 1 item per launch 167 k iterations/s, 2: 326 k, 4: 482 k, 8: 630 k)
 
 
