@@ -143,6 +143,12 @@ VISMA_ICP_API int visma_icp_set_clouds_f64_voxel_target(visma_icp_ctx *ctx, cons
                                                         int src_stride, const double *scene_xyz, int64_t n_scene,
                                                         int scene_stride, double voxel_size, int64_t *nt_out);
 VISMA_ICP_API int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out, int64_t nt);
+/* The max_correspondence_distance the NEXT registration on this context will use (RegistrationICP's third argument,
+ * Registration.h:102-107), told before the clouds are uploaded: visma_icp_set_clouds_f64 then builds the search
+ * structure on the GPU while the host is still staging the source (C4: 0.7 ms of a 3.7 ms registration hidden).
+ * Without a hint the radius of the context's previous registration is assumed; 0 clears the hint.  A wrong value
+ * only costs the wasted build: results never depend on it. */
+VISMA_ICP_API int visma_icp_set_radius_hint(visma_icp_ctx *ctx, double max_correspondence_distance);
 /* feh::ICPRefinement's clouds (src/evaluation.cpp:248-271) made on the device, source side too:
  *   for every model: SamplePointCloudFromMesh(V, F, samples) (include/geometry.h:29-64; visma_icp_sample_mesh's
  *   draws: mesh k uses the stream `seed + k`, reference_quirks as there), PointCloud::Transform(model_to_scene)

@@ -118,10 +118,13 @@ inline const double *xyz(const std::vector<Eigen::Vector3d> &v)
     return v.empty() ? nullptr : v[0].data();
 }
 
+// `radius`: the max_correspondence_distance of the registration that follows (> 0: the library builds its search
+// structure on the GPU while it is still staging the source, visma_icp_set_radius_hint)
 template <typename Cloud>
-inline visma_icp_ctx *upload(const Cloud &source, const Cloud &target, bool normals)
+inline visma_icp_ctx *upload(const Cloud &source, const Cloud &target, bool normals, double radius = 0.0)
 {
     visma_icp_ctx *ctx = ThreadContext::instance().get();
+    if (radius > 0.0) check(ctx, visma_icp_set_radius_hint(ctx, radius), "visma_icp_set_radius_hint");
     check(ctx, visma_icp_set_clouds_f64(ctx, xyz(source.points_), (int64_t)source.points_.size(), 3,
                                         xyz(target.points_), (int64_t)target.points_.size(), 3),
           "visma_icp_set_clouds_f64");
@@ -214,7 +217,7 @@ inline RegistrationResult EvaluateRegistration(
 {
     RegistrationResult result(transformation);
     if (max_correspondence_distance <= 0.0) return result;
-    visma_icp_ctx *ctx = detail::upload(source, target, false);
+    visma_icp_ctx *ctx = detail::upload(source, target, false, max_correspondence_distance);
     double T[16];
     detail::to_rowmajor(transformation, T);
     visma_icp_result r;
@@ -250,7 +253,7 @@ inline RegistrationResult RegistrationICP(
         return RegistrationResult(init);
     }
     RegistrationResult result(init);
-    visma_icp_ctx *ctx = detail::upload(source, target, plane);
+    visma_icp_ctx *ctx = detail::upload(source, target, plane, max_correspondence_distance);
     double T[16];
     detail::to_rowmajor(init, T);
     visma_icp_result r;
@@ -323,7 +326,7 @@ inline Eigen::Matrix4d RegisterModelToScene(const PointCloud &model, const Point
     const bool plane_ready = point_to_plane && model.HasNormals() && scene.HasNormals();
     if ((!point_to_plane || plane_ready) && rotation_level > 0 && distance_threshold > 0.0) {
         // all levels in one library call (the sweep is advanced on the GPU), either estimator
-        visma_icp_ctx *ctx = detail::upload(model, scene, point_to_plane);
+        visma_icp_ctx *ctx = detail::upload(model, scene, point_to_plane, distance_threshold);
         visma_icp_result b;
         int level = -1;
         const ICPConvergenceCriteria c;

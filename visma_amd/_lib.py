@@ -131,6 +131,7 @@ def _bind(L):
     L.visma_icp_set_clouds_meshes_f64.argtypes = [C.c_void_p, C.POINTER(CMeshSource), C.c_int, C.c_int, C.c_uint64, _dp,
                                                   C.c_int64, C.c_int, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.visma_icp_get_mesh_source.argtypes = [C.c_void_p, _dp, C.c_int64]
+    L.visma_icp_set_radius_hint.argtypes = [C.c_void_p, C.c_double]
     L.visma_icp_set_target.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
     L.visma_icp_set_source.argtypes = [C.c_void_p, _fp, C.c_int64, C.c_int]
     L.visma_icp_set_target_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -299,6 +300,10 @@ class Context:
                                                          C.byref(ns), C.byref(nt)))
         self.ns, self.nt = int(ns.value), int(nt.value)
         return self.ns, self.nt
+
+    def set_radius_hint(self, r):
+        """The search radius of the next registration: the next upload builds the grid while it stages the source."""
+        self._chk(self.L.visma_icp_set_radius_hint(self._h, float(r)))
 
     def get_mesh_source(self, ns):
         out = np.empty((int(ns), 3), np.float64)

@@ -301,6 +301,14 @@ int visma_icp_set_clouds_meshes_f64(visma_icp_ctx *ctx, const visma_icp_mesh_sou
     return VISMA_ICP_OK;
 }
 
+int visma_icp_set_radius_hint(visma_icp_ctx *ctx, double max_correspondence_distance)
+{
+    CTX_CHECK();
+    if (!(max_correspondence_distance >= 0.0)) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad radius");
+    ctx->radius_hint = max_correspondence_distance;
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_get_mesh_source(visma_icp_ctx *ctx, double *xyz_out, int64_t ns)
 {
     CTX_CHECK();
@@ -374,6 +382,14 @@ static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns
         raw_source = true;
         ns = *ms->ns_out;
     } else if (raw_target) {
+        // the radius of the coming registration, if known (visma_icp_set_radius_hint, or the last one used): the grid
+        // is built on the stream while the source is staged
+        const double hint = ctx->radius_hint > 0.0 ? ctx->radius_hint : ctx->last_radius;
+        if (hint > 0.0 && ctx->search_precision == 1) {
+            ctx->eng->set_exact(true);
+            rc = ctx->eng->prepare_search(ns, want64 && ctx->eng->supports_device_loop(), hint);
+            if (rc) return ctx->eng_fail(rc);
+        }
         rc = ctx->eng->set_source_f64(src, ns, sstride, c, want64 && ctx->eng->supports_device_loop(), ctx->src_order);
         raw_source = rc == VISMA_ICP_OK;
         if (!raw_source && rc != VISMA_ICP_ERR_STATE) return ctx->eng_fail(rc);

@@ -10,6 +10,8 @@ struct visma_icp_ctx {
     std::unique_ptr<Engine> eng;
     std::string err;
     double centre[3] = {0, 0, 0};
+    double radius_hint = 0.0;         // visma_icp_set_radius_hint: the search radius the next registration will use
+    double last_radius = 0.0;         // ... else the one the last registration used (a caller's loop keeps it)
     int search_precision = 1;         // 0 fp32 search, 1 f64 for small clouds (auto, default), 2 f64 always
     bool fixed_centre = false;        // centre given by the caller (target-sharded ranks share one)
     bool target_sharded = false;
@@ -108,6 +110,7 @@ struct visma_icp_ctx {
         std::memset(out, 0, sizeof(*out));
         std::memcpy(out->transformation, init, sizeof(double) * 16);
         if (!(max_dist > 0.0)) return VISMA_ICP_OK;                 // Registration.cpp:148-151
+        last_radius = max_dist;
         if (plane && !eng->has_normals()) return VISMA_ICP_OK;      // Registration.cpp:152-157
         if (!have_src || !have_tgt) return fail(VISMA_ICP_ERR_STATE, "clouds not set");
         Mat4 Tc = to_centred(Mat4::from(init), centre);

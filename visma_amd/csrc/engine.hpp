@@ -319,6 +319,9 @@ public:
     virtual int set_source_meshes_f64(const MeshSource *, int, int /* quirks */, unsigned long long /* seed */, const double * /* centre */,
                                       bool, std::vector<int32_t> &, int64_t * /* ns */) { return VISMA_ICP_ERR_STATE; }
     virtual int get_mesh_source(double *, int64_t) { return VISMA_ICP_ERR_STATE; }
+    // between the target upload and set_source_f64(ns points, want64): build the search structure for `max_dist` NOW,
+    // on the stream, so that it runs while the host stages the source (HIP engine; others: nothing to do)
+    virtual int prepare_search(int64_t /* ns */, bool /* want64 */, double /* max_dist */) { return VISMA_ICP_OK; }
     virtual int set_source64(const Pt64 *) { return VISMA_ICP_ERR_STATE; }
     // The source likewise: raw f64 up, then expanded, Morton-ordered and gathered on the device (order.hip);
     // `order` receives the original index of the point at every position.
