@@ -117,6 +117,9 @@ public:
             double *pin = reinterpret_cast<double *>(staging(2, (size_t)nt * 6));
             const int64_t nch_all = (nt + kHostChunk - 1) / kHostChunk;
             std::vector<double> part(compute_centre ? (size_t)nch_all * 3 : 0, 0.0);
+            // bounding box of the caller's values, per chunk (the grid build then needs no kernel and no round trip
+            // for it: x -> (float)(x - c) is monotone, so the box of the fp32 target is the image of this one)
+            std::vector<double> lohi((size_t)nch_all * 6);
             const int64_t piece = 1 << 20;                       // (a parallel_for starts its threads anew)
             struct Piece { int64_t lo, hi; bool f32; };
             std::vector<Piece> pieces;
@@ -130,6 +133,18 @@ public:
                     parallel_for(nch, 1, [&](int64_t ch) {
                         const int64_t a = lo + ch * kHostChunk, b = std::min(hi, a + kHostChunk);
                         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                        double lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+                        for (int64_t j = a; j < b; j++) {
+                            const double *q = xyz + (size_t)j * stride;
+                            for (int k = 0; k < 3; k++) {
+                                if (q[k] < lo3[k]) lo3[k] = q[k];
+                                if (q[k] > hi3[k]) hi3[k] = q[k];
+                            }
+                        }
+                        {
+                            const int64_t g = a / kHostChunk;
+                            for (int k = 0; k < 3; k++) { lohi[6 * g + k] = lo3[k]; lohi[6 * g + 3 + k] = hi3[k]; }
+                        }
                         if (as32) {
                             // the piece's fp32 copy lives at the start of its own f64 area of the staging buffer
                             float *f = reinterpret_cast<float *>(pin + 3 * lo) + 3 * (a - lo);
@@ -183,6 +198,14 @@ public:
                                               d_tgt64_ ? (Pt64 *)d_tgt64_ + pc.lo : nullptr, stream_, pc.lo));
             }
             last_upload_f32_ = !pieces.empty() && pieces.back().f32;
+            double lo3[3] = {INFINITY, INFINITY, INFINITY}, hi3[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (int64_t ch = 0; ch < nch_all; ch++)
+                for (int k = 0; k < 3; k++) {
+                    lo3[k] = std::min(lo3[k], lohi[6 * ch + k]);
+                    hi3[k] = std::max(hi3[k], lohi[6 * ch + 3 + k]);
+                }
+            for (int k = 0; k < 3; k++) { host_mn_[k] = (float)(lo3[k] - c[k]); host_mx_[k] = (float)(hi3[k] - c[k]); }
+            host_box_valid_ = std::isfinite(host_mn_[0] + host_mn_[1] + host_mn_[2] + host_mx_[0] + host_mx_[1] + host_mx_[2]);
         } else if (compute_centre) {
             c[0] = c[1] = c[2] = 0.0;
         }
@@ -190,6 +213,8 @@ public:
         return VISMA_ICP_OK;
     }
     bool last_upload_f32_ = false;   // (reported by VISMA_ICP_UPLOAD_TRACE)
+    bool host_box_valid_ = false;    // the fp32 target's bounding box is known from the staging pass
+    float host_mn_[3] = {0, 0, 0}, host_mx_[3] = {0, 0, 0};
 
     // open3d::VoxelDownSample(scene, voxel) (O3D/Core/Geometry/DownSample.cpp:179-220) + the target upload of
     // RegistrationICP as ONE step (src/evaluation.cpp:258-271, src/annotation.cpp:112): the scene goes up once, is
@@ -1645,6 +1670,7 @@ private:
         if (nt > 0x7fffffff - 4096) { err_ = "target too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
         free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         has_normals_ = false;
+        host_box_valid_ = false;
         // pad to a whole number of LDS chunks with +inf points (never accepted)
         nt_pad_ = ((nt + kTChunk - 1) / kTChunk) * kTChunk;
         if (nt_pad_ == 0) nt_pad_ = kTChunk;
@@ -1697,13 +1723,24 @@ private:
     {
         int e0 = -1;
         if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-        if (!d_box_) HIP_TRY(hipMalloc(&d_box_, sizeof(unsigned) * 8));
-        HIP_TRY(launch_grid_bbox((const float4 *)d_tgt_, nt_, (unsigned *)d_box_, stream_));
-        unsigned box[6];
-        HIP_TRY(hipMemcpyAsync(box, d_box_, sizeof(box), hipMemcpyDeviceToHost, stream_));
-        HIP_TRY(hipStreamSynchronize(stream_));
         float mn[3], mx[3];
-        grid_decode_bbox(box, mn, mx);
+        static const bool check_box = std::getenv("VISMA_ICP_CHECK_BOX") != nullptr;   // (tests: both ways, must agree)
+        if (!host_box_valid_ || check_box) {
+            if (!d_box_) HIP_TRY(hipMalloc(&d_box_, sizeof(unsigned) * 8));
+            HIP_TRY(launch_grid_bbox((const float4 *)d_tgt_, nt_, (unsigned *)d_box_, stream_));
+            unsigned box[6];
+            HIP_TRY(hipMemcpyAsync(box, d_box_, sizeof(box), hipMemcpyDeviceToHost, stream_));
+            HIP_TRY(hipStreamSynchronize(stream_));
+            grid_decode_bbox(box, mn, mx);
+            if (host_box_valid_ && (std::memcmp(mn, host_mn_, sizeof(mn)) != 0 || std::memcmp(mx, host_mx_, sizeof(mx)) != 0)) {
+                err_ = "bounding box from the staging pass differs from the device's";
+                return VISMA_ICP_ERR_ENGINE;
+            }
+        } else {
+            // (known from the upload's staging pass: no kernel, no round trip)
+            std::memcpy(mn, host_mn_, sizeof(mn));
+            std::memcpy(mx, host_mx_, sizeof(mx));
+        }
         grid_ = grid_plan(mn, mx, max_dist, kGridMaxCells, grid_sub_);
         if ((int64_t)nt_ > sorted_cap_) {
             free_dev(d_sorted_); free_dev(d_cell_of_);
