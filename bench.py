@@ -807,8 +807,9 @@ def c5_corpus():
     return scenes, cads, items
 
 
-C5_CHUNK = int(os.environ.get("VISMA_C5_CHUNK", "8"))          # work items a rank takes from the counter at a time: 8 x 24 = 192 ICPs in flight per launch
-                      # (measured on one MI355X: 1 item per launch 167 k iterations/s, 2: 326 k, 4: 482 k, 8: 630 k)
+C5_CHUNK = int(os.environ.get("VISMA_C5_CHUNK", "16"))         # work items a worker takes from the counter at a time: 16 x 24 = 384 ICPs in flight per launch
+                      # (measured on one MI355X, round 2, one worker: 1 item per launch 167 k iterations/s, 2: 326 k, 4: 482 k,
+                      #  8: 630 k; round 3, three workers per GPU: 4: 1.80 M, 8: 2.02 M, 12: 2.08 M, 16: 2.17 M, 24: 2.02 M)
 
 
 def c5_chunk_problems(scenes, cads, chunk_items, radius, level):
