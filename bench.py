@@ -705,24 +705,13 @@ def run_c3(R, args):
     ctxs = [_lib.Context(R.local_rank) for _ in range(W)]
     ctx = ctxs[0]
     iters = 30
-    parts = [set(mine_order[w::W]) for w in range(W)]
-    batches, part_queries = [], []
-    for w in range(W):
-        pw = [p[:4] for p in probs if p[4] in parts[w]]
-        part_queries.append(sum(len(p[0]) for p in pw))
-        batches.append(ctxs[w].make_batch(pw))     # the C array of problems, built once (not part of a step)
-    my_queries = part_queries[0]
-
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=W)
+    my = [p[:4] for p in probs if p[4] in mine]
+    batch = ctx.make_batch(my)                  # the C array of problems, built once (not part of a step)
 
     def one_step():
-        # (ctypes releases the GIL for the duration of visma_icp_run_batch)
-        futs = [pool.submit(ctxs[w].run_batch, batches[w], iters) for w in range(1, W)]
-        res = list(ctxs[0].run_batch(batches[0], max_iter=iters))
-        for f in futs:
-            res += list(f.result())
-        return res
+        # visma_icp_run_batch_multi: problems over the same target stay together, the groups go to the W worker
+        # contexts by size, every worker runs its share as one batch on its own host thread and stream
+        return _lib.run_batch_multi(ctxs, batch, max_iter=iters)
 
     for _ in range(max(args.warmup, 1)):
         one_step()
@@ -734,19 +723,21 @@ def run_c3(R, args):
         its += sum(r.iterations for r in res)
     R.barrier_sync()
     elapsed = R.reduce_max(time.perf_counter() - t0)
-    # the search launches of ONE worker's batch, alone on the GPU, timed by HIP events (after the timed region)
+    # the search launches of the WHOLE batch on one context, alone on the GPU, timed by HIP events (after the timed
+    # region)
     ctx.set_profiling(1)
     ctx.get_timing(reset=True)
-    ctx.run_batch(batches[0], max_iter=iters)
+    ctx.run_batch(batch, max_iter=iters)
     tm = ctx.get_timing(reset=True)
     ctx.set_profiling(0)
+    my_queries = sum(len(p[0]) for p in my)
     total_its = R.reduce_sum(float(its))
     nl = max(tm["nn_launches"], 1)
     nn_ms = R.reduce_max(tm["nn_ms"] / nl)
     out = None
     if R.rank == 0:
         queries = my_queries
-        nt_total = sum(len(objs[i][1]) for i in parts[0])
+        nt_total = sum(len(objs[i][1]) for i in mine)
         roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True,
                                  "warm" if ctx.search_kernel_used() == "warm" else "serial")
         roofline["launches_timed"] = tm["nn_launches"]
@@ -760,7 +751,7 @@ def run_c3(R, args):
                        "problems": len(probs), "source_points_per_pass": sum(len(p[0]) for p in probs),
                        "search": ctx.search_mode_used(),
                        "parallelism": "replicas only: objects dealt round-robin by size over %d rank(s) x %d worker context(s) "
-                                      "per GPU (each its own stream, batches side by side), no collective" % (R.world, W)},
+                                      "per GPU (visma_icp_run_batch_multi: each its own stream and host thread, shares side by side), no collective" % (R.world, W)},
             "problems_per_sec": len(probs) * args.steps / elapsed,
             "roofline": roofline,
         }
@@ -784,7 +775,6 @@ def run_c3(R, args):
                                    "sample": "6 of the 288 problems, %d iterations each, one after another "
                                              "(KD-tree builds included)" % iters,
                                    "gpu_vs_cpu_rel_frobenius": worst}
-    pool.shutdown()
     for c in ctxs:
         c.close()
     return out

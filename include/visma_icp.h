@@ -284,6 +284,14 @@ VISMA_ICP_API int visma_icp_run_batch(visma_icp_ctx *ctx, const visma_icp_proble
                                       int n, int max_iter, double rel_fitness,
                                       double rel_rmse, int solver,
                                       visma_icp_result *out);
+/* The same batch over several WORKER contexts (any number on the same GPU -- each has its own stream -- and/or on
+ * several GPUs): problems that pass the same target cloud stay together, the groups are dealt to the contexts by
+ * size, every context runs its share as one visma_icp_run_batch on its own host thread, the shares side by side:
+ * while one worker packs, uploads or solves, the others' searches have the GPU (config 3 on one MI355X: two workers
+ * ~1.15x one).  out[] equals the single-context call's.  Returns the first error (message in errbuf). */
+VISMA_ICP_API int visma_icp_run_batch_multi(visma_icp_ctx *const *ctxs, int n_ctx, const visma_icp_problem *probs, int n,
+                                            int max_iter, double rel_fitness, double rel_rmse, int solver,
+                                            visma_icp_result *out, char *errbuf, size_t errbuf_len);
 /* The same with the point-to-plane estimator (TransformationEstimationPointToPlane,
  * O3D/Core/Registration/TransformationEstimation.cpp:101-134): tgt_normals[i] are the normals of
  * probs[i].tgt_xyz (AoS f64, stride 3; the same pointer wherever the same target pointer is

@@ -115,3 +115,30 @@ def test_batch_point_to_plane_without_normals_returns_the_initial_transform(lib)
     got = ctx.run_batch_point_to_plane([(src, tgt, nrm, init, r), (src, tgt.copy(), None, init, r)], max_iter=5)
     assert got[0].num_correspondences > 0 and not np.allclose(got[0].transformation_, init)
     assert np.array_equal(got[1].transformation_, init)          # Registration.cpp:152-157
+
+
+def test_abi_exports_the_multi_context_batch(lib):
+    assert hasattr(lib.load(), "visma_icp_run_batch_multi")
+
+
+@pytest.mark.gpu
+def test_batch_over_worker_contexts_equals_one_context(lib):
+    """visma_icp_run_batch_multi: the problems dealt (targets kept together) to 1, 2 and 3 contexts on the same GPU,
+    shares side by side -- every problem's result is the single-context batch's, bit for bit."""
+    from visma_amd import _lib, synth
+    rng = np.random.default_rng(5)
+    probs = []
+    for k, (ns, nt) in enumerate(((3000, 9000), (7000, 5000), (1500, 12000), (5000, 5000), (900, 700))):
+        src, tgt, T_gt, _ = synth.make_pair(ns, nt, seed_t=30 + k, seed_s=60 + k, motion="fixed")
+        for yaw in (0.0, 0.2, -0.3):
+            probs.append((src, tgt, synth.make_T(synth.rot_y(yaw), rng.normal(size=3) * 0.01), 0.05 + 0.01 * k))
+    ctxs = [_lib.Context(0) for _ in range(3)]
+    want = ctxs[0].run_batch(probs, max_iter=15)
+    for W in (1, 2, 3):
+        got = _lib.run_batch_multi(ctxs[:W], probs, max_iter=15)
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a.num_correspondences == b.num_correspondences and a.iterations == b.iterations
+            assert np.array_equal(a.transformation_, b.transformation_)
+    for c in ctxs:
+        c.close()

@@ -139,6 +139,8 @@ def _bind(L):
     L.visma_icp_set_target_normals_f64.argtypes = [C.c_void_p, _dp, C.c_int64, C.c_int]
     L.visma_icp_get_search_kernel_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_forget_winners.argtypes = [C.c_void_p]
+    L.visma_icp_run_batch_multi.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CProblem), C.c_int, C.c_int, C.c_double,
+                                            C.c_double, C.c_int, C.POINTER(CResult), C.c_char_p, C.c_size_t]
     L.visma_icp_run_corpus.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(CCorpusItem), C.c_int64,
                                        C.POINTER(CCorpusParams), C.POINTER(C.c_int64), C.POINTER(CCorpusResult),
                                        C.c_char_p, C.c_size_t]
@@ -644,6 +646,21 @@ class Corpus:
             raise IcpError(rc, err.value.decode(errors="replace"))
         return [(Result(self.results[i].best), int(self.results[i].best_level), int(self.results[i].device),
                  int(self.results[i].iterations_all_starts)) for i in range(self.n)]
+
+
+def run_batch_multi(ctxs, problems, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, solver=SOLVER_KABSCH):
+    """visma_icp_run_batch_multi: one batch over several worker contexts (same GPU or several).  problems: the value
+    of Context.make_batch() (or a list of (src, tgt, init, radius) tuples) -> list of Result."""
+    L = load()
+    arr, n, _keep, out = problems if (isinstance(problems, tuple) and len(problems) == 4 and
+                                      isinstance(problems[1], int)) else ctxs[0].make_batch(problems)
+    h = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    err = C.create_string_buffer(512)
+    rc = L.visma_icp_run_batch_multi(h, len(ctxs), arr, n, int(max_iter), float(rel_fitness), float(rel_rmse), int(solver),
+                                     out, err, 512)
+    if rc != 0:
+        raise IcpError(rc, err.value.decode(errors="replace"))
+    return [Result(out[i]) for i in range(n)]
 
 
 def device_count():

@@ -4,6 +4,7 @@
 // (src/annotation.cpp:29-64) when there are many objects: one host thread per context (= per GPU) pulls
 // chunks of items from an atomic counter and runs each chunk's yaw starts as ONE batch on its GPU.  Built on
 // the public C ABI only (visma_icp_run_batch); nothing here touches HIP.
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -122,4 +123,71 @@ extern "C" int visma_icp_run_corpus(visma_icp_ctx *const *ctxs, int n_ctx, const
     for (auto &t : th) t.join();
     if (s.rc != VISMA_ICP_OK && errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "%s", s.err.c_str());
     return s.rc;
+}
+
+// ---- one batch of problems over several worker contexts (BASELINE config 3: all objects of one scene) -----------
+// Problems that pass the same target cloud stay together (they share one upload and one grid inside
+// visma_icp_run_batch); the groups are dealt to the contexts largest first, each to the least loaded one; every
+// context runs its share as ONE visma_icp_run_batch on its own stream and host thread, the shares side by side.
+// A problem's result does not depend on what else is in its batch, so out[] equals the single-context call's.
+extern "C" int visma_icp_run_batch_multi(visma_icp_ctx *const *ctxs, int n_ctx, const visma_icp_problem *probs, int n,
+                                         int max_iter, double rel_fitness, double rel_rmse, int solver,
+                                         visma_icp_result *out, char *errbuf, size_t errbuf_len)
+{
+    auto bad = [&](const char *m) {
+        if (errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "%s", m);
+        return (int)VISMA_ICP_ERR_INVALID;
+    };
+    if (errbuf && errbuf_len) errbuf[0] = 0;
+    if (!ctxs || n_ctx < 1 || n < 0 || (n > 0 && (!probs || !out))) return bad("bad batch arguments");
+    for (int w = 0; w < n_ctx; w++)
+        if (!ctxs[w]) return bad("NULL context");
+    if (n == 0) return VISMA_ICP_OK;
+    // groups of problems over the same target
+    struct Group { const double *tgt; int64_t nt; double work; std::vector<int> members; };
+    std::vector<Group> groups;
+    for (int i = 0; i < n; i++) {
+        size_t g = 0;
+        for (; g < groups.size(); g++)
+            if (groups[g].tgt == probs[i].tgt_xyz && groups[g].nt == probs[i].nt) break;
+        if (g == groups.size()) groups.push_back(Group{probs[i].tgt_xyz, probs[i].nt, 0.0, {}});
+        groups[g].members.push_back(i);
+        groups[g].work += (double)probs[i].ns;
+    }
+    std::vector<size_t> order(groups.size());
+    for (size_t g = 0; g < order.size(); g++) order[g] = g;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return groups[a].work > groups[b].work; });
+    const int W = (int)std::min<size_t>((size_t)n_ctx, groups.size());
+    std::vector<std::vector<int>> share((size_t)W);
+    std::vector<double> load((size_t)W, 0.0);
+    for (size_t g : order) {
+        int best = 0;
+        for (int w = 1; w < W; w++)
+            if (load[(size_t)w] < load[(size_t)best]) best = w;
+        share[(size_t)best].insert(share[(size_t)best].end(), groups[g].members.begin(), groups[g].members.end());
+        load[(size_t)best] += groups[g].work;
+    }
+    std::mutex mu;
+    int rc_all = VISMA_ICP_OK;
+    std::string err;
+    auto run_share = [&](int w) {
+        std::vector<int> &idx = share[(size_t)w];
+        std::sort(idx.begin(), idx.end());                       // (the caller's order inside a share)
+        std::vector<visma_icp_problem> p(idx.size());
+        std::vector<visma_icp_result> r(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) p[k] = probs[idx[k]];
+        const int rc = visma_icp_run_batch(ctxs[w], p.data(), (int)p.size(), max_iter, rel_fitness, rel_rmse, solver, r.data());
+        if (rc != VISMA_ICP_OK) {
+            std::lock_guard<std::mutex> g(mu);
+            if (rc_all == VISMA_ICP_OK) { rc_all = rc; err = visma_icp_last_error(ctxs[w]); }
+            return;
+        }
+        for (size_t k = 0; k < idx.size(); k++) out[idx[k]] = r[k];
+    };
+    std::vector<std::thread> th;
+    for (int w = 1; w < W; w++) th.emplace_back(run_share, w);
+    run_share(0);                                               // the calling thread drives context 0
+    for (auto &t : th) t.join();
+    if (rc_all != VISMA_ICP_OK && errbuf && errbuf_len) std::snprintf(errbuf, errbuf_len, "%s", err.c_str());
+    return rc_all;
 }
