@@ -330,7 +330,8 @@ __device__ __forceinline__ void coop_body(
                         const unsigned cnt = meta[u] >> 16;
                         const float4 p = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_qp) + (meta[u] & 0xFFF0u));
                         float d = sqdist_f32(make_float4(c4[u].x, c4[u].y, c4[u].z, 0.f), p.x, p.y, p.z);
-                        d = (unsigned)l8 < cnt ? d : INFINITY;
+                        const bool mine = (unsigned)l8 < cnt;            // (lane 0 of the octet: the chunk exists)
+                        d = mine ? d : INFINITY;
                         const float m = octet_min(d);
                         // (a lane past the chunk's end holds +inf: never within m + W of a finite minimum; a null
                         //  descriptor's result is not stored)
@@ -338,7 +339,7 @@ __device__ __forceinline__ void coop_body(
                         const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
                         // the result takes the place of the descriptor's second word: the chunk minimum rounded DOWN to
                         // 16 mantissa bits | the flag byte (the first word, the chunk's position, stays)
-                        if (l8 == 0 && cnt) items[t + u * 8 + oct].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
+                        if (l8 == 0 && mine) items[t + u * 8 + oct].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
