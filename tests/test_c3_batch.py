@@ -142,3 +142,25 @@ def test_batch_over_worker_contexts_equals_one_context(lib):
             assert np.array_equal(a.transformation_, b.transformation_)
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_batch_over_worker_contexts_edge_cases(lib):
+    """more contexts than target groups, an empty batch, a failing share (message comes back)"""
+    src, tgt, _, _ = synth.make_pair(2000, 4000, seed_t=3, seed_s=4, motion="fixed")
+    ctxs = [_lib.Context(0) for _ in range(3)]
+    probs = [(src, tgt, synth.make_T(synth.rot_y(0.1 * k), [0, 0, 0]), 0.05) for k in range(4)]   # ONE target group
+    want = ctxs[0].run_batch(probs, max_iter=8)
+    got = _lib.run_batch_multi(ctxs, probs, max_iter=8)              # only one context gets work
+    for a, b in zip(got, want):
+        assert np.array_equal(a.transformation_, b.transformation_) and a.num_correspondences == b.num_correspondences
+    assert _lib.run_batch_multi(ctxs, [], max_iter=8) == []
+    L = _lib.load()
+    import ctypes as C
+    h = (C.c_void_p * 2)(ctxs[0]._h, None)
+    err = C.create_string_buffer(256)
+    arr, n, _keep, out = ctxs[0].make_batch(probs)
+    assert L.visma_icp_run_batch_multi(h, 2, arr, n, 8, 1e-6, 1e-6, 0, out, err, 256) != 0 and b"NULL context" in err.value
+    assert L.visma_icp_run_batch_multi(h, 1, arr, n, 8, 1e-6, 1e-6, 99, out, err, 256) != 0 and len(err.value) > 0   # unknown solver
+    for c in ctxs:
+        c.close()
