@@ -104,6 +104,8 @@ typedef struct {
     double tile_phase_cycles[7];     /* shader cycles per workgroup phase, summed over workgroups: source + transform,
                                         run bounds + footprint rows + scan, tile streaming, search + re-rank,
                                         winner fetch, moments + row; [6] unused */
+    double grid_certified;           /* queries of profiled passes whose previous winner was CERTIFIED unchanged (no search:
+                                        the warm-started kernel's triangle-inequality test, visma_amd/csrc/grid_coop.hip) */
 } visma_icp_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
     const ProbDesc *__restrict__ descs, int nprob, const Pt64 *__restrict__ src64 = nullptr,
     const Pt64 *__restrict__ sorted64 = nullptr, double r2d = 0.0, const Pt64 *__restrict__ nrm64 = nullptr,
     const FoldArgs fold = FoldArgs{}, double *__restrict__ d64_out = nullptr,
-    float4 *__restrict__ prevq_out = nullptr)
+    Pt64 *__restrict__ prevq_out = nullptr)
 {
     static_assert(!(F64 && HYB), "F64 and HYB are different searches");
     // The exact search only ranks with the fp32 copy (the winner's index comes from the f64 copy), so it
@@ -878,9 +878,13 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         if (sub == 0) {
             if constexpr (HYB) {
                 if (prevq_out) {
-                    float4 w4 = make_float4(NAN, NAN, NAN, 0.f);
-                    if (bpos != 0xFFFFFFFFu) { const P12 t = s12[bpos]; w4 = make_float4(t.x, t.y, t.z, 0.f); }
-                    prevq_out[i] = w4;
+                    // the state of grid_coop.hip: the winner's f64 point, original index | LB << 32 with LB = 0
+                    // (this kernel bounds no runner-up: the next pass searches, and leaves a bound)
+                    Pt64 w8;
+                    w8.x = w8.y = w8.z = __longlong_as_double(-1ll);
+                    w8.w = 0xFFFFFFFFull;
+                    if (bpos != 0xFFFFFFFFu) { w8 = sorted64[bpos]; w8.w &= 0xFFFFFFFFull; }
+                    prevq_out[i] = w8;
                 }
             }
             if constexpr (S64) {
@@ -936,7 +940,7 @@ static void launch_grid_t(int nblocks, hipStream_t stream, const float4 *src, in
                           const Offset64 &off, float r2f, int *idx_out, float *d2_out,
                           double *partials, unsigned long long *cand, const DevIcpState *st,
                           int nprob, long long out_stride, const Pt64 *src64, const Pt64 *sorted64, double r2d,
-                          const Pt64 *nrm64, int exact, const FoldArgs &fold, double *d64_out, float4 *prevq_out)
+                          const Pt64 *nrm64, int exact, const FoldArgs &fold, double *d64_out, Pt64 *prevq_out)
 {
     // one query per lane? (see ONE above)
     const long long total_groups = (long long)nblocks * (kBlock / G);
@@ -965,7 +969,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  unsigned long long *cand_count, const DevIcpState *st,
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
                                  const Pt64 *sorted64, double r2d, const Pt64 *nrm64, int exact,
-                                 const FoldArgs *fold, double *d64_out, float4 *prevq_io, int warm)
+                                 const FoldArgs *fold, double *d64_out, Pt64 *prevq_io, int warm, const Xform64 *Tprev)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     Offset64 off;
@@ -984,7 +988,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
             hipError_t e = launch_nn_coop(nblocks * nprob, nblocks, nprob, nullptr, (int)ns, (const float *)sorted, start, g,
                                           tgt_normals, nrm64, T64, off, r2f, point_to_plane, one ? 1 : 0, idx_out, d2_out,
                                           partials, cand_count, st, (long long)out_stride, src64, sorted64, fa, d64_out,
-                                          prevq_io, warm, stream);
+                                          prevq_io, warm, stream, Tprev);
             if (nblocks_out) *nblocks_out = nblocks;
             return e;
         }
@@ -1019,7 +1023,7 @@ static void launch_grid_batch_t(int total_blocks, hipStream_t stream, const floa
                                 int nprob, int *idx_out, float *d2_out, double *partials,
                                 const DevIcpState *st, const Pt64 *src64, const Pt64 *sorted64, const FoldArgs &fold,
                                 unsigned long long *cand, const float4 *nrm = nullptr, const Pt64 *nrm64 = nullptr,
-                                float4 *prevq_out = nullptr)
+                                Pt64 *prevq_out = nullptr)
 {
     const Xform32 T32{};
     const Xform64 T64{};
@@ -1040,7 +1044,7 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        int lanes_per_query, int one_per_lane, const DevIcpState *st,
                                        hipStream_t stream, const Pt64 *src64, const Pt64 *sorted64, int exact,
                                        const FoldArgs *fold, unsigned long long *cand_count,
-                                       const float4 *nrm, const Pt64 *nrm64, float4 *prevq_io, int warm)
+                                       const float4 *nrm, const Pt64 *nrm64, Pt64 *prevq_io, int warm)
 {
     if (!st || !descs || (src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     const bool plane = nrm != nullptr || nrm64 != nullptr;

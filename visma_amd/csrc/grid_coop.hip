@@ -11,7 +11,7 @@
 //
 // Two changes, both exact:
 //  * WARM START.  ICP asks the same queries again after a small motion.  The previous pass's winner
-//    (prevq_io: its fp32 coordinates, 16 bytes per query, streamed in with the source point) gives
+//    (wst_io: its f64 point, 32 bytes per query, streamed in with the source point; ranked on as fp32) gives
 //    d_ub = |p - q_prev|^2 BEFORE anything is gathered, so ALL pruning happens up front and per CELL: only
 //    the rows whose slab reaches within d_ub are looked up in the cell table (1.9 of 9), and of their cells
 //    only those whose slab bound (same margins as the lane-serial kernel) does not exceed d_ub are listed
@@ -26,6 +26,19 @@
 //    octet in flight).
 // A query's chain is  source + previous winner -> row bounds -> chunks -> f64 winner:  4 dependent trips
 // instead of ~17.
+//  * CERTIFICATE (round 4).  The per-query state is the winner's f64 point (x, y, z, original index) and, in the
+//    upper half of its last word, LB: a lower bound of the distance from the query AS IT STOOD to every target
+//    point BUT the winner (to every target point when the query had no partner).  A full search leaves it behind:
+//    the smallest of (a) the second-best examined candidate (second chunk minimum, and the best non-flagged
+//    candidate of every chunk), (b) the slab bounds of the cells of the 27 that were not listed, (c) the distance
+//    to the outside of the 27 cells (or to the grid's bounding box for a query far from it), less the rounding
+//    band.  The next pass moves the query by delta = |T s - T_prev s| (computed per query), so every other target
+//    point is still at least t = LB - delta away (triangle inequality); if the old winner's NEW distance --
+//    the reference's f64 arithmetic -- is inside the radius and below t, it is the unique nearest neighbour again:
+//    no cell-table row, no chunk, no gather -- source + state in (64 B), distance + state word out.  A query
+//    without a partner stays without one when t exceeds the radius.  ICP's motion shrinks geometrically: after a
+//    few iterations almost every query certifies and the pass streams.  LB <- t; anything else runs the search
+//    below and renews LB.  Near-ties (more than one flagged candidate, a re-scan) leave LB = 0: never certified.
 //
 // Exactness without per-candidate top-2 bookkeeping: the eight lanes of a chunk reduce
 // their fp32 d2 to the chunk minimum m (three DPP steps) and flag every candidate with d2 <= m + W, W an
@@ -91,7 +104,7 @@ __device__ __forceinline__ void coop_body(
     const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,
     int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,
     const Pt64 *__restrict__ nrm64, const FoldArgs &fold, double *__restrict__ d64_out,
-    float4 *__restrict__ prevq_io, int warm)
+    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev)
 {
     constexpr int NACC = Acc<PLANE>::N;
     const P12 *s12 = reinterpret_cast<const P12 *>(s12f);
@@ -127,7 +140,7 @@ __device__ __forceinline__ void coop_body(
         out_stride = 0;
         idx_out += d.out_off;
         d2_out += d.out_off;
-        prevq_io += d.out_off;
+        wst_io += d.out_off;
     } else {
         prob = blockIdx.x / bpp;
         lb = blockIdx.x - prob * bpp;
@@ -137,16 +150,26 @@ __device__ __forceinline__ void coop_body(
     {
         Xform32 T32_unused;
         if (!load_loop_state(st, T32_unused, T64, off, r2f)) return;
+        if (st) {
+            // device-resident loop: the transform of the previous pass travels with the state (advance_state)
+            warm &= ~4;
+            if (st->have_prev && !(warm & 8)) {              // (warm & 8: certificates switched off, A/B timing)
+                warm |= 4;
+#pragma unroll
+                for (int k = 0; k < 12; k++) Tprev.m[k] = st->Tc_prev[k];
+            }
+        }
+        if (!(warm & 1)) warm &= ~4;
     }
     const double r2d = (double)r2f;                         // (double)(float)(r*r): KDTreeFlann.cpp:184-185
     COOP_PROBE_BEGIN();
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
-    prevq_io += (long long)prob * out_stride;
+    wst_io += (long long)prob * out_stride;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
-    unsigned ncand = 0, ncand_all = 0;
+    unsigned ncand = 0, ncand_all = 0, ncert = 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int oct = lane >> 3, l8 = lane & 7;
@@ -162,26 +185,43 @@ __device__ __forceinline__ void coop_body(
     __shared__ float4 s_qp[kBlock];                         // (px, py, pz, W) of the query of each lane
     __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, completed by chunk results (+ 64 null
                                                             // descriptors behind the last one: the list is read unguarded)
+    __shared__ float s_sec[kBlock / 64][kCoopCap + 64];     // per chunk: its best candidate OUTSIDE the rounding band
     uint2 *items = s_item[wave];
+    float *secs = s_sec[wave];
 
-    // one query (or none: the lanes past the end still work on the others' chunks)
-    auto query = [&](long long i, bool active) {
-        // ---- the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
-        Pt64 s8 = Pt64{0.0, 0.0, 0.0, 0ull};
-        float4 qprev = make_float4(NAN, NAN, NAN, 0.f);     // the previous pass's winner (fp32 view), NaN = none
+    // outputs + moments of one query: the correspondence, the state for the next pass, the Jacobian / residual moments
+    auto finish = [&](long long i, bool active, bool cert, double pxd, double pyd, double pzd, double bd, unsigned bidx,
+                      bool found, double qx, double qy, double qz, float lb_new) {
         if (active) {
-            s8 = src64[i];
-            if (warm & 1) qprev = prevq_io[i];
+            const unsigned long long lbw = (unsigned long long)__float_as_uint(lb_new) << 32;
+            idx_out[i] = found ? (int)bidx : -1;             // (also when certified: later stages may reuse the array)
+            if (cert) {
+                // (winner unchanged: only the bound moves)
+                reinterpret_cast<unsigned *>(&wst_io[i].w)[1] = __float_as_uint(lb_new);
+            } else {
+                Pt64 o8;
+                o8.x = o8.y = o8.z = __longlong_as_double(-1ll);
+                o8.w = 0xFFFFFFFFull | lbw;
+                if (found) { o8.x = qx; o8.y = qy; o8.z = qz; o8.w = (unsigned long long)bidx | lbw; }
+                wst_io[i] = o8;
+            }
+            d2_out[i] = (float)bd;
+            if (d64_out) d64_out[i] = bd;                    // (target-sharded ranks compare shards in f64)
+            if (found) {
+                double nx = 0.0, ny = 0.0, nz = 0.0;
+                if (PLANE) {
+                    if (nrm64) { const Pt64 n8 = nrm64[bidx]; nx = n8.x; ny = n8.y; nz = n8.z; }
+                    else { const float4 n4 = nrm[bidx]; nx = n4.x; ny = n4.y; nz = n4.z; }
+                }
+                accumulate_pq_d<PLANE>(acc, pxd, pyd, pzd, qx, qy, qz, nx, ny, nz, off);
+            }
         }
-        // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
-        double pd[3];
-        {
-            const double sv[3] = {s8.x, s8.y, s8.z};
-            se3_act(T64.m, sv, pd);
-        }
-        const double pxd = pd[0], pyd = pd[1], pzd = pd[2];
-        const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
-        COOP_PHASE(0, 0u, px + py + pz + qprev.x + qprev.y + qprev.z);   // source + previous winner arrived
+    };
+    // ---- The slot ranges of the query at (px, py, pz) that can hold a candidate at or within the squared fp32 distance
+    // bound0: xb[k] .. xe[k] of row k = (dy, dz) of the 3 x 3 x 3 cells around it, and lbgeo2, a lower bound (squared) of
+    // the distance to every target point that lies in NONE of those ranges.  `want`: this lane looks its rows up at all.
+    auto list_rows = [&](const float px, const float py, const float pz, const float E, const float bound0, const bool want,
+                         unsigned (&xb)[9], unsigned (&xe)[9], float &lbgeo2, unsigned &looked) {
         const int cx = cell_coord(px, g.mn[0], g.inv_h, g.dim[0]);
         const int cy = cell_coord(py, g.mn[1], g.inv_hs, g.dim[1]);
         const int cz = cell_coord(pz, g.mn[2], g.inv_hs, g.dim[2]);
@@ -193,21 +233,12 @@ __device__ __forceinline__ void coop_body(
         const bool yok[3] = {cy - 1 >= 0 && cy - 1 < g.dim[1], cy >= 0 && cy < g.dim[1], cy + 1 >= 0 && cy + 1 < g.dim[1]};
         const bool zok[3] = {cz - 1 >= 0 && cz - 1 < g.dim[2], cz >= 0 && cz < g.dim[2], cz + 1 >= 0 && cz + 1 < g.dim[2]};
         const int row_c = (cz * g.dim[1] + cy) * g.dim[0] + x0, pitch_y = g.dim[0], pitch_z = g.dim[1] * g.dim[0];
-        auto load_row = [&](int k, bool want) {
-            const bool ok = want && span > 0 && zok[k / 3] && yok[k % 3];
+        auto load_row = [&](int k, bool wanted) {
+            const bool ok = wanted && span > 0 && zok[k / 3] && yok[k % 3];
             u4a v = {0u, 0u, 0u, 0u};
             if (ok) v = *reinterpret_cast<const u4a *>(reinterpret_cast<const char *>(start) + (unsigned)(row_c + (k / 3 - 1) * pitch_z + (k % 3 - 1) * pitch_y) * 4u);
             return v;
         };
-        // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
-        // which a candidate cannot be accepted in f64; W >= band(m) - m for every m < L
-        const float r_f = sqrtf(r2f);
-        const float rup = r_f * (1.0f + 2.4e-7f);
-        const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
-        const float tlim = rup + 2.0f * E;
-        const float L = tlim * tlim * (1.0f + 6e-7f);
-        const float W = (4.0f * E * tlim + 4.0f * E * E) * (1.0f + 1e-6f) + L * 5e-7f;
-        s_qp[tid] = make_float4(px, py, pz, W);
         // slab distances (in cells) of the neighbouring rows / cells, margins as in nn_grid_reduce_kernel
         const float fx = (px - g.mn[0]) * g.inv_h - (float)cx;
         const float fy = (py - g.mn[1]) * g.inv_hs - (float)cy;
@@ -217,43 +248,62 @@ __device__ __forceinline__ void coop_body(
         const float lo_y = fmaxf(fy - mgn, 0.f), hi_y = fmaxf(1.0f - fy - mgn, 0.f);
         const float lo_z = fmaxf(fz - mgn, 0.f), hi_z = fmaxf(1.0f - fz - mgn, 0.f);
         const float h2 = g.hs * g.hs * (1.0f - 1e-5f);
-        float exq[3];
+        // LB, geometric part: what everything outside the 27 cells is at least away (squared): one cell plus the
+        // nearest face of the own cell; a query far outside the grid's bounding box (clamped cell coordinate): its
+        // distance to the box, in cells (same fp32 binning, same margin).  The cells NOT listed: pruned2 below.
+        float out2;
+        {
+            const float face = fminf(fminf(fminf(lo_x, hi_x), fminf(lo_y, hi_y)), fminf(lo_z, hi_z));
+            const float ux = fx + (float)cx, uy = fy + (float)cy, uz = fz + (float)cz;
+            const float far = fmaxf(fmaxf(fmaxf(-ux, ux - (float)g.dim[0]), fmaxf(-uy, uy - (float)g.dim[1])),
+                                    fmaxf(-uz, uz - (float)g.dim[2])) - 2.0f * mgn;
+            const float outc = fmaxf(1.0f + face, far);
+            out2 = outc * outc * h2;
+        }
+        float exq[3];                                        // (a cell past the span: +inf -- never listed, bounds nothing)
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int xi = x0 + j;
             const float ex = xi == cx ? 0.f : (xi < cx ? lo_x + (float)(cx - xi - 1) : hi_x + (float)(xi - cx - 1));
-            exq[j] = ex * ex * h2;
+            exq[j] = j < span ? ex * ex * h2 : INFINITY;
         }
         const float ey2[3] = {lo_y * lo_y, 0.f, hi_y * hi_y}, ez2[3] = {lo_z * lo_z, 0.f, hi_z * hi_z};
-        float rowB[9];                                       // squared slab bound of row k = (dy, dz)
+        float rowB[9];                                       // squared slab bound of row k = (dy, dz); a row that does not exist: +inf
 #pragma unroll
-        for (int k = 0; k < 9; k++) rowB[k] = (ey2[k % 3] + ez2[k / 3]) * h2;
-        auto row_bound_of = [&](int k) { return rowB[k]; };
-        // what nothing nearer than can be missed by: the previous winner's distance now, or the radius
-        float bound0 = L;
-        {
-            const float dprev = sqdist_f32(qprev, px, py, pz);
-            if (dprev < L) bound0 = dprev;                   // (NaN = no previous winner: the radius)
-        }
+        for (int k = 0; k < 9; k++) rowB[k] = (zok[k / 3] && yok[k % 3]) ? (ey2[k % 3] + ez2[k / 3]) * h2 : INFINITY;
         // ---- only the rows whose slab can hold a point at or within bound0 are looked up at all (a converged
         // pass needs 1.9 of the 9 per query), all of them in ONE round of gathers: nothing depends on a load
         // from here to the candidates
         u4a cs[9];
+        looked = 0u;
 #pragma unroll
-        for (int k = 0; k < 9; k++) cs[k] = load_row(k, active && !(row_bound_of(k) > bound0));
+        for (int k = 0; k < 9; k++) {
+            const bool w = want && !(rowB[k] > bound0);
+            cs[k] = load_row(k, w);
+            looked += (w && span > 0) ? 1u : 0u;             // (profiling)
+        }
         // ---- the slots of each row that can hold a candidate at or within bound0: cells whose slab bound
         // (y, z and x slab distances, squared) does not exceed it.  A skipped cell holds nothing that could
         // win or tie (margins: fp32 binning + rounding band, as in the lane-serial kernel).
         // (B + exq[j] <= bound0 tested as B <= bound0 - exq[j]: the slab bounds carry a relative margin of ~1e-3, a
         //  rounding of the subtraction cannot drop a cell that matters; a cell that does not exist: -inf)
-        const float lim0 = span > 0 ? bound0 - exq[0] : -INFINITY;
-        const float lim1 = span > 1 ? bound0 - exq[1] : -INFINITY;
-        const float lim2 = span > 2 ? bound0 - exq[2] : -INFINITY;
-        unsigned xb[9], xe[9];
+        const float lim0 = bound0 - exq[0];                  // (-inf for a cell past the span)
+        const float lim1 = bound0 - exq[1];
+        const float lim2 = bound0 - exq[2];
+        float pruned2 = INFINITY;                            // smallest slab bound (squared) among the cells NOT listed
+        const float thr0 = bound0 * (1.0f - 1e-6f);
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const float B = row_bound_of(k);
+            const float B = rowB[k];
             const bool n0 = B <= lim0, n1 = B <= lim1, n2 = B <= lim2;
+            // (a cell is NOT listed iff B > fl(bound0 - exq[j]), which implies fl(B + exq[j]) > bound0 (1 - 2e-7): every
+            //  such cell is in this minimum; a listed cell within 1e-6 of bound0 may be too -- its slab bound holds as well.
+            //  Own comparisons, so that the 27 listing masks need not stay live)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const float S = B + exq[j];
+                pruned2 = fminf(pruned2, S >= thr0 ? S : INFINITY);
+            }
             const u4a v = cs[k];                             // (a row not looked up reads as zeros: empty)
             const unsigned b = n0 ? v.x : (n1 ? v.y : v.z);
             unsigned e = n2 ? v.w : (n1 ? v.z : (n0 ? v.y : b));
@@ -261,17 +311,111 @@ __device__ __forceinline__ void coop_body(
             xb[k] = b;
             xe[k] = e;
         }
-        COOP_PHASE(1, xb[0] ^ xe[8] ^ xb[4] ^ xe[2] ^ xb[6], 0.f);            // row bounds arrived, rows pruned
-        if (cand_count) {
-            // profiling only (one uniform branch): candidates listed, cell-table rows looked up
+        lbgeo2 = fminf(out2, pruned2);
+    };
+    // one query (or none: the lanes past the end still work on the others' chunks)
+    auto query = [&](long long i, bool active) {
+        // ---- the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
+        Pt64 s8 = Pt64{0.0, 0.0, 0.0, 0ull};
+        // the state the previous pass left: its winner's f64 point (NaN = none), original index | LB << 32
+        // (all bits set = nothing known: NaN coordinates, NaN bound)
+        Pt64 w8;
+        w8.x = w8.y = w8.z = __longlong_as_double(-1ll);
+        w8.w = ~0ull;
+        if (active) {
+            s8 = src64[i];
+            if (warm & 1) w8 = wst_io[i];
+        }
+        // (fp32 view of the previous winner: the value the candidate array holds for that point)
+        const float4 qprev = make_float4((float)w8.x, (float)w8.y, (float)w8.z, 0.f);
+        // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
+        double pd[3];
+        {
+            const double sv[3] = {s8.x, s8.y, s8.z};
+            se3_act(T64.m, sv, pd);
+        }
+        const double pxd = pd[0], pyd = pd[1], pzd = pd[2];
+        const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
+        COOP_PHASE(0, 0u, px + py + pz + qprev.x + qprev.y + qprev.z);   // source + previous winner arrived
+        // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
+        // which a candidate cannot be accepted in f64; W >= band(m) - m for every m < L
+        const float r_f = sqrtf(r2f);
+        const float rup = r_f * (1.0f + 2.4e-7f);
+        const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
+        const float tlim = rup + 2.0f * E;
+        const float L = tlim * tlim * (1.0f + 6e-7f);
+        const float W = (4.0f * E * tlim + 4.0f * E * E) * (1.0f + 1e-6f) + L * 5e-7f;
+        // ---- the certificate: has the query moved by less than the room its previous result left?
+        const unsigned widx = (unsigned)w8.w;
+        const bool has_w = w8.x == w8.x;                     // (NaN: no previous winner)
+        bool cert = false;
+        double d2w = r2d;                                    // the previous winner's distance now (reference arithmetic)
+        float lb_new = 0.f;                                  // what this pass leaves as LB
+        if (warm & 4) {
+            // delta = |T s - T_prev s|: same products, same order as the transform itself, so the two computed
+            // points are the ones the bounds speak about; rounded up
+            double pp[3];
+            {
+                const double sv[3] = {s8.x, s8.y, s8.z};
+                se3_act(Tprev.m, sv, pp);
+            }
+            const double ex = pxd - pp[0], ey = pyd - pp[1], ez = pzd - pp[2];
+            const float del = sqrtf((float)(ex * ex + ey * ey + ez * ez)) * (1.0f + 1e-6f);
+            // (the bound of an unknown state is NaN: every comparison below is false.  The two ulps taken off cover the
+            //  rounding of this subtraction and the ~1e-16 |p| by which the f64 difference above can be off -- the band
+            //  E itself was taken off once, when the bound was formed: taking it off every pass would wear a 1 mm gap
+            //  down in a few hundred certified passes and send the query back to the search for nothing)
+            const float t = (__uint_as_float((unsigned)(w8.w >> 32)) - del) * (1.0f - 2.4e-7f);
+            if (has_w) {
+                // flann L2 (dist.h:159-176), as rank() below
+                const double dx = w8.x - pxd, dy = w8.y - pyd, dz = w8.z - pzd;
+                double d = dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                d2w = d;
+                cert = active && t > 0.f && d < r2d && d < (double)t * (double)t * (1.0 - 1e-6);
+            } else {
+                cert = active && widx == 0xFFFFFFFFu && t > tlim * (1.0f + 1e-6f);
+            }
+            lb_new = t;
+        }
+        const bool need = active && !cert;
+        if (cand_count && cert) ncert++;                     // (profiling)
+        if (__builtin_amdgcn_ballot_w64(need) == 0ull) {
+            // (wave-uniform) every query of the wave is certified: source + state in, distance + bound out
+            const bool found = cert && has_w;
+            finish(i, active, cert, pxd, pyd, pzd, found ? d2w : r2d, widx, found, w8.x, w8.y, w8.z, lb_new);
+            return;
+        }
+        double bd = r2d;                                     // best d2 so far (strictly below r2d once set)
+        unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
+        Pt64 bq = Pt64{0.0, 0.0, 0.0, 0ull};
+        s_qp[tid] = make_float4(px, py, pz, W);
+        // what nothing nearer than can be missed by: the previous winner's distance now, or the radius
+        float bound0 = L;
+        {
+            const float dprev = sqdist_f32(qprev, px, py, pz);
+            if (dprev < L) bound0 = dprev;                   // (NaN = no previous winner: the radius)
+        }
+        unsigned xb[9], xe[9];
+        float lbgeo2;                                        // LB, geometric part (squared)
+        {
+            unsigned looked;
+            list_rows(px, py, pz, E, bound0, need, xb, xe, lbgeo2, looked);
+            // (pin the value here: left to itself the compiler sinks the whole slab arithmetic down to the bound's only
+            //  use at the end of the query and spills its 40 inputs across the chunk phase instead)
+            asm volatile("" : "+v"(lbgeo2));
+            if (cand_count) {
+                // profiling only (one uniform branch): candidates listed, cell-table rows looked up
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                ncand += xe[k] - xb[k];
-                if (active && !(row_bound_of(k) > bound0) && span > 0 && zok[k / 3] && yok[k % 3]) ncand_all++;
+                for (int k = 0; k < 9; k++) ncand += xe[k] - xb[k];
+                ncand_all += looked;
             }
         }
+        COOP_PHASE(1, xb[0] ^ xe[8] ^ xb[4] ^ xe[2] ^ xb[6], 0.f);            // row bounds arrived, rows pruned
         // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
-        float gh0 = L, gh1 = L, gh2 = L;
+        float gh0 = INFINITY, gh1 = INFINITY, gh2 = INFINITY;
+        float gsec = INFINITY;                               // best candidate outside the rounding band of its chunk's minimum
         unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
         auto chunk_insert = [&](float m, unsigned b, unsigned flags) {
             const bool c1 = m < gh0, c2 = m < gh1;
@@ -335,11 +479,17 @@ __device__ __forceinline__ void coop_body(
                         const float m = octet_min(d);
                         // (a lane past the chunk's end holds +inf: never within m + W of a finite minimum; a null
                         //  descriptor's result is not stored)
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(d <= m + p.w);
+                        const bool fl = d <= m + p.w;
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(fl);
                         const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
+                        // the chunk's best candidate that is NOT flagged (for the LB the query leaves behind)
+                        const float sec = octet_min(fl ? INFINITY : d);
                         // the result takes the place of the descriptor's second word: the chunk minimum rounded DOWN to
                         // 16 mantissa bits | the flag byte (the first word, the chunk's position, stays)
-                        if (l8 == 0 && mine) items[t + u * 8 + oct].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
+                        if (l8 == 0 && mine) {
+                            items[t + u * 8 + oct].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
+                            secs[t + u * 8 + oct] = sec;
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -348,16 +498,20 @@ __device__ __forceinline__ void coop_body(
                 // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
                 for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
                     uint2 r[4];
+                    float rs[4];
                     bool in[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const unsigned j = off_q - w0 + c0 + (unsigned)u;
                         in[u] = c0 + (unsigned)u < nq && j < (unsigned)kCoopCap;
                         r[u] = items[in[u] ? j : 0u];
+                        rs[u] = secs[in[u] ? j : 0u];
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
+                    for (int u = 0; u < 4; u++) {
                         chunk_insert(in[u] ? __uint_as_float(r[u].y & 0xFFFFFF00u) : INFINITY, r[u].x, r[u].y & 0xFFu);
+                        gsec = fminf(gsec, in[u] ? rs[u] : INFINITY);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -366,10 +520,16 @@ __device__ __forceinline__ void coop_body(
             for (unsigned w0 = 0; w0 < M; w0 += kCoopCap) window(w0);
         }
         COOP_PHASE(4, gb0 + gb1 + gm0 + gm1, gh0 + gh1 + gh2);              // chunk results merged per query
-        // ---- the f64 decision: flagged candidates of the kept chunks inside g + W
-        double bd = r2d;                                     // best d2 so far (strictly below r2d once set)
-        unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
-        Pt64 bq = Pt64{0.0, 0.0, 0.0, 0ull};
+        // ---- the f64 decision: flagged candidates of the kept chunks inside g + W.
+        // The query itself comes back from where it lies -- the f64 source point (re-transformed: same products, same
+        // order, same bits), its fp32 view and W from LDS, the band re-derived -- instead of occupying 17 registers
+        // across the listing and the chunk phase, where the kernel sits at the 128 it may use (4 waves per SIMD).
+        auto tail = [&](const double pxd, const double pyd, const double pzd, const float px, const float py, const float pz,
+                        const float W) {
+        const float rup = sqrtf(r2f) * (1.0f + 2.4e-7f);
+        const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
+        const float tlim = rup + 2.0f * E;
+        const float L = tlim * tlim * (1.0f + 6e-7f);
         auto rank = [&](const Pt64 &c8, unsigned pos) {
             // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
             const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
@@ -387,10 +547,11 @@ __device__ __forceinline__ void coop_body(
         // (the kept chunk minima were rounded down by < 2^-15 relative: g_up bounds the fp32 minimum from above, and
         //  the tests below stay on the safe side -- a chunk or candidate more is ranked in f64, never one less)
         const float g_up = gh0 * (1.0f + 6.2e-5f);
-        if (active && gb0 != 0xFFFFFFFFu) {
+        int n = 0;                                           // candidates ranked in f64
+        // (chunk minima at or beyond L cannot be accepted in f64: such chunks only serve the LB)
+        if (need && gh0 < L) {
             const float thr = g_up + W;
             unsigned c[4] = {0u, 0u, 0u, 0u};
-            int n = 0;
             slow = gh2 <= thr;                               // a third chunk reaches into the band
             auto add = [&](unsigned b, unsigned flags) {
                 while (flags) {
@@ -430,12 +591,19 @@ __device__ __forceinline__ void coop_body(
             const float qrup = rup, qE = bcast_f(E);
             const float sl = fminf(sqrtf(bcast_f(g_up)), qrup) + 2.0f * qE;
             const float Ls = sl * sl * (1.0f + 6e-7f);       // fp32 distances beyond it cannot win or tie in f64
+            // the query's slot ranges, listed again (its lane alone looks the rows up) against Ls: nothing at or within
+            // it is left out, and nothing was kept in registers for this rare path
             unsigned qb[9], pre[10];
             pre[0] = 0u;
+            {
+                unsigned sb[9], se[9], looked_unused;
+                float geo_unused;
+                list_rows(px, py, pz, E, Ls, lane == q, sb, se, geo_unused, looked_unused);
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                qb[k] = bcast_u(xb[k]);
-                pre[k + 1] = pre[k] + (bcast_u(xe[k]) - qb[k]);
+                for (int k = 0; k < 9; k++) {
+                    qb[k] = bcast_u(sb[k]);
+                    pre[k + 1] = pre[k] + (bcast_u(se[k]) - qb[k]);
+                }
             }
             double ld = r2d;
             unsigned lid = 0xFFFFFFFFu, lpos = 0xFFFFFFFFu;
@@ -504,21 +672,43 @@ __device__ __forceinline__ void coop_body(
                 }
             }
         }
+        // ---- LB: what every target point but the winner (every target point, without a winner) is at least away
+        if (need) {
+            float lb2 = fminf(lbgeo2, fminf(gh1, gsec));
+            if (bpos == 0xFFFFFFFFu) lb2 = fminf(lb2, gh0);  // nothing accepted: the best candidate bounds like the rest
+            // (examined candidates: |d64 - sqrt(d2_32)| <= E inside the radius, <= 2E out to the corners of the 27 cells)
+            float lb = sqrtf(lb2) * (1.0f - 1e-6f) - 4.0f * E;
+            // a near-tie (several candidates ranked in f64, a re-scan): the runner-up was not bounded
+            if (slow || n > 1) lb = 0.f;
+            lb_new = fminf(fmaxf(lb, 0.f), 3.0e38f);
+        }
+        bool found = bpos != 0xFFFFFFFFu;
+        if (cert && has_w) {
+            // a certified query in a wave that searched: the previous winner again (re-read: nothing of it was kept
+            // across the search), at its new distance -- flann L2 as above
+            const Pt64 c8 = wst_io[i];
+            const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
+            double d = dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            bd = d;
+            bidx = (unsigned)c8.w;
+            bq.x = c8.x; bq.y = c8.y; bq.z = c8.z;
+            found = true;
+        }
         COOP_PHASE(5, bidx, (float)(bd + bq.x));                            // f64 winner arrived and ranked
-        if (active) {
-            idx_out[i] = (bpos == 0xFFFFFFFFu) ? -1 : (int)bidx;
-            d2_out[i] = (float)bd;
-            // the winner as the candidate array holds it (fp32 rounding of the same f64 value): next pass's bound
-            prevq_io[i] = bpos == 0xFFFFFFFFu ? make_float4(NAN, NAN, NAN, 0.f) : make_float4((float)bq.x, (float)bq.y, (float)bq.z, 0.f);
-            if (d64_out) d64_out[i] = bd;                    // (target-sharded ranks compare shards in f64)
-            if (bpos != 0xFFFFFFFFu) {
-                double nx = 0.0, ny = 0.0, nz = 0.0;
-                if (PLANE) {
-                    if (nrm64) { const Pt64 n8 = nrm64[(unsigned)bq.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
-                    else { const float4 n4 = nrm[(unsigned)bq.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
-                }
-                accumulate_pq_d<PLANE>(acc, pxd, pyd, pzd, bq.x, bq.y, bq.z, nx, ny, nz, off);
-            }
+        finish(i, active, cert, pxd, pyd, pzd, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
+        };   // tail
+        {
+            unsigned z;                                      // (a zero the compiler cannot see through: no value is carried over)
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            Pt64 r8 = Pt64{0.0, 0.0, 0.0, 0ull};
+            if (active) r8 = src64[i + z];
+            const float4 me = s_qp[tid + z];
+            double rd[3];
+            const double sv[3] = {r8.x, r8.y, r8.z};
+            se3_act(T64.m, sv, rd);
+            tail(rd[0], rd[1], rd[2], me.x, me.y, me.z, me.w);
         }
     };
     if constexpr (ONE) {
@@ -531,16 +721,20 @@ __device__ __forceinline__ void coop_body(
     block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
     COOP_MARK(7);                                            // workgroup's partial row stored
     if (cand_count) {
-        unsigned long long c = ncand, ca = ncand_all;
+        unsigned long long c = ncand, ca = ncand_all, cc = ncert;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             c += __shfl_down(c, o, 64);
             ca += __shfl_down(ca, o, 64);
+            cc += __shfl_down(cc, o, 64);
         }
-        if ((threadIdx.x & 63) == 0 && ca) {
+        if ((threadIdx.x & 63) == 0) {
             unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
-            atomicAdd(slot, c);
-            atomicAdd(slot + 1, ca);
+            if (ca) {
+                atomicAdd(slot, c);
+                atomicAdd(slot + 1, ca);
+            }
+            if (cc) atomicAdd(cand_count + 2 * 4096 + (blockIdx.x & 4095), cc);   // queries certified (no search)
         }
     }
     if (fold.tickets) fused_fold<PLANE, kBlock>(fold, partials, row0, lb, bpp, prob);
@@ -554,10 +748,10 @@ __device__ __forceinline__ void coop_body(
         const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,   \
         int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,                            \
         const Pt64 *__restrict__ nrm64, const FoldArgs fold, double *__restrict__ d64_out,                       \
-        float4 *__restrict__ prevq_io, int warm
+        Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev
 #define VISMA_COOP_ARGS                                                                                          \
     ns, s12f, start, g, nrm, T64, off, r2f, idx_out, d2_out, partials, cand_count, st, bpp, out_stride, descs,   \
-        nprob, src64, sorted64, nrm64, fold, d64_out, prevq_io, warm
+        nprob, src64, sorted64, nrm64, fold, d64_out, wst_io, warm, Tprev
 // One query per lane: C4's 262,144 queries are 4096 waves, all resident at once only at 4 waves per SIMD
 // (<= 128 VGPRs; the kernel needs 104).  Several queries per lane: the 23 / 29 f64 moments stay live across
 // the queries, so the compiler gets the registers it asks for (2 waves per SIMD; such launches have more
@@ -578,21 +772,27 @@ __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 #define VISMA_COOP_LAUNCH(KERNEL_)                                                                               \
     hipLaunchKernelGGL(KERNEL_, dim3(total_blocks), dim3(kBlock), 0, stream, ns, s12, start, g, nrm, T64, off,   \
                        r2f, idx_out, d2_out, partials, cand_count, st, bpp, out_stride, descs, nprob, src64,     \
-                       sorted64, nrm64, fold, d64_out, prevq_io, warm)
+                       sorted64, nrm64, fold, d64_out, wst_io, warm, Tp)
 
 // The warm-started, flattened exact search.  Shared clouds: `nprob` problems of `bpp` workgroups each
 // (descs == NULL); own clouds: descs[nprob], total_blocks workgroups.  `one`: at most one query per lane.
 // warm & 2: a workgroup -> problem map (int per workgroup) follows descs[nprob].
-// prevq_io (one float4 per query, laid out like idx_out): read when `warm & 1` (the winners of the previous pass
-// over the SAME source order and target, as fp32 points of the candidate array; NaN = none), always written.
+// wst_io (one Pt64 per query, laid out like idx_out): read when `warm & 1` (the winners of the previous pass
+// over the SAME source order and target: f64 point, original index | LB << 32; NaN coordinates = none, all bits
+// set = nothing known), always written.  warm & 4: Tprev is the transform of the pass that left the state
+// (device loops take it from their DevIcpState instead) -- queries whose winner provably cannot have changed skip
+// the search (the certificate above).
 hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *descs, int ns, const float *s12,
                           const unsigned *start, const GridParams &g, const float4 *nrm, const Pt64 *nrm64,
                           const Xform64 &T64, const Offset64 &off, float r2f, int point_to_plane, int one,
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
-                          const FoldArgs &fold, double *d64_out, float4 *prevq_io, int warm, hipStream_t stream)
+                          const FoldArgs &fold, double *d64_out, Pt64 *wst_io, int warm, hipStream_t stream,
+                          const Xform64 *Tprev)
 {
-    if (!src64 || !sorted64 || !s12 || !prevq_io) return hipErrorInvalidValue;
+    if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
+    Xform64 Tp{};
+    if (Tprev) { Tp = *Tprev; warm |= 4; } else warm &= ~4;
     if (point_to_plane) {
         if (one) VISMA_COOP_LAUNCH(nn_coop_kernel_one<true>); else VISMA_COOP_LAUNCH(nn_coop_kernel_many<true>);
     } else {

@@ -71,9 +71,10 @@ public:
         HIP_TRY(hipMalloc(&d_partials_, sizeof(double) * kReduceAcc * kGridMaxBlocks));
         partial_rows_ = (size_t)kGridMaxBlocks;
         HIP_TRY(hipMalloc(&d_stats_, sizeof(double) * kNStats));
-        HIP_TRY(hipMalloc(&d_cand_, 2 * 4096 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&d_cand_, 3 * 4096 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(d_cand_, 0, 3 * 4096 * sizeof(unsigned long long)));
         if (const char *e = std::getenv("VISMA_ICP_COOP")) coop_enabled_ = std::atoi(e) != 0;
+        if (const char *e = std::getenv("VISMA_ICP_CERT")) cert_enabled_ = std::atoi(e) != 0;
         if (const char *e = std::getenv("VISMA_ICP_GRID_LANES")) {
             const int v = std::atoi(e);
             if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
@@ -712,9 +713,10 @@ public:
                                           &nblocks, lanes,
                                           prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                           1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                          exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (float4 *)d_pos_, 1));
+                                          exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1, cert_prev()));
             last_kernel_ = pass_kernel(lanes);
             pos_fresh_ = d_pos_ != nullptr;
+            note_state_pass(T64);
             if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (!tshard_ && !fused) {
                 if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -817,8 +819,9 @@ public:
                                           (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                           &nblocks, (last_kernel_ = pass_kernel(pass_lanes()), pass_lanes()), nullptr, nullptr, 1, 0, stream_,
                                           f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0,
-                                          nullptr, nullptr, (float4 *)d_pos_, 1));
+                                          nullptr, nullptr, (Pt64 *)d_pos_, 1, cert_prev()));
             pos_fresh_ = d_pos_ != nullptr;
+            note_state_pass(T64);
             grid_pending_ = false;
         } else if (!use_grid_ && !brute_reduced_) {
             // brute-force pass without a reduction yet: the index is recovered by
@@ -946,9 +949,10 @@ public:
                                                   profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
                                                   nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
                                                   exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr,
-                                                  (float4 *)d_pos_, 1));
+                                                  (Pt64 *)d_pos_, cert_enabled_ ? 1 : (1 | 8)));
                     last_kernel_ = pass_kernel(lanes);
                     pos_fresh_ = d_pos_ != nullptr;
+                    prev_T_valid_ = false;                   // (the state's pose now lives in the device loop's state)
                     if (tshard_) {
                         // the shards' winners compared on the stream (two MIN all-reduces), the owners' moments
                         // into the partial rows: everything stream-ordered, the host is not involved
@@ -1136,12 +1140,12 @@ public:
             free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_pos_);
             HIP_TRY(hipMalloc(&bt_idx_, sizeof(int32_t) * std::max<int64_t>(out_tot, 1)));
             HIP_TRY(hipMalloc(&bt_d2_, sizeof(float) * std::max<int64_t>(out_tot, 1)));
-            HIP_TRY(hipMalloc(&bt_pos_, sizeof(float4) * std::max<int64_t>(out_tot, 1)));
+            HIP_TRY(hipMalloc(&bt_pos_, sizeof(Pt64) * std::max<int64_t>(out_tot, 1)));
             bt_out_cap_ = out_tot;
         }
         tr.mark("layout, buffers");
         // (new problems: no previous winners)
-        HIP_TRY(hipMemsetAsync(bt_pos_, 0xFF, sizeof(float4) * (size_t)std::max<int64_t>(out_tot, 1), stream_));
+        HIP_TRY(hipMemsetAsync(bt_pos_, 0xFF, sizeof(Pt64) * (size_t)std::max<int64_t>(out_tot, 1), stream_));
         {
             bool any_raw = false;
             for (int b = 0; b < B; b++) any_raw = any_raw || pb[b].tgt_raw != nullptr;
@@ -1292,7 +1296,7 @@ public:
                                                     profiling_ ? (unsigned long long *)d_cand_ : nullptr,
                                                     (lp.plane && !f64) ? (const float4 *)bt_nrm_ : nullptr,
                                                     (lp.plane && f64) ? (const Pt64 *)bt_nrm64_ : nullptr,
-                                                    (float4 *)bt_pos_, 1 | 2));   // warm | workgroup map behind the descriptors
+                                                    (Pt64 *)bt_pos_, cert_enabled_ ? (1 | 2) : (1 | 2 | 8)));   // warm | workgroup map behind the descriptors
                 last_kernel_ = (coop && fresh) ? 2 : 1;
                 fresh = true;
                 if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
@@ -1567,15 +1571,17 @@ public:
     void set_profiling(int level) override { profiling_ = level < 0 ? 0 : level; prof_tick_ = 0; }
     void get_timing(visma_icp_timing *t, bool reset) override
     {
-        std::vector<unsigned long long> slots(2 * 4096, 0ull);
+        std::vector<unsigned long long> slots(3 * 4096, 0ull);
         (void)hipSetDevice(device_);
         (void)hipStreamSynchronize(stream_);
         (void)collect_timing();
         (void)hipMemcpy(slots.data(), d_cand_, slots.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         double c[2] = {0.0, 0.0};
-        for (size_t i = 0; i < slots.size(); i += 2) { c[0] += (double)slots[i]; c[1] += (double)slots[i + 1]; }
+        for (size_t i = 0; i < 2 * 4096; i += 2) { c[0] += (double)slots[i]; c[1] += (double)slots[i + 1]; }
         timing_.grid_candidates = c[0];
         timing_.grid_candidates_27cell = c[1];
+        timing_.grid_certified = 0.0;
+        for (size_t i = 2 * 4096; i < 3 * 4096; i++) timing_.grid_certified += (double)slots[i];
         if (d_tstats_) {
             std::vector<unsigned long long> ts(24 * 512, 0ull);
             (void)hipMemcpy(ts.data(), d_tstats_, ts.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
@@ -1596,7 +1602,7 @@ public:
         *t = timing_;
         if (reset) {
             std::memset(&timing_, 0, sizeof(timing_));
-            (void)hipMemset(d_cand_, 0, 2 * 4096 * sizeof(unsigned long long));
+            (void)hipMemset(d_cand_, 0, 3 * 4096 * sizeof(unsigned long long));
             if (d_tstats_) (void)hipMemset(d_tstats_, 0, 24 * 512 * sizeof(unsigned long long));
         }
     }
@@ -1687,7 +1693,7 @@ private:
             free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_);
             HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * (ns_pad > 0 ? ns_pad : 1)));
             HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * (ns_pad > 0 ? ns_pad : 1)));
-            HIP_TRY(hipMalloc(&d_pos_, sizeof(float4) * (ns_pad > 0 ? ns_pad : 1)));
+            HIP_TRY(hipMalloc(&d_pos_, sizeof(Pt64) * (ns_pad > 0 ? ns_pad : 1)));
             aux_cap_ = ns_pad;
             return invalidate_pos();
         }
@@ -1911,12 +1917,20 @@ private:
     // the warm-started kernel).
     void *d_pos_ = nullptr;
     bool pos_fresh_ = false;
+    // the certificate of grid_coop.hip: the transform of the pass that left the state (host-driven passes over ONE
+    // problem; device loops carry it in their DevIcpState and leave prev_T_valid_ false behind them)
+    Xform64 prev_T_{};
+    bool prev_T_valid_ = false;
+    int cert_enabled_ = 1;       // VISMA_ICP_CERT=0: every query searched every pass (A/B timing)
+    const Xform64 *cert_prev() const { return (cert_enabled_ && prev_T_valid_ && pos_fresh_) ? &prev_T_ : nullptr; }
+    void note_state_pass(const Xform64 &T) { prev_T_ = T; prev_T_valid_ = true; }
     int last_kernel_ = 0;        // what the last pass ran: 0 brute force, 1 lane-serial grid, 2 warm-started cooperative grid
     int coop_enabled_ = 1;       // VISMA_ICP_COOP=0: every pass on the lane-serial kernel
     int invalidate_pos()
     {
         pos_fresh_ = false;
-        if (d_pos_ && aux_cap_ > 0) HIP_TRY(hipMemsetAsync(d_pos_, 0xFF, sizeof(float4) * (size_t)aux_cap_, stream_));
+        prev_T_valid_ = false;
+        if (d_pos_ && aux_cap_ > 0) HIP_TRY(hipMemsetAsync(d_pos_, 0xFF, sizeof(Pt64) * (size_t)aux_cap_, stream_));
         return VISMA_ICP_OK;
     }
     bool coop_ok() const

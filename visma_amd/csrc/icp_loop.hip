@@ -56,6 +56,9 @@ __device__ __forceinline__ void advance_state(DevIcpState *st)
         Tn = to_centred(upd * from_centred(Tc, st->centre), st->centre);
     else
         Tn = upd * Tc;
+    // (the pose the pass just folded was searched at: what the next pass's certificates measure their motion from)
+    for (int i = 0; i < 12; i++) st->Tc_prev[i] = st->Tc[i];
+    st->have_prev = 1;
     for (int i = 0; i < 12; i++) st->Tc[i] = Tn.m[i];
     st->iter += 1;
     st->fit_prev = fit;

@@ -40,7 +40,8 @@ struct DevIcpState {
     int active;          // 1 while the loop is still running
     int max_iter, solver, scaling, plane, world_frame, check_stop;
     float r2f;
-    int pad_;
+    int have_prev;       // Tc_prev holds the transform of the previous NN pass (the certificate of grid_coop.hip)
+    double Tc_prev[12];
 };
 
 // The fold of the partial rows inside the search launch (device_common.h: fused_fold).
@@ -306,9 +307,11 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  const Pt64 *src64 = nullptr, const Pt64 *sorted64 = nullptr,
                                  double r2d = 0.0, const Pt64 *nrm64 = nullptr, int exact = 0,
                                  const FoldArgs *fold = nullptr, double *d64_out = nullptr,
-                                 float4 *prevq_io = nullptr, int warm = 0);
-// prevq_io (one float4 per query, laid out like idx_out): the exact searches write their winners there as the
-// candidate array holds them (fp32, NaN = none); the warm-started search (kCoopLanes) reads them when `warm`.
+                                 Pt64 *wst_io = nullptr, int warm = 0, const Xform64 *Tprev = nullptr);
+// wst_io (one Pt64 per query, laid out like idx_out): the exact searches leave their winners there (f64 point,
+// original index | LB << 32 -- see grid_coop.hip; NaN coordinates = none, all bits set = nothing known); the
+// warm-started search (kCoopLanes) reads them when `warm & 1`, and with Tprev (the transform of the pass that left
+// them; device loops: from their DevIcpState) skips the search of queries whose winner provably cannot have changed.
 // The exact search with the candidates of a wave flattened over its lanes (grid_coop.hip); selected by
 // lanes_per_query = kCoopLanes (G = 1, U = 99) in the two launchers around it, which fall back to the
 // lane-serial kernel where it does not apply (fp32-only / all-f64 search, half-pitch rows).
@@ -318,7 +321,8 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
                           const Xform64 &T64, const Offset64 &off, float r2f, int point_to_plane, int one,
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
-                          const FoldArgs &fold, double *d64_out, float4 *prevq_io, int warm, hipStream_t stream);
+                          const FoldArgs &fold, double *d64_out, Pt64 *wst_io, int warm, hipStream_t stream,
+                          const Xform64 *Tprev = nullptr);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
 // offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
@@ -329,7 +333,7 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
                                        const Pt64 *sorted64 = nullptr, int exact = 0,
                                        const FoldArgs *fold = nullptr, unsigned long long *cand_count = nullptr,
                                        const float4 *nrm = nullptr, const Pt64 *nrm64 = nullptr,
-                                       float4 *prevq_io = nullptr, int warm = 0);
+                                       Pt64 *wst_io = nullptr, int warm = 0);
 // (nrm / nrm64: target normals concatenated like the UNSORTED targets -> the point-to-plane estimator)
 hipError_t launch_finalize_solve_batch(const double *partials, const ProbDesc *descs, DevIcpState *st,
                                        int nprob, hipStream_t stream, int plane = 0);
