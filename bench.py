@@ -56,6 +56,9 @@ import time
 
 # the CPU baseline's OpenMP runtime reads this when it is loaded (all cores, threads pinned close)
 os.environ.setdefault("OMP_PROC_BIND", "close")
+# the host driver only supports dmabuf IPC: ranks started by an external torchrun must get this too, before the HIP
+# runtime is loaded, or hipIpcGetMemHandle fails and the fastest transport (peer mailboxes over xGMI) is lost
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

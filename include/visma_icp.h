@@ -148,7 +148,8 @@ VISMA_ICP_API int visma_icp_get_voxel_target(visma_icp_ctx *ctx, double *xyz_out
 /* The max_correspondence_distance the NEXT registration on this context will use (RegistrationICP's third argument,
  * Registration.h:102-107), told before the clouds are uploaded: visma_icp_set_clouds_f64 then builds the search
  * structure on the GPU while the host is still staging the source (C4: 0.7 ms of a 3.7 ms registration hidden).
- * Without a hint the radius of the context's previous registration is assumed; 0 clears the hint.  A wrong value
+ * One-shot: the upload that uses the hint clears it.  Without a hint the radius of the context's previous
+ * registration is assumed; 0 clears a pending hint.  A wrong value
  * only costs the wasted build: results never depend on it. */
 VISMA_ICP_API int visma_icp_set_radius_hint(visma_icp_ctx *ctx, double max_correspondence_distance);
 /* feh::ICPRefinement's clouds (src/evaluation.cpp:248-271) made on the device, source side too:

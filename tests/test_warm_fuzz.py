@@ -1,5 +1,5 @@
 """tools/fuzz_warm_vs_serial.py inside the suite: hostile configurations (lattices on cell faces, duplicated points,
-planes, elongated boxes, far offsets, extreme radii), seven passes each -- the warm-started wave-cooperative search and
+planes, elongated boxes, far offsets, extreme radii), thirteen passes each (incl. the decaying motions the certificate decides) -- the warm-started wave-cooperative search and
 the lane-serial kernel agree bit for bit (indices, distances, the 38 statistics)."""
 import os
 import subprocess
@@ -16,4 +16,4 @@ def test_warm_search_equals_lane_serial_on_hostile_clouds(lib, seed):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_warm_vs_serial.py"), "60", str(seed)],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0 and "0 mismatches" in p.stdout, p.stdout[-3000:] + p.stderr[-2000:]
-    assert "'warm': 360" in p.stdout, p.stdout[-500:]
+    assert "'warm': 720" in p.stdout, p.stdout[-500:]

@@ -115,6 +115,9 @@ extern "C" int visma_icp_run_corpus(visma_icp_ctx *const *ctxs, int n_ctx, const
     Shared s;
     s.ctxs = ctxs; s.items = items; s.n_items = n_items; s.p = *params; s.results = results;
     if (s.p.chunk <= 0) s.p.chunk = 8;
+    // a worker allocates chunk * level problems per pull and hands that count to visma_icp_run_batch as an int
+    if ((int64_t)s.p.chunk > n_items) s.p.chunk = (int)std::max<int64_t>(n_items, 1);
+    if ((int64_t)s.p.chunk * (int64_t)s.p.level > (int64_t)(1 << 20)) return bad("corpus chunk x level exceeds 1048576 registrations per batch");
     int64_t own = 0;
     s.counter = counter ? counter : &own;
     std::vector<std::thread> th;

@@ -384,7 +384,10 @@ static int set_clouds_f64_impl(visma_icp_ctx *ctx, const double *src, int64_t ns
     } else if (raw_target) {
         // the radius of the coming registration, if known (visma_icp_set_radius_hint, or the last one used): the grid
         // is built on the stream while the source is staged
+        // (the hint speaks about the NEXT registration only: consumed here, so that a context that once got one and is
+        //  later driven with another radius falls back to its previous radius instead of building a wasted grid per upload)
         const double hint = ctx->radius_hint > 0.0 ? ctx->radius_hint : ctx->last_radius;
+        ctx->radius_hint = 0.0;
         if (hint > 0.0 && ctx->search_precision == 1) {
             ctx->eng->set_exact(true);
             rc = ctx->eng->prepare_search(ns, want64 && ctx->eng->supports_device_loop(), hint);

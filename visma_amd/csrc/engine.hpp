@@ -33,6 +33,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unistd.h>
 #include <unordered_map>
 #include <vector>
 
@@ -110,10 +111,18 @@ public:
     static constexpr int kPools = 4;
     static HostPool &instance(int k)
     {
-        static HostPool *p[kPools] = {new HostPool(32), new HostPool(16), new HostPool(16), new HostPool(16)};
+        static HostPool *p[kPools] = {(owner_pid(), new HostPool(32)), new HostPool(16), new HostPool(16), new HostPool(16)};
         return *p[k];
     }
+    static pid_t owner_pid()
+    {
+        static const pid_t pid = getpid();                         // (first call: the process that starts the workers)
+        return pid;
+    }
     int size() const { return (int)workers_; }
+    // the pools' threads exist only in the process that started them: a child made by fork() (Python multiprocessing's
+    // default start method) inherits the bookkeeping but no workers and would wait for them forever
+    static bool usable() { return owner_pid() == getpid(); }
     // fn(i) for i in [0, n) on up to `threads` threads including the caller's; false: busy, nothing was run
     template <typename F>
     bool run(int64_t n, int threads, F &fn)
@@ -186,9 +195,15 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
     if (nt > 32) nt = 32;
     if (nt < 1) nt = 1;
     if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
-    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i); return; }
-    for (int k = 0; k < HostPool::kPools; k++)
-        if (HostPool::instance(k).run(n, (int)nt, fn)) return;
+    // (a pass started from inside a pass -- fn itself calling parallel_for -- runs on the calling thread: the pools'
+    //  run mutex is not recursive)
+    static thread_local bool inside = false;
+    if (nt <= 1 || inside) { for (int64_t i = 0; i < n; i++) fn(i); return; }
+    struct Guard { bool &f; explicit Guard(bool &x) : f(x) { f = true; } ~Guard() { f = false; } } guard(inside);
+    HostPool::instance(0);                                         // (starts the pools in the first process that asks)
+    if (HostPool::usable())
+        for (int k = 0; k < HostPool::kPools; k++)
+            if (HostPool::instance(k).run(n, (int)nt, fn)) return;
     if (nt > 16) nt = 16;
     std::vector<std::thread> th;
     std::atomic<int64_t> next(0);

@@ -422,35 +422,73 @@ hipError_t estimate_normals_device(const double *h_xyz, int64_t n, const double 
         cell = next;
     }
     int type = search_type;
+    std::vector<int> cnt;                                        // (Radius) neighbours per query, cell order
     if (search_type == 1) {
         // Radius: count every point's neighbours, then run as a Hybrid search that keeps them all
         int *d_cnt = nullptr;
         NRM_TRY(B.alloc(&d_cnt, (size_t)n));
         a.count_out = d_cnt;
         NRM_TRY((launch_normals<1, 2, false>(a, stream)));
-        std::vector<int> cnt((size_t)n);
+        cnt.resize((size_t)n);
         NRM_TRY(hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, stream));
         NRM_TRY(hipStreamSynchronize(stream));
-        cap = std::max(1, *std::max_element(cnt.begin(), cnt.end()));
-        a.cap = cap;
         type = 2;
     }
-    if (cap <= kNormalsMaxList) {
-        if (type == 0) NRM_TRY((launch_normals<0, 0, false>(a, stream)));
-        else NRM_TRY((launch_normals<2, 0, false>(a, stream)));
+    // Runs of queries (cell order) and the list capacity each needs.  KNN / Hybrid: one run, the caller's bound.
+    // Radius: the capacity of a run is the largest count AMONG ITS OWN queries (one dense corner of a scan
+    // used to give every query of the cloud a list -- and, beyond the LDS, a global-memory heap -- of that corner's
+    // length); runs of kSlab queries, neighbouring runs whose lists fit the LDS merged into one launch.
+    struct Run { int64_t q0, qn; int cap; };
+    std::vector<Run> runs;
+    if (search_type == 1) {
+        const int64_t kSlab = 16384;
+        for (int64_t q0 = 0; q0 < n; q0 += kSlab) {
+            const int64_t qn = std::min<int64_t>(kSlab, n - q0);
+            const int c = std::max(1, *std::max_element(cnt.begin() + q0, cnt.begin() + q0 + qn));
+            if (!runs.empty() && c <= kNormalsMaxList && runs.back().cap <= kNormalsMaxList) {
+                runs.back().qn += qn;
+                runs.back().cap = std::max(runs.back().cap, c);
+            } else {
+                runs.push_back(Run{q0, qn, c});
+            }
+        }
     } else {
-        // lists longer than the LDS holds: one max-heap per query in global memory, a slab of queries at a time
-        const size_t budget = (size_t)1 << 30;
-        int64_t slab = (int64_t)std::max<size_t>(1024, budget / ((size_t)cap * 12));
-        slab = std::min<int64_t>(slab, n);
-        double *d_sd = nullptr;
-        int *d_si = nullptr;
-        NRM_TRY(B.alloc(&d_sd, (size_t)cap * (size_t)slab));
-        NRM_TRY(B.alloc(&d_si, (size_t)cap * (size_t)slab));
+        runs.push_back(Run{0, n, cap});
+    }
+    // lists longer than the LDS holds: one max-heap per query in global memory, a slab of queries at a time; the
+    // slab's heaps take at most 1 GiB or half of what the device has free
+    size_t budget = (size_t)1 << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 2);
+    }
+    size_t spill_entries = 0;
+    for (Run &r : runs)
+        if (r.cap > kNormalsMaxList) {
+            if ((size_t)r.cap * 12 * 64 > budget) return hipErrorOutOfMemory;   // (64 queries' heaps do not fit)
+            const int64_t slab = std::min<int64_t>(r.qn, std::max<int64_t>(64, (int64_t)(budget / ((size_t)r.cap * 12))));
+            spill_entries = std::max(spill_entries, (size_t)r.cap * (size_t)slab);
+        }
+    double *d_sd = nullptr;
+    int *d_si = nullptr;
+    if (spill_entries) {
+        NRM_TRY(B.alloc(&d_sd, spill_entries));
+        NRM_TRY(B.alloc(&d_si, spill_entries));
         a.spill_d2 = d_sd; a.spill_id = d_si;
-        for (int64_t q0 = 0; q0 < n; q0 += slab) {
+    }
+    for (const Run &r : runs) {
+        a.cap = r.cap;
+        if (r.cap <= kNormalsMaxList) {
+            a.q_begin = (int)r.q0;
+            a.q_count = (int)r.qn;
+            if (type == 0) NRM_TRY((launch_normals<0, 0, false>(a, stream)));
+            else NRM_TRY((launch_normals<2, 0, false>(a, stream)));
+            continue;
+        }
+        const int64_t slab = std::min<int64_t>(r.qn, std::max<int64_t>(64, (int64_t)(budget / ((size_t)r.cap * 12))));
+        for (int64_t q0 = r.q0; q0 < r.q0 + r.qn; q0 += slab) {
             a.q_begin = (int)q0;
-            a.q_count = (int)std::min<int64_t>(slab, n - q0);
+            a.q_count = (int)std::min<int64_t>(slab, r.q0 + r.qn - q0);
             if (type == 0) NRM_TRY((launch_normals<0, 0, true>(a, stream)));
             else NRM_TRY((launch_normals<2, 0, true>(a, stream)));
         }
