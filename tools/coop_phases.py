@@ -27,12 +27,14 @@ def main():
     c = _lib.Context(0)
     c.set_clouds_f64(src, tgt)
     c.set_nn_mode(_lib.NN_GRID)
-    c.iterate(np.eye(4), r, 6)
+    T0, _ = c.iterate(np.eye(4), r, int(os.environ.get('PROBE_WARMUP', '6')))
+    if os.environ.get('PROBE_CONTINUE', '1') != '1':
+        T0 = np.eye(4)                                       # (restart from the identity: the jump defeats the certificates)
     L = _lib.load()
     out = (C.c_ulonglong * 16)()
     L.visma_debug_coop_phases(out, 1)
     steps = 10
-    c.iterate(np.eye(4), r, steps)
+    c.iterate(T0, r, steps)
     L.visma_debug_coop_phases(out, 0)
     nwg = (ns + 255) // 256 * steps
     tot = sum(out[k] for k in range(9))
@@ -61,15 +63,49 @@ def main():
     if "--spans" in sys.argv:
         mk = (C.c_ulonglong * (16 * nw))()
         L.visma_debug_coop_marks(mk, 16 * nw)
-        m = np.array(mk[:], dtype=np.int64).reshape(nw, 16)[:, :7]
-        prev = a[:, 0]
+        m = np.array(mk[:], dtype=np.int64).reshape(nw, 16)
         first, last = (seq * 8 // nb) < 2, (seq * 8 // nb) >= 6
-        print("  phase durations per wave, us: median all | first-dispatched quarter | last-dispatched quarter | max")
-        for k in range(7):
-            d = (m[:, k] - prev) / 100.0
+        order = [(9, "A: src+state, certificate"), (10, "barrier 1"), (0, "S src+prev again"), (1, "S bounds, prune"),
+                 (2, "S list written"), (3, "S chunks"), (4, "S merge"), (5, "S f64 winner"), (11, "S outputs"),
+                 (12, "barrier 2"), (13, "C moments"), (7, "partial row"), (8, "fold")]
+        searching = m[:, 11] > 0
+        print("  waves that searched: %d of %d" % (int(searching.sum()), nw))
+        print("  phase END times since the wave's start and durations, us: median end | median dur all | first quarter | last quarter | max dur  (S = searching waves only)")
+        prev = a[:, 0].copy()
+        for k, name in order:
             ok = m[:, k] > 0
-            print("    %-22s %6.2f | %6.2f | %6.2f | %6.2f" % (NAMES[k], np.median(d[ok]), np.median(d[ok & first]), np.median(d[ok & last]), d[ok].max()))
+            if not ok.any():
+                continue
+            d = (m[:, k] - prev) / 100.0
+            e = (m[:, k] - a[:, 0]) / 100.0
+            print("    %-28s %6.2f | %6.2f | %6.2f | %6.2f | %6.2f   (%d waves)" % (name, np.median(e[ok]), np.median(d[ok]), np.median(d[ok & first]) if (ok & first).any() else -1, np.median(d[ok & last]) if (ok & last).any() else -1, d[ok].max(), int(ok.sum())))
             prev = np.where(ok, m[:, k], prev)
+        # where the waves ran: HW_ID = wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
+        hw, xcc = m[:, 14], m[:, 15] & 0xF
+        simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+        wv = np.arange(nw) & 3
+        print("  SIMD of wave k of a workgroup (rows: wave 0..3; columns: SIMD 0..3): " +
+              " | ".join(" ".join("%4d" % int(((wv == k) & (simd == s_)).sum()) for s_ in range(4)) for k in range(4)))
+        print("  block b -> XCC: " + " ".join("%d" % int(xcc[4 * b]) for b in range(16)))
+        cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+        for b in (0, 8, 16, 24, 256, 512, 768):
+            if 4 * b < nw:
+                print("    block %4d: xcc %d se %d sh %d cu %2d, simd of waves %s" % (b, xcc[4 * b], se[4 * b], sh[4 * b], cu[4 * b], simd[4 * b:4 * b + 4].tolist()))
+        # blocks sharing a CU with block 0 of XCC 0
+        same = np.flatnonzero(cuid[::4] == cuid[0])
+        print("    blocks on the CU of block 0: %s" % same[:12].tolist())
+        srch = searching.reshape(-1, 4)
+        ssimd = simd.reshape(-1, 4)
+        # searching waves per (CU, SIMD)
+        key = cuid[searching] * 4 + simd[searching]
+        if key.size:
+            cnts = np.bincount(np.unique(key, return_inverse=True)[1])
+            print("    searching waves per (CU, SIMD) that has any: mean %.2f max %d; histogram %s" % (cnts.mean(), cnts.max(), np.bincount(cnts).tolist()))
+        t0g = a[:, 0].min()
+        for k, name in ((9, "A done"), (10, "past barrier 1"), (11, "search done"), (12, "past barrier 2"), (7, "partial row stored"), (8, "fold / ticket done")):
+            ok = m[:, k] > 0
+            if ok.any():
+                print("    launch clock, %-20s percentiles %s: %s" % (name, q, np.percentile((m[ok, k] - t0g) / 100.0, q).round(2).tolist()))
     late = np.argsort(en)[-8:]
     print("  last waves: " + ", ".join("w%d %.2f-%.2f" % (w, st[w], en[w]) for w in late))
 

@@ -58,7 +58,8 @@ namespace visma {
 namespace {
 
 struct P12 { float x, y, z; };                // fp32 rounding of a cell-sorted f64 target point
-constexpr int kCoopCap = 512;                 // chunk descriptors per wave and list window (4 KiB)
+constexpr int kCoopCap = 384;                 // chunk descriptors per wave and list window (3 KiB; a wave of 64 searched
+                                              // queries lists ~250-300 chunks while the pose still moves, fewer later)
 #ifndef VISMA_COOP_DEPTH
 #define VISMA_COOP_DEPTH 7
 #endif
@@ -169,7 +170,6 @@ __device__ __forceinline__ void coop_body(
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
-    unsigned ncand = 0, ncand_all = 0, ncert = 0;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int oct = lane >> 3, l8 = lane & 7;
@@ -186,36 +186,41 @@ __device__ __forceinline__ void coop_body(
     __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, completed by chunk results (+ 64 null
                                                             // descriptors behind the last one: the list is read unguarded)
     __shared__ float s_sec[kBlock / 64][kCoopCap + 64];     // per chunk: its best candidate OUTSIDE the rounding band
+    __shared__ double s_p64[kBlock][3];                     // the transformed query of every HOME lane, f64 (what a searcher
+                                                            // takes over instead of loading and transforming the source again)
+    __shared__ float s_dprev[kBlock];                       // ... its squared fp32 distance to its previous winner (NaN: none)
+    __shared__ unsigned short s_home[kBlock];               // the home thread of the query each searcher lane took over
+    __shared__ unsigned s_need[kBlock / 64];                // queries queued by each wave this round (see `round` below)
+    __shared__ unsigned short s_queue[kBlock / 64][64];     // their home threads
     uint2 *items = s_item[wave];
     float *secs = s_sec[wave];
 
-    // outputs + moments of one query: the correspondence, the state for the next pass, the Jacobian / residual moments
-    auto finish = [&](long long i, bool active, bool cert, double pxd, double pyd, double pzd, double bd, unsigned bidx,
-                      bool found, double qx, double qy, double qz, float lb_new) {
-        if (active) {
-            const unsigned long long lbw = (unsigned long long)__float_as_uint(lb_new) << 32;
-            idx_out[i] = found ? (int)bidx : -1;             // (also when certified: later stages may reuse the array)
-            if (cert) {
-                // (winner unchanged: only the bound moves)
-                reinterpret_cast<unsigned *>(&wst_io[i].w)[1] = __float_as_uint(lb_new);
-            } else {
-                Pt64 o8;
-                o8.x = o8.y = o8.z = __longlong_as_double(-1ll);
-                o8.w = 0xFFFFFFFFull | lbw;
-                if (found) { o8.x = qx; o8.y = qy; o8.z = qz; o8.w = (unsigned long long)bidx | lbw; }
-                wst_io[i] = o8;
-            }
-            d2_out[i] = (float)bd;
-            if (d64_out) d64_out[i] = bd;                    // (target-sharded ranks compare shards in f64)
-            if (found) {
-                double nx = 0.0, ny = 0.0, nz = 0.0;
-                if (PLANE) {
-                    if (nrm64) { const Pt64 n8 = nrm64[bidx]; nx = n8.x; ny = n8.y; nz = n8.z; }
-                    else { const float4 n4 = nrm[bidx]; nx = n4.x; ny = n4.y; nz = n4.z; }
-                }
-                accumulate_pq_d<PLANE>(acc, pxd, pyd, pzd, qx, qy, qz, nx, ny, nz, off);
-            }
+    // outputs of one query: the correspondence and the state for the next pass
+    auto emit = [&](long long i, bool cert, double bd, unsigned bidx, bool found, double qx, double qy, double qz,
+                    float lb_new) {
+        const unsigned long long lbw = (unsigned long long)__float_as_uint(lb_new) << 32;
+        idx_out[i] = found ? (int)bidx : -1;                 // (also when certified: later stages may reuse the array)
+        if (cert) {
+            // (winner unchanged: only the bound moves)
+            reinterpret_cast<unsigned *>(&wst_io[i].w)[1] = __float_as_uint(lb_new);
+        } else {
+            Pt64 o8;
+            o8.x = o8.y = o8.z = __longlong_as_double(-1ll);
+            o8.w = 0xFFFFFFFFull | lbw;
+            if (found) { o8.x = qx; o8.y = qy; o8.z = qz; o8.w = (unsigned long long)bidx | lbw; }
+            wst_io[i] = o8;
         }
+        d2_out[i] = (float)bd;
+        if (d64_out) d64_out[i] = bd;                        // (target-sharded ranks compare shards in f64)
+    };
+    // the Jacobian / residual moments of one correspondence (p, q), on the query's HOME lane
+    auto moments = [&](double pxd, double pyd, double pzd, unsigned bidx, double qx, double qy, double qz) {
+        double nx = 0.0, ny = 0.0, nz = 0.0;
+        if (PLANE) {
+            if (nrm64) { const Pt64 n8 = nrm64[bidx]; nx = n8.x; ny = n8.y; nz = n8.z; }
+            else { const float4 n4 = nrm[bidx]; nx = n4.x; ny = n4.y; nz = n4.z; }
+        }
+        accumulate_pq_d<PLANE>(acc, pxd, pyd, pzd, qx, qy, qz, nx, ny, nz, off);
     };
     // ---- The slot ranges of the query at (px, py, pz) that can hold a candidate at or within the squared fp32 distance
     // bound0: xb[k] .. xe[k] of row k = (dy, dz) of the 3 x 3 x 3 cells around it, and lbgeo2, a lower bound (squared) of
@@ -313,30 +318,28 @@ __device__ __forceinline__ void coop_body(
         }
         lbgeo2 = fminf(out2, pruned2);
     };
-    // one query (or none: the lanes past the end still work on the others' chunks)
-    auto query = [&](long long i, bool active) {
-        // ---- the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
-        Pt64 s8 = Pt64{0.0, 0.0, 0.0, 0ull};
-        // the state the previous pass left: its winner's f64 point (NaN = none), original index | LB << 32
-        // (all bits set = nothing known: NaN coordinates, NaN bound)
-        Pt64 w8;
-        w8.x = w8.y = w8.z = __longlong_as_double(-1ll);
-        w8.w = ~0ull;
-        if (active) {
-            s8 = src64[i];
-            if (warm & 1) w8 = wst_io[i];
-        }
-        // (fp32 view of the previous winner: the value the candidate array holds for that point)
-        const float4 qprev = make_float4((float)w8.x, (float)w8.y, (float)w8.z, 0.f);
-        // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
-        double pd[3];
+    // ---- B: one queued query per lane of the first ceil(nq_all / 64) waves
+    auto search = [&](const int it, const unsigned (&cnt_w)[kBlock / 64], const unsigned nq_all) {
+        const bool active = (unsigned)tid < nq_all;          // this lane has a query to search
+        const bool need = active;
+        unsigned home = 0;                                   // ... the one of this thread of the workgroup
         {
-            const double sv[3] = {s8.x, s8.y, s8.z};
-            se3_act(T64.m, sv, pd);
+            unsigned base = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) {
+                if ((unsigned)tid >= base && (unsigned)tid < base + cnt_w[w]) home = s_queue[w][(unsigned)tid - base];
+                base += cnt_w[w];
+            }
+            s_home[tid] = (unsigned short)home;              // (read back at the end: nothing is carried across the search)
         }
-        const double pxd = pd[0], pyd = pd[1], pzd = pd[2];
+#if defined(VISMA_COOP_STOP_AFTER)
+        const long long i = (long long)(vb * kBlock + (int)home) * per_group + it;   // (COOP_PHASE of the truncation builds)
+#endif
+        // the query as its home lane transformed it (phase A), and its distance to the previous winner
+        const double pxd = s_p64[home][0], pyd = s_p64[home][1], pzd = s_p64[home][2];
+        const float dprev = active ? s_dprev[home] : __uint_as_float(~0u);
         const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
-        COOP_PHASE(0, 0u, px + py + pz + qprev.x + qprev.y + qprev.z);   // source + previous winner arrived
+        COOP_PHASE(0, 0u, px + py + pz + dprev);                         // the query taken over from its home lane
         // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
         // which a candidate cannot be accepted in f64; W >= band(m) - m for every m < L
         const float r_f = sqrtf(r2f);
@@ -345,58 +348,14 @@ __device__ __forceinline__ void coop_body(
         const float tlim = rup + 2.0f * E;
         const float L = tlim * tlim * (1.0f + 6e-7f);
         const float W = (4.0f * E * tlim + 4.0f * E * E) * (1.0f + 1e-6f) + L * 5e-7f;
-        // ---- the certificate: has the query moved by less than the room its previous result left?
-        const unsigned widx = (unsigned)w8.w;
-        const bool has_w = w8.x == w8.x;                     // (NaN: no previous winner)
-        bool cert = false;
-        double d2w = r2d;                                    // the previous winner's distance now (reference arithmetic)
         float lb_new = 0.f;                                  // what this pass leaves as LB
-        if (warm & 4) {
-            // delta = |T s - T_prev s|: same products, same order as the transform itself, so the two computed
-            // points are the ones the bounds speak about; rounded up
-            double pp[3];
-            {
-                const double sv[3] = {s8.x, s8.y, s8.z};
-                se3_act(Tprev.m, sv, pp);
-            }
-            const double ex = pxd - pp[0], ey = pyd - pp[1], ez = pzd - pp[2];
-            const float del = sqrtf((float)(ex * ex + ey * ey + ez * ez)) * (1.0f + 1e-6f);
-            // (the bound of an unknown state is NaN: every comparison below is false.  The two ulps taken off cover the
-            //  rounding of this subtraction and the ~1e-16 |p| by which the f64 difference above can be off -- the band
-            //  E itself was taken off once, when the bound was formed: taking it off every pass would wear a 1 mm gap
-            //  down in a few hundred certified passes and send the query back to the search for nothing)
-            const float t = (__uint_as_float((unsigned)(w8.w >> 32)) - del) * (1.0f - 2.4e-7f);
-            if (has_w) {
-                // flann L2 (dist.h:159-176), as rank() below
-                const double dx = w8.x - pxd, dy = w8.y - pyd, dz = w8.z - pzd;
-                double d = dx * dx;
-                d += dy * dy;
-                d += dz * dz;
-                d2w = d;
-                cert = active && t > 0.f && d < r2d && d < (double)t * (double)t * (1.0 - 1e-6);
-            } else {
-                cert = active && widx == 0xFFFFFFFFu && t > tlim * (1.0f + 1e-6f);
-            }
-            lb_new = t;
-        }
-        const bool need = active && !cert;
-        if (cand_count && cert) ncert++;                     // (profiling)
-        if (__builtin_amdgcn_ballot_w64(need) == 0ull) {
-            // (wave-uniform) every query of the wave is certified: source + state in, distance + bound out
-            const bool found = cert && has_w;
-            finish(i, active, cert, pxd, pyd, pzd, found ? d2w : r2d, widx, found, w8.x, w8.y, w8.z, lb_new);
-            return;
-        }
         double bd = r2d;                                     // best d2 so far (strictly below r2d once set)
         unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
         Pt64 bq = Pt64{0.0, 0.0, 0.0, 0ull};
         s_qp[tid] = make_float4(px, py, pz, W);
         // what nothing nearer than can be missed by: the previous winner's distance now, or the radius
         float bound0 = L;
-        {
-            const float dprev = sqdist_f32(qprev, px, py, pz);
-            if (dprev < L) bound0 = dprev;                   // (NaN = no previous winner: the radius)
-        }
+        if (dprev < L) bound0 = dprev;                       // (NaN = no previous winner: the radius)
         unsigned xb[9], xe[9];
         float lbgeo2;                                        // LB, geometric part (squared)
         {
@@ -406,10 +365,22 @@ __device__ __forceinline__ void coop_body(
             //  use at the end of the query and spills its 40 inputs across the chunk phase instead)
             asm volatile("" : "+v"(lbgeo2));
             if (cand_count) {
-                // profiling only (one uniform branch): candidates listed, cell-table rows looked up
+                // profiling only (one uniform branch): candidates listed, cell-table rows looked up -- summed over the
+                // wave and added to the launch's counters right here (counters carried to the end of the kernel were
+                // spilled across the search)
+                unsigned long long c = 0, ca = looked;
 #pragma unroll
-                for (int k = 0; k < 9; k++) ncand += xe[k] - xb[k];
-                ncand_all += looked;
+                for (int k = 0; k < 9; k++) c += xe[k] - xb[k];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    c += __shfl_down(c, o, 64);
+                    ca += __shfl_down(ca, o, 64);
+                }
+                if (lane == 0 && ca) {
+                    unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
+                    atomicAdd(slot, c);
+                    atomicAdd(slot + 1, ca);
+                }
             }
         }
         COOP_PHASE(1, xb[0] ^ xe[8] ^ xb[4] ^ xe[2] ^ xb[6], 0.f);            // row bounds arrived, rows pruned
@@ -682,61 +653,171 @@ __device__ __forceinline__ void coop_body(
             if (slow || n > 1) lb = 0.f;
             lb_new = fminf(fmaxf(lb, 0.f), 3.0e38f);
         }
-        bool found = bpos != 0xFFFFFFFFu;
-        if (cert && has_w) {
-            // a certified query in a wave that searched: the previous winner again (re-read: nothing of it was kept
-            // across the search), at its new distance -- flann L2 as above
-            const Pt64 c8 = wst_io[i];
-            const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
-            double d = dx * dx;
-            d += dy * dy;
-            d += dz * dz;
-            bd = d;
-            bidx = (unsigned)c8.w;
-            bq.x = c8.x; bq.y = c8.y; bq.z = c8.z;
-            found = true;
-        }
+        const bool found = bpos != 0xFFFFFFFFu;
         COOP_PHASE(5, bidx, (float)(bd + bq.x));                            // f64 winner arrived and ranked
-        finish(i, active, cert, pxd, pyd, pzd, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
+        if (active) {
+            const long long i = (long long)(vb * kBlock + (int)s_home[tid]) * per_group + it;   // its home thread's query of the round
+            emit(i, false, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
+        }
+        // the hand-over to the query's home lane (phase C): the winner's f64 point and index, where this wave's chunk
+        // list lay (the list has been worked off: the windows end with a wave barrier)
+        {
+            Pt64 r8;
+            r8.x = bq.x; r8.y = bq.y; r8.z = bq.z;
+            r8.w = found ? (unsigned long long)bidx : 0xFFFFFFFFull;
+            reinterpret_cast<Pt64 *>(items)[lane] = r8;
+        }
         };   // tail
         {
-            unsigned z;                                      // (a zero the compiler cannot see through: no value is carried over)
-            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
-            Pt64 r8 = Pt64{0.0, 0.0, 0.0, 0ull};
-            if (active) r8 = src64[i + z];
-            const float4 me = s_qp[tid + z];
-            double rd[3];
-            const double sv[3] = {r8.x, r8.y, r8.z};
-            se3_act(T64.m, sv, rd);
-            tail(rd[0], rd[1], rd[2], me.x, me.y, me.z, me.w);
+            // (the query again from where it lies in LDS: nothing of it was carried across the listing and the chunk phase)
+            const float4 me = s_qp[tid];
+            const unsigned h = s_home[tid];
+            tail(s_p64[h][0], s_p64[h][1], s_p64[h][2], me.x, me.y, me.z, me.w);
+        }
+    };
+    // ---- One ROUND = one query per lane of the workgroup, in three phases.
+    //  A  every lane, its own ("home") query: source point + state in, the certificate; a certified query writes its
+    //     outputs here, the others queue up (per-wave segments: the queue's order does not depend on arrival).
+    //  B  the queued queries, COMPACTED over the lanes of the workgroup: thread k searches the k-th queued query
+    //     (whoever's it is) -- waves k/64 beyond the queue's length skip the phase, so the search costs what the
+    //     uncertified queries cost, not what the waves that hold one cost (after a few ICP iterations most waves hold
+    //     a handful: without the compaction every one of them ran the whole search for those).  A query's result does
+    //     not depend on the lane that searched it.
+    //  C  home lanes again: the moments of the round's correspondence (from registers when certified, from the
+    //     searcher's hand-over in LDS otherwise) -- the query -> lane map and the summation tree of the lane-serial
+    //     kernel, so the 38 statistics stay bit-identical to its.
+    auto round = [&](const int it) {
+        const long long i = i_begin + it;
+        const bool active = i < i_end;
+        // ---- A: the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
+        Pt64 s8 = Pt64{0.0, 0.0, 0.0, 0ull};
+        // the state the previous pass left: its winner's f64 point (NaN = none), original index | LB << 32
+        // (all bits set = nothing known: NaN coordinates, NaN bound)
+        Pt64 w8;
+        w8.x = w8.y = w8.z = __longlong_as_double(-1ll);
+        w8.w = ~0ull;
+        if (active) {
+            s8 = src64[i];
+            if (warm & 1) w8 = wst_io[i];
+        }
+        // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
+        double hp[3];                                        // the home query's point: kept for phase C
+        {
+            const double sv[3] = {s8.x, s8.y, s8.z};
+            se3_act(T64.m, sv, hp);
+        }
+        // ---- the certificate: has the query moved by less than the room its previous result left?
+        const unsigned widx = (unsigned)w8.w;
+        const bool has_w = w8.x == w8.x;                     // (NaN: no previous winner)
+        bool cert = false;
+        if (warm & 4) {
+            const float hx = (float)hp[0], hy = (float)hp[1], hz = (float)hp[2];
+            const float rup = sqrtf(r2f) * (1.0f + 2.4e-7f);
+            const float E = 2.4e-7f * (fabsf(hx) + fabsf(hy) + fabsf(hz) + rup) + 4.8e-7f * rup;
+            const float tlim = rup + 2.0f * E;
+            // delta = |T s - T_prev s|: same products, same order as the transform itself, so the two computed
+            // points are the ones the bounds speak about; rounded up
+            double pp[3];
+            {
+                const double sv[3] = {s8.x, s8.y, s8.z};
+                se3_act(Tprev.m, sv, pp);
+            }
+            const double ex = hp[0] - pp[0], ey = hp[1] - pp[1], ez = hp[2] - pp[2];
+            const float del = sqrtf((float)(ex * ex + ey * ey + ez * ez)) * (1.0f + 1e-6f);
+            // (the bound of an unknown state is NaN: every comparison below is false.  The two ulps taken off cover the
+            //  rounding of this subtraction and the ~1e-16 |p| by which the f64 difference above can be off -- the band
+            //  E itself was taken off once, when the bound was formed: taking it off every pass would wear a 1 mm gap
+            //  down in a few hundred certified passes and send the query back to the search for nothing)
+            const float t = (__uint_as_float((unsigned)(w8.w >> 32)) - del) * (1.0f - 2.4e-7f);
+            double d2w = r2d;                                // the previous winner's distance now (reference arithmetic)
+            if (has_w) {
+                // flann L2 (dist.h:159-176), as rank() below
+                const double dx = w8.x - hp[0], dy = w8.y - hp[1], dz = w8.z - hp[2];
+                double d = dx * dx;
+                d += dy * dy;
+                d += dz * dz;
+                d2w = d;
+                cert = active && t > 0.f && d < r2d && d < (double)t * (double)t * (1.0 - 1e-6);
+            } else {
+                cert = active && widx == 0xFFFFFFFFu && t > tlim * (1.0f + 1e-6f);
+            }
+            // (wave-uniform skip of the stores when nobody certified)
+#ifndef VISMA_COOP_X_NOEMIT   /* (timing experiment: what the certified queries' stores cost the searching wave) */
+            if (cert) emit(i, true, has_w ? d2w : r2d, widx, has_w, w8.x, w8.y, w8.z, t);
+#endif
+        }
+        const bool need = active && !cert;
+        const bool cfound = cert && has_w;                   // certified WITH a partner: (hp, w8) is the correspondence
+        // the transformed query, for its searcher (phase B) and for this lane itself in phase C
+        s_p64[tid][0] = hp[0]; s_p64[tid][1] = hp[1]; s_p64[tid][2] = hp[2];
+        if (need) {
+            // (fp32 view of the previous winner: the value the candidate array holds for that point; NaN = none)
+            s_dprev[tid] = sqdist_f32(make_float4((float)w8.x, (float)w8.y, (float)w8.z, 0.f), (float)hp[0], (float)hp[1], (float)hp[2]);
+        }
+        if (cand_count) {
+            // (profiling) queries certified: no search
+            const unsigned cc = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cert));
+            if (lane == 0 && cc) atomicAdd(cand_count + 2 * 4096 + (blockIdx.x & 4095), (unsigned long long)cc);
+        }
+        if constexpr (!ONE) {
+            // (several rounds: the accumulators are live anyway; round order per lane is what the sums depend on)
+            if (cfound) moments(hp[0], hp[1], hp[2], widx, w8.x, w8.y, w8.z);
+        }
+        // ---- queue the others: position = queries queued by the lower waves + by the lower lanes of this wave
+        const unsigned long long needers = __builtin_amdgcn_ballot_w64(need);
+        const unsigned rank = (unsigned)__builtin_popcountll(needers & ((1ull << lane) - 1ull));
+        if (need) s_queue[wave][rank] = (unsigned short)tid;
+        if (lane == 0) s_need[wave] = (unsigned)__builtin_popcountll(needers);
+        COOP_MARK(9);                                        // phase A done
+        __syncthreads();
+        COOP_MARK(10);
+        unsigned cnt_w[kBlock / 64], nq_all = 0, kpos = rank;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) {
+            cnt_w[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_need[w]);   // (uniform: scalar registers)
+            if (w < wave) kpos += cnt_w[w];
+            nq_all += cnt_w[w];
+        }
+        // ---- B: thread k < nq_all searches the k-th queued query
+        const bool searching = (unsigned)(wave * 64) < nq_all;           // (wave-uniform)
+        if (searching) {
+            search(it, cnt_w, nq_all);
+            COOP_MARK(11);                                   // search done
+        } else if constexpr (ONE) {
+            // (a wave without a search: the moments of its certified queries while the others search -- straight from
+            //  the registers of phase A)
+            if (cfound) moments(hp[0], hp[1], hp[2], widx, w8.x, w8.y, w8.z);
+        }
+        __syncthreads();
+        COOP_MARK(12);
+        // ---- C: the moments of the round's correspondence, on the home lane
+        if constexpr (ONE) {
+            // A wave that searched kept nothing of its home queries across the search, where the kernel sits at the 128
+            // registers it may use (4 waves per SIMD): the transformed query comes back from LDS, a certified winner
+            // from the state (a line this lane touched a few us ago), a searched one from its searcher's hand-over.
+            const bool late = searching && cfound;
+            Pt64 c8 = Pt64{0.0, 0.0, 0.0, 0xFFFFFFFFull};
+            if (late) c8 = wst_io[i];
+            else if (need) c8 = reinterpret_cast<const Pt64 *>(s_item[kpos >> 6])[kpos & 63];
+            if ((late || need) && (unsigned)c8.w != 0xFFFFFFFFu)
+                moments(s_p64[tid][0], s_p64[tid][1], s_p64[tid][2], (unsigned)c8.w, c8.x, c8.y, c8.z);
+        } else {
+            if (need) {
+                const Pt64 r8 = reinterpret_cast<const Pt64 *>(s_item[kpos >> 6])[kpos & 63];
+                if ((unsigned)r8.w != 0xFFFFFFFFu) moments(hp[0], hp[1], hp[2], (unsigned)r8.w, r8.x, r8.y, r8.z);
+            }
         }
     };
     if constexpr (ONE) {
-        query(i_begin, i_begin < i_end);
+        round(0);
+        COOP_MARK(13);                                       // phase C done
     } else {
-        for (int it = 0; it < per_group; it++) query(i_begin + it, i_begin + it < i_end);   // wave-uniform trip count
+        for (int it = 0; it < per_group; it++) round(it);    // (workgroup-uniform trip count: the rounds hold barriers)
     }
     COOP_MARK(6);                                            // outputs + moments
     COOP_WAVE_DONE();
     block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
     COOP_MARK(7);                                            // workgroup's partial row stored
-    if (cand_count) {
-        unsigned long long c = ncand, ca = ncand_all, cc = ncert;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            c += __shfl_down(c, o, 64);
-            ca += __shfl_down(ca, o, 64);
-            cc += __shfl_down(cc, o, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
-            if (ca) {
-                atomicAdd(slot, c);
-                atomicAdd(slot + 1, ca);
-            }
-            if (cc) atomicAdd(cand_count + 2 * 4096 + (blockIdx.x & 4095), cc);   // queries certified (no search)
-        }
-    }
     if (fold.tickets) fused_fold<PLANE, kBlock>(fold, partials, row0, lb, bpp, prob);
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
 }

@@ -8,6 +8,8 @@
 //                                 results are garbage): launch time as a function of how far the queries get
 // COOP_PHASE(k, u, f) sits at the border after phase k inside coop_body's per-query lambda and names a 32-bit and a
 // float value that the work so far produced (kept alive by the stop / the forced wait); COOP_MARK(k) only stamps.
+// Marks of a round (round 4: certificate + compaction): 9 phase A done | 10 past the first barrier | 0..5 the search
+// (searching waves only) | 11 search done | 12 past the second barrier | 13 phase C done | 6 rounds done | 7 partial row | 8 fold.
 #pragma once
 
 #if defined(VISMA_COOP_DEBUG_PHASES) || defined(VISMA_COOP_STOP_AFTER)
@@ -25,10 +27,24 @@ __device__ unsigned long long g_coop_span[4 * 8192];        // per wave of the l
 __device__ unsigned long long g_coop_marks[16 * 8192];      // mode 2: per wave, the clock at every phase border
 }  // namespace visma
 
+#if VISMA_COOP_DEBUG_PHASES == 2
+#define COOP_PROBE_CLEAR()                                                                                      \
+    do {                                                                                                        \
+        if ((threadIdx.x & 63) < 14 && blockIdx.x < 2048)      /* (a wave that skips a phase leaves no stale stamp) */ \
+            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 63)] = 0ull;               \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {    /* where the wave runs: HW_ID (4), XCC_ID (20) */   \
+            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); \
+        }                                                                                                       \
+    } while (0)
+#else
+#define COOP_PROBE_CLEAR() do { } while (0)
+#endif
 #define COOP_PROBE_BEGIN()                                                                                      \
     unsigned long long stamp_ = __builtin_amdgcn_s_memrealtime();                                               \
     const unsigned long long stamp0_ = stamp_;                                                                  \
-    (void)stamp0_
+    (void)stamp0_;                                                                                              \
+    COOP_PROBE_CLEAR()
 
 #if VISMA_COOP_DEBUG_PHASES == 1
 #define COOP_MARK(k)                                                                                            \
