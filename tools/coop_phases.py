@@ -65,9 +65,9 @@ def main():
         L.visma_debug_coop_marks(mk, 16 * nw)
         m = np.array(mk[:], dtype=np.int64).reshape(nw, 16)
         first, last = (seq * 8 // nb) < 2, (seq * 8 // nb) >= 6
-        order = [(9, "A: src+state, certificate"), (10, "barrier 1"), (0, "S src+prev again"), (1, "S bounds, prune"),
-                 (2, "S list written"), (3, "S chunks"), (4, "S merge"), (5, "S f64 winner"), (11, "S outputs"),
-                 (12, "barrier 2"), (13, "C moments"), (7, "partial row"), (8, "fold")]
+        order = [(9, "A: src+state, certificate"), (10, "barrier 1"), (0, "S query taken over"), (1, "S rows asked for"),
+                 (2, "S list written (+2 barriers)"), (3, "S chunks worked off"), (4, "S merged (+1 barrier)"), (5, "S f64 winner"),
+                 (11, "S outputs"), (12, "last barrier"), (13, "C moments"), (7, "partial row"), (8, "fold")]
         searching = m[:, 11] > 0
         print("  waves that searched: %d of %d" % (int(searching.sum()), nw))
         print("  phase END times since the wave's start and durations, us: median end | median dur all | first quarter | last quarter | max dur  (S = searching waves only)")

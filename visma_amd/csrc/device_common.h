@@ -227,10 +227,10 @@ __device__ __forceinline__ double wave_sum_multi(double *v)
 
 // wavefront shuffle reduction -> LDS across the 4 waves -> one partial row
 // (row = nullptr: partials + blockIdx.x * kReduceAcc; agent: write-through stores for the fused fold)
-template <int NACC>
+template <int NACC, int NWAVES = kBlock / 64>
 __device__ __forceinline__ void block_reduce_store(double *acc, double *partials, bool agent = false)
 {
-    __shared__ double wsum[kBlock / 64][NACC];
+    __shared__ double wsum[NWAVES][NACC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double tot = wave_sum_multi<NACC>(acc);
     const int slot = multi_index<NACC>(lane);
@@ -239,7 +239,7 @@ __device__ __forceinline__ void block_reduce_store(double *acc, double *partials
     if (threadIdx.x < NACC) {
         double v = wsum[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < kBlock / 64; w++) v += wsum[w][threadIdx.x];
+        for (int w = 1; w < NWAVES; w++) v += wsum[w][threadIdx.x];
         double *dst = partials + (long long)blockIdx.x * kReduceAcc + threadIdx.x;
         if (agent) store_agent_f64(dst, v);
         else *dst = v;

@@ -51,7 +51,7 @@
 // g + W, or more than four flagged candidates, sends the query to the f64 re-scan of its 27 cells (points
 // given several times).
 #include "device_common.h"
-#include "grid_coop_probe.h"   // COOP_PHASE / COOP_MARK: no-ops outside the measurement builds
+#include "grid_coop_probe.h"   // COOP_MARK: no-ops outside the measurement builds
 
 namespace visma {
 
@@ -97,7 +97,7 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int)
 
 }  // namespace
 
-template <bool PLANE, bool ONE>
+template <bool PLANE, bool ONE, int NTH>
 __device__ __forceinline__ void coop_body(
     int ns, const float *__restrict__ s12f, const unsigned *__restrict__ start, GridParams g,
     const float4 *__restrict__ nrm, Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out,
@@ -173,27 +173,30 @@ __device__ __forceinline__ void coop_body(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int oct = lane >> 3, l8 = lane & 7;
+    constexpr int NW = NTH / 64;                             // waves of the workgroup
+    constexpr unsigned kCapAll = (unsigned)(NW * kCoopCap);  // chunk descriptors of the workgroup's list window
     // the query -> lane map of nn_grid_reduce_kernel<G = 1> (XCD-aware chunking of the Morton order)
     int vb = lb;
     if ((bpp & 7) == 0) vb = (lb & 7) * (bpp >> 3) + (lb >> 3);
-    const int total_groups = bpp * kBlock;
+    const int total_groups = bpp * NTH;
     const int per_group = (ns + total_groups - 1) / total_groups;
-    const int gid = vb * kBlock + tid;
+    const int gid = vb * NTH + tid;
     const long long i_begin = (long long)gid * per_group;
     const long long i_end = i_begin + per_group < ns ? i_begin + per_group : ns;
 
-    __shared__ float4 s_qp[kBlock];                         // (px, py, pz, W) of the query of each lane
-    __shared__ uint2 s_item[kBlock / 64][kCoopCap + 64];    // chunk descriptors, completed by chunk results (+ 64 null
-                                                            // descriptors behind the last one: the list is read unguarded)
-    __shared__ float s_sec[kBlock / 64][kCoopCap + 64];     // per chunk: its best candidate OUTSIDE the rounding band
-    __shared__ double s_p64[kBlock][3];                     // the transformed query of every HOME lane, f64 (what a searcher
+    __shared__ float4 s_qp[NTH];                            // (px, py, pz, W) of the query each SEARCHER thread took over
+    __shared__ uint2 s_item[kCapAll];                       // the workgroup's chunk descriptors, completed by chunk results
+    __shared__ float s_sec[kCapAll];                        // per chunk: its best candidate OUTSIDE the rounding band
+    __shared__ double s_p64[NTH][3];                        // the transformed query of every HOME lane, f64 (what a searcher
                                                             // takes over instead of loading and transforming the source again)
-    __shared__ float s_dprev[kBlock];                       // ... its squared fp32 distance to its previous winner (NaN: none)
-    __shared__ unsigned short s_home[kBlock];               // the home thread of the query each searcher lane took over
-    __shared__ unsigned s_need[kBlock / 64];                // queries queued by each wave this round (see `round` below)
-    __shared__ unsigned short s_queue[kBlock / 64][64];     // their home threads
-    uint2 *items = s_item[wave];
-    float *secs = s_sec[wave];
+    __shared__ double s_q64[NTH][3];                        // the partner of every home lane's query: the certified winner
+                                                            // (phase A) or what the query's searcher found (phase B)
+    __shared__ float s_dprev[NTH];                          // home lane's squared fp32 distance to its previous winner (NaN:
+                                                            // none) for the searcher; then the partner's index (bits; ~0: none)
+    __shared__ unsigned short s_home[NTH];                  // the home thread of the query each searcher thread took over
+    __shared__ unsigned s_need[NW];                         // queries queued by each wave this round (see `round` below)
+    __shared__ unsigned s_m[NW];                            // chunks listed by each wave's searchers
+    __shared__ unsigned short s_queue[NW][64];              // the queued queries' home threads
 
     // outputs of one query: the correspondence and the state for the next pass
     auto emit = [&](long long i, bool cert, double bd, unsigned bidx, bool found, double qx, double qy, double qz,
@@ -318,374 +321,19 @@ __device__ __forceinline__ void coop_body(
         }
         lbgeo2 = fminf(out2, pruned2);
     };
-    // ---- B: one queued query per lane of the first ceil(nq_all / 64) waves
-    auto search = [&](const int it, const unsigned (&cnt_w)[kBlock / 64], const unsigned nq_all) {
-        const bool active = (unsigned)tid < nq_all;          // this lane has a query to search
-        const bool need = active;
-        unsigned home = 0;                                   // ... the one of this thread of the workgroup
-        {
-            unsigned base = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) {
-                if ((unsigned)tid >= base && (unsigned)tid < base + cnt_w[w]) home = s_queue[w][(unsigned)tid - base];
-                base += cnt_w[w];
-            }
-            s_home[tid] = (unsigned short)home;              // (read back at the end: nothing is carried across the search)
-        }
-#if defined(VISMA_COOP_STOP_AFTER)
-        const long long i = (long long)(vb * kBlock + (int)home) * per_group + it;   // (COOP_PHASE of the truncation builds)
-#endif
-        // the query as its home lane transformed it (phase A), and its distance to the previous winner
-        const double pxd = s_p64[home][0], pyd = s_p64[home][1], pzd = s_p64[home][2];
-        const float dprev = active ? s_dprev[home] : __uint_as_float(~0u);
-        const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
-        COOP_PHASE(0, 0u, px + py + pz + dprev);                         // the query taken over from its home lane
-        // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
-        // which a candidate cannot be accepted in f64; W >= band(m) - m for every m < L
-        const float r_f = sqrtf(r2f);
-        const float rup = r_f * (1.0f + 2.4e-7f);
-        const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
-        const float tlim = rup + 2.0f * E;
-        const float L = tlim * tlim * (1.0f + 6e-7f);
-        const float W = (4.0f * E * tlim + 4.0f * E * E) * (1.0f + 1e-6f) + L * 5e-7f;
-        float lb_new = 0.f;                                  // what this pass leaves as LB
-        double bd = r2d;                                     // best d2 so far (strictly below r2d once set)
-        unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
-        Pt64 bq = Pt64{0.0, 0.0, 0.0, 0ull};
-        s_qp[tid] = make_float4(px, py, pz, W);
-        // what nothing nearer than can be missed by: the previous winner's distance now, or the radius
-        float bound0 = L;
-        if (dprev < L) bound0 = dprev;                       // (NaN = no previous winner: the radius)
-        unsigned xb[9], xe[9];
-        float lbgeo2;                                        // LB, geometric part (squared)
-        {
-            unsigned looked;
-            list_rows(px, py, pz, E, bound0, need, xb, xe, lbgeo2, looked);
-            // (pin the value here: left to itself the compiler sinks the whole slab arithmetic down to the bound's only
-            //  use at the end of the query and spills its 40 inputs across the chunk phase instead)
-            asm volatile("" : "+v"(lbgeo2));
-            if (cand_count) {
-                // profiling only (one uniform branch): candidates listed, cell-table rows looked up -- summed over the
-                // wave and added to the launch's counters right here (counters carried to the end of the kernel were
-                // spilled across the search)
-                unsigned long long c = 0, ca = looked;
-#pragma unroll
-                for (int k = 0; k < 9; k++) c += xe[k] - xb[k];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    c += __shfl_down(c, o, 64);
-                    ca += __shfl_down(ca, o, 64);
-                }
-                if (lane == 0 && ca) {
-                    unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
-                    atomicAdd(slot, c);
-                    atomicAdd(slot + 1, ca);
-                }
-            }
-        }
-        COOP_PHASE(1, xb[0] ^ xe[8] ^ xb[4] ^ xe[2] ^ xb[6], 0.f);            // row bounds arrived, rows pruned
-        // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
-        float gh0 = INFINITY, gh1 = INFINITY, gh2 = INFINITY;
-        float gsec = INFINITY;                               // best candidate outside the rounding band of its chunk's minimum
-        unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
-        auto chunk_insert = [&](float m, unsigned b, unsigned flags) {
-            const bool c1 = m < gh0, c2 = m < gh1;
-            gh2 = __builtin_amdgcn_fmed3f(gh1, gh2, m);
-            gh1 = __builtin_amdgcn_fmed3f(gh0, gh1, m);
-            gh0 = fminf(gh0, m);
-            gb1 = c2 ? b : gb1; gm1 = c2 ? flags : gm1;
-            gb1 = c1 ? gb0 : gb1; gm1 = c1 ? gm0 : gm1;
-            gb0 = c1 ? b : gb0; gm0 = c1 ? flags : gm0;
-        };
-        // ---- the rows, chunked and flattened over the wave.  A query's chunks take CONSECUTIVE list entries: the
-        // owner reads its results back as one short run (walking the rows again, one LDS round trip per chunk, took
-        // 2.5 us of every wave's 17).
-        {
-            unsigned nq = 0;
-#pragma unroll
-            for (int k = 0; k < 9; k++) nq += (xe[k] - xb[k] + 7u) >> 3;
-            const unsigned incl = wave_scan_incl(nq, lane);
-            const unsigned M = (unsigned)__shfl((int)incl, 63, 64);
-            const unsigned off_q = incl - nq;
-            auto window = [&](const unsigned w0) {
-                {
-                    // descriptor: (the chunk's first slot, owner's query in LDS | candidates << 16); a query's chunks
-                    // take CONSECUTIVE list entries, row after row
-                    const unsigned own = (unsigned)tid << 4; // where this lane's query lies in s_qp
-                    unsigned j = off_q - w0;                 // (a run that begins before the window wraps: never < cap)
-#pragma unroll
-                    for (int k = 0; k < 9; k++) {
-                        unsigned b = xb[k];
-                        while (b < xe[k]) {
-                            if (j < (unsigned)kCoopCap) items[j] = make_uint2(b, own | (min(xe[k] - b, 8u) << 16));
-                            j++;
-                            b += 8u;
-                        }
-                    }
-                }
-                const unsigned Mw = min(M - w0, (unsigned)kCoopCap);
-                items[Mw + lane] = make_uint2(0u, 0u);       // null descriptors (count 0) for the last, partial trip
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                COOP_MARK(2);                                // chunk list written
-                for (unsigned t = 0; t < Mw; t += 8u * kCoopDepth) {
-                    // kCoopDepth chunks per lane octet in flight: every load of the list is independent
-                    P12 c4[kCoopDepth];
-                    unsigned meta[kCoopDepth];
-#pragma unroll
-                    for (int u = 0; u < kCoopDepth; u++) {
-                        const uint2 dsc = items[t + u * 8 + oct];
-                        meta[u] = dsc.y;
-                        // scalar base + 32-bit byte offset (the launcher keeps 12 * slots below 2^32; the array carries
-                        // kSortedSlack entries of slack)
-                        c4[u] = *reinterpret_cast<const P12 *>(reinterpret_cast<const char *>(s12) + (((dsc.x * 3u) << 2) + (unsigned)l8 * 12u));
-                    }
-#pragma unroll
-                    for (int u = 0; u < kCoopDepth; u++) {
-                        const unsigned cnt = meta[u] >> 16;
-                        const float4 p = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_qp) + (meta[u] & 0xFFF0u));
-                        float d = sqdist_f32(make_float4(c4[u].x, c4[u].y, c4[u].z, 0.f), p.x, p.y, p.z);
-                        const bool mine = (unsigned)l8 < cnt;            // (lane 0 of the octet: the chunk exists)
-                        d = mine ? d : INFINITY;
-                        const float m = octet_min(d);
-                        // (a lane past the chunk's end holds +inf: never within m + W of a finite minimum; a null
-                        //  descriptor's result is not stored)
-                        const bool fl = d <= m + p.w;
-                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(fl);
-                        const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
-                        // the chunk's best candidate that is NOT flagged (for the LB the query leaves behind)
-                        const float sec = octet_min(fl ? INFINITY : d);
-                        // the result takes the place of the descriptor's second word: the chunk minimum rounded DOWN to
-                        // 16 mantissa bits | the flag byte (the first word, the chunk's position, stays)
-                        if (l8 == 0 && mine) {
-                            items[t + u * 8 + oct].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
-                            secs[t + u * 8 + oct] = sec;
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                COOP_MARK(3);                                // chunks worked off
-                // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
-                for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
-                    uint2 r[4];
-                    float rs[4];
-                    bool in[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const unsigned j = off_q - w0 + c0 + (unsigned)u;
-                        in[u] = c0 + (unsigned)u < nq && j < (unsigned)kCoopCap;
-                        r[u] = items[in[u] ? j : 0u];
-                        rs[u] = secs[in[u] ? j : 0u];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        chunk_insert(in[u] ? __uint_as_float(r[u].y & 0xFFFFFF00u) : INFINITY, r[u].x, r[u].y & 0xFFu);
-                        gsec = fminf(gsec, in[u] ? rs[u] : INFINITY);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            };
-            // (one window unless the cloud is very dense)
-            for (unsigned w0 = 0; w0 < M; w0 += kCoopCap) window(w0);
-        }
-        COOP_PHASE(4, gb0 + gb1 + gm0 + gm1, gh0 + gh1 + gh2);              // chunk results merged per query
-        // ---- the f64 decision: flagged candidates of the kept chunks inside g + W.
-        // The query itself comes back from where it lies -- the f64 source point (re-transformed: same products, same
-        // order, same bits), its fp32 view and W from LDS, the band re-derived -- instead of occupying 17 registers
-        // across the listing and the chunk phase, where the kernel sits at the 128 it may use (4 waves per SIMD).
-        auto tail = [&](const double pxd, const double pyd, const double pzd, const float px, const float py, const float pz,
-                        const float W) {
-        const float rup = sqrtf(r2f) * (1.0f + 2.4e-7f);
-        const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
-        const float tlim = rup + 2.0f * E;
-        const float L = tlim * tlim * (1.0f + 6e-7f);
-        auto rank = [&](const Pt64 &c8, unsigned pos) {
-            // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
-            const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
-            double d = dx * dx;
-            d += dy * dy;
-            d += dz * dz;
-            const unsigned id = (unsigned)c8.w;
-            const bool lt = d < bd || (d == bd && id < bidx && bidx != 0xFFFFFFFFu);
-            bd = lt ? d : bd;
-            bidx = lt ? id : bidx;
-            bpos = lt ? pos : bpos;
-            bq.x = lt ? c8.x : bq.x; bq.y = lt ? c8.y : bq.y; bq.z = lt ? c8.z : bq.z; bq.w = lt ? c8.w : bq.w;
-        };
-        bool slow = false;                                   // needs every listed candidate ranked in f64
-        // (the kept chunk minima were rounded down by < 2^-15 relative: g_up bounds the fp32 minimum from above, and
-        //  the tests below stay on the safe side -- a chunk or candidate more is ranked in f64, never one less)
-        const float g_up = gh0 * (1.0f + 6.2e-5f);
-        int n = 0;                                           // candidates ranked in f64
-        // (chunk minima at or beyond L cannot be accepted in f64: such chunks only serve the LB)
-        if (need && gh0 < L) {
-            const float thr = g_up + W;
-            unsigned c[4] = {0u, 0u, 0u, 0u};
-            slow = gh2 <= thr;                               // a third chunk reaches into the band
-            auto add = [&](unsigned b, unsigned flags) {
-                while (flags) {
-                    const unsigned pos = b + (unsigned)__builtin_ctz(flags);
-                    flags &= flags - 1u;
-                    if (n == 0) c[0] = pos; else if (n == 1) c[1] = pos; else if (n == 2) c[2] = pos; else if (n == 3) c[3] = pos;
-                    else slow = true;
-                    n++;
-                }
-            };
-            add(gb0, gm0);
-            if (gh1 <= thr) add(gb1, gm1);
-            // (a second flagged candidate: one query in a thousand; a third: duplicated points)
-            Pt64 c8a = Pt64{0.0, 0.0, 0.0, 0ull}, c8b = c8a;
-            if (n > 0) c8a = sorted64[c[0]];
-            if (n > 1) c8b = sorted64[c[1]];
-            if (n > 0) rank(c8a, c[0]);
-            if (n > 1) rank(c8b, c[1]);
-            if (n > 2) rank(sorted64[c[2]], c[2]);
-            if (n > 3) rank(sorted64[c[3]], c[3]);
-        }
-        // ---- the re-scan, by the WHOLE WAVE for one such query at a time (a few per launch at C4, and the launch
-        // lasts as long as its slowest wave: one lane walking its 27 cells alone -- ~90 dependent loads -- put 6 us
-        // on the tail of every launch).  The query's listed slot ranges (everything that can win or tie lies in
-        // them, see the pruning above) are flattened over the lanes: one fp32 filter load, one f64 load, a
-        // butterfly over (d2, original index), the winner's coordinates handed to the owner lane.
-        for (unsigned long long rem = __builtin_amdgcn_ballot_w64(slow); rem; rem &= rem - 1ull) {
-            const int q = (int)__builtin_ctzll(rem);         // wave-uniform
-            auto bcast_u = [&](unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, q); };
-            auto bcast_f = [&](float v) { return __uint_as_float(bcast_u(__float_as_uint(v))); };
-            auto bcast_d = [&](double v) {
-                const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-                return __longlong_as_double((long long)(((unsigned long long)bcast_u((unsigned)(u >> 32)) << 32) | bcast_u((unsigned)u)));
-            };
-            const float qx = bcast_f(px), qy = bcast_f(py), qz = bcast_f(pz);
-            const double qxd = bcast_d(pxd), qyd = bcast_d(pyd), qzd = bcast_d(pzd);
-            const float qrup = rup, qE = bcast_f(E);
-            const float sl = fminf(sqrtf(bcast_f(g_up)), qrup) + 2.0f * qE;
-            const float Ls = sl * sl * (1.0f + 6e-7f);       // fp32 distances beyond it cannot win or tie in f64
-            // the query's slot ranges, listed again (its lane alone looks the rows up) against Ls: nothing at or within
-            // it is left out, and nothing was kept in registers for this rare path
-            unsigned qb[9], pre[10];
-            pre[0] = 0u;
-            {
-                unsigned sb[9], se[9], looked_unused;
-                float geo_unused;
-                list_rows(px, py, pz, E, Ls, lane == q, sb, se, geo_unused, looked_unused);
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    qb[k] = bcast_u(sb[k]);
-                    pre[k + 1] = pre[k] + (bcast_u(se[k]) - qb[k]);
-                }
-            }
-            double ld = r2d;
-            unsigned lid = 0xFFFFFFFFu, lpos = 0xFFFFFFFFu;
-            Pt64 lq = Pt64{0.0, 0.0, 0.0, 0ull};
-            for (unsigned f0 = 0; f0 < pre[9]; f0 += 128u) {  // (one trip unless the rows are very dense)
-                unsigned j[2];
-                bool in[2];
-                P12 t[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const unsigned f = f0 + (unsigned)u * 64u + (unsigned)lane;
-                    in[u] = f < pre[9];
-                    unsigned jj = 0u;
-#pragma unroll
-                    for (int k = 0; k < 9; k++)
-                        if (f >= pre[k] && f < pre[k + 1]) jj = qb[k] + (f - pre[k]);
-                    j[u] = jj;
-                    t[u] = P12{0.f, 0.f, 0.f};
-                    if (in[u]) t[u] = s12[jj];
-                }
-                Pt64 c8[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    in[u] = in[u] && sqdist_f32(make_float4(t[u].x, t[u].y, t[u].z, 0.f), qx, qy, qz) <= Ls;
-                    c8[u] = Pt64{0.0, 0.0, 0.0, 0ull};
-                    if (in[u]) c8[u] = sorted64[j[u]];
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++)
-                    if (in[u]) {
-                        // flann L2 (dist.h:159-176), as rank() above
-                        const double dx = c8[u].x - qxd, dy = c8[u].y - qyd, dz = c8[u].z - qzd;
-                        double d = dx * dx;
-                        d += dy * dy;
-                        d += dz * dz;
-                        const unsigned id = (unsigned)c8[u].w;
-                        const bool lt = d < ld || (d == ld && id < lid && lid != 0xFFFFFFFFu);
-                        if (lt) { ld = d; lid = id; lpos = j[u]; lq = c8[u]; }
-                    }
-            }
-            // minimum over the lanes by (d2, original index); lanes without a candidate hold (r2d, none)
-            double rd = ld;
-            unsigned rid = lid;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const double od = __shfl_xor(rd, o, 64);
-                const unsigned oid = (unsigned)__shfl_xor((int)rid, o, 64);
-                const bool lt = oid != 0xFFFFFFFFu && (od < rd || (od == rd && oid < rid));
-                rd = lt ? od : rd;
-                rid = lt ? oid : rid;
-            }
-            if (rid != 0xFFFFFFFFu) {                        // (wave-uniform)
-                const unsigned long long holders = __builtin_amdgcn_ballot_w64(lid == rid && ld == rd);
-                const int wl = (int)__builtin_ctzll(holders);
-                auto from_w = [&](unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, wl); };
-                auto from_w64 = [&](unsigned long long u) { return ((unsigned long long)from_w((unsigned)(u >> 32)) << 32) | from_w((unsigned)u); };
-                Pt64 w8;
-                w8.x = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.x)));
-                w8.y = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.y)));
-                w8.z = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.z)));
-                w8.w = from_w64(lq.w);
-                const unsigned wpos = from_w(lpos);
-                if (lane == q) {
-                    const bool lt = rd < bd || (rd == bd && rid < bidx && bidx != 0xFFFFFFFFu);
-                    if (lt) { bd = rd; bidx = rid; bpos = wpos; bq = w8; }
-                }
-            }
-        }
-        // ---- LB: what every target point but the winner (every target point, without a winner) is at least away
-        if (need) {
-            float lb2 = fminf(lbgeo2, fminf(gh1, gsec));
-            if (bpos == 0xFFFFFFFFu) lb2 = fminf(lb2, gh0);  // nothing accepted: the best candidate bounds like the rest
-            // (examined candidates: |d64 - sqrt(d2_32)| <= E inside the radius, <= 2E out to the corners of the 27 cells)
-            float lb = sqrtf(lb2) * (1.0f - 1e-6f) - 4.0f * E;
-            // a near-tie (several candidates ranked in f64, a re-scan): the runner-up was not bounded
-            if (slow || n > 1) lb = 0.f;
-            lb_new = fminf(fmaxf(lb, 0.f), 3.0e38f);
-        }
-        const bool found = bpos != 0xFFFFFFFFu;
-        COOP_PHASE(5, bidx, (float)(bd + bq.x));                            // f64 winner arrived and ranked
-        if (active) {
-            const long long i = (long long)(vb * kBlock + (int)s_home[tid]) * per_group + it;   // its home thread's query of the round
-            emit(i, false, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
-        }
-        // the hand-over to the query's home lane (phase C): the winner's f64 point and index, where this wave's chunk
-        // list lay (the list has been worked off: the windows end with a wave barrier)
-        {
-            Pt64 r8;
-            r8.x = bq.x; r8.y = bq.y; r8.z = bq.z;
-            r8.w = found ? (unsigned long long)bidx : 0xFFFFFFFFull;
-            reinterpret_cast<Pt64 *>(items)[lane] = r8;
-        }
-        };   // tail
-        {
-            // (the query again from where it lies in LDS: nothing of it was carried across the listing and the chunk phase)
-            const float4 me = s_qp[tid];
-            const unsigned h = s_home[tid];
-            tail(s_p64[h][0], s_p64[h][1], s_p64[h][2], me.x, me.y, me.z, me.w);
-        }
-    };
-    // ---- One ROUND = one query per lane of the workgroup, in three phases.
+    // ---- One ROUND = one query per lane of the workgroup.
     //  A  every lane, its own ("home") query: source point + state in, the certificate; a certified query writes its
     //     outputs here, the others queue up (per-wave segments: the queue's order does not depend on arrival).
-    //  B  the queued queries, COMPACTED over the lanes of the workgroup: thread k searches the k-th queued query
-    //     (whoever's it is) -- waves k/64 beyond the queue's length skip the phase, so the search costs what the
+    //  B  the queued queries, COMPACTED over the threads of the workgroup: thread k searches the k-th queued query
+    //     (whoever's it is) -- waves k/64 beyond the queue's length list nothing, so the search costs what the
     //     uncertified queries cost, not what the waves that hold one cost (after a few ICP iterations most waves hold
-    //     a handful: without the compaction every one of them ran the whole search for those).  A query's result does
-    //     not depend on the lane that searched it.
+    //     a handful: without the compaction every one of them ran the whole search for those).  The searchers' chunks
+    //     go to ONE list of the workgroup, which ALL its waves work off -- the waves without a searcher too: the
+    //     gathers of a workgroup with 30 queued queries are one trip of all its lanes, not three of one wave's.
+    //     A query's result does not depend on the thread that searched it or the lanes that ranked its chunks.
     //  C  home lanes again: the moments of the round's correspondence (from registers when certified, from the
     //     searcher's hand-over in LDS otherwise) -- the query -> lane map and the summation tree of the lane-serial
-    //     kernel, so the 38 statistics stay bit-identical to its.
+    //     kernel (for NTH = kBlock), so the 38 statistics stay bit-identical to its.
     auto round = [&](const int it) {
         const long long i = i_begin + it;
         const bool active = i < i_end;
@@ -701,7 +349,7 @@ __device__ __forceinline__ void coop_body(
             if (warm & 1) w8 = wst_io[i];
         }
         // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
-        double hp[3];                                        // the home query's point: kept for phase C
+        double hp[3];
         {
             const double sv[3] = {s8.x, s8.y, s8.z};
             se3_act(T64.m, sv, hp);
@@ -741,10 +389,7 @@ __device__ __forceinline__ void coop_body(
             } else {
                 cert = active && widx == 0xFFFFFFFFu && t > tlim * (1.0f + 1e-6f);
             }
-            // (wave-uniform skip of the stores when nobody certified)
-#ifndef VISMA_COOP_X_NOEMIT   /* (timing experiment: what the certified queries' stores cost the searching wave) */
             if (cert) emit(i, true, has_w ? d2w : r2d, widx, has_w, w8.x, w8.y, w8.z, t);
-#endif
         }
         const bool need = active && !cert;
         const bool cfound = cert && has_w;                   // certified WITH a partner: (hp, w8) is the correspondence
@@ -753,15 +398,15 @@ __device__ __forceinline__ void coop_body(
         if (need) {
             // (fp32 view of the previous winner: the value the candidate array holds for that point; NaN = none)
             s_dprev[tid] = sqdist_f32(make_float4((float)w8.x, (float)w8.y, (float)w8.z, 0.f), (float)hp[0], (float)hp[1], (float)hp[2]);
+        } else {
+            // certified (or no query): the correspondence of phase C is known now
+            s_q64[tid][0] = w8.x; s_q64[tid][1] = w8.y; s_q64[tid][2] = w8.z;
+            s_dprev[tid] = __uint_as_float(cfound ? widx : 0xFFFFFFFFu);
         }
         if (cand_count) {
             // (profiling) queries certified: no search
             const unsigned cc = (unsigned)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cert));
             if (lane == 0 && cc) atomicAdd(cand_count + 2 * 4096 + (blockIdx.x & 4095), (unsigned long long)cc);
-        }
-        if constexpr (!ONE) {
-            // (several rounds: the accumulators are live anyway; round order per lane is what the sums depend on)
-            if (cfound) moments(hp[0], hp[1], hp[2], widx, w8.x, w8.y, w8.z);
         }
         // ---- queue the others: position = queries queued by the lower waves + by the lower lanes of this wave
         const unsigned long long needers = __builtin_amdgcn_ballot_w64(need);
@@ -771,42 +416,375 @@ __device__ __forceinline__ void coop_body(
         COOP_MARK(9);                                        // phase A done
         __syncthreads();
         COOP_MARK(10);
-        unsigned cnt_w[kBlock / 64], nq_all = 0, kpos = rank;
+        unsigned nq_all = 0;                                 // (uniform values: scalar registers)
+        unsigned home = 0;                                   // the home thread of the query this thread searches
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) {
-            cnt_w[w] = (unsigned)__builtin_amdgcn_readfirstlane((int)s_need[w]);   // (uniform: scalar registers)
-            if (w < wave) kpos += cnt_w[w];
-            nq_all += cnt_w[w];
+        for (int w = 0; w < NW; w++) {
+            const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)s_need[w]);
+            if ((unsigned)tid >= nq_all && (unsigned)tid < nq_all + c) home = s_queue[w][(unsigned)tid - nq_all];
+            nq_all += c;
         }
         // ---- B: thread k < nq_all searches the k-th queued query
         const bool searching = (unsigned)(wave * 64) < nq_all;           // (wave-uniform)
-        if (searching) {
-            search(it, cnt_w, nq_all);
-            COOP_MARK(11);                                   // search done
-        } else if constexpr (ONE) {
-            // (a wave without a search: the moments of its certified queries while the others search -- straight from
-            //  the registers of phase A)
-            if (cfound) moments(hp[0], hp[1], hp[2], widx, w8.x, w8.y, w8.z);
+        const bool sact = (unsigned)tid < nq_all;                        // this thread has a query to search
+        if (nq_all != 0u) {                                  // (workgroup-uniform: the stages below hold barriers)
+            // -- B1 (searchers): the query taken over, its rows' slot ranges, its chunk count
+            unsigned xb[9], xe[9];
+            float lbgeo2 = 0.f;                              // LB, geometric part (squared)
+            unsigned nq = 0, off_q = 0;                      // this query's chunks; where its run begins in its wave's part
+            if (searching) {
+                s_home[tid] = (unsigned short)home;          // (read back at the end: nothing is carried across the search)
+                // the query as its home lane transformed it (phase A), and its distance to the previous winner
+                const double pxd = s_p64[home][0], pyd = s_p64[home][1], pzd = s_p64[home][2];
+                const float dprev = sact ? s_dprev[home] : __uint_as_float(~0u);
+                const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
+                COOP_MARK(0);                                // the query taken over from its home lane
+                // rounding band (exact_band): E bounds |d64 - sqrt(d2_32)|; L = squared fp32 distance at or beyond
+                // which a candidate cannot be accepted in f64; W >= band(m) - m for every m < L
+                const float rup = sqrtf(r2f) * (1.0f + 2.4e-7f);
+                const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
+                const float tlim = rup + 2.0f * E;
+                const float L = tlim * tlim * (1.0f + 6e-7f);
+                const float W = (4.0f * E * tlim + 4.0f * E * E) * (1.0f + 1e-6f) + L * 5e-7f;
+                s_qp[tid] = make_float4(px, py, pz, W);
+                // what nothing nearer than can be missed by: the previous winner's distance now, or the radius
+                float bound0 = L;
+                if (dprev < L) bound0 = dprev;               // (NaN = no previous winner: the radius)
+                unsigned looked;
+                list_rows(px, py, pz, E, bound0, sact, xb, xe, lbgeo2, looked);
+                // (pin the value here: left to itself the compiler sinks the whole slab arithmetic down to the bound's
+                //  only use at the end of the query and spills its 40 inputs across the chunk phase instead)
+                asm volatile("" : "+v"(lbgeo2));
+                if (cand_count) {
+                    // profiling only (one uniform branch): candidates listed, cell-table rows looked up -- summed over
+                    // the wave and added to the launch's counters right here (counters carried to the end of the
+                    // kernel were spilled across the search)
+                    unsigned long long c = 0, ca = looked;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) c += xe[k] - xb[k];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        c += __shfl_down(c, o, 64);
+                        ca += __shfl_down(ca, o, 64);
+                    }
+                    if (lane == 0 && ca) {
+                        unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
+                        atomicAdd(slot, c);
+                        atomicAdd(slot + 1, ca);
+                    }
+                }
+                COOP_MARK(1);                                // row bounds asked for, rows pruned
+#pragma unroll
+                for (int k = 0; k < 9; k++) nq += (xe[k] - xb[k] + 7u) >> 3;
+                const unsigned incl = wave_scan_incl(nq, lane);
+                off_q = incl - nq;
+                if (lane == 63) s_m[wave] = incl;
+            } else {
+                if (lane == 0) s_m[wave] = 0u;
+            }
+            __syncthreads();
+            unsigned m_all = 0;                              // chunks of the workgroup (uniform)
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)s_m[w]);
+                if (w < wave) off_q += c;                    // ... in the workgroup's list
+                m_all += c;
+            }
+            // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
+            float gh0 = INFINITY, gh1 = INFINITY, gh2 = INFINITY;
+            float gsec = INFINITY;                           // best candidate outside the rounding band of its chunk's minimum
+            unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
+            auto chunk_insert = [&](float m, unsigned b, unsigned flags) {
+                const bool c1 = m < gh0, c2 = m < gh1;
+                gh2 = __builtin_amdgcn_fmed3f(gh1, gh2, m);
+                gh1 = __builtin_amdgcn_fmed3f(gh0, gh1, m);
+                gh0 = fminf(gh0, m);
+                gb1 = c2 ? b : gb1; gm1 = c2 ? flags : gm1;
+                gb1 = c1 ? gb0 : gb1; gm1 = c1 ? gm0 : gm1;
+                gb0 = c1 ? b : gb0; gm0 = c1 ? flags : gm0;
+            };
+            // -- B2: the list, one window at a time (one window unless the cloud is very dense).  A query's chunks take
+            // CONSECUTIVE entries, row after row: the owner reads its results back as one short run.
+            for (unsigned w0 = 0; w0 < m_all; w0 += kCapAll) {
+                if (searching) {
+                    // descriptor: (the chunk's first slot, owner's query in s_qp | candidates << 16)
+                    const unsigned own = (unsigned)tid << 4;
+                    unsigned j = off_q - w0;                 // (a run that begins before the window wraps: never < cap)
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        unsigned b = xb[k];
+                        while (b < xe[k]) {
+                            if (j < kCapAll) s_item[j] = make_uint2(b, own | (min(xe[k] - b, 8u) << 16));
+                            j++;
+                            b += 8u;
+                        }
+                    }
+                    COOP_MARK(2);                            // chunk list written
+                }
+                __syncthreads();
+                // ---- ALL waves: the window's chunks, eight lanes per chunk, one candidate per lane, kCoopDepth chunks
+                // per lane octet in flight (every load of the list is independent)
+                const unsigned mw = min(m_all - w0, kCapAll);
+                for (unsigned tb = 0; tb < mw; tb += (unsigned)(NW * 8 * kCoopDepth)) {            // (uniform trip count)
+                    const unsigned t = tb + (unsigned)(wave * 8 + oct);
+                    P12 c4[kCoopDepth];
+                    unsigned meta[kCoopDepth];
+#pragma unroll
+                    for (int u = 0; u < kCoopDepth; u++) {
+                        const unsigned c = t + (unsigned)(u * NW * 8);
+                        uint2 dsc = make_uint2(0u, 0u);      // (past the window's end: a null descriptor, count 0)
+                        if (c < mw) dsc = s_item[c];
+                        meta[u] = dsc.y;
+                        // scalar base + 32-bit byte offset (the launcher keeps 12 * slots below 2^32; the array carries
+                        // kSortedSlack entries of slack)
+                        c4[u] = *reinterpret_cast<const P12 *>(reinterpret_cast<const char *>(s12) + (((dsc.x * 3u) << 2) + (unsigned)l8 * 12u));
+                    }
+#pragma unroll
+                    for (int u = 0; u < kCoopDepth; u++) {
+                        const unsigned c = t + (unsigned)(u * NW * 8);
+                        const unsigned cnt = meta[u] >> 16;
+                        const float4 p = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(s_qp) + (meta[u] & 0xFFF0u));
+                        float d = sqdist_f32(make_float4(c4[u].x, c4[u].y, c4[u].z, 0.f), p.x, p.y, p.z);
+                        const bool mine = (unsigned)l8 < cnt;            // (lane 0 of the octet: the chunk exists)
+                        d = mine ? d : INFINITY;
+                        const float m = octet_min(d);
+                        // (a lane past the chunk's end holds +inf: never within m + W of a finite minimum; a null
+                        //  descriptor's result is not stored)
+                        const bool fl = d <= m + p.w;
+                        const unsigned long long bal = __builtin_amdgcn_ballot_w64(fl);
+                        const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
+                        // the chunk's best candidate that is NOT flagged (for the LB the query leaves behind)
+                        const float sec = octet_min(fl ? INFINITY : d);
+                        // the result takes the place of the descriptor's second word: the chunk minimum rounded DOWN to
+                        // 16 mantissa bits | the flag byte (the first word, the chunk's position, stays)
+                        if (l8 == 0 && mine) {
+                            s_item[c].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
+                            s_sec[c] = sec;
+                        }
+                    }
+                }
+                if (searching) COOP_MARK(3);                 // chunks worked off (this wave's share)
+                __syncthreads();
+                if (searching) {
+                    // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
+                    for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
+                        uint2 r[4];
+                        float rs[4];
+                        bool in[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const unsigned j = off_q - w0 + c0 + (unsigned)u;
+                            in[u] = c0 + (unsigned)u < nq && j < kCapAll;
+                            r[u] = s_item[in[u] ? j : 0u];
+                            rs[u] = s_sec[in[u] ? j : 0u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            chunk_insert(in[u] ? __uint_as_float(r[u].y & 0xFFFFFF00u) : INFINITY, r[u].x, r[u].y & 0xFFu);
+                            gsec = fminf(gsec, in[u] ? rs[u] : INFINITY);
+                        }
+                    }
+                    COOP_MARK(4);                            // chunk results merged per query
+                }
+                if (w0 + kCapAll < m_all) __syncthreads();   // (the list is re-used by the next window)
+            }
+            // -- B3 (searchers): the f64 decision -- flagged candidates of the kept chunks inside g + W.
+            // The query itself comes back from where it lies in LDS -- its f64 point from its home lane's slot, its
+            // fp32 view and W from the searcher's, the band re-derived -- instead of occupying 17 registers across the
+            // listing and the chunk phase, where the kernel sits at the 128 it may use (4 waves per SIMD).
+            if (searching) {
+                const bool need = sact, active = sact;
+                float lb_new = 0.f;                          // what this pass leaves as LB
+                double bd = r2d;                             // best d2 so far (strictly below r2d once set)
+                unsigned bidx = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
+                Pt64 bq = Pt64{0.0, 0.0, 0.0, 0ull};
+                auto tail = [&](const double pxd, const double pyd, const double pzd, const float px, const float py, const float pz,
+                                const float W) {
+                const float rup = sqrtf(r2f) * (1.0f + 2.4e-7f);
+                const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
+                const float tlim = rup + 2.0f * E;
+                const float L = tlim * tlim * (1.0f + 6e-7f);
+                auto rank = [&](const Pt64 &c8, unsigned pos) {
+                    // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
+                    const double dx = c8.x - pxd, dy = c8.y - pyd, dz = c8.z - pzd;
+                    double d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    const unsigned id = (unsigned)c8.w;
+                    const bool lt = d < bd || (d == bd && id < bidx && bidx != 0xFFFFFFFFu);
+                    bd = lt ? d : bd;
+                    bidx = lt ? id : bidx;
+                    bpos = lt ? pos : bpos;
+                    bq.x = lt ? c8.x : bq.x; bq.y = lt ? c8.y : bq.y; bq.z = lt ? c8.z : bq.z; bq.w = lt ? c8.w : bq.w;
+                };
+                bool slow = false;                                   // needs every listed candidate ranked in f64
+                // (the kept chunk minima were rounded down by < 2^-15 relative: g_up bounds the fp32 minimum from above, and
+                //  the tests below stay on the safe side -- a chunk or candidate more is ranked in f64, never one less)
+                const float g_up = gh0 * (1.0f + 6.2e-5f);
+                int n = 0;                                           // candidates ranked in f64
+                // (chunk minima at or beyond L cannot be accepted in f64: such chunks only serve the LB)
+                if (need && gh0 < L) {
+                    const float thr = g_up + W;
+                    unsigned c[4] = {0u, 0u, 0u, 0u};
+                    slow = gh2 <= thr;                               // a third chunk reaches into the band
+                    auto add = [&](unsigned b, unsigned flags) {
+                        while (flags) {
+                            const unsigned pos = b + (unsigned)__builtin_ctz(flags);
+                            flags &= flags - 1u;
+                            if (n == 0) c[0] = pos; else if (n == 1) c[1] = pos; else if (n == 2) c[2] = pos; else if (n == 3) c[3] = pos;
+                            else slow = true;
+                            n++;
+                        }
+                    };
+                    add(gb0, gm0);
+                    if (gh1 <= thr) add(gb1, gm1);
+                    // (a second flagged candidate: one query in a thousand; a third: duplicated points)
+                    Pt64 c8a = Pt64{0.0, 0.0, 0.0, 0ull}, c8b = c8a;
+                    if (n > 0) c8a = sorted64[c[0]];
+                    if (n > 1) c8b = sorted64[c[1]];
+                    if (n > 0) rank(c8a, c[0]);
+                    if (n > 1) rank(c8b, c[1]);
+                    if (n > 2) rank(sorted64[c[2]], c[2]);
+                    if (n > 3) rank(sorted64[c[3]], c[3]);
+                }
+                // ---- the re-scan, by the WHOLE WAVE for one such query at a time (a few per launch at C4, and the launch
+                // lasts as long as its slowest wave: one lane walking its 27 cells alone -- ~90 dependent loads -- put 6 us
+                // on the tail of every launch).  The query's listed slot ranges (everything that can win or tie lies in
+                // them, see the pruning above) are flattened over the lanes: one fp32 filter load, one f64 load, a
+                // butterfly over (d2, original index), the winner's coordinates handed to the owner lane.
+                for (unsigned long long rem = __builtin_amdgcn_ballot_w64(slow); rem; rem &= rem - 1ull) {
+                    const int q = (int)__builtin_ctzll(rem);         // wave-uniform
+                    auto bcast_u = [&](unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, q); };
+                    auto bcast_f = [&](float v) { return __uint_as_float(bcast_u(__float_as_uint(v))); };
+                    auto bcast_d = [&](double v) {
+                        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+                        return __longlong_as_double((long long)(((unsigned long long)bcast_u((unsigned)(u >> 32)) << 32) | bcast_u((unsigned)u)));
+                    };
+                    const float qx = bcast_f(px), qy = bcast_f(py), qz = bcast_f(pz);
+                    const double qxd = bcast_d(pxd), qyd = bcast_d(pyd), qzd = bcast_d(pzd);
+                    const float qrup = rup, qE = bcast_f(E);
+                    const float sl = fminf(sqrtf(bcast_f(g_up)), qrup) + 2.0f * qE;
+                    const float Ls = sl * sl * (1.0f + 6e-7f);       // fp32 distances beyond it cannot win or tie in f64
+                    // the query's slot ranges, listed again (its lane alone looks the rows up) against Ls: nothing at or within
+                    // it is left out, and nothing was kept in registers for this rare path
+                    unsigned qb[9], pre[10];
+                    pre[0] = 0u;
+                    {
+                        unsigned sb[9], se[9], looked_unused;
+                        float geo_unused;
+                        list_rows(px, py, pz, E, Ls, lane == q, sb, se, geo_unused, looked_unused);
+        #pragma unroll
+                        for (int k = 0; k < 9; k++) {
+                            qb[k] = bcast_u(sb[k]);
+                            pre[k + 1] = pre[k] + (bcast_u(se[k]) - qb[k]);
+                        }
+                    }
+                    double ld = r2d;
+                    unsigned lid = 0xFFFFFFFFu, lpos = 0xFFFFFFFFu;
+                    Pt64 lq = Pt64{0.0, 0.0, 0.0, 0ull};
+                    for (unsigned f0 = 0; f0 < pre[9]; f0 += 128u) {  // (one trip unless the rows are very dense)
+                        unsigned j[2];
+                        bool in[2];
+                        P12 t[2];
+        #pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            const unsigned f = f0 + (unsigned)u * 64u + (unsigned)lane;
+                            in[u] = f < pre[9];
+                            unsigned jj = 0u;
+        #pragma unroll
+                            for (int k = 0; k < 9; k++)
+                                if (f >= pre[k] && f < pre[k + 1]) jj = qb[k] + (f - pre[k]);
+                            j[u] = jj;
+                            t[u] = P12{0.f, 0.f, 0.f};
+                            if (in[u]) t[u] = s12[jj];
+                        }
+                        Pt64 c8[2];
+        #pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            in[u] = in[u] && sqdist_f32(make_float4(t[u].x, t[u].y, t[u].z, 0.f), qx, qy, qz) <= Ls;
+                            c8[u] = Pt64{0.0, 0.0, 0.0, 0ull};
+                            if (in[u]) c8[u] = sorted64[j[u]];
+                        }
+        #pragma unroll
+                        for (int u = 0; u < 2; u++)
+                            if (in[u]) {
+                                // flann L2 (dist.h:159-176), as rank() above
+                                const double dx = c8[u].x - qxd, dy = c8[u].y - qyd, dz = c8[u].z - qzd;
+                                double d = dx * dx;
+                                d += dy * dy;
+                                d += dz * dz;
+                                const unsigned id = (unsigned)c8[u].w;
+                                const bool lt = d < ld || (d == ld && id < lid && lid != 0xFFFFFFFFu);
+                                if (lt) { ld = d; lid = id; lpos = j[u]; lq = c8[u]; }
+                            }
+                    }
+                    // minimum over the lanes by (d2, original index); lanes without a candidate hold (r2d, none)
+                    double rd = ld;
+                    unsigned rid = lid;
+        #pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double od = __shfl_xor(rd, o, 64);
+                        const unsigned oid = (unsigned)__shfl_xor((int)rid, o, 64);
+                        const bool lt = oid != 0xFFFFFFFFu && (od < rd || (od == rd && oid < rid));
+                        rd = lt ? od : rd;
+                        rid = lt ? oid : rid;
+                    }
+                    if (rid != 0xFFFFFFFFu) {                        // (wave-uniform)
+                        const unsigned long long holders = __builtin_amdgcn_ballot_w64(lid == rid && ld == rd);
+                        const int wl = (int)__builtin_ctzll(holders);
+                        auto from_w = [&](unsigned v) { return (unsigned)__builtin_amdgcn_readlane((int)v, wl); };
+                        auto from_w64 = [&](unsigned long long u) { return ((unsigned long long)from_w((unsigned)(u >> 32)) << 32) | from_w((unsigned)u); };
+                        Pt64 w8;
+                        w8.x = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.x)));
+                        w8.y = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.y)));
+                        w8.z = __longlong_as_double((long long)from_w64((unsigned long long)__double_as_longlong(lq.z)));
+                        w8.w = from_w64(lq.w);
+                        const unsigned wpos = from_w(lpos);
+                        if (lane == q) {
+                            const bool lt = rd < bd || (rd == bd && rid < bidx && bidx != 0xFFFFFFFFu);
+                            if (lt) { bd = rd; bidx = rid; bpos = wpos; bq = w8; }
+                        }
+                    }
+                }
+                // ---- LB: what every target point but the winner (every target point, without a winner) is at least away
+                if (need) {
+                    float lb2 = fminf(lbgeo2, fminf(gh1, gsec));
+                    if (bpos == 0xFFFFFFFFu) lb2 = fminf(lb2, gh0);  // nothing accepted: the best candidate bounds like the rest
+                    // (examined candidates: |d64 - sqrt(d2_32)| <= E inside the radius, <= 2E out to the corners of the 27 cells)
+                    float lb = sqrtf(lb2) * (1.0f - 1e-6f) - 4.0f * E;
+                    // a near-tie (several candidates ranked in f64, a re-scan): the runner-up was not bounded
+                    if (slow || n > 1) lb = 0.f;
+                    lb_new = fminf(fmaxf(lb, 0.f), 3.0e38f);
+                }
+                const bool found = bpos != 0xFFFFFFFFu;
+                COOP_MARK(5);                                // f64 winner arrived and ranked
+                if (active) {
+                    const long long i = (long long)(vb * NTH + (int)s_home[tid]) * per_group + it;   // its home thread's query of the round
+                    emit(i, false, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
+                }
+                        // the hand-over to the query's home lane (phase C): the winner's f64 point and index
+                if (active) {
+                    const unsigned h = s_home[tid];
+                    s_q64[h][0] = bq.x; s_q64[h][1] = bq.y; s_q64[h][2] = bq.z;
+                    s_dprev[h] = __uint_as_float(found ? bidx : 0xFFFFFFFFu);
+                }
+                };   // tail
+                const float4 me = s_qp[tid];
+                const unsigned h = s_home[tid];
+                tail(s_p64[h][0], s_p64[h][1], s_p64[h][2], me.x, me.y, me.z, me.w);
+                COOP_MARK(11);                               // search done
+            }
         }
         __syncthreads();
         COOP_MARK(12);
-        // ---- C: the moments of the round's correspondence, on the home lane
-        if constexpr (ONE) {
-            // A wave that searched kept nothing of its home queries across the search, where the kernel sits at the 128
-            // registers it may use (4 waves per SIMD): the transformed query comes back from LDS, a certified winner
-            // from the state (a line this lane touched a few us ago), a searched one from its searcher's hand-over.
-            const bool late = searching && cfound;
-            Pt64 c8 = Pt64{0.0, 0.0, 0.0, 0xFFFFFFFFull};
-            if (late) c8 = wst_io[i];
-            else if (need) c8 = reinterpret_cast<const Pt64 *>(s_item[kpos >> 6])[kpos & 63];
-            if ((late || need) && (unsigned)c8.w != 0xFFFFFFFFu)
-                moments(s_p64[tid][0], s_p64[tid][1], s_p64[tid][2], (unsigned)c8.w, c8.x, c8.y, c8.z);
-        } else {
-            if (need) {
-                const Pt64 r8 = reinterpret_cast<const Pt64 *>(s_item[kpos >> 6])[kpos & 63];
-                if ((unsigned)r8.w != 0xFFFFFFFFu) moments(hp[0], hp[1], hp[2], (unsigned)r8.w, r8.x, r8.y, r8.z);
-            }
+        // ---- C: the moments of the round's correspondence, on the home lane: query and partner from LDS (nothing of
+        // them was kept across the search, where the kernel sits at the 128 registers it may use: 4 waves per SIMD)
+        {
+            const unsigned pidx = __float_as_uint(s_dprev[tid]);
+            if (active && pidx != 0xFFFFFFFFu)
+                moments(s_p64[tid][0], s_p64[tid][1], s_p64[tid][2], pidx, s_q64[tid][0], s_q64[tid][1], s_q64[tid][2]);
         }
+        if constexpr (!ONE) __syncthreads();                 // (the next round re-uses the slots, the list and the queue)
     };
     if constexpr (ONE) {
         round(0);
@@ -816,9 +794,9 @@ __device__ __forceinline__ void coop_body(
     }
     COOP_MARK(6);                                            // outputs + moments
     COOP_WAVE_DONE();
-    block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
+    block_reduce_store<NACC, NW>(acc, partials, fold.tickets != nullptr);
     COOP_MARK(7);                                            // workgroup's partial row stored
-    if (fold.tickets) fused_fold<PLANE, kBlock>(fold, partials, row0, lb, bpp, prob);
+    if (fold.tickets) fused_fold<PLANE, NTH>(fold, partials, row0, lb, bpp, prob);
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
 }
 
@@ -840,12 +818,12 @@ __device__ __forceinline__ void coop_body(
 template <bool PLANE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn_coop_kernel_one(VISMA_COOP_PARAMS)
 {
-    coop_body<PLANE, true>(VISMA_COOP_ARGS);
+    coop_body<PLANE, true, kBlock>(VISMA_COOP_ARGS);
 }
 template <bool PLANE>
 __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 {
-    coop_body<PLANE, false>(VISMA_COOP_ARGS);
+    coop_body<PLANE, false, kBlock>(VISMA_COOP_ARGS);
 }
 #undef VISMA_COOP_PARAMS
 #undef VISMA_COOP_ARGS

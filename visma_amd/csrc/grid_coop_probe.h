@@ -1,25 +1,18 @@
-// grid_coop_probe.h -- the measurement builds of grid_coop.hip.  The product build defines none of the macros below
-// and gets no-ops; side libraries built by tools/coop_phases.py and tools/truncate_probe.py define
-//   -DVISMA_COOP_DEBUG_PHASES=1   clocks between the phase borders of wave 0 of every workgroup, summed over the
-//                                 workgroups (shared atomics and forced waits: perturbs the launch by ~30 %)
+// grid_coop_probe.h -- the measurement build of grid_coop.hip.  The product build defines none of the macros below
+// and gets no-ops; the side library built by tools/coop_phases.py defines
 //   -DVISMA_COOP_DEBUG_PHASES=2   per-wave clocks: one store per wave per phase border, nothing shared, nothing forced
-//                                 (the build DESIGN 4.1c's per-wave picture comes from)
-//   -DVISMA_COOP_STOP_AFTER=k     every query's work ends after phase k (k = 0, 1, 4, 5; the fold still runs, the
-//                                 results are garbage): launch time as a function of how far the queries get
-// COOP_PHASE(k, u, f) sits at the border after phase k inside coop_body's per-query lambda and names a 32-bit and a
-// float value that the work so far produced (kept alive by the stop / the forced wait); COOP_MARK(k) only stamps.
-// Marks of a round (round 4: certificate + compaction): 9 phase A done | 10 past the first barrier | 0..5 the search
-// (searching waves only) | 11 search done | 12 past the second barrier | 13 phase C done | 6 rounds done | 7 partial row | 8 fold.
+//                                 (the build DESIGN 4.1c's per-wave pictures come from)
+//   -DVISMA_COOP_DEBUG_PHASES=1   the same clocks of wave 0 of every workgroup, summed over the workgroups (shared
+//                                 atomics: perturbs the launch)
+// COOP_MARK(k) stamps the wave's clock into slot k.  Marks of a round (round 4: certificate + compaction + the
+// workgroup's chunk list): 9 phase A done | 10 past the first barrier | 0 query taken over | 1 rows asked for |
+// 2 list written | 3 chunks worked off | 4 merged | 5 f64 winner ranked | 11 search done (0..5, 11: searching waves
+// only) | 12 past the last barrier | 13 phase C done | 6 rounds done | 7 partial row | 8 fold; 14, 15: HW_ID, XCC_ID.
+// (The truncation builds of round 3 -- every query's work cut off after phase k -- went with the barriers the phases
+// now hold.)
 #pragma once
 
-#if defined(VISMA_COOP_DEBUG_PHASES) || defined(VISMA_COOP_STOP_AFTER)
-
-#ifndef VISMA_COOP_DEBUG_PHASES
-#define VISMA_COOP_DEBUG_PHASES 0
-#endif
-#ifndef VISMA_COOP_STOP_AFTER
-#define VISMA_COOP_STOP_AFTER 99
-#endif
+#if defined(VISMA_COOP_DEBUG_PHASES)
 
 namespace visma {
 __device__ unsigned long long g_coop_phase[16];             // mode 1: clocks per phase, summed over workgroups
@@ -53,28 +46,15 @@ __device__ unsigned long long g_coop_marks[16 * 8192];      // mode 2: per wave,
         if (threadIdx.x == 0) atomicAdd(&g_coop_phase[k], now_ - stamp_);                                       \
         stamp_ = now_;                                                                                          \
     } while (0)
-#define COOP_KEEP(u, f) asm volatile("" ::"v"(u), "v"(f))
 #elif VISMA_COOP_DEBUG_PHASES == 2
 #define COOP_MARK(k)                                                                                            \
     do {                                                                                                        \
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                                       \
             g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
     } while (0)
-#define COOP_KEEP(u, f) do { } while (0)
 #else
 #define COOP_MARK(k) do { (void)stamp_; } while (0)
-#define COOP_KEEP(u, f) do { } while (0)
 #endif
-
-#define COOP_PHASE(k, u, f)                                                                                     \
-    do {                                                                                                        \
-        COOP_KEEP(u, f);                                                                                        \
-        COOP_MARK(k);                                                                                           \
-        if (VISMA_COOP_STOP_AFTER == (k)) {                                                                     \
-            if (active) { idx_out[i] = (int)(u); d2_out[i] = (float)(f); }                                      \
-            return;                                                                                             \
-        }                                                                                                       \
-    } while (0)
 
 #define COOP_WAVE_DONE()                                                                                        \
     do {                                                                                                        \
@@ -107,7 +87,6 @@ extern "C" __attribute__((visibility("default"))) int visma_debug_coop_phases(un
 
 #define COOP_PROBE_BEGIN() do { } while (0)
 #define COOP_MARK(k) do { } while (0)
-#define COOP_PHASE(k, u, f) do { } while (0)
 #define COOP_WAVE_DONE() do { } while (0)
 
 #endif
