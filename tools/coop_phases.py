@@ -44,6 +44,8 @@ def main():
     print("  total %.2f us" % (tot / nwg / 100.0))
     # when the waves of the LAST launch started and reached the block reduction (100 MHz clock)
     nw = min((ns + 255) // 256, 2048) * 4
+    # (waves per workgroup of the kernel under test)
+    WPB = int(os.environ.get('PROBE_WPB', 4))
     sp = (C.c_ulonglong * (2 * nw))()
     L.visma_debug_coop_spans(sp, 2 * nw)
     a = np.array(sp[:], dtype=np.int64).reshape(nw, 2)
@@ -54,7 +56,7 @@ def main():
     print("  wave done   us, percentiles %s: %s" % (q, np.percentile(en, q).round(2).tolist()))
     print("  wave length us, percentiles %s: %s" % (q, np.percentile(en - st, q).round(2).tolist()))
     ln = en - st
-    blk = np.arange(nw) // 4
+    blk = np.arange(nw) // WPB
     print("  mean / max wave length by XCD (block & 7): " + ", ".join("%d: %.1f/%.1f" % (x, ln[(blk & 7) == x].mean(), ln[(blk & 7) == x].max()) for x in range(8)))
     seq = blk >> 3
     nb = max(int(seq.max()) + 1, 1)
@@ -83,24 +85,36 @@ def main():
         # where the waves ran: HW_ID = wave_id[3:0] simd_id[5:4] pipe_id[7:6] cu_id[11:8] sh_id[12] se_id[15:13] ...
         hw, xcc = m[:, 14], m[:, 15] & 0xF
         simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
-        wv = np.arange(nw) & 3
+        wv = np.arange(nw) % WPB
         print("  SIMD of wave k of a workgroup (rows: wave 0..3; columns: SIMD 0..3): " +
-              " | ".join(" ".join("%4d" % int(((wv == k) & (simd == s_)).sum()) for s_ in range(4)) for k in range(4)))
-        print("  block b -> XCC: " + " ".join("%d" % int(xcc[4 * b]) for b in range(16)))
+              " | ".join(" ".join("%4d" % int(((wv == k) & (simd == s_)).sum()) for s_ in range(4)) for k in range(min(WPB, 4))))
+        print("  block b -> XCC: " + " ".join("%d" % int(xcc[WPB * b]) for b in range(16)))
         cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
         for b in (0, 8, 16, 24, 256, 512, 768):
-            if 4 * b < nw:
-                print("    block %4d: xcc %d se %d sh %d cu %2d, simd of waves %s" % (b, xcc[4 * b], se[4 * b], sh[4 * b], cu[4 * b], simd[4 * b:4 * b + 4].tolist()))
+            if WPB * b < nw:
+                print("    block %4d: xcc %d se %d sh %d cu %2d, simd of waves %s" % (b, xcc[WPB * b], se[WPB * b], sh[WPB * b], cu[WPB * b], simd[WPB * b:WPB * b + WPB].tolist()))
         # blocks sharing a CU with block 0 of XCC 0
-        same = np.flatnonzero(cuid[::4] == cuid[0])
+        same = np.flatnonzero(cuid[::WPB] == cuid[0])
         print("    blocks on the CU of block 0: %s" % same[:12].tolist())
-        srch = searching.reshape(-1, 4)
-        ssimd = simd.reshape(-1, 4)
         # searching waves per (CU, SIMD)
         key = cuid[searching] * 4 + simd[searching]
         if key.size:
             cnts = np.bincount(np.unique(key, return_inverse=True)[1])
             print("    searching waves per (CU, SIMD) that has any: mean %.2f max %d; histogram %s" % (cnts.mean(), cnts.max(), np.bincount(cnts).tolist()))
+        # the slowest searching waves: where did they lose their time?
+        if searching.any():
+            sd = np.where(searching, m[:, 11], 0)
+            worst = np.argsort(sd)[-6:]
+            names = [n for _, n in order]
+            print("    slowest searching waves (durations per phase, us):")
+            for w in worst:
+                prevt = a[w, 0]
+                parts = []
+                for k, name in order[:9]:
+                    if m[w, k] > 0:
+                        parts.append("%s %.2f" % (name.split()[1] if name.startswith("S ") else name.split(":")[0], (m[w, k] - prevt) / 100.0))
+                        prevt = m[w, k]
+                print("      wave %5d (block %4d, xcc %d): " % (w, w // WPB, int(xcc[w])) + " | ".join(parts))
         t0g = a[:, 0].min()
         for k, name in ((9, "A done"), (10, "past barrier 1"), (11, "search done"), (12, "past barrier 2"), (7, "partial row stored"), (8, "fold / ticket done")):
             ok = m[:, k] > 0

@@ -64,6 +64,10 @@ constexpr int kCoopCap = 384;                 // chunk descriptors per wave and 
 #define VISMA_COOP_DEPTH 7
 #endif
 constexpr int kCoopDepth = VISMA_COOP_DEPTH;  // chunks per lane octet in flight
+#ifndef VISMA_COOP_ROOM
+#define VISMA_COOP_ROOM 0.04f
+#endif
+constexpr float kCoopRoom = VISMA_COOP_ROOM;  // listing margin beyond the previous winner's distance, in search radii
 
 // minimum over the 8 lanes of an aligned lane octet: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror.
 // (v_min_f32_dpp reads its first source through the permutation; a VALU result needs two wait states
@@ -397,7 +401,14 @@ __device__ __forceinline__ void coop_body(
         s_p64[tid][0] = hp[0]; s_p64[tid][1] = hp[1]; s_p64[tid][2] = hp[2];
         if (need) {
             // (fp32 view of the previous winner: the value the candidate array holds for that point; NaN = none)
-            s_dprev[tid] = sqdist_f32(make_float4((float)w8.x, (float)w8.y, (float)w8.z, 0.f), (float)hp[0], (float)hp[1], (float)hp[2]);
+            const float dp = sqdist_f32(make_float4((float)w8.x, (float)w8.y, (float)w8.z, 0.f), (float)hp[0], (float)hp[1], (float)hp[2]);
+            // ROOM for the certificates to come: cells are listed out to the previous winner's distance PLUS a margin
+            // (any bound at or above that distance is a valid one).  Listing exactly to the winner's distance leaves
+            // the cells just beyond it un-examined, and their slab bounds -- which can lie a hair above the winner's
+            // distance -- then cap the LB this search leaves behind: one query in eight failed its certificate for
+            // that reason alone, pass after pass.  The margin costs the candidates of a thin shell.
+            const float sq = sqrtf(dp) + kCoopRoom * sqrtf(r2f);
+            s_dprev[tid] = sq * sq;                          // (NaN stays NaN)
         } else {
             // certified (or no query): the correspondence of phase C is known now
             s_q64[tid][0] = w8.x; s_q64[tid][1] = w8.y; s_q64[tid][2] = w8.z;

@@ -20,14 +20,15 @@ __device__ unsigned long long g_coop_span[4 * 8192];        // per wave of the l
 __device__ unsigned long long g_coop_marks[16 * 8192];      // mode 2: per wave, the clock at every phase border
 }  // namespace visma
 
+#define COOP_WAVE_SLOT() ((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)))   /* waves of the launch, in order */
 #if VISMA_COOP_DEBUG_PHASES == 2
 #define COOP_PROBE_CLEAR()                                                                                      \
     do {                                                                                                        \
-        if ((threadIdx.x & 63) < 14 && blockIdx.x < 2048)      /* (a wave that skips a phase leaves no stale stamp) */ \
-            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (threadIdx.x & 63)] = 0ull;               \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {    /* where the wave runs: HW_ID (4), XCC_ID (20) */   \
-            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
-            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 15] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); \
+        if ((threadIdx.x & 63) < 14 && COOP_WAVE_SLOT() < 8192)      /* (a wave that skips a phase leaves no stale stamp) */ \
+            g_coop_marks[COOP_WAVE_SLOT() * 16 + (threadIdx.x & 63)] = 0ull;               \
+        if ((threadIdx.x & 63) == 0 && COOP_WAVE_SLOT() < 8192) {    /* where the wave runs: HW_ID (4), XCC_ID (20) */   \
+            g_coop_marks[COOP_WAVE_SLOT() * 16 + 14] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); \
+            g_coop_marks[COOP_WAVE_SLOT() * 16 + 15] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); \
         }                                                                                                       \
     } while (0)
 #else
@@ -49,8 +50,8 @@ __device__ unsigned long long g_coop_marks[16 * 8192];      // mode 2: per wave,
 #elif VISMA_COOP_DEBUG_PHASES == 2
 #define COOP_MARK(k)                                                                                            \
     do {                                                                                                        \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048)                                                       \
-            g_coop_marks[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
+        if ((threadIdx.x & 63) == 0 && COOP_WAVE_SLOT() < 8192)                                                       \
+            g_coop_marks[COOP_WAVE_SLOT() * 16 + (k)] = __builtin_amdgcn_s_memrealtime();  \
     } while (0)
 #else
 #define COOP_MARK(k) do { (void)stamp_; } while (0)
@@ -58,8 +59,8 @@ __device__ unsigned long long g_coop_marks[16 * 8192];      // mode 2: per wave,
 
 #define COOP_WAVE_DONE()                                                                                        \
     do {                                                                                                        \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < 2048) {                                                     \
-            const int w_ = blockIdx.x * 4 + (threadIdx.x >> 6);                                                 \
+        if ((threadIdx.x & 63) == 0 && COOP_WAVE_SLOT() < 8192) {                                                     \
+            const int w_ = COOP_WAVE_SLOT();                                                 \
             g_coop_span[2 * w_] = stamp0_;                                                                      \
             g_coop_span[2 * w_ + 1] = __builtin_amdgcn_s_memrealtime();                                         \
         }                                                                                                       \
