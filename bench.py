@@ -321,28 +321,40 @@ def brute_roofline(ns_local, nt, nn_ms, tile, traffic):
     }
 
 
-def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, traffic, exact, kernel="serial"):
-    """ALGORITHMIC (examined) bytes of ONE grid launch on one rank.  Per query: the source point (32 B f64 in the
-    exact search, 16 B fp32 otherwise) + 8 B (index, d2) out, and in the exact search 32 B x 1.05 (the winner and
-    the near-ties in f64) + 16 B (the winner written for the next pass) + 16 B (the previous winner read, warm
-    kernel); plus 16 B per cell-table row LOOKED UP (counted by the kernel: all 9 in the lane-serial kernel, the
-    1.9 the previous winner's distance cannot exclude in the warm-started one) and 12 B (exact: packed x,y,z) or
-    16 B per candidate EXAMINED / LISTED (counted by the kernel).
+def warm_bytes(queries, certified, rows, cand):
+    """ALGORITHMIC bytes of warm-kernel launches (round 4: certificate).  Every query streams its source point (32 B) and
+    its state (32 B: the previous winner's f64 point, index, LB) in.  A CERTIFIED query writes 12 B (index, d2, the new
+    LB) and touches nothing else.  A SEARCHED query: 16 B per cell-table row looked up and 12 B per candidate listed
+    (both counted by the kernel), 32 B x 1.05 for the f64 winner and near-ties, 32 B of state and 8 B (index, d2) out."""
+    searched = queries - certified
+    return queries * 64.0 + certified * 12.0 + searched * (33.6 + 32.0 + 8.0) + 16.0 * rows + 12.0 * cand
+
+
+def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, traffic, exact, kernel="serial",
+                  certified_per_launch=0.0):
+    """ALGORITHMIC (examined) bytes of ONE grid launch on one rank.  Lane-serial kernel, per query: the source point
+    (32 B f64 in the exact search, 16 B fp32 otherwise) + 8 B (index, d2) out, and in the exact search 32 B x 1.05 (the
+    winner and the near-ties in f64) + 32 B (the state written for the next pass); plus 16 B per cell-table row LOOKED
+    UP (all 9) and 12 B (exact: packed x,y,z) or 16 B per candidate EXAMINED (counted by the kernel).  Warm kernel:
+    warm_bytes() above.
     `compulsory` = every source and target point once.  The fraction on examined bytes falls when the search gets
     smarter (fewer bytes AND less time); the fraction on compulsory bytes and `traffic_frac` (fabric bytes of the
     PMC passes) do not have that defect."""
     if exact:
-        per_query = 32.0 + 8.0 + 33.6 + 16.0 + (16.0 if kernel == "warm" else 0.0)
+        per_query = 32.0 + 8.0 + 33.6 + 32.0
         cand_bytes = 12.0
     else:
         per_query, cand_bytes = 16.0 + 8.0, 16.0
     b_alg = queries * per_query + 16.0 * rows_per_launch + cand_bytes * cand_per_launch
+    if exact and kernel == "warm":
+        b_alg = warm_bytes(queries, certified_per_launch, rows_per_launch, cand_per_launch)
     comp = nt_total * cand_bytes + queries * (32.0 + 8.0 if exact else 24.0)
     nn_ms = max(nn_ms, 1e-9)
     gbps = b_alg / (nn_ms * 1e-3) / 1e9
     return {
-        "kernel": {"warm": "nn_coop_kernel (warm-started wave-cooperative exact search: previous winner bounds the query, "
-                           "reachable cells listed, chunks flattened over the wave; f64 re-rank; fold fused)",
+        "kernel": {"warm": "nn_coop_kernel (warm-started exact search: certified queries -- winner provably unchanged -- skip "
+                           "the search; the others, compacted over the workgroup: previous winner bounds the query, reachable "
+                           "cells listed, one chunk list per workgroup ranked by all its waves; f64 re-rank; fold fused)",
                    "serial": "nn_grid_reduce_kernel" + (" (exact: fp32 ranking + f64 re-rank of the rounding band; fold fused)"
                                                         if exact else "")}[kernel],
         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
@@ -352,6 +364,7 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
         "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_alg,
         "candidates_per_query": cand_per_launch / max(queries, 1),
         "cell_table_rows_per_query": rows_per_launch / max(queries, 1),
+        "certified_fraction": certified_per_launch / max(queries, 1),
         "compulsory_bytes": comp,
         "frac_on_compulsory_bytes": comp / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
         "note": "one launch per iteration: transform + exact NN + Jacobian/residual reduction + fold.  `frac` is on the "
@@ -424,7 +437,46 @@ def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None):
     key = {"warm": "grid_warm", "serial": "grid"}.get(kind, "grid")
     return grid_roofline(ns_local, nt_local, tm["nn_ms"] / nl, tm["grid_candidates"] / nl,
                          tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
-                         ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial")
+                         ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial",
+                         tm["grid_certified"] / nl)
+
+
+def c4_variant(R, device, src, tgt, radius, T_gt, steps, what):
+    """One more C4-shaped registration measured like the headline, on its own context (rank 0, N = 1 only): iterations
+    1..K from the identity (first pass cold, the rest warm-started while the pose moves) and the K iterations after
+    2K more (the `value` regime), each the median of three, with the roofline object of the search kernel."""
+    from visma_amd import _lib, synth
+    c = _lib.Context(device)
+    c.set_clouds_f64(src, tgt)
+    c.set_nn_mode(_lib.NN_GRID)
+    c.iterate(np.eye(4), radius, 2)                                  # grid build, buffers
+    first, cont = [], []
+    T = np.eye(4)
+    for _ in range(3):
+        c.forget_winners()
+        T, last, el = timed_block(R, c, np.eye(4), radius, steps)
+        first.append(el)
+    T, _ = c.iterate(T, radius, steps)
+    for _ in range(3):
+        T, last, el = timed_block(R, c, T, radius, steps)
+        cont.append(el)
+    c.set_profiling(1)
+    c.get_timing(reset=True)
+    T, last = c.iterate(T, radius, 8)
+    tm = c.get_timing(reset=True)
+    c.set_profiling(0)
+    out = {"workload": what, "ns": len(src), "nt": len(tgt), "radius": radius, "steps": steps,
+           "from_initial_pose": {"icp_iterations_per_sec": steps / float(np.median(first)),
+                                 "ms_per_step": float(np.median(first)) / steps * 1e3},
+           "continuing": {"icp_iterations_per_sec": steps / float(np.median(cont)),
+                          "ms_per_step": float(np.median(cont)) / steps * 1e3,
+                          "iterations": "%d..%d" % (2 * steps + 1, 5 * steps)},
+           "fitness": last.fitness_, "K": last.num_correspondences, "inlier_rmse": last.inlier_rmse_,
+           "err_vs_T_gt": synth.rel_frobenius(T, T_gt),
+           "roofline": kernel_roofline(c, len(src), len(tgt), tm, traffic_kind="none")}
+    out["roofline"]["launches_timed"] = tm["nn_launches"]
+    c.close()
+    return out
 
 
 def c4_end_to_end(device, src, tgt, radius, iters=30, repeats=5):
@@ -596,7 +648,8 @@ def run_c4(R, args):
         if mode == "grid":
             roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, tm["grid_candidates_27cell"] / nl,
                                      load_traffic("grid_warm" if kernel_kind == "warm" else "grid", ns_local, nt_local),
-                                     exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial")
+                                     exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial",
+                                     tm["grid_certified"] / nl)
         else:
             roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
         roofline["launches_timed"] = tm["nn_launches"]
@@ -632,6 +685,30 @@ def run_c4(R, args):
         }
         if initial is not None:
             out["from_initial_pose"] = initial
+            # (first-class: a registration as its caller starts it, next to `value`, which continues at the converged pose)
+            out["value_from_initial_pose"] = initial["icp_iterations_per_sec"]
+            out["config"]["workload"] += "; value = iterations %d..%d continuing at the converged pose (%.0f it/s), " \
+                                         "iterations 1..%d from the identity: %.0f it/s" % (
+                                             args.warmup + 1, args.warmup + args.steps * blocks, args.steps / elapsed,
+                                             args.steps, initial["icp_iterations_per_sec"])
+        if R.world == 1 and not args.no_extras and mode == "grid":
+            # what the reference's callers register: a model against a PARTIAL scan (fitness ~0.5: half of the queries
+            # find nothing within the radius, every pass), same sizes, same radius rule, same motion
+            psrc, ptgt, pT, pr = synth.make_partial_pair(ns, nt, overlap=0.5)
+            out["partial_overlap"] = c4_variant(R, R.local_rank, psrc, ptgt, pr, pT, args.steps,
+                                                "C4 sizes, the whole model against a scan of half of its surface "
+                                                "(synth.make_partial_pair; the compiled reference's result on it: "
+                                                "tests/golden/c4_partial_ref.npz)")
+            out["value_partial_overlap"] = out["partial_overlap"]["continuing"]["icp_iterations_per_sec"]
+            out["value_partial_overlap_from_initial_pose"] = out["partial_overlap"]["from_initial_pose"]["icp_iterations_per_sec"]
+            del psrc, ptgt
+            # SURVEY 8d's literal ground truth (5 deg yaw, 1 deg pitch, ~3 cm) needs a radius of 0.15 m to converge:
+            # twelve point spacings at 65,536 target points -- at 4,194,304 points that radius holds 15,000 points
+            # per query, outside what a radius-sized cell grid is for
+            lsrc, ltgt, lT, _ = synth.make_pair(16384, 65536, motion="fixed")
+            out["literal_T_gt"] = c4_variant(R, R.local_rank, lsrc, ltgt, 0.15, lT, args.steps,
+                                             "SURVEY 8d's T_gt = R_y(5 deg) R_x(1 deg), t = (0.02, -0.01, 0.015) on "
+                                             "S-surf 16,384 -> 65,536, radius 0.15")
         if brute is not None:
             b = brute_roofline(ns_local, nt_local, brute["nn_ms"], tile, load_traffic("brute", ns_local, nt_local))
             b.update(steps=brute["steps"], ms_per_step=brute["ms_per_step"],
@@ -742,7 +819,7 @@ def run_c3(R, args):
         queries = my_queries
         nt_total = sum(len(objs[i][1]) for i in mine)
         roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True,
-                                 "warm" if ctx.search_kernel_used() == "warm" else "serial")
+                                 "warm" if ctx.search_kernel_used() == "warm" else "serial", tm["grid_certified"] / nl)
         roofline["launches_timed"] = tm["nn_launches"]
         out = {
             "metric": "icp_iterations_per_sec", "value": total_its / elapsed, "unit": "ICP iterations/s",
@@ -905,7 +982,7 @@ def run_c5(R, args, tag=""):
             tm = ctx.get_timing(reset=True)
             nl = tm["nn_launches"]
             q = sum(len(cads[c]) for s, c in chunk) * level
-            b_alg += nl * q * (32.0 + 8.0 + 33.6 + 16.0 + 16.0) + 16.0 * tm["grid_candidates_27cell"] + 12.0 * tm["grid_candidates"]
+            b_alg += warm_bytes(nl * q, tm["grid_certified"], tm["grid_candidates_27cell"], tm["grid_candidates"])
             b_comp += nl * (sum(len(scenes[s]) for s, c in chunk) * 12.0 + q * 72.0)
             ms += tm["nn_ms"]
             launches += nl

@@ -14,7 +14,8 @@ reference returned for
 A correspondence checksum is (sum of target indices, sum of (i + 1) * index mod 2^61 - 1): a swap of two
 partners or a single changed index moves the second one.
 
-    python tests/golden/gen_c4.py
+    python tests/golden/gen_c4.py [--partial]      (--partial: tests/golden/c4_partial_ref.npz, the whole model
+                                                    against a scan of half of its surface: fitness ~ 0.5)
 Runs in THIS container only (needs oracle/_ref; ~1 minute on 8 cores); the .npz travels."""
 import os
 import sys
@@ -34,6 +35,11 @@ M61 = (1 << 61) - 1
 def clouds():
     """The C4 clouds of bench.py / tests/test_gpu_fullsize.py."""
     return synth.make_pair(NS, NT, motion="radius")
+
+
+def partial_clouds():
+    """The partial-overlap variant of C4 (bench.py: `partial_overlap`): the whole model against half of its surface."""
+    return synth.make_partial_pair(NS, NT, overlap=0.5)
 
 
 def eval_pose(r):
@@ -65,7 +71,12 @@ def input_checksum(a):
 def main():
     from oracle.oracle import Ref
     ref = Ref()
-    src, tgt, T_gt, r = clouds()
+    if "--partial" in sys.argv:
+        src, tgt, T_gt, r = partial_clouds()
+        name = "c4_partial_ref.npz"
+    else:
+        src, tgt, T_gt, r = clouds()
+        name = "c4_ref.npz"
     out = {"ns": NS, "nt": NT, "radius": r, "iters": ITERS,
            "src_checksum": np.uint64(input_checksum(src)), "tgt_checksum": np.uint64(input_checksum(tgt))}
     t0 = time.time()
@@ -82,7 +93,7 @@ def main():
     out.update(ref_T=np.asarray(w.T).reshape(4, 4), ref_k=w.k, ref_fitness=w.fitness, ref_rmse=w.rmse,
                ref_sum=np.int64(s1), ref_wsum=np.int64(s2))
     print("icp x%d: K=%d fitness=%.6f rmse=%.9f  (%.1f s)" % (ITERS, w.k, w.fitness, w.rmse, time.time() - t0))
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c4_ref.npz")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     np.savez_compressed(path, **out)
     print("wrote", path)
 

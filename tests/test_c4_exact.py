@@ -117,3 +117,64 @@ def test_c4_exact_search_is_bit_identical_to_the_all_f64_search(lib, ctx, c4):
     assert np.array_equal(out["exact"][0], out["f64"][0])
     assert np.array_equal(out["exact"][1].view(np.uint32), out["f64"][1].view(np.uint32))
     assert np.array_equal(out["exact"][2].view(np.uint64), out["f64"][2].view(np.uint64))
+
+
+# ---- the partial-overlap variant (bench.py: `partial_overlap`): the whole model against a scan of half of its surface.
+# Half of the 262,144 queries have NO partner within the radius: the reject path at full size, every pass
+# (tests/golden/c4_partial_ref.npz, written by `gen_c4.py --partial` from the compiled reference).
+GP = np.load(os.path.join(HERE, "golden", "c4_partial_ref.npz"))
+
+
+@pytest.fixture(scope="module")
+def c4p():
+    src, tgt, T_gt, r = gen_c4.partial_clouds()
+    return src, tgt, r
+
+
+def test_partial_fixture_inputs_regenerate_bit_for_bit(c4p):
+    src, tgt, r = c4p
+    assert src.shape == (int(GP["ns"]), 3) and tgt.shape == (int(GP["nt"]), 3)
+    assert gen_c4.input_checksum(src) == int(GP["src_checksum"])
+    assert gen_c4.input_checksum(tgt) == int(GP["tgt_checksum"])
+    assert r == float(GP["radius"])
+    assert 0.45 < float(GP["ref_fitness"]) < 0.55             # what the variant is for
+
+
+@pytest.mark.gpu
+def test_c4_partial_one_pass_equals_the_reference_evaluation(lib, ctx, c4p):
+    src, tgt, r = c4p
+    ctx.set_nn_mode(lib.NN_GRID)
+    ctx.set_clouds_f64(src, tgt)
+    ctx.nn_pass(GP["eval_T"], r)
+    st = ctx.reduce()
+    idx = ctx.correspondence_index()
+    ctx.set_nn_mode(lib.NN_AUTO)
+    s1, s2, k = gen_c4.checksum(idx)
+    assert k == int(GP["eval_k"]) == int(st[0])
+    assert (s1, s2) == (int(GP["eval_sum"]), int(GP["eval_wsum"]))
+    assert k / len(src) == float(GP["eval_fitness"])
+    rmse = np.sqrt(st[1] / st[0])
+    assert abs(rmse - float(GP["eval_rmse"])) < 1e-12 * float(GP["eval_rmse"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loop", ["host", "device"])
+def test_c4_partial_ten_iterations_equal_the_reference_run(lib, ctx, c4p, loop):
+    """RegistrationICP from identity, criteria (0, 0, 10): passes 2..11 run the warm-started kernel -- certificates for
+    the matched queries AND for the ones that stay without a partner, the compacted search for the rest."""
+    src, tgt, r = c4p
+    ctx.set_nn_mode(lib.NN_AUTO)
+    ctx.set_device_loop(loop == "device")
+    ctx.set_clouds_f64(src, tgt)
+    got = ctx.run(np.eye(4), r, int(GP["iters"]), 0.0, 0.0)
+    ctx.set_device_loop(None)
+    assert ctx.search_mode_used() == "exact" and ctx.nn_mode_used() == lib.NN_GRID
+    assert ctx.search_kernel_used() == "warm"
+    assert got.num_correspondences == int(GP["ref_k"])
+    s1, s2, k = gen_c4.checksum(ctx.correspondence_index())
+    assert (s1, s2, k) == (int(GP["ref_sum"]), int(GP["ref_wsum"]), int(GP["ref_k"]))
+    e = synth.rel_frobenius(got.transformation_, GP["ref_T"])
+    print("C4 partial overlap vs compiled reference after %d iterations: %.3e" % (int(GP["iters"]), e))
+    assert e < 1e-9
+    assert got.fitness_ == float(GP["ref_fitness"])
+    assert abs(got.inlier_rmse_ - float(GP["ref_rmse"])) < 1e-12 * float(GP["ref_rmse"])

@@ -139,6 +139,40 @@ def make_pair(ns, nt, seed_t=1234, seed_s=5678, noise=1e-3, offset=None, motion=
     return src, tgt, T, default_radius(nt)
 
 
+def partial_surface_points(n, seed, keep=0.5):
+    """n points of the part of the S-surf surface a scan from ONE side would see: the `keep` fraction of the surface
+    (by area, approximately) on the near side of a slanted plane.  Drawn from the same stream as surface_points --
+    the first n of an over-sampled cloud that lie on the kept side -- so (n, seed, keep) fixes the cloud."""
+    normal = np.array([0.8, 0.1, 0.59])
+    normal /= np.linalg.norm(normal)
+    # the plane's offset for the requested share, from a fixed probe sample of the full surface
+    probe = surface_points(200000, 99) @ normal
+    cut = float(np.quantile(probe, keep))
+    over = int(n / keep * 1.08) + 1024
+    pts = surface_points(over, seed)
+    kept = pts[(pts @ normal) <= cut]
+    if len(kept) < n:
+        raise RuntimeError("partial_surface_points: over-sampling too small")
+    return kept[:n]
+
+
+def make_partial_pair(ns, nt, overlap=0.5, seed_t=4321, seed_s=8765, noise=1e-3):
+    """A CAD model against a PARTIAL scan of it (what the reference's callers register: fitness 0.37-0.62 in Open3D's
+    own tutorial, docs/tutorial/Basic/icp_registration.rst:91,116): the source samples the whole surface, the target
+    only the `overlap` share of it one side of a plane (nt points: denser, like a scan), 1 mm noise.  About
+    (1 - overlap) of the source has no partner within the radius -- those queries list their cells against the radius
+    every pass.  Same radius rule and ground-truth motion as make_pair(..., motion="radius").
+    Returns (source, target, T_gt, radius); clouds are float32-rounded f64."""
+    tgt = partial_surface_points(nt, seed_t, overlap)
+    rng = np.random.Generator(np.random.Philox(seed_t + 1))
+    tgt = tgt + rng.standard_normal(tgt.shape) * noise
+    src = surface_points(ns, seed_s)
+    T = T_gt_scaled(default_radius(nt))
+    Ti = np.linalg.inv(T)
+    src = src @ Ti[:3, :3].T + Ti[:3, 3]
+    return (src.astype(np.float32).astype(np.float64), tgt.astype(np.float32).astype(np.float64), T, default_radius(nt))
+
+
 def make_source(ns, nt, seed_s=5678, motion="radius"):
     """The source cloud make_pair(ns, nt, seed_s=seed_s, motion=motion) returns, without generating the target
     again (the ground-truth motion depends on nt through the radius only)."""
