@@ -50,6 +50,8 @@
 // exact ties, strict d2 < (double)(float)r2) returns the reference's correspondence; a third chunk inside
 // g + W, or more than four flagged candidates, sends the query to the f64 re-scan of its 27 cells (points
 // given several times).
+#include <cstdlib>
+
 #include "device_common.h"
 #include "grid_coop_probe.h"   // COOP_MARK: no-ops outside the measurement builds
 
@@ -861,6 +863,16 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
                           const Xform64 *Tprev)
 {
     if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
+    // batches (problems with their own clouds) and sweeps over shared clouds: round 3's wave-synchronous kernel
+    // (grid_wave.hip says why); VISMA_ICP_COOP_KERNEL=cert / wave forces one of the two (A/B timing)
+    static const int forced = [] {
+        const char *e = std::getenv("VISMA_ICP_COOP_KERNEL");
+        return !e ? 0 : (e[0] == 'c' ? 1 : (e[0] == 'w' ? 2 : 0));
+    }();
+    if (forced == 2 || (forced == 0 && (descs || nprob > 1)))
+        return launch_nn_wave(total_blocks, bpp, nprob, descs, ns, s12, start, g, nrm, nrm64, T64, off, r2f, point_to_plane, one,
+                              idx_out, d2_out, partials, cand_count, st, out_stride, src64, sorted64, fold, d64_out, wst_io,
+                              warm & 3, stream);
     Xform64 Tp{};
     if (Tprev) { Tp = *Tprev; warm |= 4; } else warm &= ~4;
     if (point_to_plane) {

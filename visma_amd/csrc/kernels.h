@@ -316,6 +316,13 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
 // lanes_per_query = kCoopLanes (G = 1, U = 99) in the two launchers around it, which fall back to the
 // lane-serial kernel where it does not apply (fp32-only / all-f64 search, half-pitch rows).
 constexpr int kCoopLanes = 9901;
+// (grid_wave.hip: round 3's kernel behind the same lanes code -- launch_nn_coop hands batches and sweeps to it)
+hipError_t launch_nn_wave(int total_blocks, int bpp, int nprob, const ProbDesc *descs, int ns, const float *s12,
+                          const unsigned *start, const GridParams &g, const float4 *nrm, const Pt64 *nrm64,
+                          const Xform64 &T64, const Offset64 &off, float r2f, int point_to_plane, int one,
+                          int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
+                          const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
+                          const FoldArgs &fold, double *d64_out, Pt64 *prevq_io, int warm, hipStream_t stream);
 hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *descs, int ns, const float *s12,
                           const unsigned *start, const GridParams &g, const float4 *nrm, const Pt64 *nrm64,
                           const Xform64 &T64, const Offset64 &off, float r2f, int point_to_plane, int one,
