@@ -13,5 +13,13 @@
 // class and the GPU-backed RegistrationICP driver on whichever types it found.
 #pragma once
 
+#ifdef VISMA_ICP_OPEN3D_NO_UMBRELLA
+// (an Open3D source tree that CMake has not configured has no Open3DConfig.h for its umbrella header to include: the
+//  headers of the path, one by one -- tests/cpp/build_shim.py compiles the drivers against the reference's tree so)
+#include <Core/Geometry/PointCloud.h>
+#include <Core/Registration/Registration.h>
+#include <IO/ClassIO/PointCloudIO.h>
+#else
 #include "Core/Core.h"
+#endif
 #include "visma_icp_open3d.hpp"

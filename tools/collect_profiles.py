@@ -8,7 +8,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.json"), ("bench_c5.json", "%s_bench_c5.json"),
@@ -48,11 +48,12 @@ p = os.path.join(src, "pmc_traffic_summary.csv")
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 for key, match, label in (("grid:262144x4194304", "nn_grid_reduce_kernel", "nn_grid_reduce_kernel<false,1,8,true,false,true> (lane-serial exact search: first pass of a registration; fold fused)"),
-                          ("grid_warm:262144x4194304", "nn_coop_kernel", "nn_coop_kernel_one<false> (warm-started wave-cooperative exact search: every later pass; fold fused)")):
+                          ("grid_warm:262144x4194304", "nn_coop_kernel", "nn_coop_kernel_one<false> (warm-started exact search with certificates, passes 28..47 of a registration; fold fused)")):
     vals = {}
     if os.path.exists(p):
         for r in csv.DictReader(open(p)):
-            if match in r["kernel"]:
+            # (the warm kernel: its last 20 dispatches -- the converged passes bench.py's `value` times)
+            if match in r["kernel"] and (("[last" in r["kernel"]) == (match == "nn_coop_kernel")):
                 vals[r["counter"]] = float(r["mean_per_dispatch"])
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         tj[key] = {
@@ -68,7 +69,7 @@ p = os.path.join(src, "pmc_traffic_saturated_summary.csv")
 vals = {}
 if os.path.exists(p):
     for r in csv.DictReader(open(p)):
-        if "nn_coop_kernel" in r["kernel"]:
+        if "nn_coop_kernel" in r["kernel"] and "[last" in r["kernel"]:
             vals[r["counter"]] = float(r["mean_per_dispatch"])
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     tj["grid_warm:4194304x4194304"] = {

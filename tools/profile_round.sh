@@ -2,7 +2,7 @@
 # Round profile set (run on the GPU box through gpurun; outputs under gpurun_out/prof_$1):
 #   bench lines of the three workloads, rocprofv3 kernel stats of the default bench command,
 #   PMC passes (separate runs, --kernel-trace only) incl. FETCH_SIZE / WRITE_SIZE for roofline.traffic
-tag=${1:-r03}
+tag=${1:-r04}
 out=/root/repo/gpurun_out/prof_$tag
 mkdir -p $out; export TMPDIR=/tmp
 cd /root/repo

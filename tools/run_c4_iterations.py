@@ -1,4 +1,5 @@
-"""What the PMC passes profile: one cold pass (lane-serial kernel) + five warm-started ones at C4
+"""What the PMC passes profile: one cold pass (lane-serial kernel) + VISMA_PASSES - 1 (default 46) warm-started ones at C4
+-- the last 20 are the regime bench.py's `value` is timed in (tools/pmc_summarize.py tabulates them separately) --
 (VISMA_NS overrides the source size: the saturated launches of bench.py's roofline_saturated)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,5 +13,5 @@ else:
     _, tgt, T_gt, r = synth.make_pair(1024, nt, motion="radius")
     src = synth.make_source(ns, nt, seed_s=5678 + ns % 9973)
 c = _lib.Context(0); c.set_clouds_f64(src, tgt); c.set_nn_mode(_lib.NN_GRID)
-c.iterate(np.eye(4), r, 6)
+c.iterate(np.eye(4), r, int(os.environ.get('VISMA_PASSES', '47')) - 1)
 c.close()
