@@ -180,6 +180,10 @@ def attach_comm(R, ctx, make_ctx, args):
     if want in ("", "ipc") and args.shard == "source":
         ok = 1
         try:
+            # (VISMA_BENCH_FAIL_IPC_EXPORT_RANK / _INIT_RANK = k: rank k's bring-up fails on purpose -- the test of the
+            #  fall-back chain: every rank must land on the NEXT transport together, tests/test_multi_gpu_bench.py)
+            if os.environ.get("VISMA_BENCH_FAIL_IPC_EXPORT_RANK") == str(R.rank):
+                raise RuntimeError("injected failure")
             mine = ctx.comm_ipc_export()
         except Exception as e:      # noqa: BLE001
             print("bench: rank %d: mailbox export failed (%s)" % (R.rank, e), file=sys.stderr)
@@ -191,6 +195,8 @@ def attach_comm(R, ctx, make_ctx, args):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()):
             try:
+                if os.environ.get("VISMA_BENCH_FAIL_IPC_INIT_RANK") == str(R.rank):
+                    raise RuntimeError("injected failure")
                 ctx.comm_ipc_init(R.rank, R.world, [bytes(x.cpu().tolist()) for x in lst])
             except Exception as e:      # noqa: BLE001
                 print("bench: rank %d: mailbox mapping failed (%s)" % (R.rank, e), file=sys.stderr)
@@ -349,8 +355,14 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
     if exact and kernel == "warm":
         b_alg = warm_bytes(queries, certified_per_launch, rows_per_launch, cand_per_launch)
     comp = nt_total * cand_bytes + queries * (32.0 + 8.0 if exact else 24.0)
+    # SURVEY 8d / BASELINE.md 3: B_alg = ceil(NS / S_TILE) NT 16 + NS 24 -- a search that reads the target once has
+    # S_TILE = NS: B_min = NT 16 + NS 24.  Since round 4 `achieved` / `frac` are quoted on THESE bytes (the same formula
+    # every round; r3: 0.29): the examined bytes fell 3.3x with the certificates, and a fraction on them reports a
+    # faster kernel as a worse one (r3 0.37 -> r4 0.13); it stays in the line as frac_on_examined_bytes.
+    b_survey = nt_total * 16.0 + queries * 24.0
     nn_ms = max(nn_ms, 1e-9)
-    gbps = b_alg / (nn_ms * 1e-3) / 1e9
+    gbps_examined = b_alg / (nn_ms * 1e-3) / 1e9
+    gbps = b_survey / (nn_ms * 1e-3) / 1e9
     return {
         "kernel": {"warm": "nn_coop_kernel (warm-started exact search: certified queries -- winner provably unchanged -- skip "
                            "the search; the others, compacted over the workgroup: previous winner bounds the query, reachable "
@@ -361,18 +373,22 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
         "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS, "traffic": traffic,
         "traffic_source": "profiles/traffic.json (PMC passes of a profiled run of this command, not this run)",
         "traffic_frac": (traffic / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS) if traffic else None,
-        "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_alg,
+        "avg_launch_ms": nn_ms, "alg_bytes_per_launch": b_survey,
+        "alg_bytes_formula": "SURVEY 8d B_min = NT x 16 + NS x 24",
+        "examined_bytes_per_launch": b_alg, "achieved_on_examined_bytes": gbps_examined,
+        "frac_on_examined_bytes": gbps_examined / PEAK_HBM_GBPS,
         "candidates_per_query": cand_per_launch / max(queries, 1),
         "cell_table_rows_per_query": rows_per_launch / max(queries, 1),
         "certified_fraction": certified_per_launch / max(queries, 1),
         "compulsory_bytes": comp,
         "frac_on_compulsory_bytes": comp / (nn_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
-        "note": "one launch per iteration: transform + exact NN + Jacobian/residual reduction + fold.  `frac` is on the "
-                "bytes the search EXAMINES (it falls when pruning improves: fewer bytes and less time); "
-                "`frac_on_compulsory_bytes` prices the same launch on every point once; `traffic_frac` on the fabric "
-                "bytes the PMC counters saw.  At 262,144 queries the chip holds every wave at once: the launch lasts "
-                "as long as one wave's chain of dependent phases (DESIGN.md 4.1c); `roofline_saturated` shows the "
-                "same kernel with the chip refilled.",
+        "note": "one launch per iteration: transform + exact NN + Jacobian/residual reduction + fold.  `frac` is on "
+                "SURVEY 8d's bytes (every target point 16 B, every source point 24 B, once); `frac_on_examined_bytes` on "
+                "what the search really touches (counted by the kernel: it FALLS when pruning and the certificates "
+                "improve -- fewer bytes and less time); `traffic_frac` on the fabric bytes the PMC counters saw.  At "
+                "262,144 queries the chip holds every wave at once and the launch lasts as long as one workgroup's chain "
+                "of dependent phases: latency-bound, 70 % of the wave cycles waiting (DESIGN.md 4.1d); "
+                "`roofline_saturated` shows the same kernel with the chip refilled.",
     }
 
 
@@ -630,6 +646,27 @@ def run_c4(R, args):
                         "ideal weak scaling keeps icp_iterations_per_sec at the N = 1 value of this line's `value`"}
         wctx.close()
 
+    # a LARGE source against the same target, source-sharded (strong scaling): 64 x the headline's queries -- the one grid
+    # workload whose iteration is long enough (1 ms at N = 1) for eight ranks to divide it
+    large = None
+    if not args.no_extras and mode == "grid" and args.shard == "source" and args.nn != "brute":
+        lns = 64 * ns
+        lsrc = synth.make_source(lns, nt, seed_s=97)
+        lctx, lns_local, _ = c4_context(R, args, lsrc, tgt, lns, nt)
+        if R.dist is not None:
+            lctx, _ = attach_comm(R, lctx, lambda: c4_context(R, args, lsrc, tgt, lns, nt)[0], args)
+        _, llast, lel, _, _ = timed_iterations(R, lctx, radius, 2, 10, args.nn, 0, 3)
+        lelapsed = float(np.median(lel))
+        large = {"ns": lns, "nt": nt, "queries_per_rank": lns_local, "steps": 10, "ms_per_step": lelapsed / 10 * 1e3,
+                 "icp_iterations_per_sec": 10 / lelapsed, "fitness": llast.fitness_, "median_of_blocks": 3,
+                 "expectation": "per-rank launches of 16.8 M / 8.4 M / 4.2 M / 2.1 M queries at N = 1 / 2 / 4 / 8 against "
+                                "the full target; measured on one GPU at those sizes (tools/ab_probe.py, "
+                                "profiles/r04_ab_probe.jsonl): 1.4-1.8 ms / 0.45-0.60 ms / 0.24-0.31 ms / 0.12-0.17 ms "
+                                "per iteration -- 8x or more at 8 GPUs before the 608-byte exchange costs anything (above "
+                                "8.4 M queries a lane takes two queries in turn: the one-GPU launch is the slow one)"}
+        lctx.close()
+        del lsrc
+
     # configuration 5 (replicas only) for a few passes, so that the N = 1, 2, 4, 8 lines of this same command
     # also carry a workload that shards without any exchange
     c5 = None
@@ -735,6 +772,8 @@ def run_c4(R, args):
                               "source_points": weak["ns"]} if weak is not None else
                              {"icp_iterations_per_sec": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
                               "source_points": ns})
+            if large is not None:
+                sw["c4_large_strong"] = large
             if c5 is not None:
                 sw["c5_replicas"] = c5
             out["scaling_workloads"] = sw

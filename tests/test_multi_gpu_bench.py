@@ -86,3 +86,18 @@ def test_two_target_sharded_ranks_on_one_gpu(lib, one_rank):
     two = _bench(["--shard", "target", "--no-weak", "--no-extras"], {"VISMA_BENCH_COMM": "torch", "VISMA_TEST_SHARE_GPU": "1"}, 2)
     _same_registration(one_rank, two)
     assert "target-sharded x2" in two["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("where", ["EXPORT", "INIT"])
+def test_one_ranks_failed_mailbox_moves_every_rank_to_the_next_transport(lib, one_rank, where):
+    """The fall-back chain of bench.py: attach_comm.  Rank 1's hipIpc bring-up fails (injected: at
+    the export, or after every rank has exported, when the peers' handles are mapped -- rank 0 HAS mapped by then and
+    must let go again): both ranks must leave the mailboxes together and meet on the next transport that works here
+    (RCCL refuses two ranks on one GPU: the host callback), and the registration must still be the one-rank one."""
+    two = _bench(["--shard", "source", "--no-weak", "--no-extras"],
+                 {"VISMA_BENCH_FAIL_IPC_%s_RANK" % where: "1", "VISMA_TEST_SHARE_GPU": "1"}, 2)
+    _same_registration(one_rank, two)
+    par = two["config"]["parallelism"].lower()
+    assert "callback" in par and "hipipc" not in par and "x2" in par, par
