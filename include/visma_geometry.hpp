@@ -4,6 +4,8 @@
 //   feh::gpu::SamplePointCloudFromMesh   geometry.h:29-64
 //   feh::gpu::ComputeErrorMetric         geometry.h:85-101 (host)
 //   feh::gpu::MeasureSurfaceError        geometry.h:117-141
+//   feh::gpu::FindPlaneNormal            geometry.h:18-26;  RotationBetweenVectors  core/utils.h:229-233
+//   feh::gpu::AnnotateObjects            the per-object loop of AnnotationTool, src/annotation.cpp:103-168
 //
 // Header-only over the C ABI in visma_icp.h; works with either Eigen storage
 // order (VISMA compiles with -DEIGEN_DEFAULT_TO_ROW_MAJOR, CMakeLists.txt:11-12).
@@ -24,6 +26,8 @@
 #include <Eigen/Core>
 
 #include <cstdint>
+#include <cstdio>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -222,6 +226,112 @@ open3d::RegistrationResult ICPRefinementMap(const open3d::PointCloud &scene, con
         models.push_back(m);
     }
     return ICPRefinement(scene, models, T_scene_src, samples_per_model, voxel_size, max_distance, mode, seed);
+}
+
+// ---- feh::AnnotationTool's steps around RegisterModelToScene (src/annotation.cpp:71-168) --------------------------
+// feh::FindPlaneNormal (include/geometry.h:18-26): with the sign Eigen's JacobiSVD gives the singular vector
+template <typename T>
+inline Eigen::Matrix<T, 3, 1> FindPlaneNormal(const Eigen::Matrix<T, Eigen::Dynamic, 3> &pts)
+{
+    const std::vector<double> p = detail::rows3(pts);
+    double n[3];
+    if (visma_geom_find_plane_normal(p.data(), (int64_t)pts.rows(), n) != VISMA_ICP_OK) throw std::runtime_error("visma_geom_find_plane_normal");
+    return Eigen::Matrix<T, 3, 1>((T)n[0], (T)n[1], (T)n[2]);
+}
+inline Eigen::Vector3d FindPlaneNormal(const std::vector<Eigen::Vector3d> &pts)
+{
+    double n[3];
+    if (visma_geom_find_plane_normal(open3d::cicp::detail::xyz(pts), (int64_t)pts.size(), n) != VISMA_ICP_OK) throw std::runtime_error("visma_geom_find_plane_normal");
+    return Eigen::Vector3d(n[0], n[1], n[2]);
+}
+// feh::RotationBetweenVectors (core/utils.h:229-233)
+inline Eigen::Matrix3d RotationBetweenVectors(const Eigen::Vector3d &u, const Eigen::Vector3d &v)
+{
+    const double a[3] = {u(0), u(1), u(2)}, b[3] = {v(0), v(1), v(2)};
+    double R[9];
+    if (visma_geom_rotation_between_vectors(a, b, R) != VISMA_ICP_OK) throw std::runtime_error("visma_geom_rotation_between_vectors: zero vector");
+    Eigen::Matrix3d M;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = R[3 * i + j];
+    return M;
+}
+// T0 of src/annotation.cpp:82-89: the rotation that turns the floor's normal onto +Y (translation zero: the reference
+// leaves T0's fourth column uninitialised; zero is the reading under which its output means something)
+inline Eigen::Matrix4d GravityAlignment(const open3d::PointCloud &floor)
+{
+    Eigen::Matrix4d T0 = Eigen::Matrix4d::Identity();
+    T0.block<3, 3>(0, 0) = RotationBetweenVectors(FindPlaneNormal(floor.points_), Eigen::Vector3d(0.0, 1.0, 0.0));
+    return T0;
+}
+
+struct AnnotationObject {
+    std::string name;                                        // the key in alignment.json (the scan's name)
+    std::shared_ptr<open3d::PointCloud> scan;                // the object's fragment, raw (sensor frame)
+    Eigen::Matrix<double, Eigen::Dynamic, 3> V;              // its CAD model
+    Eigen::Matrix<int, Eigen::Dynamic, 3> F;
+};
+struct AnnotationPose {
+    Eigen::Matrix4d T1, T2, T3, Ttot;                        // src/annotation.cpp:114-153
+    int n_scan = 0, n_model = 0;                             // |down-sampled scan|, model samples (2 x that)
+};
+
+// The loop of AnnotationTool (src/annotation.cpp:103-168) over MANY objects: per object the scan is voxel-down-sampled
+// on the device (:112), turned upright (T0) and centred on the floor (T1), the model sampled on the device with
+// 2 x |scan| points (:126) and centred (T2); all (model, scan) pairs are then registered TOGETHER by the native work
+// queue (RegisterModelsToScenes: rotation_level yaw starts per pair in flight), and Ttot = (T1 T0)^-1 T3 T2 comes back
+// per object.  `alignment_json` (optional): written as the tool writes it (:156, 170-186).
+inline std::vector<AnnotationPose> AnnotateObjects(const std::vector<AnnotationObject> &objects, const Eigen::Matrix4d &T0,
+                                                   double voxel_size, int rotation_level, double distance_threshold,
+                                                   const std::string &alignment_json = std::string(),
+                                                   SamplingMode mode = SamplingMode::Surface, uint64_t seed = 0,
+                                                   const std::vector<int> &devices = std::vector<int>())
+{
+    const size_t n = objects.size();
+    std::vector<AnnotationPose> out(n);
+    std::vector<std::pair<std::shared_ptr<open3d::PointCloud>, std::shared_ptr<open3d::PointCloud>>> pairs(n);
+    auto shift = [](open3d::PointCloud &pc, const Eigen::Matrix4d &T) {          // PointCloud::Transform, rows 0..2
+        for (auto &p : pc.points_) {
+            const Eigen::Vector4d q = T * Eigen::Vector4d(p(0), p(1), p(2), 1.0);
+            p = q.head<3>();
+        }
+    };
+    for (size_t k = 0; k < n; k++) {
+        const AnnotationObject &o = objects[k];
+        auto scan = voxel_size > 0.0 ? open3d::cicp::VoxelDownSample(*o.scan, voxel_size) : std::make_shared<open3d::PointCloud>(*o.scan);
+        shift(*scan, T0);
+        double t[3];
+        out[k].T1.setIdentity();
+        if (visma_geom_centre_on_floor(open3d::cicp::detail::xyz(scan->points_), (int64_t)scan->points_.size(), t) != VISMA_ICP_OK)
+            throw std::runtime_error("AnnotateObjects: empty scan '" + o.name + "'");
+        out[k].T1.block<3, 1>(0, 3) = Eigen::Vector3d(t[0], t[1], t[2]);
+        shift(*scan, out[k].T1);
+        auto model = std::make_shared<open3d::PointCloud>();
+        model->points_ = SamplePointCloudFromMesh(o.V, o.F, (int)(scan->points_.size() << 1), mode, seed + k);
+        out[k].T2.setIdentity();
+        if (visma_geom_centre_on_floor(open3d::cicp::detail::xyz(model->points_), (int64_t)model->points_.size(), t) != VISMA_ICP_OK)
+            throw std::runtime_error("AnnotateObjects: no samples from the model of '" + o.name + "'");
+        out[k].T2.block<3, 1>(0, 3) = Eigen::Vector3d(t[0], t[1], t[2]);
+        shift(*model, out[k].T2);
+        out[k].n_scan = (int)scan->points_.size();
+        out[k].n_model = (int)model->points_.size();
+        pairs[k] = std::make_pair(model, scan);
+    }
+    const std::vector<Eigen::Matrix4d> T3 = open3d::cicp::RegisterModelsToScenes(pairs, rotation_level, distance_threshold, devices);
+    std::vector<visma_io_pose> poses(n);
+    for (size_t k = 0; k < n; k++) {
+        out[k].T3 = T3[k];
+        double a[4][16], tot[16];
+        open3d::cicp::detail::to_rowmajor(T0, a[0]);
+        open3d::cicp::detail::to_rowmajor(out[k].T1, a[1]);
+        open3d::cicp::detail::to_rowmajor(out[k].T2, a[2]);
+        open3d::cicp::detail::to_rowmajor(out[k].T3, a[3]);
+        visma_annot_total_pose(a[0], a[1], a[2], a[3], tot);
+        out[k].Ttot = open3d::cicp::detail::from_rowmajor(tot);
+        std::snprintf(poses[k].name, sizeof(poses[k].name), "%s", objects[k].name.c_str());
+        for (int i = 0; i < 12; i++) poses[k].T[i] = tot[i];
+    }
+    if (!alignment_json.empty() && visma_io_write_alignment_json(alignment_json.c_str(), poses.data(), (int64_t)n) != 0)
+        throw std::runtime_error(std::string("visma_io_write_alignment_json: ") + visma_io_last_error());
+    return out;
 }
 
 }  // namespace gpu

@@ -338,6 +338,25 @@ VISMA_ICP_API int visma_icp_run_corpus(visma_icp_ctx *const *ctxs, int n_ctx, co
                                        int64_t n_items, const visma_icp_corpus_params *params, int64_t *counter,
                                        visma_icp_corpus_result *results, char *errbuf, size_t errbuf_len);
 
+/* ---- the gravity alignment and pose composition of feh::AnnotationTool (src/annotation.cpp:82-91, 111-153) --------
+ * Host arithmetic (no context): the steps between the scan / the CAD model and RegisterModelToScene.
+ *   visma_geom_find_plane_normal       feh::FindPlaneNormal (include/geometry.h:18-26): unit normal of the plane through
+ *                                      n points = right singular vector of the smallest singular value of their
+ *                                      covariance, WITH THE SIGN Eigen 3.3.2's JacobiSVD gives it (the reference turns
+ *                                      this normal onto +Y: the sign decides which way up the scene ends)
+ *   visma_geom_jacobi_svd3             Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV), row-major 3x3
+ *   visma_geom_rotation_between_vectors  feh::RotationBetweenVectors (core/utils.h:229-233) =
+ *                                      Eigen::Quaterniond::FromTwoVectors(u, v).toRotationMatrix(), row-major 3x3
+ *   visma_geom_centre_on_floor         (-mean_x, -min_y, -mean_z) of a cloud: the translation of T1 / T2
+ *                                      (src/annotation.cpp:114-119, 128-132)
+ *   visma_annot_total_pose             Ttot = (T1 T0)^-1 T3 T2 with the reference's rigid inverse (:147-153), row-major 4x4 */
+VISMA_ICP_API int visma_geom_find_plane_normal(const double *xyz, int64_t n, double normal_out[3]);
+VISMA_ICP_API int visma_geom_jacobi_svd3(const double A[9], double U[9], double S[3], double V[9]);
+VISMA_ICP_API int visma_geom_rotation_between_vectors(const double u[3], const double v[3], double R[9]);
+VISMA_ICP_API int visma_geom_centre_on_floor(const double *xyz, int64_t n, double t_out[3]);
+VISMA_ICP_API int visma_annot_total_pose(const double T0[16], const double T1[16], const double T2[16], const double T3[16],
+                                         double Ttot[16]);
+
 /* ---- options / measurement --------------------------------------------- */
 /* AUTO (default) uses the radius-cell grid whenever the target/radius make it
  * worthwhile and the LDS-tiled brute-force kernel otherwise; BRUTE / GRID force

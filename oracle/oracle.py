@@ -417,6 +417,22 @@ class Ref:
                                            _ptr(cl, _dp))
         return d2, face, cl
 
+    # ---- gravity alignment of feh::AnnotationTool (oracle/ref_igl.cpp: the reference's expressions on the vendored Eigen)
+    def find_plane_normal(self, xyz):
+        xyz = _f64(xyz, (-1, 3)); out = np.empty(3)
+        self.lib.ref_find_plane_normal(_ptr(xyz, _dp), C.c_int64(len(xyz)), _ptr(out, _dp))
+        return out
+
+    def jacobi_svd3(self, A):
+        A = _f64(A, (9,)); U = np.empty(9); S = np.empty(3); V = np.empty(9)
+        self.lib.ref_jacobi_svd3(_ptr(A, _dp), _ptr(U, _dp), _ptr(S, _dp), _ptr(V, _dp))
+        return U.reshape(3, 3), S, V.reshape(3, 3)
+
+    def rotation_between_vectors(self, u, v):
+        u = _f64(u, (3,)); v = _f64(v, (3,)); R = np.empty(9)
+        self.lib.ref_rotation_between_vectors(_ptr(u, _dp), _ptr(v, _dp), _ptr(R, _dp))
+        return R.reshape(3, 3)
+
     # ---- file readers (open3d::ReadPointCloudFromPLY / ReadTriangleMeshFromPLY, igl::readOBJ) ----
     def _take(self, ptr, n, dtype):
         a = np.ctypeslib.as_array(ptr, shape=(max(n, 1),)).astype(dtype)[:n].copy()

@@ -49,3 +49,47 @@ extern "C" int ref_igl_read_obj(const char *path, double **V, int64_t *nv, int *
     for (int64_t i = 0; i < Fm.rows(); i++) for (int a = 0; a < Fm.cols(); a++) (*F)[i * Fm.cols() + a] = Fm(i, a);
     return 1;
 }
+
+// ---- the gravity-alignment helpers of feh::AnnotationTool (src/annotation.cpp:82-91) ------------------------------
+// include/geometry.h:18-26 (FindPlaneNormal) and core/utils.h:229-233 (RotationBetweenVectors) cannot be compiled
+// here (utils.h: OpenCV, jsoncpp, abseil).  Both are three Eigen expressions; what decides their output -- the sign of
+// the normal included -- is Eigen's JacobiSVD / Quaternion, and THOSE are the vendored library itself below: the
+// expressions restated on the real Eigen 3.3.2.
+#include <Eigen/SVD>
+#include <Eigen/Geometry>
+
+extern "C" void ref_find_plane_normal(const double *xyz, int64_t n, double out[3])
+{
+    Eigen::Matrix<double, Eigen::Dynamic, 3> pts(n, 3);
+    for (int64_t i = 0; i < n; i++) for (int a = 0; a < 3; a++) pts(i, a) = xyz[3 * i + a];
+    // geometry.h:20-25
+    auto pts_n = pts.rowwise() - pts.colwise().mean();
+    auto P = pts_n.transpose() * pts_n / pts.rows();
+    // (geometry.h:22 also passes ComputeThinU: on a fixed-size 3 x 3 matrix that trips an eigen_assert in a build
+    //  without NDEBUG -- JacobiSVD.h:632 -- and in the reference's release build only decides whether U is formed;
+    //  V, the only factor used, is the same)
+    Eigen::JacobiSVD<Eigen::Matrix<double, 3, 3>> svd(P, Eigen::ComputeFullV);
+    Eigen::Matrix<double, 3, 1> nrm = svd.matrixV().col(2);
+    nrm.normalize();
+    for (int a = 0; a < 3; a++) out[a] = nrm(a);
+}
+
+// Eigen::JacobiSVD of a 3x3 matrix (row-major in / out), full U and V: the decomposition FindPlaneNormal rests on
+extern "C" void ref_jacobi_svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+    Eigen::Matrix<double, 3, 3> M;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M(i, j) = A[3 * i + j];
+    Eigen::JacobiSVD<Eigen::Matrix<double, 3, 3>> svd(M, Eigen::ComputeFullU | Eigen::ComputeFullV);
+    for (int i = 0; i < 3; i++) {
+        S[i] = svd.singularValues()(i);
+        for (int j = 0; j < 3; j++) { U[3 * i + j] = svd.matrixU()(i, j); V[3 * i + j] = svd.matrixV()(i, j); }
+    }
+}
+
+// core/utils.h:231-232
+extern "C" void ref_rotation_between_vectors(const double u[3], const double v[3], double R[9])
+{
+    const Eigen::Matrix<double, 3, 3> M =
+        Eigen::Quaternion<double>::FromTwoVectors(Eigen::Vector3d(u[0], u[1], u[2]), Eigen::Vector3d(v[0], v[1], v[2])).toRotationMatrix();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[3 * i + j] = M(i, j);
+}

@@ -31,7 +31,9 @@ def build():
     for name, extra, cpp in (("shim_driver", [], "shim_driver.cpp"),
                              ("shim_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"], "shim_driver.cpp"),
                              ("mesh_refine_driver", [], "mesh_refine_driver.cpp"),
-                             ("mesh_refine_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"], "mesh_refine_driver.cpp")):
+                             ("mesh_refine_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"], "mesh_refine_driver.cpp"),
+                             ("annotate_driver", [], "annotate_driver.cpp"),
+                             ("annotate_driver_rowmajor", ["-DEIGEN_DEFAULT_TO_ROW_MAJOR"], "annotate_driver.cpp")):
         src = os.path.join(HERE, cpp)
         out = os.path.join(OUT, name)
         cmd = ["g++", "-std=c++11", "-O2", "-w"] + extra + [
@@ -69,7 +71,7 @@ def build_real():
             os.path.join(ROOT, "interpose", "open3d_registration_interpose.cpp"), "-o", so,
             "-L" + os.path.join(ROOT, "visma_amd", "lib"), "-lvisma_icp", "-Wl,-rpath,$ORIGIN/../../../visma_amd/lib"])
         outs.append(so)
-        for cpp in ("interpose_driver.cpp", "shim_driver.cpp", "mesh_refine_driver.cpp"):
+        for cpp in ("interpose_driver.cpp", "shim_driver.cpp", "mesh_refine_driver.cpp", "annotate_driver.cpp"):
             obj = os.path.join(OUT, cpp.replace(".cpp", "_real_headers%s.o" % tag))
             subprocess.check_call(["g++", "-std=c++11", "-O2", "-w", "-c", "-DVISMA_ICP_OPEN3D_NO_UMBRELLA"] + extra + inc +
                                   [os.path.join(HERE, cpp), "-o", obj])

@@ -739,6 +739,52 @@ def _poses(fn, *args):
     return out
 
 
+# ---- the gravity alignment and pose composition of feh::AnnotationTool (host arithmetic, no context) -------------
+def find_plane_normal(xyz):
+    """feh::FindPlaneNormal (include/geometry.h:18-26), with Eigen's sign of the singular vector."""
+    xyz = _f64(xyz, (-1, 3)); out = np.empty(3)
+    rc = load().visma_geom_find_plane_normal(_p(xyz, _dp), C.c_int64(len(xyz)), _p(out, _dp))
+    if rc != OK:
+        raise IcpError(rc, "visma_geom_find_plane_normal")
+    return out
+
+
+def jacobi_svd3(A):
+    """Eigen::JacobiSVD<Matrix3d>(A, ComputeFullU | ComputeFullV) -> (U, S, V)."""
+    A = _f64(A, (9,)); U = np.empty(9); S = np.empty(3); V = np.empty(9)
+    rc = load().visma_geom_jacobi_svd3(_p(A, _dp), _p(U, _dp), _p(S, _dp), _p(V, _dp))
+    if rc != OK:
+        raise IcpError(rc, "visma_geom_jacobi_svd3")
+    return U.reshape(3, 3), S, V.reshape(3, 3)
+
+
+def rotation_between_vectors(u, v):
+    """feh::RotationBetweenVectors (core/utils.h:229-233)."""
+    u = _f64(u, (3,)); v = _f64(v, (3,)); R = np.empty(9)
+    rc = load().visma_geom_rotation_between_vectors(_p(u, _dp), _p(v, _dp), _p(R, _dp))
+    if rc != OK:
+        raise IcpError(rc, "visma_geom_rotation_between_vectors")
+    return R.reshape(3, 3)
+
+
+def centre_on_floor(xyz):
+    """(-mean_x, -min_y, -mean_z): the translation of T1 / T2 (src/annotation.cpp:114-119, 128-132)."""
+    xyz = _f64(xyz, (-1, 3)); t = np.empty(3)
+    rc = load().visma_geom_centre_on_floor(_p(xyz, _dp), C.c_int64(len(xyz)), _p(t, _dp))
+    if rc != OK:
+        raise IcpError(rc, "visma_geom_centre_on_floor")
+    return t
+
+
+def annot_total_pose(T0, T1, T2, T3):
+    """Ttot = (T1 T0)^-1 T3 T2 (src/annotation.cpp:147-153)."""
+    a = [_f64(T, (16,)) for T in (T0, T1, T2, T3)]; out = np.empty(16)
+    rc = load().visma_annot_total_pose(*[_p(x, _dp) for x in a], _p(out, _dp))
+    if rc != OK:
+        raise IcpError(rc, "visma_annot_total_pose")
+    return out.reshape(4, 4)
+
+
 def read_alignment_json(path):
     """alignment.json (name -> 3x4 pose) -> list of dict(name, T), in key order like the reference's loop."""
     return _poses("visma_io_read_alignment_json", str(path).encode())

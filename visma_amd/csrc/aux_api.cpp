@@ -1,6 +1,7 @@
 // aux_api.cpp -- C ABI of the steps either side of the ICP loop: VoxelDownSample, EstimateNormals, mesh sampling
 // and point-to-mesh distance, the error metric, and the SO(3) / SE(3) functions (host + device self-tests).
 #include "driver_ctx.hpp"
+#include "plane_math.hpp"
 
 extern "C" {
 
@@ -249,6 +250,62 @@ int visma_icp_selftest_so3_jac(const double *w, int n, double *R, double *dR_dw,
     else g_create_error = "so3 selftest: HIP call failed (no GPU?)";
     for (int k = 0; k < 6; k++) (void)hipFree(d[k]);
     return rc;
+}
+
+// ---- the gravity alignment and pose composition of feh::AnnotationTool (src/annotation.cpp:82-91, 111-153): host
+// code (plane_math.hpp); the clouds it looks at are the ones about to be uploaded
+int visma_geom_find_plane_normal(const double *xyz, int64_t n, double normal_out[3])
+{
+    if (!normal_out || n < 0 || (n > 0 && !xyz)) return VISMA_ICP_ERR_INVALID;
+    visma::plane::find_plane_normal(xyz, n, normal_out);
+    return VISMA_ICP_OK;
+}
+
+int visma_geom_jacobi_svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+    if (!A || !U || !S || !V) return VISMA_ICP_ERR_INVALID;
+    visma::plane::jacobi_svd3(A, U, S, V);
+    return VISMA_ICP_OK;
+}
+
+int visma_geom_rotation_between_vectors(const double u[3], const double v[3], double R[9])
+{
+    if (!u || !v || !R) return VISMA_ICP_ERR_INVALID;
+    const double lu = u[0] * u[0] + u[1] * u[1] + u[2] * u[2], lv = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    if (!(lu > 0.0) || !(lv > 0.0)) return VISMA_ICP_ERR_INVALID;
+    visma::plane::rotation_between_vectors(u, v, R);
+    return VISMA_ICP_OK;
+}
+
+int visma_geom_centre_on_floor(const double *xyz, int64_t n, double t_out[3])
+{
+    if (!t_out || n <= 0 || !xyz) return VISMA_ICP_ERR_INVALID;
+    visma::plane::centre_on_floor(xyz, n, t_out);
+    return VISMA_ICP_OK;
+}
+
+// Ttot = (T1 T0)^-1 T3 T2 with the reference's rigid inverse (rotation transposed, t <- -R^T t), row-major 4x4
+int visma_annot_total_pose(const double T0[16], const double T1[16], const double T2[16], const double T3[16], double Ttot[16])
+{
+    if (!T0 || !T1 || !T2 || !T3 || !Ttot) return VISMA_ICP_ERR_INVALID;
+    auto mul = [](const double *a, const double *b, double *c) {
+        double r[16];
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                double v = 0.0;
+                for (int k = 0; k < 4; k++) v += a[4 * i + k] * b[4 * k + j];
+                r[4 * i + j] = v;
+            }
+        for (int i = 0; i < 16; i++) c[i] = r[i];
+    };
+    double A[16], Ai[16];
+    mul(T1, T0, A);
+    for (int i = 0; i < 16; i++) Ai[i] = A[i];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ai[4 * i + j] = A[4 * j + i];      // block<3,3>.transposeInPlace()
+    for (int i = 0; i < 3; i++) Ai[4 * i + 3] = -(Ai[4 * i] * A[3] + Ai[4 * i + 1] * A[7] + Ai[4 * i + 2] * A[11]);
+    mul(Ai, T3, A);
+    mul(A, T2, Ttot);
+    return VISMA_ICP_OK;
 }
 
 }  // extern "C"
