@@ -38,8 +38,9 @@ barrier + synchronize pair; `value` is the MEDIAN block, min / max beside it), `
 transformation out: upload, grid build, 31 passes; the PCIe-inclusive rate -- never `value`),
 `roofline_saturated` (the same kernel and target with 1 M and 4 M queries per launch: the chip refilled many
 times over, no single-round latency chain) and `scaling_workloads` (what N = 1, 2, 4, 8 runs of this command
-can be divided by each other: C4 strong with the grid, C4 strong with north_star's brute-force kernel -- 115 ms
-of pair evaluations per iteration that shard linearly --, C4 weak, C5 replicas).
+can be divided by each other: C4 strong with the grid, C4 LARGE strong -- 16.8 M queries against the same target,
+1.4-1.8 ms per iteration at N = 1, source-sharded --, C4 weak, C5 replicas; north_star's brute-force kernel is frozen as
+a cross-check since round 4 and reported under `brute_force` only).
 
 Ranks meet over torch.distributed's GLOO backend (handles, unique ids, barriers, MAX of the elapsed times): PyTorch's
 own NCCL/RCCL backend is never initialised, the library brings up its own transport (peer-to-peer mailboxes over
@@ -764,10 +765,6 @@ def run_c4(R, args):
                                                     "per rank does not halve it (DESIGN.md 5: 1.19x / 1.37x / 1.50x at "
                                                     "2 / 4 / 8 GPUs measured at the per-rank sizes, before the exchange "
                                                     "costs anything)"}}
-            if brute is not None:
-                sw["c4_brute_strong"] = {"icp_iterations_per_sec": 1e3 / brute["ms_per_step"], "ms_per_step": brute["ms_per_step"],
-                                         "expectation": "north_star's kernel: NS/N x NT pair evaluations per rank and "
-                                                        "iteration, 608 bytes exchanged: shards linearly"}
             sw["c4_weak"] = ({"icp_iterations_per_sec": weak["icp_iterations_per_sec"], "ms_per_step": weak["ms_per_step"],
                               "source_points": weak["ns"]} if weak is not None else
                              {"icp_iterations_per_sec": args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,

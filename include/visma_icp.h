@@ -390,23 +390,6 @@ VISMA_ICP_API int visma_icp_set_search_precision(visma_icp_ctx *ctx, int mode);
 VISMA_ICP_API int visma_icp_get_search_precision_used(visma_icp_ctx *ctx, int *is_f64);
 /* Which search the last nn_pass used (VISMA_ICP_NN_BRUTE or VISMA_ICP_NN_GRID). */
 VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
-/* Which kernel the last grid pass ran: 0 brute force, 1 the lane-serial grid search (first pass of a
- * registration: progressive pruning, nothing known about the queries), 2 the warm-started wave-cooperative
- * search (visma_amd/csrc/grid_coop.hip: every later pass; each query starts from its previous winner, which
- * bounds it before anything is gathered).  Same results, bit for bit.
- * visma_icp_forget_winners drops what the passes so far remembered (the library does so itself whenever the
- * source, the target or the radius changes): the next pass then runs like the first of a new registration.
- * Replaces nothing in the reference (KDTreeFlann keeps no state between searches, KDTreeFlann.cpp:164-189). */
-VISMA_ICP_API int visma_icp_get_search_kernel_used(visma_icp_ctx *ctx, int *kernel);
-VISMA_ICP_API int visma_icp_forget_winners(visma_icp_ctx *ctx);
-/* Where the ICP loop runs.  1: ON THE DEVICE (per-iteration solve, compose and
- * stop test in a one-thread kernel epilogue, the host reads the state back
- * every 8 passes); 0: on the host (statistics published to mapped host memory,
- * host spin-waits, solves in f64, relaunches); -1 (default): automatic -- host
- * loop for a single problem, device loop for visma_icp_run_yaw_sweep, whose
- * `level` problems then advance together with one set of launches per
- * iteration.  Results agree to rounding. */
-VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
 /* Kernel timing with HIP events on the context's stream (read with
  * visma_icp_get_timing).  0 = off, 1 = every launch, n > 1 = every n-th ICP pass
  * (the event records themselves cost ~3 us each; sampling keeps a timed run close
@@ -414,12 +397,6 @@ VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out,
                                        int reset);
-/* Compile-time tile constants, for roofline accounting: S_TILE source points
- * per workgroup, target chunk staged per LDS fill, workgroup size. */
-VISMA_ICP_API int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block);
-/* Launch geometry of the last nn_pass: source tiles x target splits. */
-VISMA_ICP_API int visma_icp_get_launch_config(visma_icp_ctx *ctx, int *src_tiles,
-                                              int *tgt_splits);
 
 /* ---- multi-GPU (one process per GPU; source-sharded) -------------------- */
 
@@ -528,13 +505,6 @@ VISMA_ICP_API int visma_icp_point_mesh_distance(visma_icp_ctx *ctx, const double
                                                 const double *V, int64_t nv, const int32_t *F,
                                                 int64_t nf, double *d2, int32_t *face,
                                                 double *closest);
-/* Device time (HIP events) of the distance kernel, and of building the search
- * structure (Morton sort + BVH), of the last visma_icp_point_mesh_distance /
- * visma_icp_measure_surface_error call.  Either pointer may be NULL. */
-VISMA_ICP_API int visma_icp_last_mesh_kernel_ms(visma_icp_ctx *ctx, double *query_ms, double *build_ms);
-/* 0 = choose (default: BVH from 64 faces up), 1 = brute force over all faces,
- * 2 = BVH.  Both give the same minimum, face and closest point, bit for bit. */
-VISMA_ICP_API int visma_icp_set_mesh_search(visma_icp_ctx *ctx, int method);
 /* feh::ComputeErrorMetric (include/geometry.h:85-101): out = mean, std, median
  * (sorted[n >> 1]), min, max.  Host only. */
 VISMA_ICP_API int visma_icp_error_metric(const double *errors, int64_t n, double out[5]);
@@ -546,15 +516,6 @@ VISMA_ICP_API int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const doub
                                                   int64_t num_samples, int reference_quirks,
                                                   uint64_t seed, double out[5]);
 
-/* Device self-test of the SO(3) math the kernels are built on (restatement of
- * core/rodrigues.h:143-226 in visma_amd/csrc/so3.h): for n axis-angle vectors
- * w (3n doubles) computes, ON THE GPU, R = rodrigues(w) (9n) and
- * w_back = invrodrigues(R) (3n). */
-VISMA_ICP_API int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n);
-/* The same ON THE GPU with the derivatives and the projection: for n axis-angle vectors w,
- * R (9n), dR/dw (27n), w_back (3n), dw/dR (27n) and project_so3 of a sheared copy of R (9n). */
-VISMA_ICP_API int visma_icp_selftest_so3_jac(const double *w, int n, double *R, double *dR_dw,
-                                             double *w_back, double *dw_dR, double *proj);
 
 /* ---- SO(3) maps and their derivatives (host; the device versions are the same code) ----------
  * core/rodrigues.h of the reference on plain arrays.  3x3 matrices row-major; a derivative of
@@ -568,12 +529,10 @@ VISMA_ICP_API int visma_icp_selftest_so3_jac(const double *w, int n, double *R, 
  * Jacobian arguments may be NULL. */
 /* SE3Type of core/se3.h:79-169 as plain functions on g = [R | t], row-major 3x4: composition (:96-100),
  * action on a point (:103-106: what every search kernel applies to a source point), inverse (:108-110).
- * Host functions; visma_icp_selftest_se3 runs the same code on the GPU for n elements. */
+ * Host functions (visma_icp_testing.h: visma_icp_selftest_se3 runs the same code on the GPU). */
 VISMA_ICP_API int visma_se3_compose(const double a[12], const double b[12], double out[12]);
 VISMA_ICP_API int visma_se3_act(const double g[12], const double v[3], double out[3]);
 VISMA_ICP_API int visma_se3_inv(const double g[12], double out[12]);
-VISMA_ICP_API int visma_icp_selftest_se3(const double *g, const double *h, const double *v, int n,
-                                         double *gh, double *gv, double *g_inv);
 VISMA_ICP_API int visma_so3_rodrigues(const double w[3], double R[9], double dR_dw[27]);
 VISMA_ICP_API int visma_so3_invrodrigues(const double R[9], double w[3], double dw_dR[27]);
 VISMA_ICP_API int visma_so3_project(const double A[9], double R[9]);

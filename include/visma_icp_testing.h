@@ -1,5 +1,5 @@
-/* visma_icp_testing.h -- the TEST SEAM of the library's host driver.  Not part of the product ABI:
- * libvisma_icp.so does not export this entry point; only the side build
+/* visma_icp_testing.h -- (1) the TEST SEAM of the library's host driver and (2) the measurement / A-B knobs.  Neither
+ * is part of the product ABI.  (1): libvisma_icp.so does not export visma_icp_create_with_engine; only the side build
  * (visma_amd/lib/libvisma_icp_experiments.so, -DVISMA_TEST_SEAMS, built by visma_amd.build.build_experiments)
  * does, and only tests load it. */
 #ifndef VISMA_ICP_TESTING_H
@@ -27,6 +27,58 @@ typedef struct {
 VISMA_ICP_API int visma_icp_create_with_engine(visma_icp_ctx **out,
                                                const visma_icp_engine *engine,
                                                void *user);
+
+/* ---- measurement and A/B knobs ------------------------------------------------------------------------------------
+ * Exported by libvisma_icp.so too (bench.py, tools/ and the tests reach them through ctypes), but NOT part of the
+ * drop-in boundary: nothing of the reference corresponds to them and no caller of the path needs them (round 4: moved
+ * here from visma_icp.h). */
+/* Which kernel the last grid pass ran: 0 brute force, 1 the lane-serial grid search (first pass of a
+ * registration: progressive pruning, nothing known about the queries), 2 the warm-started wave-cooperative
+ * search (visma_amd/csrc/grid_coop.hip: every later pass; each query starts from its previous winner, which
+ * bounds it before anything is gathered).  Same results, bit for bit.
+ * visma_icp_forget_winners drops what the passes so far remembered (the library does so itself whenever the
+ * source, the target or the radius changes): the next pass then runs like the first of a new registration.
+ * Replaces nothing in the reference (KDTreeFlann keeps no state between searches, KDTreeFlann.cpp:164-189). */
+VISMA_ICP_API int visma_icp_get_search_kernel_used(visma_icp_ctx *ctx, int *kernel);
+VISMA_ICP_API int visma_icp_forget_winners(visma_icp_ctx *ctx);
+
+/* Where the ICP loop runs.  1: ON THE DEVICE (per-iteration solve, compose and
+ * stop test in a one-thread kernel epilogue, the host reads the state back
+ * every 8 passes); 0: on the host (statistics published to mapped host memory,
+ * host spin-waits, solves in f64, relaunches); -1 (default): automatic -- host
+ * loop for a single problem, device loop for visma_icp_run_yaw_sweep, whose
+ * `level` problems then advance together with one set of launches per
+ * iteration.  Results agree to rounding. */
+VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
+
+/* Compile-time tile constants, for roofline accounting: S_TILE source points
+ * per workgroup, target chunk staged per LDS fill, workgroup size. */
+VISMA_ICP_API int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block);
+/* Launch geometry of the last nn_pass: source tiles x target splits. */
+VISMA_ICP_API int visma_icp_get_launch_config(visma_icp_ctx *ctx, int *src_tiles,
+                                              int *tgt_splits);
+
+/* Device time (HIP events) of the distance kernel, and of building the search
+ * structure (Morton sort + BVH), of the last visma_icp_point_mesh_distance /
+ * visma_icp_measure_surface_error call.  Either pointer may be NULL. */
+VISMA_ICP_API int visma_icp_last_mesh_kernel_ms(visma_icp_ctx *ctx, double *query_ms, double *build_ms);
+/* 0 = choose (default: BVH from 64 faces up), 1 = brute force over all faces,
+ * 2 = BVH.  Both give the same minimum, face and closest point, bit for bit. */
+VISMA_ICP_API int visma_icp_set_mesh_search(visma_icp_ctx *ctx, int method);
+
+/* Device self-test of the SO(3) math the kernels are built on (restatement of
+ * core/rodrigues.h:143-226 in visma_amd/csrc/so3.h): for n axis-angle vectors
+ * w (3n doubles) computes, ON THE GPU, R = rodrigues(w) (9n) and
+ * w_back = invrodrigues(R) (3n). */
+VISMA_ICP_API int visma_icp_selftest_so3(const double *w, double *R, double *w_back, int n);
+/* The same ON THE GPU with the derivatives and the projection: for n axis-angle vectors w,
+ * R (9n), dR/dw (27n), w_back (3n), dw/dR (27n) and project_so3 of a sheared copy of R (9n). */
+VISMA_ICP_API int visma_icp_selftest_so3_jac(const double *w, int n, double *R, double *dR_dw,
+                                             double *w_back, double *dw_dR, double *proj);
+
+/* visma_se3_compose / _act / _inv (visma_icp.h) run ON THE GPU for n elements */
+VISMA_ICP_API int visma_icp_selftest_se3(const double *g, const double *h, const double *v, int n,
+                                         double *gh, double *gv, double *g_inv);
 
 #ifdef __cplusplus
 }

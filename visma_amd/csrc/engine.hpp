@@ -11,9 +11,8 @@
 #pragma once
 
 #include "../../include/visma_icp.h"
-#ifdef VISMA_TEST_SEAMS
-#include "../../include/visma_icp_testing.h"
-#endif
+#include "../../include/visma_icp_testing.h"   // (the knobs it declares are exported by the product; the engine seam
+                                                // -- visma_icp_create_with_engine -- is DEFINED under VISMA_TEST_SEAMS only)
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>

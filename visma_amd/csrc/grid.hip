@@ -1007,10 +1007,10 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
         launched = true;                                                                           \
     }
     bool launched = false;
-    // the (G, U) pairs the driver's policies use, plus a few neighbours for VISMA_ICP_GRID_LANES
-    // experiments (every pair is 12 kernel instantiations: PLANE x ONE x {fp32, f64, exact})
+    // the (G, U) pairs the driver's policies use (HipEngine::grid_lanes: 801, 1201, 402, 802, 804, 408) and no others
+    // since round 4 -- every pair is 12 kernel instantiations: PLANE x ONE x {fp32, f64, exact}
     VISMA_GRID_CASE(1, 8) VISMA_GRID_CASE(1, 12) VISMA_GRID_CASE(2, 4) VISMA_GRID_CASE(2, 8)
-    VISMA_GRID_CASE(4, 4) VISMA_GRID_CASE(4, 8) VISMA_GRID_CASE(8, 4) VISMA_GRID_CASE(1, 4)
+    VISMA_GRID_CASE(4, 8) VISMA_GRID_CASE(8, 4)
     if (!launched) return hipErrorInvalidValue;
 #undef VISMA_GRID_CASE
     if (nblocks_out) *nblocks_out = nblocks;
@@ -1092,8 +1092,8 @@ hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, 
             launch_grid_batch_t<GG, UU, false, false, false>(VISMA_BATCH_ARGS, nullptr, nullptr, fa, cand_count, nullptr, nullptr, prevq_io);         \
         launched = true;                                                                                      \
     }
-    VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(2, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(1, 12)
-    VISMA_BATCH_CASE(2, 4) VISMA_BATCH_CASE(4, 4)
+    // (the batch policy of HipEngine::run_batch: 801, 804, 402 -- the other pairs went in round 4)
+    VISMA_BATCH_CASE(4, 8) VISMA_BATCH_CASE(1, 8) VISMA_BATCH_CASE(2, 4)
 #undef VISMA_BATCH_CASE
 #undef VISMA_BATCH_ARGS
     if (!launched) return hipErrorInvalidValue;
