@@ -141,6 +141,23 @@ def test_gpu_lists_longer_than_the_lds_holds(lib, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_gpu_radius_search_with_one_dense_corner(lib, oracle):
+    """a Radius search used to give EVERY query a list as long as the longest one in the cloud -- one dense
+    corner turned the whole call into global-memory heaps.  Lists are sized per run of 16,384 queries (cell order)
+    now: the sparse runs keep their short LDS lists, the corner's run spills; values as before."""
+    rng = np.random.default_rng(77)
+    sparse = synth.surface_points(40000, 51) + rng.normal(size=(40000, 3)) * 1e-3
+    corner = np.array([1.05, 0.45, -0.9]) + rng.normal(size=(900, 3)) * 0.004        # 900 points within a few mm
+    pts = np.concatenate([sparse, corner])
+    ctx = _lib.Context(0)
+    want = oracle.estimate_normals(pts, knn=None, radius=0.03)
+    got = ctx.estimate_normals(pts, knn=None, radius=0.03)
+    assert np.abs(got - want).max() < 1e-9
+    assert np.array_equal(got, ctx.estimate_normals(pts, knn=None, radius=0.03))     # deterministic
+
+
+@pytest.mark.gpu
 def test_gpu_argument_errors(lib):
     ctx = _lib.Context(0)
     pts = np.random.default_rng(0).normal(size=(100, 3))

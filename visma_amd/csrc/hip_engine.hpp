@@ -1,0 +1,587 @@
+// hip_engine.hpp -- class HipEngine: the product engine of the ICP driver (gfx950 kernels on one HIP stream).
+// Members, small inline methods and the declarations of the large ones, which live in
+//   hip_engine_clouds.cpp   uploads and layout, the radius-cell grid, buffers and pools, timing
+//   hip_engine_passes.cpp   the per-pass launches, the fused fold, the device-resident loops (single, sweeps, batches)
+//   hip_engine_comm.cpp     the transports of the source- and target-sharded modes (IPC mailboxes, RCCL, exchanges)
+//   hip_engine.cpp          the factory
+#pragma once
+#include "engine.hpp"
+
+namespace visma {
+namespace drv {
+
+class HipEngine : public Engine {
+public:
+    explicit HipEngine(int device) : device_(device) {}
+    ~HipEngine() override
+    {
+        if (!inited_) { (void)hipGetLastError(); return; }   // never touched the device
+        (void)hipSetDevice(device_);
+        if (comm_) g_rccl.CommDestroy(comm_);
+        for (int r = 0; r < ipc_n_; r++)
+            if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
+        free_dev(d_mbox_); free_dev(d_ipc_flag_); free_dev(d_raw_); free_dev(d_sorted12_); free_dev(bt_sorted12_);
+        free_dev(d_pend_count_); free_dev(d_pend_q32_); free_dev(d_pend_q64_); free_dev(d_pend_best_); free_dev(d_pend_idx_);
+        for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
+        free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
+        free_dev(d_claim_); free_dev(d_d64_);
+        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
+        for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
+        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_partials_); free_dev(d_stats_);
+        if (d_vox_out_) (void)hipFree(d_vox_out_);
+        free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
+        free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
+        free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
+        free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_pos_); free_dev(bt_tgt_); free_dev(bt_sorted_);
+        free_dev(bt_nrm_); free_dev(bt_nrm64_); free_dev(bt_raw_);
+        free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
+        free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
+        if (h_state_) (void)hipHostFree(h_state_);
+        if (h_stats_) (void)hipHostFree(h_stats_);
+        pool_trim(0);
+        if (stream_) (void)hipStreamDestroy(stream_);
+    }
+
+    int init();
+
+    int set_target_f64(const double *xyz, int64_t nt, int stride, double *c, bool compute_centre, bool want64) override;
+    bool last_upload_f32_ = false;   // (reported by VISMA_ICP_UPLOAD_TRACE)
+    bool host_box_valid_ = false;    // the fp32 target's bounding box is known from the staging pass
+    float host_mn_[3] = {0, 0, 0}, host_mx_[3] = {0, 0, 0};
+
+    int set_target_voxel_f64(const double *xyz, int64_t n, int stride, double voxel, double *c, bool compute_centre,
+                             bool want64, int64_t *nt_out) override;
+    // the down-sampled cloud of the last set_target_voxel_f64 (kept on the device until the next one), for callers
+    // that want the points as well
+    int get_voxel_target(double *out, int64_t n) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (n != vox_out_n_) { err_ = "no down-sampled target of that size"; return VISMA_ICP_ERR_STATE; }
+        if (n > 0) HIP_TRY(hipMemcpy(out, d_vox_out_, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+        return VISMA_ICP_OK;
+    }
+    double *d_vox_out_ = nullptr;
+    int64_t vox_out_n_ = -1;
+    int prepare_search(int64_t ns, bool want64, double max_dist) override;
+    int64_t prepared_ns_ = -1;
+    bool prepared_want64_ = false;
+    int begin_raw_source(int64_t ns, bool want64, std::vector<int32_t> &order);
+    int ensure_raw(size_t points)
+    {
+        if (points * 24 > raw_bytes_) {
+            free_dev(d_raw_);
+            int rc = pool_alloc(&d_raw_, points * 24);
+            if (rc) return rc;
+            raw_bytes_ = points * 24;
+        }
+        return VISMA_ICP_OK;
+    }
+    int finish_raw_source(int64_t ns, const double *c, std::vector<int32_t> &order);
+    int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
+                       std::vector<int32_t> &order) override;
+    int set_source_meshes_f64(const MeshSource *meshes, int n_meshes, int quirks, unsigned long long seed, const double *c,
+                              bool want64, std::vector<int32_t> &order, int64_t *ns_out) override;
+    int get_mesh_source(double *out, int64_t ns) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (ns != raw_source_points_ || !d_raw_) { err_ = "no mesh-sampled source of that size on this context"; return VISMA_ICP_ERR_STATE; }
+        if (ns > 0) HIP_TRY(hipMemcpy(out, d_raw_, sizeof(double) * 3 * (size_t)ns, hipMemcpyDeviceToHost));
+        return VISMA_ICP_OK;
+    }
+    int64_t raw_source_points_ = 0;                        // > 0: d_raw_ holds the mesh-sampled source (caller order)
+    int set_source64(const Pt64 *src) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        free_dev(d_src64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
+        grid_valid_ = false;
+        { int irc = invalidate_pos(); if (irc) return irc; }
+        if (!src || !d_tgt64_) { err_ = "set_source64 without an f64 target"; return VISMA_ICP_ERR_STATE; }
+        { int prc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns_, 1)); if (prc) return prc; }
+        if (ns_ > 0) HIP_TRY(hipMemcpyAsync(d_src64_, src, sizeof(Pt64) * ns_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    void *d_raw_ = nullptr;
+    size_t raw_bytes_ = 0;
+    void *d_sorted12_ = nullptr;                           // packed (x,y,z) copy of d_sorted_ for the exact search
+    const float4 *search_sorted() const                    // what launch_nn_grid_reduce gets as `sorted`
+    {
+        if (exact_ && d_src64_ && d_sorted64_ && d_sorted12_) return (const float4 *)d_sorted12_;
+        return (const float4 *)d_sorted_;
+    }
+    int set_clouds64(const Pt64 *src, const Pt64 *tgt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
+        grid_valid_ = false;                                     // the sorted f64 copy is built with the grid
+        { int irc = invalidate_pos(); if (irc) return irc; }
+        if (!src || !tgt) return VISMA_ICP_OK;
+        { int prc = pool_alloc(&d_src64_, sizeof(Pt64) * (size_t)std::max<int64_t>(ns_, 1)); if (prc) return prc; }
+        { int prc = pool_alloc(&d_tgt64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt_, 1)); if (prc) return prc; }
+        if (ns_ > 0) HIP_TRY(hipMemcpyAsync(d_src64_, src, sizeof(Pt64) * ns_, hipMemcpyHostToDevice, stream_));
+        if (nt_ > 0) HIP_TRY(hipMemcpyAsync(d_tgt64_, tgt, sizeof(Pt64) * nt_, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    // arithmetic of the last pass / loop / batch: 0 fp32 ranking only, 1 exact (fp32 + f64 re-rank), 2 f64
+    bool search_is_f64() const override { return last_mode_ == 2; }
+    bool search_is_exact() const override { return last_mode_ != 0; }
+    int grid_search_mode() const { return (use_grid_ && d_src64_ && d_sorted64_) ? (exact_ ? 1 : 2) : (brute_exact() ? 1 : 0); }
+    // the brute-force kernels run their exact flavour when the f64 clouds are there (not on sharded ranks,
+    // which exchange the fp32 keys of this path)
+    bool brute_exact() const { return !use_grid_ && exact_ && d_src64_ && d_tgt64_ && !tshard_; }
+    int ensure_second(int64_t ns_pad, int splits);
+    void *d_pend_count_ = nullptr, *d_pend_q32_ = nullptr, *d_pend_q64_ = nullptr, *d_pend_best_ = nullptr,
+         *d_pend_idx_ = nullptr;
+    BruteExact bex_store_{};
+    const BruteExact *bex_ptr()
+    {
+        if (!brute_exact()) return nullptr;
+        bex_store_ = brute_ex();
+        return &bex_store_;
+    }
+    BruteExact brute_ex() const
+    {
+        BruteExact e;
+        e.src64 = (const Pt64 *)d_src64_;
+        e.tgt64 = (const Pt64 *)d_tgt64_;
+        e.nrm64 = (const Pt64 *)d_nrm64_;
+        e.second = (const float *)d_second_;
+        e.nt = nt_;
+        e.pend = BrutePend{};
+        if (d_pend_count_ && 2 * reduce_max_blocks() <= (int)partial_rows_) {
+            e.pend.count = (int *)d_pend_count_;
+            e.pend.q32 = (float4 *)d_pend_q32_;
+            e.pend.q64 = (Pt64 *)d_pend_q64_;
+            e.pend.best = (unsigned long long *)d_pend_best_;
+            e.pend.best_idx = (unsigned *)d_pend_idx_;
+        }
+        return e;
+    }
+    void set_exact(bool on) override { exact_ = on; }
+    int set_target_normals64(const Pt64 *n) override;
+
+    float *staging(int slot, size_t nfloats) override
+    {
+        slot &= 3;
+        if (pin_cap_[slot] < nfloats) {
+            if (pin_[slot]) (void)hipHostFree(pin_[slot]);
+            pin_[slot] = nullptr;
+            pin_cap_[slot] = 0;
+            const size_t want = nfloats + nfloats / 4 + 1024;
+            if (hipSetDevice(device_) != hipSuccess ||
+                hipHostMalloc((void **)&pin_[slot], want * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                pin_[slot] = nullptr;
+                return Engine::staging(slot, nfloats);     // pageable memory still works, only slower
+            }
+            pin_cap_[slot] = want;
+        }
+        return pin_[slot];
+    }
+    int set_source(const float *xyzw, int64_t ns) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_source(ns);
+        if (rc) return rc;
+        if (ns > 0) HIP_TRY(hipMemcpyAsync(d_src_, xyzw, sizeof(float4) * ns, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_source_device(const void *d, int64_t ns) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_source(ns);
+        if (rc) return rc;
+        if (ns > 0) HIP_TRY(hipMemcpyAsync(d_src_, d, sizeof(float4) * ns, hipMemcpyDeviceToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_target(const float *xyzw, int64_t nt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_target(nt);
+        if (rc) return rc;
+        if (nt > 0) HIP_TRY(hipMemcpyAsync(d_tgt_, xyzw, sizeof(float4) * nt, hipMemcpyHostToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_target_device(const void *d, int64_t nt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        int rc = ensure_target(nt);
+        if (rc) return rc;
+        if (nt > 0) HIP_TRY(hipMemcpyAsync(d_tgt_, d, sizeof(float4) * nt, hipMemcpyDeviceToDevice, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return VISMA_ICP_OK;
+    }
+    int set_target_normals(const float *nxyzw, int64_t nt) override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (nt != nt_) { err_ = "normals count != target count"; return VISMA_ICP_ERR_INVALID; }
+        free_dev(d_nrm_);
+        HIP_TRY(hipMalloc(&d_nrm_, sizeof(float4) * (nt > 0 ? nt : 1)));
+        if (nt > 0) HIP_TRY(hipMemcpy(d_nrm_, nxyzw, sizeof(float4) * nt, hipMemcpyHostToDevice));
+        has_normals_ = true;
+        return VISMA_ICP_OK;
+    }
+
+    int nn_pass(const Mat4 &Tc, double max_dist) override;
+
+    int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) override;
+
+    int get_correspondences(int32_t *idx, float *d2) override;
+
+    bool supports_device_loop() const override { return true; }
+
+    void select_problem(int b) override { view_offset_ = (int64_t)b * loop_out_stride_; }
+
+    int run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopResult *out) override;
+
+    int run_loop_batch(const LoopParams &lp, const std::vector<BatchProblem> &pb, LoopResult *out) override;
+
+    int set_nn_mode(int mode) override
+    {
+        if (mode != VISMA_ICP_NN_AUTO && mode != VISMA_ICP_NN_BRUTE && mode != VISMA_ICP_NN_GRID) {
+            err_ = "unknown nn mode";
+            return VISMA_ICP_ERR_INVALID;
+        }
+        nn_mode_ = mode;
+        return VISMA_ICP_OK;
+    }
+    int nn_mode_used() const override { return use_grid_ ? VISMA_ICP_NN_GRID : VISMA_ICP_NN_BRUTE; }
+    int search_kernel_used() const override { return use_grid_ ? last_kernel_ : 0; }
+    int forget_winners() override { HIP_TRY(hipSetDevice(device_)); return invalidate_pos(); }
+
+    int set_target_shard(int64_t offset, int64_t global_nt) override;
+    void set_minreduce(visma_icp_minreduce_fn fn, void *user) override { minreduce_ = fn; minreduce_user_ = user; }
+
+    int shard_exchange(const Xform64 &T64, bool plane, const double offset[3], double *pub, unsigned long long seq);
+
+    // Target shards in the device loop: the f64 protocol of shard_exchange with RCCL's stream-ordered
+    // all-reduces; the kernels read transform / frame / radius from the state.
+    bool shard_loop_on_device() const override { return tshard_ && comm_ != nullptr && shard_f64_protocol(); }
+    int shard_exchange_on_stream(const DevIcpState *st, int plane, int *nblocks);
+
+    int comm_init(int rank, int nranks, const void *id) override;
+    bool has_device_allreduce() const override { return comm_ != nullptr || ipc_n_ > 1; }
+    int bind_device() override { HIP_TRY(hipSetDevice(device_)); return VISMA_ICP_OK; }
+    hipStream_t aux_stream() override { return stream_; }
+
+    int ensure_mailbox();
+    int ipc_export(void *out) override;
+    int ipc_init(int rank, int nranks, const void *handles) override;
+
+    void set_profiling(int level) override { profiling_ = level < 0 ? 0 : level; prof_tick_ = 0; }
+    void get_timing(visma_icp_timing *t, bool reset) override;
+    void launch_config(int *tiles, int *splits) override { *tiles = plan_.src_tiles; *splits = plan_.tgt_splits; }
+
+private:
+    // Cloud-sized device buffers are recycled: a registration after another of about the same size
+    // (every caller's loop) re-uses them instead of paying hipFree + hipMalloc (a device sync and ~0.5 ms
+    // per 100 MB).  pool_alloc'ed pointers are returned by the ordinary free_dev.
+    std::unordered_map<void *, size_t> pool_live_;
+    std::vector<std::pair<void *, size_t>> pool_free_;
+    int pool_alloc(void **p, size_t bytes);
+    void pool_trim(size_t keep)
+    {
+        while (pool_free_.size() > keep) {
+            (void)hipFree(pool_free_.front().first);
+            pool_free_.erase(pool_free_.begin());
+        }
+    }
+    void free_dev(void *&p)
+    {
+        if (!p) return;
+        auto it = pool_live_.find(p);
+        if (it == pool_live_.end()) {
+            (void)hipFree(p);
+        } else {
+            pool_free_.push_back({p, it->second});
+            pool_live_.erase(it);
+            pool_trim(10);
+        }
+        p = nullptr;
+    }
+    int ensure_source(int64_t ns)
+    {
+        if (ns < 0) { err_ = "negative point count"; return VISMA_ICP_ERR_INVALID; }
+        if (ns > 0x7fffffff - 4096) { err_ = "source too large for 32-bit indices"; return VISMA_ICP_ERR_INVALID; }
+        free_dev(d_src_);
+        { int prc = pool_alloc(&d_src_, sizeof(float4) * (size_t)(ns > 0 ? ns : 1)); if (prc) return prc; }
+        ns_ = ns;
+        have_pass_ = false;
+        free_dev(d_src64_);                                      // belongs to the previous source
+        return invalidate_pos();
+    }
+    int ensure_target(int64_t nt);
+    int ensure_aux(int64_t ns_pad);
+    int choose_mode(double max_dist);
+    int build_grid(double max_dist);
+    int next_event_pair()
+    {
+        if (ev_used_ + 2 > (int)ev_.size()) {
+            for (int i = 0; i < 2; i++) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) return 0;
+                ev_.push_back(e);
+            }
+        }
+        int r = ev_used_;
+        ev_used_ += 2;
+        return r;
+    }
+    // event pairs are only read back in bulk (get_timing, or when many are pending)
+    int maybe_collect_timing()
+    {
+        if (pending_.size() < 2048) return VISMA_ICP_OK;
+        HIP_TRY(hipStreamSynchronize(stream_));
+        return collect_timing();
+    }
+    int collect_timing();
+
+    int device_;
+    hipStream_t stream_ = nullptr;
+    void *d_src_ = nullptr, *d_tgt_ = nullptr, *d_nrm_ = nullptr, *d_keys_ = nullptr;
+    void *d_idx_ = nullptr, *d_d2_ = nullptr, *d_partials_ = nullptr, *d_stats_ = nullptr;
+    double *h_stats_ = nullptr, *h_stats_dev_ = nullptr;
+    unsigned long long pub_seq_ = 0;
+    bool inited_ = false;
+    int64_t nt_pad_ = 0, ns_pad_ = 0, aux_cap_ = 0;
+    size_t keys_bytes_ = 0;
+    NNLaunch plan_{0, 0, 0};
+    Xform32 T32_{};
+    float r2f_ = 0.f;
+    bool have_pass_ = false;
+    int profiling_ = 0;        // 0 off, 1 every launch, n every n-th reduce pass
+    unsigned prof_tick_ = 0;
+    std::vector<hipEvent_t> ev_;
+    int ev_used_ = 0;
+    std::vector<std::pair<int, int>> pending_;
+    visma_icp_timing timing_{};
+    void *d_src64_ = nullptr, *d_tgt64_ = nullptr, *d_sorted64_ = nullptr;   // double-precision search
+    void *d_nrm64_ = nullptr;
+    float *pin_[4] = {nullptr, nullptr, nullptr, nullptr};   // pinned staging (see staging())
+    size_t pin_cap_[4] = {0, 0, 0, 0};
+    NcclComm comm_ = nullptr;
+    void *d_mbox_ = nullptr, *d_ipc_flag_ = nullptr;      // peer-to-peer all-reduce: own mailbox, timeout flag
+    IpcPeers peers_{};
+    int ipc_rank_ = 0, ipc_n_ = 0;
+    // (the exchange counter lives next to the timeout flag in device memory: d_ipc_flag_ + 8 bytes)
+    unsigned long long *ipc_seq_dev() const { return reinterpret_cast<unsigned long long *>((char *)d_ipc_flag_ + 8); }
+    bool tshard_ = false;                 // target-sharded rank (else: source-sharded / single)
+    int64_t tgt_offset_ = 0, tgt_global_ = 0, gkeys_cap_ = 0;
+    void *d_gkeys_ = nullptr, *d_claim_ = nullptr, *d_d64_ = nullptr;   // shard exchange: keys, index claims, local f64 d2
+    int64_t d64_cap_ = 0;
+    // target-sharded rank running the exact / f64 grid search: the buffer its f64 distances go to
+    // Which exchange the sharded ranks run must not depend on what a rank happens to hold (an empty
+    // shard, a degenerate grid): every rank with f64 clouds and without a forced brute-force search
+    // compares in f64.
+    bool shard_f64_protocol() const { return tshard_ && d_src64_ && d_tgt64_ && nn_mode_ != VISMA_ICP_NN_BRUTE; }
+    double *shard_d64()
+    {
+        if (!shard_f64_protocol()) return nullptr;
+        if (ns_ > d64_cap_) {
+            free_dev(d_d64_);
+            if (hipMalloc(&d_d64_, sizeof(double) * std::max<int64_t>(ns_, 1)) != hipSuccess) { (void)hipGetLastError(); d_d64_ = nullptr; d64_cap_ = 0; return nullptr; }
+            d64_cap_ = ns_;
+        }
+        return (double *)d_d64_;
+    }
+    std::vector<unsigned long long> h_gkeys_;
+    visma_icp_minreduce_fn minreduce_ = nullptr;
+    void *minreduce_user_ = nullptr;
+    // radius-cell grid (valid for one target + one radius)
+    int nn_mode_ = VISMA_ICP_NN_AUTO;
+    bool use_grid_ = false, grid_valid_ = false, grid_pending_ = false, brute_reduced_ = false;
+    double grid_radius_ = 0.0;
+    GridParams grid_{};
+    void *d_box_ = nullptr, *d_sorted_ = nullptr, *d_cell_of_ = nullptr, *d_count_ = nullptr;
+    void *d_start_ = nullptr, *d_bsum_ = nullptr, *d_cand_ = nullptr;
+    void *d_state_ = nullptr;
+    DevIcpState *h_state_ = nullptr;
+    int state_cap_ = 0;
+    size_t partial_rows_ = 0;
+    // batch of problems with their own clouds (concatenated arrays)
+    void *bt_src_ = nullptr, *bt_idx_ = nullptr, *bt_d2_ = nullptr, *bt_pos_ = nullptr, *bt_tgt_ = nullptr, *bt_sorted_ = nullptr;
+    void *bt_src64_ = nullptr, *bt_tgt64_ = nullptr, *bt_sorted64_ = nullptr;
+    int64_t bt_src64_cap_ = 0, bt_tgt64_cap_ = 0;
+    void *bt_sorted12_ = nullptr;                          // packed copy of bt_sorted_ (exact search)
+    int64_t bt_sorted12_cap_ = 0;
+    void *bt_raw_ = nullptr;                               // targets as uploaded (caller's f64 values)
+    size_t bt_raw_bytes_ = 0;
+    void *bt_nrm_ = nullptr, *bt_nrm64_ = nullptr;         // point-to-plane batches: target normals
+    int64_t bt_nrm_cap_ = 0, bt_nrm64_cap_ = 0;
+    void *bt_cell_of_ = nullptr, *bt_count_ = nullptr, *bt_start_ = nullptr, *bt_bsum_ = nullptr, *bt_descs_ = nullptr;
+    int64_t bt_src_cap_ = 0, bt_tgt_cap_ = 0, bt_cell_cap_ = 0, bt_out_cap_ = 0;
+    int bt_bsum_cap_ = 0;
+    size_t bt_desc_cap_ = 0;
+    std::vector<char> bt_desc_host_;                       // (kept: the copy is asynchronous)
+    int64_t view_offset_ = 0, loop_out_stride_ = 0;
+    static constexpr int kGridMaxBlocks = 32768;   // (8 M queries at one per lane: the warm kernel keeps 4 waves per SIMD only there)
+    double r2d_ = 0.0;
+    const Pt64 *f64_src() const { return d_sorted64_ ? (const Pt64 *)d_src64_ : nullptr; }
+    const Pt64 *f64_sorted() const { return d_src64_ ? (const Pt64 *)d_sorted64_ : nullptr; }
+    int grid_sub_ = 1;         // row refinement the planner may use (VISMA_ICP_GRID_SUB=2: 25 half-pitch rows --
+                               // 42 % fewer candidates at C4 but slower, 59 vs 51 us: more rows, 4x the table)
+    int grid_blocks_env_ = 0;  // VISMA_ICP_GRID_BLOCKS override of the workgroup cap below
+    int grid_blocks() const
+    {
+        // workgroup cap of the single-problem grid launch.  Up to 262,144 sources 1024
+        // workgroups give one query per lane group (the kernel's ONE variant); beyond that
+        // more workgroups keep it that way -- the fold of their partial rows costs less
+        // than running the multi-round variant (1M sources: 0.12 vs 0.17 ms per iteration)
+        if (grid_blocks_env_ > 0) return grid_blocks_env_;
+        if (ns_ <= 262144) return 1024;
+        return (int)std::min<int64_t>(kGridMaxBlocks, (ns_ + kBlock - 1) / kBlock);
+    }
+    // ---- warm start (grid_coop.hip): every query's winner as the candidate array holds it (fp32 point),
+    // written by every exact grid search.  The array is kept CONSISTENT with the current source order and
+    // target -- every entry is NaN (all bits set) or a point of the current target (reset whenever either
+    // changes) -- so any pass may read it; pos_fresh_ only says that some pass has filled it since (policy:
+    // the first pass of a registration runs the lane-serial kernel, which prunes progressively; the later ones
+    // the warm-started kernel).
+    void *d_pos_ = nullptr;
+    bool pos_fresh_ = false;
+    // the certificate of grid_coop.hip: the transform of the pass that left the state (host-driven passes over ONE
+    // problem; device loops carry it in their DevIcpState and leave prev_T_valid_ false behind them)
+    Xform64 prev_T_{};
+    bool prev_T_valid_ = false;
+    int cert_enabled_ = 1;       // VISMA_ICP_CERT=0: every query searched every pass (A/B timing)
+    const Xform64 *cert_prev() const { return (cert_enabled_ && prev_T_valid_ && pos_fresh_) ? &prev_T_ : nullptr; }
+    void note_state_pass(const Xform64 &T) { prev_T_ = T; prev_T_valid_ = true; }
+    int last_kernel_ = 0;        // what the last pass ran: 0 brute force, 1 lane-serial grid, 2 warm-started cooperative grid
+    int coop_enabled_ = 1;       // VISMA_ICP_COOP=0: every pass on the lane-serial kernel
+    int invalidate_pos()
+    {
+        pos_fresh_ = false;
+        prev_T_valid_ = false;
+        if (d_pos_ && aux_cap_ > 0) HIP_TRY(hipMemsetAsync(d_pos_, 0xFF, sizeof(Pt64) * (size_t)aux_cap_, stream_));
+        return VISMA_ICP_OK;
+    }
+    bool coop_ok() const
+    {
+        // (the kernel addresses the candidate array with 32-bit byte offsets: 12 bytes per slot)
+        return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1 &&
+               (nt_ + kSortedSlack) * 12 < (1ll << 32);
+    }
+    // which kernel a lanes code selects (see launch_nn_grid_reduce)
+    int pass_kernel(int lanes) const { return (lanes == kCoopLanes && coop_ok()) ? 2 : 1; }
+    // lanes code of the next grid pass over `nprob` problems sharing the clouds
+    int pass_lanes(int nprob = 1) const
+    {
+        if (grid_lanes_ > 0) return grid_lanes_;
+        if (coop_ok() && pos_fresh_) return kCoopLanes;
+        return grid_lanes(nprob);
+    }
+    int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
+    int grid_lanes(int nprob = 1) const
+    {
+        if (grid_lanes_ > 0) return grid_lanes_;
+        const int64_t q = ns_ * (int64_t)nprob;                  // queries of one launch
+        // measured on MI355X: small clouds need the extra parallelism, large ones the locality
+        // (lanes per query, loads in flight per lane), encoded G + 100*U
+        if (f64_src() && exact_)   // exact search (re-measured with the branch-free insertion: tools/lanes_probe.py,
+                                   // bench.py --workload c5: sweeps of ~200 k queries 801 309 k it/s, 402 295 k, 802 274 k)
+            // single problems (also the source shards of 2 / 4 / 8 ranks against a 4 M-point target, tools/lanes_probe.py
+            // 32768 / 65536 / 131072 x 4194304: 804 31.6 us vs 408 34.0; 802 34.0; 1201 41.5 vs 801 43.0, 802 47.6)
+            return nprob > 1 ? (q <= 32768 ? 408 : (q <= 98304 ? 402 : 801))
+                             : (q <= 32768 ? 804 : (q <= 98304 ? 802 : (q <= 196608 ? 1201 : 801)));
+        if (f64_src())   // 32-byte candidates: fewer in flight per lane (measured 5k: 408 15.8 us vs 804 18.1)
+            return q <= 32768 ? 408 : (nprob > 1 ? 402 : (q <= 131072 ? 802 : 801));
+        if (nprob > 1) return q <= 32768 ? 804 : 402;          // sweeps: many queries per launch
+        return ns_ <= 32768 ? 804 : (ns_ <= 98304 ? 802 : 1201);
+    }
+    int64_t sorted_cap_ = 0, cell_cap_ = 0;
+
+    // ---- streamed search with exact tie-breaks + fused fold (tile.hip) --------------------
+    bool exact_ = true;          // search precision "exact" (default): fp32 ranking, f64 re-rank of near-ties
+    int tile_enabled_ = 0;       // VISMA_ICP_TILE=1: the LDS-streamed kernel (tile.hip, experimental)
+    int fused_fold_ = 1;         // VISMA_ICP_FUSED_FOLD=0: fold the partial rows in a second launch
+    int tile_config_ = -1;       // VISMA_ICP_TILE_CONFIG: LDS tile geometry (see launch_nn_tile_reduce)
+    int tile_fallback_ = 0;      // VISMA_ICP_TILE_FALLBACK=1: every workgroup searches from global memory (tests)
+    int tile_fused_fold_ = 1;    // VISMA_ICP_TILE_FOLD=0: fold the partial rows in a second launch (experiments)
+    void *d_partials2_ = nullptr, *d_tickets_ = nullptr, *d_tstats_ = nullptr;
+    size_t tickets_cap_ = 0;     // words in d_tickets_ (= rows in d_partials2_)
+    Xform64 T64_last_{};         // transform of the last nn_pass, f64
+    void *d_second_ = nullptr;   // brute force, exact flavour: runner-up distances [splits][ns_pad]
+    size_t second_bytes_ = 0;
+    int last_mode_ = 0;          // see search_is_f64()
+    // (tile.hip is an experiment that lost -- 2.4-3x slower than the gather kernels, DESIGN.md 4.1b -- and is
+    //  only compiled into the side build -DVISMA_WITH_TILE that tests/test_tile_kernel.py loads)
+    bool use_tile() const
+    {
+#ifdef VISMA_WITH_TILE
+        return tile_enabled_ && use_grid_ && exact_ && d_src64_ && d_sorted64_ && grid_.sub == 1 && !tshard_;
+#else
+        return false;
+#endif
+    }
+    int tile_config(int64_t queries) const
+    {
+        if (tile_config_ >= 0) return tile_config_;
+        (void)queries;
+        return 0;
+    }
+#ifdef VISMA_WITH_TILE
+    // workgroups of ONE problem with ns queries
+    static int tile_blocks(int64_t ns, int config)
+    {
+        const int nth = tile_threads(config);
+        const int64_t nb = (ns + nth - 1) / nth;
+        return (int)(nb < 1 ? 1 : nb);
+    }
+#endif
+    int ensure_tile_buffers(size_t rows, size_t ticket_words);
+#ifdef VISMA_WITH_TILE
+    // the arguments every tile launch of the resident clouds shares
+    TileArgs tile_args(const Xform64 &T64, const double offset[3], bool prof) const
+    {
+        TileArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.src64 = (const Pt64 *)d_src64_;
+        a.ns = (int)ns_;
+        a.sorted = (const float4 *)d_sorted_;
+        a.sorted64 = (const Pt64 *)d_sorted64_;
+        a.start = (const unsigned *)d_start_;
+        a.g = grid_;
+        a.nrm = (const float4 *)d_nrm_;
+        a.nrm64 = (const Pt64 *)d_nrm64_;
+        a.T64 = T64;
+        for (int k = 0; k < 3; k++) a.off.v[k] = offset ? offset[k] : 0.0;
+        a.r2f = r2f_;
+        a.idx_out = (int *)d_idx_;
+        a.d2_out = (float *)d_d2_;
+        a.partials = (double *)d_partials_;
+        a.partials2 = (double *)d_partials2_;
+        a.stats = prof ? (unsigned long long *)d_tstats_ : nullptr;
+        a.nprob = 1;
+        a.force_fallback = tile_fallback_;
+        return a;
+    }
+#endif
+    // workgroups per problem of launch_nn_grid_reduce (same arithmetic as the launcher)
+    static int grid_launch_blocks(int64_t ns, int lanes, int max_blocks)
+    {
+        const int G = lanes % 100;
+        int64_t want = (ns * G + kBlock - 1) / kBlock;
+        int nb = (int)(want > max_blocks ? max_blocks : want);
+        return nb < 1 ? 1 : nb;
+    }
+    // fold arguments for `nprob` problems of `bpp` workgroups each (buffers grown as needed)
+    void add_ipc(FoldArgs *fa)
+    {
+        fa->peers = peers_;
+        fa->ipc_rank = ipc_rank_;
+        fa->ipc_n = ipc_n_;
+        fa->ipc_seq_dev = ipc_seq_dev();
+        fa->ipc_flag = (int *)d_ipc_flag_;
+        fa->ipc_spins = kIpcSpinLimit;
+    }
+    int make_fold(int bpp, int nprob, double *stats_out, long long stats_stride, double *host_out,
+                  unsigned long long seq, FoldArgs *out);
+    int ensure_f64_views();
+};
+
+}  // namespace drv
+}  // namespace visma
