@@ -353,8 +353,8 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
     else:
         per_query, cand_bytes = 16.0 + 8.0, 16.0
     b_alg = queries * per_query + 16.0 * rows_per_launch + cand_bytes * cand_per_launch
-    if exact and kernel == "warm":
-        b_alg = warm_bytes(queries, certified_per_launch, rows_per_launch, cand_per_launch)
+    if exact and kernel in ("warm", "wave"):
+        b_alg = warm_bytes(queries, certified_per_launch if kernel == "warm" else 0.0, rows_per_launch, cand_per_launch)
     comp = nt_total * cand_bytes + queries * (32.0 + 8.0 if exact else 24.0)
     # SURVEY 8d / BASELINE.md 3: B_alg = ceil(NS / S_TILE) NT 16 + NS 24 -- a search that reads the target once has
     # S_TILE = NS: B_min = NT 16 + NS 24.  Since round 4 `achieved` / `frac` are quoted on THESE bytes (the same formula
@@ -368,6 +368,8 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
         "kernel": {"warm": "nn_coop_kernel (warm-started exact search: certified queries -- winner provably unchanged -- skip "
                            "the search; the others, compacted over the workgroup: previous winner bounds the query, reachable "
                            "cells listed, one chunk list per workgroup ranked by all its waves; f64 re-rank; fold fused)",
+                   "wave": "nn_wave_kernel (grid_wave.hip: round 3's warm-started wave-cooperative exact search, no certificates: "
+                           "what batches and sweeps run after their first pass; fold fused)",
                    "serial": "nn_grid_reduce_kernel" + (" (exact: fp32 ranking + f64 re-rank of the rounding band; fold fused)"
                                                         if exact else "")}[kernel],
         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
@@ -855,7 +857,7 @@ def run_c3(R, args):
         queries = my_queries
         nt_total = sum(len(objs[i][1]) for i in mine)
         roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True,
-                                 "warm" if ctx.search_kernel_used() == "warm" else "serial", tm["grid_certified"] / nl)
+                                 "wave" if ctx.search_kernel_used() == "warm" else "serial", 0.0)   # (batches: grid_wave.hip)
         roofline["launches_timed"] = tm["nn_launches"]
         out = {
             "metric": "icp_iterations_per_sec", "value": total_its / elapsed, "unit": "ICP iterations/s",
@@ -1025,7 +1027,7 @@ def run_c5(R, args, tag=""):
         ctx.set_profiling(0)
         if ms > 0:
             gbps = b_alg / (ms * 1e-3) / 1e9
-            roofline = {"kernel": "nn_coop_kernel after each batch's first pass (%d problems per launch: %d items x 24 starts, exact search, fold fused)" % (
+            roofline = {"kernel": "nn_wave_kernel (grid_wave.hip) after each batch's first pass (%d problems per launch: %d items x 24 starts, exact search, fold fused)" % (
                             C5_CHUNK * level, C5_CHUNK),
                         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                         "traffic": None, "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": b_alg / max(launches, 1),
