@@ -21,11 +21,13 @@
 
 #include "visma_icp_open3d.hpp"
 
+#include <atomic>
+
 namespace {
-int g_calls = 0;   // how often the substituted entry points ran (a caller can check that the substitution took)
+std::atomic<int> g_calls(0);   // how often the substituted entry points ran (a caller can check that the substitution took)
 }
 
-extern "C" __attribute__((visibility("default"))) int visma_open3d_interpose_calls() { return g_calls; }
+extern "C" __attribute__((visibility("default"))) int visma_open3d_interpose_calls() { return g_calls.load(); }
 
 namespace open3d {
 
