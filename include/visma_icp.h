@@ -106,6 +106,13 @@ typedef struct {
                                         winner fetch, moments + row; [6] unused */
     double grid_certified;           /* queries of profiled passes whose previous winner was CERTIFIED unchanged (no search:
                                         the warm-started kernel's triangle-inequality test, visma_amd/csrc/grid_coop.hip) */
+    /* persistent launches (one launch of the certificate kernel running several passes of a host loop, the next
+     * transform handed over through mapped host memory): nn_ms holds their whole duration -- the time the launch
+     * waits for the host included -- and nn_launches counts their PASSES, so that nn_ms / nn_launches stays the
+     * time of one pass whichever way it ran; these two say how many launches and passes that were. */
+    double persist_launches;
+    double persist_passes;
+    double persist_ms;               /* their share of nn_ms */
 } visma_icp_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */

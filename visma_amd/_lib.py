@@ -45,7 +45,8 @@ class CTiming(C.Structure):
                 ("grid_candidates", C.c_double), ("grid_candidates_27cell", C.c_double),
                 ("tile_workgroups", C.c_double), ("tile_fallback_workgroups", C.c_double), ("tile_parts", C.c_double),
                 ("tile_points", C.c_double), ("tile_rows", C.c_double), ("f64_reranks", C.c_double),
-                ("tile_phase_cycles", C.c_double * 7), ("grid_certified", C.c_double)]
+                ("tile_phase_cycles", C.c_double * 7), ("grid_certified", C.c_double),
+                ("persist_launches", C.c_double), ("persist_passes", C.c_double), ("persist_ms", C.c_double)]
 
 
 class CProblem(C.Structure):

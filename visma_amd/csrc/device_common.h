@@ -227,20 +227,34 @@ __device__ __forceinline__ double wave_sum_multi(double *v)
 
 // wavefront shuffle reduction -> LDS across the 4 waves -> one partial row
 // (row = nullptr: partials + blockIdx.x * kReduceAcc; agent: write-through stores for the fused fold)
-template <int NACC, int NWAVES = kBlock / 64>
+// the thread's number in its workgroup; OPAQUE: as a value the compiler cannot see through (inside the loop of the
+// persistent kernel everything derived from threadIdx.x alone was hoisted out of the loop and spilled)
+template <bool OPAQUE, int NTH = kBlock>
+__device__ __forceinline__ int thread_number()
+{
+    int t = threadIdx.x;
+    if constexpr (OPAQUE) {
+        asm volatile("" : "+v"(t));
+        t &= NTH - 1;
+    }
+    return t;
+}
+
+template <int NACC, int NWAVES = kBlock / 64, bool OPAQUE_TID = false>
 __device__ __forceinline__ void block_reduce_store(double *acc, double *partials, bool agent = false)
 {
     __shared__ double wsum[NWAVES][NACC];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tidx = thread_number<OPAQUE_TID, NWAVES * 64>();
+    const int lane = tidx & 63, wave = tidx >> 6;
     const double tot = wave_sum_multi<NACC>(acc);
     const int slot = multi_index<NACC>(lane);
     if (slot >= 0) wsum[wave][slot] = tot;
     __syncthreads();
-    if (threadIdx.x < NACC) {
-        double v = wsum[0][threadIdx.x];
+    if (tidx < NACC) {
+        double v = wsum[0][tidx];
 #pragma unroll
-        for (int w = 1; w < NWAVES; w++) v += wsum[w][threadIdx.x];
-        double *dst = partials + (long long)blockIdx.x * kReduceAcc + threadIdx.x;
+        for (int w = 1; w < NWAVES; w++) v += wsum[w][tidx];
+        double *dst = partials + (long long)blockIdx.x * kReduceAcc + tidx;
         if (agent) store_agent_f64(dst, v);
         else *dst = v;
     }
@@ -397,8 +411,10 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
 // re-arm them); [0] = level 2, [1 + g] = level 1 of group g.
 constexpr int kFoldGroup = 32;
 constexpr int kFoldSingle = 256;      // up to this many rows: one level
-template <bool PLANE, int NTH>
-__device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *partials, long long row0, int lb,
+// Returns true on the ONE workgroup of the problem that finished the fold and published the statistics.
+// LOOPED: called from the loop of the persistent kernel (no exchange with peers there; opaque thread number).
+template <bool PLANE, int NTH, bool LOOPED = false>
+__device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *partials, long long row0, int lb,
                                            int bpp, int prob)
 {
     constexpr int NACC = Acc<PLANE>::N;
@@ -406,7 +422,7 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
     __shared__ double f_part[NG][33];
     __shared__ double f_tot[32];
     __shared__ int f_flag[2];
-    const int tid = threadIdx.x;
+    const int tid = thread_number<LOOPED, NTH>();
     // few rows (small clouds, the problems of a batch): ONE level -- the last workgroup sums them all;
     // otherwise groups of kFoldGroup rows, then the group sums
     const bool single = bpp <= kFoldSingle;
@@ -425,7 +441,7 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
         }
     }
     __syncthreads();
-    if (!f_flag[0]) return;
+    if (!f_flag[0]) return false;
     const int sa = tid & 31, sg = tid >> 5;
     {
         const double *grows = partials + (row0 + (long long)grp * kFoldGroup) * kReduceAcc;
@@ -465,7 +481,7 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
         }
     }
     __syncthreads();
-    if (!f_flag[1]) return;
+    if (!f_flag[1]) return false;
     {
         const double *g2 = f.partials2 + (long long)prob * f.ticket_stride * kReduceAcc;
         double v = 0.0;
@@ -499,7 +515,7 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
     __shared__ double f_stats[kNStats + 2];
     if (tid == 0) expand_moments<PLANE>(f_tot, f_stats);
     __syncthreads();
-    if (f.ipc_n > 1) {
+    if (!LOOPED && f.ipc_n > 1) {
         // source-sharded ranks: this workgroup's first wave exchanges the statistics with the peers
         // (remote stores over xGMI, rank-ordered sum) before anything is published
         // the number of THIS exchange: kept in device memory, advanced by the one workgroup that exchanges
@@ -520,7 +536,7 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
         __syncthreads();
         if (f_flag[0]) {                                   // a peer was lost: nothing is published
             if (tid < kNStats) stats[tid] = f_stats[tid];
-            return;
+            return true;
         }
     }
     if (tid < kNStats) {
@@ -531,9 +547,17 @@ __device__ __forceinline__ void fused_fold(const FoldArgs &f, const double *part
             u4_t g;
             g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
             g.z = (unsigned)f.seq; g.w = (unsigned)(f.seq >> 32);
-            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(f.host_out) + tid);
+            u4_t *dst = reinterpret_cast<u4_t *>(f.host_out) + tid;
+            if constexpr (LOOPED) {
+                // the launch goes on after this: a system-scope store (written through now -- a plain or non-temporal
+                // one may stay in the L2 until the launch ends, and the host would wait for exactly that)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(g) : "memory");
+            } else {
+                __builtin_nontemporal_store(g, dst);
+            }
         }
     }
+    return true;
 }
 
 }  // namespace visma

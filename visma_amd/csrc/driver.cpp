@@ -645,10 +645,13 @@ int visma_icp_iterate(visma_icp_ctx *ctx, double T_inout[16], double max_dist, i
         }
         return VISMA_ICP_OK;
     }
-    for (int i = 0; i < steps; i++) {
-        int rc = ctx->pass(Tc, max_dist, false, world, stats, &fit, &rmse, &k);
-        if (rc) return rc;
-        Tc = ctx->apply_update(ctx->solve(stats, solver, with_scaling != 0, false), Tc, world);
+    {
+        Engine::LoopScope scope(ctx->eng.get(), ctx->solo() ? steps : 0);
+        for (int i = 0; i < steps; i++) {
+            int rc = ctx->pass(Tc, max_dist, false, world, stats, &fit, &rmse, &k);
+            if (rc) return rc;
+            Tc = ctx->apply_update(ctx->solve(stats, solver, with_scaling != 0, false), Tc, world);
+        }
     }
     const Mat4 T = from_centred(Tc, ctx->centre);
     std::memcpy(T_inout, T.m, sizeof(T.m));

@@ -84,6 +84,9 @@ struct visma_icp_ctx {
     }
     bool use_device_loop() const { return loop_mode == 1 && device_loop_possible(); }
     bool use_device_loop_batched() const { return loop_mode != 0 && device_loop_possible(); }
+    // one rank, nothing summed on the host between a pass and the next: the engine may keep one launch alive across
+    // the passes of a loop (ranks that share a GPU would wait for each other's workgroups)
+    bool solo() const { return !host_allreduce && nranks == 1 && !target_sharded; }
     static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }
 
     // T_centred <- update o T_centred, with the update expressed in `world` or centred frame
@@ -139,6 +142,7 @@ struct visma_icp_ctx {
         }
         double stats[VISMA_ICP_NSTATS], fit, rmse;
         int64_t k;
+        Engine::LoopScope scope(eng.get(), solo() ? max_iter + 1 : 0);   // (at most max_iter + 1 passes follow, nothing else)
         int rc = pass(Tc, max_dist, plane, world, stats, &fit, &rmse, &k);  // Registration.cpp:166-168
         if (rc) return rc;
         int it = 0;

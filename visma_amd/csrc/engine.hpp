@@ -253,6 +253,18 @@ public:
     // q+offset): zero = centred frame, the cloud centre = the caller's frame.
     virtual int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) = 0;
     virtual int get_correspondences(int32_t *idx, float *d2) = 0;
+    // The host loop of ONE registration announces itself: between loop_begin(n) and loop_end() the caller runs at most
+    // n passes (nn_pass + reduce, nothing else) -- an engine may then keep ONE launch alive across them (HipEngine:
+    // the persistent certificate kernel).  loop_end() must follow on every path; LoopScope does that.
+    virtual void loop_begin(int /*max_passes*/) {}
+    virtual int loop_end() { return VISMA_ICP_OK; }
+    struct LoopScope {
+        Engine *e;
+        LoopScope(Engine *eng, int max_passes) : e(eng) { e->loop_begin(max_passes); }
+        ~LoopScope() { (void)e->loop_end(); }
+        LoopScope(const LoopScope &) = delete;
+        LoopScope &operator=(const LoopScope &) = delete;
+    };
     virtual int comm_init(int, int, const void *) { err_ = "RCCL needs the HIP engine"; return VISMA_ICP_ERR_STATE; }
     // The whole loop on the device (no per-iteration host round trip).
     struct LoopParams {

@@ -103,8 +103,9 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int)
 
 }  // namespace
 
-template <bool PLANE, bool ONE, int NTH>
-__device__ __forceinline__ void coop_body(
+// Returns true on the one workgroup that finished the fold and published the statistics (fused fold only).
+template <bool PLANE, bool ONE, int NTH, bool PERSIST = false>
+__device__ __forceinline__ bool coop_body(
     int ns, const float *__restrict__ s12f, const unsigned *__restrict__ start, GridParams g,
     const float4 *__restrict__ nrm, Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out,
     float *__restrict__ d2_out, double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
@@ -156,7 +157,7 @@ __device__ __forceinline__ void coop_body(
     if (st) st += prob;
     {
         Xform32 T32_unused;
-        if (!load_loop_state(st, T32_unused, T64, off, r2f)) return;
+        if (!load_loop_state(st, T32_unused, T64, off, r2f)) return false;
         if (st) {
             // device-resident loop: the transform of the previous pass travels with the state (advance_state)
             warm &= ~4;
@@ -177,7 +178,9 @@ __device__ __forceinline__ void coop_body(
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (inside the persistent kernel's loop: whatever derives from the thread's number alone -- LDS addresses, lane
+    //  masks -- was hoisted out of the loop and spilled; opaque, it is computed where it is used)
+    const int tid = thread_number<PERSIST, NTH>(), lane = tid & 63, wave = tid >> 6;
     const int oct = lane >> 3, l8 = lane & 7;
     constexpr int NW = NTH / 64;                             // waves of the workgroup
     constexpr unsigned kCapAll = (unsigned)(NW * kCoopCap);  // chunk descriptors of the workgroup's list window
@@ -807,10 +810,12 @@ __device__ __forceinline__ void coop_body(
     }
     COOP_MARK(6);                                            // outputs + moments
     COOP_WAVE_DONE();
-    block_reduce_store<NACC, NW>(acc, partials, fold.tickets != nullptr);
+    block_reduce_store<NACC, NW, PERSIST>(acc, partials, fold.tickets != nullptr);
     COOP_MARK(7);                                            // workgroup's partial row stored
-    if (fold.tickets) fused_fold<PLANE, NTH>(fold, partials, row0, lb, bpp, prob);
+    bool published = false;
+    if (fold.tickets) published = fused_fold<PLANE, NTH, PERSIST>(fold, partials, row0, lb, bpp, prob);
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
+    return published;
 }
 
 #define VISMA_COOP_PARAMS                                                                                         \
@@ -831,12 +836,139 @@ __device__ __forceinline__ void coop_body(
 template <bool PLANE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn_coop_kernel_one(VISMA_COOP_PARAMS)
 {
-    coop_body<PLANE, true, kBlock>(VISMA_COOP_ARGS);
+    (void)coop_body<PLANE, true, kBlock>(VISMA_COOP_ARGS);
 }
 template <bool PLANE>
 __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 {
-    coop_body<PLANE, false, kBlock>(VISMA_COOP_ARGS);
+    (void)coop_body<PLANE, false, kBlock>(VISMA_COOP_ARGS);
+}
+
+// ---- The PERSISTENT launch (kernels.h: PersistArgs): up to pa.max_passes passes of ONE registration in one launch.
+// Every workgroup of the launch must be resident at once (coop_persist_capacity; the launcher refuses otherwise): the
+// fold of a pass needs the partial row of every workgroup, and a workgroup that is not running cannot write its.
+// Between two passes
+//   * the workgroup that finished the fold -- it has just sent the statistics to the host -- polls the command block in
+//     host memory with its first wave (24 lanes: the 3 x 4 transform as 8-byte words {half | tag}, one lane: the
+//     command), one PCIe round trip per poll, and stores the words it accepted to the relay in device memory;
+//   * the first wave of every other workgroup polls the relay (agent scope: served by the fabric, not by PCIe);
+//   * the other waves sleep in the barrier.
+// A word is accepted when it carries the tag of the pass that is due: nothing orders the words among themselves, so
+// no fence (an agent- or system-scope release would write the launch's megabytes of dirty state back first).
+// Every wait gives up after its budget of 100 MHz ticks; the poller then says so in host memory and hands the others
+// an ABORT, so a launch whose host process stopped, or whose workgroups were not all resident after all, ends by
+// itself: between passes the state in memory is exactly what the last completed pass left, and the host goes on
+// with ordinary launches.
+__device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa, unsigned tag, bool poller, int pass, int lane)
+{
+    const bool mine = lane < kPersistWords;
+    unsigned long long w = 0ull;
+    const long long t0 = (long long)wall_clock64();
+    const long long budget = poller ? pa.poll_ticks : pa.wait_ticks;
+    for (;;) {
+        if (mine) {
+            if (poller) w = __hip_atomic_load(pa.host_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else w = __hip_atomic_load(pa.relay + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool ok = !mine || (unsigned)(w >> 32) == tag;
+        if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+        if ((long long)wall_clock64() - t0 > budget) {
+            // nothing came: everybody leaves (the command word decides; the transform words are not looked at)
+            w = ((unsigned long long)tag << 32) | (lane == kPersistWords - 1 ? kPersistAbort : 0u);
+            if (poller && lane == 0) __hip_atomic_store(pa.host_flag, (unsigned)pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        if (poller) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+    }
+    if (poller && mine) __hip_atomic_store(pa.relay + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return w;
+}
+
+// Everything the launch is given, as ONE by-value argument: the kernel reads it from the kernarg segment at the top of
+// EVERY pass through a pointer the compiler cannot see through.  With ordinary arguments the loop around the pass had
+// every invariant of the body hoisted out of it -- uniform and per-lane values that then stayed live across the
+// search: 225 scalar registers spilled, and the vector lanes they were spilled to spilled to scratch (584 bytes).
+struct CoopPersistParams {
+    int ns; const float *s12f; const unsigned *start; GridParams g; const float4 *nrm; Xform64 T64; Offset64 off; float r2f;
+    int *idx_out; float *d2_out; double *partials; unsigned long long *cand_count; int bpp; const Pt64 *src64;
+    const Pt64 *sorted64; const Pt64 *nrm64; FoldArgs fold; Pt64 *wst_io; int warm; Xform64 Tprev; PersistArgs pa;
+};
+
+// a (member of a) kernel argument read through the laundered kernarg pointer, word by word
+template <class T>
+__device__ __forceinline__ T ld_karg(const T __attribute__((address_space(4))) *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "words");
+    constexpr int N = (int)(sizeof(T) / 4);
+    union U { T v; unsigned w[N]; __device__ U() {} } u;
+    typedef const unsigned __attribute__((address_space(4))) *WordPtr;
+    const WordPtr pw = (WordPtr)p;
+#pragma unroll
+    for (int k = 0; k < N; k++) u.w[k] = pw[k];
+    return u.v;
+}
+
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn_coop_kernel_persist(const CoopPersistParams P)
+{
+    // The transforms of the pass that is due and of the one before it live in LDS (32-bit halves of the 2 x 12
+    // doubles, two slots used alternately) and become scalars at the top of every pass.
+    __shared__ unsigned s_tw[2][24];
+    __shared__ unsigned s_cmdw;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned long long c = (unsigned long long)__double_as_longlong(P.T64.m[k]);
+            const unsigned long long q = (unsigned long long)__double_as_longlong(P.Tprev.m[k]);
+            s_tw[0][2 * k] = (unsigned)c; s_tw[0][2 * k + 1] = (unsigned)(c >> 32);
+            s_tw[1][2 * k] = (unsigned)q; s_tw[1][2 * k + 1] = (unsigned)(q >> 32);
+        }
+    }
+    __syncthreads();
+    typedef const CoopPersistParams __attribute__((address_space(4))) *KernargPtr;
+    for (int pass = 1;; pass++) {
+        KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));                         // (nothing read through it is loop-invariant to the compiler)
+        // (member by member: scalar loads straight into registers; the fold's ipc fields stay zero: no exchange)
+#define VISMA_KARG(F_) ld_karg(&kp->F_)
+        const int cur = (pass - 1) & 1;
+        Xform64 Tc, Tp;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur][2 * k]);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur][2 * k + 1]);
+            Tc.m[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+            const unsigned plo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur ^ 1][2 * k]);
+            const unsigned phi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur ^ 1][2 * k + 1]);
+            Tp.m[k] = __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+        }
+        // (after the first pass: the state the pass before left is there, and so is its transform)
+        int w = VISMA_KARG(warm);
+        if (pass > 1) { w |= 1; if (!(w & 8)) w |= 4; }
+        FoldArgs f{};
+        f.tickets = VISMA_KARG(fold.tickets); f.partials2 = VISMA_KARG(fold.partials2);
+        f.ticket_stride = VISMA_KARG(fold.ticket_stride); f.stats_out = VISMA_KARG(fold.stats_out);
+        f.stats_stride = VISMA_KARG(fold.stats_stride); f.host_out = VISMA_KARG(fold.host_out);
+        f.seq = VISMA_KARG(fold.seq) + (unsigned long long)(pass - 1);
+        const bool published = coop_body<PLANE, true, kBlock, true>(
+            VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
+            VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
+            nullptr, 1, VISMA_KARG(src64), VISMA_KARG(sorted64), VISMA_KARG(nrm64), f, nullptr, VISMA_KARG(wst_io), w, Tp);
+        const PersistArgs pa = VISMA_KARG(pa);
+#undef VISMA_KARG
+        if (pass >= pa.max_passes) break;
+        const int tidx = thread_number<true>();
+        if (tidx < 64) {
+            const bool poller = __builtin_amdgcn_readfirstlane((int)published) != 0;     // (the same on every lane: scalar)
+            const unsigned long long cw = persist_wait(pa, pa.tag0 + (unsigned)(pass - 1), poller, pass, tidx);
+            // the new transform takes the slot of the one before the pass that just ran
+            if (tidx < 24) s_tw[cur ^ 1][tidx] = (unsigned)cw;
+            if (tidx == kPersistWords - 1) s_cmdw = (unsigned)cw;
+        }
+        __syncthreads();
+        const unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cmdw);
+        if (cmd != kPersistGo) break;
+    }
 }
 #undef VISMA_COOP_PARAMS
 #undef VISMA_COOP_ARGS
@@ -860,9 +992,25 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
                           const FoldArgs &fold, double *d64_out, Pt64 *wst_io, int warm, hipStream_t stream,
-                          const Xform64 *Tprev)
+                          const Xform64 *Tprev, const PersistArgs *persist)
 {
     if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
+    if (persist) {
+        // one registration, one query per lane, the fold and its publication inside the launch, everybody resident
+        if (descs || nprob != 1 || !one || st || !fold.tickets || !fold.host_out || fold.ipc_n > 1 || d64_out ||
+            persist->max_passes < 1 || !persist->host_cmd || !persist->relay || !persist->host_flag ||
+            total_blocks > coop_persist_capacity(point_to_plane))
+            return hipErrorInvalidValue;
+        CoopPersistParams P{};
+        P.ns = ns; P.s12f = s12; P.start = start; P.g = g; P.nrm = nrm; P.T64 = T64; P.off = off; P.r2f = r2f;
+        P.idx_out = idx_out; P.d2_out = d2_out; P.partials = partials; P.cand_count = cand_count; P.bpp = bpp;
+        P.src64 = src64; P.sorted64 = sorted64; P.nrm64 = nrm64; P.fold = fold; P.wst_io = wst_io;
+        if (Tprev) { P.Tprev = *Tprev; warm |= 4; } else warm &= ~4;
+        P.warm = warm; P.pa = *persist;
+        if (point_to_plane) hipLaunchKernelGGL(nn_coop_kernel_persist<true>, dim3(total_blocks), dim3(kBlock), 0, stream, P);
+        else hipLaunchKernelGGL(nn_coop_kernel_persist<false>, dim3(total_blocks), dim3(kBlock), 0, stream, P);
+        return hipGetLastError();
+    }
     // batches (problems with their own clouds) and sweeps over shared clouds: round 3's wave-synchronous kernel
     // (grid_wave.hip says why); VISMA_ICP_COOP_KERNEL=cert / wave forces one of the two (A/B timing)
     static const int forced = [] {
@@ -883,5 +1031,26 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
     return hipGetLastError();
 }
 #undef VISMA_COOP_LAUNCH
+
+int coop_persist_capacity(int point_to_plane)
+{
+    // (per device: contexts of one process may sit on different GPUs or partitions)
+    static int cap[2][64];
+    static bool known[2][64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    const int p = point_to_plane ? 1 : 0;
+    if (!known[p][dev]) {
+        int per_cu = 0, cus = 0;
+        hipError_t e = point_to_plane
+                           ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nn_coop_kernel_persist<true>, kBlock, 0)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nn_coop_kernel_persist<false>, kBlock, 0);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; cus = 0; }
+        cap[p][dev] = per_cu * cus;
+        known[p][dev] = true;
+    }
+    return cap[p][dev];
+}
 
 }  // namespace visma

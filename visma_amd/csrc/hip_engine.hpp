@@ -36,8 +36,11 @@ public:
         free_dev(bt_nrm_); free_dev(bt_nrm64_); free_dev(bt_raw_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
+        if (sess_live_) (void)end_session();
         if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
+        if (h_cmd_) (void)hipHostFree(h_cmd_);
+        free_dev(d_relay_);
         pool_trim(0);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -231,6 +234,19 @@ public:
     int reduce(const Mat4 &Tc, bool plane, const double offset[3], double *stats) override;
 
     int get_correspondences(int32_t *idx, float *d2) override;
+
+    // ---- the persistent launch of a host loop (kernels.h: PersistArgs; grid_coop.hip: nn_coop_kernel_persist)
+    void loop_begin(int max_passes) override
+    {
+        loop_scope_ = true;
+        loop_budget_ = max_passes;
+    }
+    int loop_end() override
+    {
+        loop_scope_ = false;
+        loop_budget_ = 0;
+        return sess_live_ ? end_session() : VISMA_ICP_OK;
+    }
 
     bool supports_device_loop() const override { return true; }
 
@@ -581,6 +597,36 @@ private:
     int make_fold(int bpp, int nprob, double *stats_out, long long stats_stride, double *host_out,
                   unsigned long long seq, FoldArgs *out);
     int ensure_f64_views();
+
+    // ---- persistent sessions: ONE launch of the certificate kernel runs the remaining passes of the host loop that
+    // announced itself (loop_begin): reduce() starts it, later reduce() calls only post the next transform to the
+    // command block in mapped host memory and wait for the statistics as always; loop_end() / anything that does not
+    // fit (another radius, plane, frame) posts STOP and waits for the launch to end.  The launch gives up by itself
+    // when no command arrives in time (the host then finds the stream idle and goes on with ordinary launches).
+    int persist_enabled_ = 1;        // VISMA_ICP_PERSIST=0: one launch per pass
+    double persist_timeout_ms_ = 200.0;   // VISMA_ICP_PERSIST_TIMEOUT_MS: the poller's patience
+    bool loop_scope_ = false;
+    int loop_budget_ = 0;            // passes the announced loop may still run
+    bool sess_live_ = false;         // a persistent launch is in flight
+    int sess_pass_ = 0, sess_max_ = 0;
+    unsigned sess_tag0_ = 0, cmd_tag_ = 0;
+    unsigned long long sess_seq0_ = 0;
+    bool sess_plane_ = false, sess_prof_ = false;
+    double sess_off_[3] = {0, 0, 0};
+    float sess_r2f_ = 0.f;
+    int sess_dev_slot_ = -1;         // this session holds the device's one persistent slot
+    int sess_e0_ = -1;               // its event pair (profiling)
+    std::vector<std::pair<int, int>> sess_pending_;   // (event pair, passes run) of finished sessions
+    unsigned long long *h_cmd_ = nullptr, *h_cmd_dev_ = nullptr;   // kPersistWords command words; word 32: the kernel's flag
+    void *d_relay_ = nullptr;
+    int persist_sessions_ = 0, persist_aborts_ = 0;
+    bool persist_possible(int lanes, int nblocks, bool fused, bool plane) const;
+    int start_session(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, int nblocks, bool prof);
+    void post_command(const Xform64 &T64, unsigned cmd);
+    int end_session();
+    void finish_session();
+    int launch_grid_pass(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, bool prof,
+                         const PersistArgs *persist, int *nblocks_out, bool *ipc_done);
 };
 
 }  // namespace drv

@@ -51,6 +51,13 @@ int HipEngine::init()
                           hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h_stats_, 0, sizeof(double) * 2 * kNStats);
     HIP_TRY(hipHostGetDevicePointer((void **)&h_stats_dev_, h_stats_, 0));
+    if (const char *e = std::getenv("VISMA_ICP_PERSIST")) persist_enabled_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMEOUT_MS")) { const double v = std::atof(e); if (v >= 1.0 && v <= 5000.0) persist_timeout_ms_ = v; }
+    HIP_TRY(hipHostMalloc((void **)&h_cmd_, sizeof(unsigned long long) * 64, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(h_cmd_, 0, sizeof(unsigned long long) * 64);
+    HIP_TRY(hipHostGetDevicePointer((void **)&h_cmd_dev_, h_cmd_, 0));
+    HIP_TRY(hipMalloc(&d_relay_, sizeof(unsigned long long) * 64));
+    HIP_TRY(hipMemset(d_relay_, 0, sizeof(unsigned long long) * 64));
     inited_ = true;
     return VISMA_ICP_OK;
 }
@@ -591,6 +598,17 @@ int HipEngine::collect_timing()
         else { timing_.aux_ms += ms; timing_.aux_launches++; }
     }
     pending_.clear();
+    // persistent launches: the whole launch is timed (waits for the host included), its passes counted
+    for (const auto &p : sess_pending_) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ev_[p.first], ev_[p.first + 1]));
+        timing_.nn_ms += ms;
+        timing_.nn_launches += p.second;
+        timing_.persist_ms += ms;
+        timing_.persist_launches += 1.0;
+        timing_.persist_passes += (double)p.second;
+    }
+    sess_pending_.clear();
     ev_used_ = 0;
     return VISMA_ICP_OK;
 }

@@ -8,6 +8,11 @@ int HipEngine::nn_pass(const Mat4 &Tc, double max_dist)
 {
     HIP_TRY(hipSetDevice(device_));
     if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+    if (sess_live_ && (float)(max_dist * max_dist) != sess_r2f_) {
+        // (another radius: the grid may be rebuilt below -- not behind a launch that waits for this thread)
+        int rc = end_session();
+        if (rc) return rc;
+    }
     const int64_t ns_min_pad = ((ns_ + kBlock - 1) / kBlock) * kBlock;
     for (int i = 0; i < 12; i++) { T32_.m[i] = (float)Tc.m[i]; T64_last_.m[i] = Tc.m[i]; }
     r2f_ = (float)(max_dist * max_dist);
@@ -66,6 +71,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     const unsigned long long seq = ++pub_seq_;
     const bool ipc = ipc_n_ > 1;
     bool ipc_done = false;                           // the exchange ran inside the search launch
+    bool in_session = false;                         // this pass runs inside a persistent launch (see hip_engine.hpp)
     double *pub = (comm_ || ipc) ? nullptr : h_stats_dev_;
 #ifdef VISMA_WITH_TILE
     if (use_tile()) {
@@ -97,36 +103,48 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
 #endif
     if (use_grid_) {
         int nblocks = 1;
-        // the fold of the partial rows runs inside the search launch (no second kernel)
         const bool fused = fused_fold_ && !tshard_;
         const int lanes = pass_lanes();
-        FoldArgs fa{};
-        if (fused) {
-            // (peer-to-peer mailboxes: the folding workgroup exchanges with the peers and publishes itself)
-            int rc = make_fold(grid_launch_blocks(ns_, lanes, grid_blocks()), 1, (double *)d_stats_, 0,
-                               ipc ? h_stats_dev_ : pub, seq, &fa);
-            if (rc) return rc;
-            if (ipc) { add_ipc(&fa); ipc_done = true; }
+        if (sess_live_) {
+            // the persistent launch is waiting for exactly this: the next transform
+            const double *o = offset;
+            const bool same = plane == sess_plane_ && r2f_ == sess_r2f_ && o[0] == sess_off_[0] && o[1] == sess_off_[1] &&
+                              o[2] == sess_off_[2] && sess_pass_ < sess_max_ && seq == sess_seq0_ + (unsigned long long)sess_pass_ &&
+                              lanes == kCoopLanes;
+            if (same) {
+                post_command(T64, kPersistGo);
+                sess_pass_++;
+                in_session = true;
+                last_kernel_ = 2;
+                note_state_pass(T64);
+            } else {
+                int rc = end_session();
+                if (rc) return rc;
+            }
         }
-        if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-        HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
-                                      (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
-                                      T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
-                                      (float *)d_d2_, (double *)d_partials_, grid_blocks(),
-                                      &nblocks, lanes,
-                                      prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
-                                      1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                      exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1, cert_prev()));
-        last_kernel_ = pass_kernel(lanes);
-        pos_fresh_ = d_pos_ != nullptr;
-        note_state_pass(T64);
-        if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
-        if (!tshard_ && !fused) {
-            if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-            HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
-                                    (double *)d_stats_, stream_, pub, seq));
-            if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+        if (!in_session) {
+            const int nb = grid_launch_blocks(ns_, lanes, grid_blocks());
+            PersistArgs pa{};
+            const PersistArgs *pp = nullptr;
+            if (loop_scope_ && loop_budget_ >= 2 && persist_possible(lanes, nb, fused, plane)) {
+                int rc = start_session(T64, plane, offset, seq, nb, profiling_ > 0);
+                if (rc == VISMA_ICP_OK && sess_live_) {
+                    pa.host_cmd = h_cmd_dev_;
+                    pa.relay = (unsigned long long *)d_relay_;
+                    pa.host_flag = reinterpret_cast<unsigned *>(h_cmd_dev_ + 32);
+                    pa.max_passes = sess_max_;
+                    pa.tag0 = sess_tag0_;
+                    pa.poll_ticks = (long long)(persist_timeout_ms_ * 1e5);     // (100 MHz)
+                    pa.wait_ticks = 2 * pa.poll_ticks;
+                    pp = &pa;
+                }
+            }
+            int rc = launch_grid_pass(T64, plane, offset, seq, pp ? sess_prof_ : prof, pp, &nblocks, &ipc_done);
+            if (rc) { if (pp) finish_session(); return rc; }
+            if (pp) { sess_pass_ = 1; in_session = true; }
         }
+        if (loop_budget_ > 0) loop_budget_--;
+        (void)nblocks;
         grid_pending_ = false;
     } else {
         if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
@@ -170,13 +188,39 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         return true;
     };
     bool seen = false;
-    for (long long spin = 0; spin < 400000000ll; ++spin) {
-        if (all_tagged()) { seen = true; break; }
-        if ((spin & 0xFFFFF) == 0xFFFFF && hipStreamQuery(stream_) != hipErrorNotReady) {
-            seen = all_tagged();
-            break;
+    auto wait_published = [&]() {
+        for (long long spin = 0; spin < 400000000ll; ++spin) {
+            if (all_tagged()) return true;
+            // (in a session the launch ends by itself when its patience runs out: look more often)
+            if ((spin & (in_session ? 0xFFFFll : 0xFFFFFll)) == (in_session ? 0xFFFFll : 0xFFFFFll) &&
+                hipStreamQuery(stream_) != hipErrorNotReady)
+                return all_tagged();
+        }
+        return false;
+    };
+    seen = wait_published();
+    if (!seen && in_session) {
+        // The persistent launch ended without running this pass: it waited for the command longer than its patience
+        // (a stopped or descheduled host thread; workgroups that were not all resident after all).  Nothing of the
+        // pass has happened -- the state in memory is what the last completed pass left -- so it runs as an
+        // ordinary launch, and so do the passes after it.
+        HIP_TRY(hipStreamSynchronize(stream_));
+        seen = all_tagged();
+        if (!seen) {
+            persist_aborts_++;
+            if (std::getenv("VISMA_ICP_PERSIST_TRACE"))
+                std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
+                             reinterpret_cast<volatile unsigned *>(h_cmd_ + 32)[0], cmd_tag_, sess_tag0_);
+            finish_session();
+            persist_enabled_ = 0;
+            in_session = false;
+            int nblocks = 1;
+            int rc = launch_grid_pass(T64, plane, offset, seq, false, nullptr, &nblocks, &ipc_done);
+            if (rc) return rc;
+            seen = wait_published();
         }
     }
+    if (in_session && seen && sess_live_ && sess_pass_ >= sess_max_) finish_session();   // (its last pass: the launch ends by itself)
     if (!seen) {
         HIP_TRY(hipStreamSynchronize(stream_));   // surfaces a kernel fault, if any
         if (!all_tagged()) {
@@ -192,7 +236,141 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         const unsigned long long v = g[2 * i];
         std::memcpy(&stats[i], &v, sizeof(double));
     }
-    return maybe_collect_timing();
+    return sess_live_ ? VISMA_ICP_OK : maybe_collect_timing();   // (no stream synchronisation while a session waits for the host)
+}
+
+// One search launch over the resident clouds (lane-serial, certificate, or -- persist != NULL -- the persistent form
+// of the certificate kernel), with the fold inside the launch where that applies.
+int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, bool prof,
+                                const PersistArgs *persist, int *nblocks_out, bool *ipc_done)
+{
+    const bool ipc = ipc_n_ > 1;
+    double *pub = (comm_ || ipc) ? nullptr : h_stats_dev_;
+    // the fold of the partial rows runs inside the search launch (no second kernel)
+    const bool fused = fused_fold_ && !tshard_;
+    const int lanes = pass_lanes();
+    int nblocks = 1, e0 = -1;
+    FoldArgs fa{};
+    if (fused) {
+        // (peer-to-peer mailboxes: the folding workgroup exchanges with the peers and publishes itself)
+        int rc = make_fold(grid_launch_blocks(ns_, lanes, grid_blocks()), 1, (double *)d_stats_, 0,
+                           ipc ? h_stats_dev_ : pub, seq, &fa);
+        if (rc) return rc;
+        if (ipc) { add_ipc(&fa); *ipc_done = true; }
+    }
+    if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+    HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
+                                  (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
+                                  T32_, T64, offset, r2f_, plane ? 1 : 0, (int32_t *)d_idx_,
+                                  (float *)d_d2_, (double *)d_partials_, grid_blocks(),
+                                  &nblocks, lanes,
+                                  prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
+                                  1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
+                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1, cert_prev(), persist));
+    last_kernel_ = pass_kernel(lanes);
+    pos_fresh_ = d_pos_ != nullptr;
+    note_state_pass(T64);
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_));
+        if (persist) sess_e0_ = e0;                          // (accounted when the session ends: its passes are known then)
+        else pending_.push_back({e0, 0});
+    }
+    if (!tshard_ && !fused) {
+        if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+        HIP_TRY(launch_finalize((const double *)d_partials_, nblocks, plane ? 1 : 0,
+                                (double *)d_stats_, stream_, pub, seq));
+        if (prof) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
+    }
+    *nblocks_out = nblocks;
+    return VISMA_ICP_OK;
+}
+
+// ---- persistent sessions -----------------------------------------------------------------------------------------
+namespace {
+std::atomic<int> g_persist_slot[64];   // one persistent launch per device and process at a time: two of them would
+                                       // each hold a part of the compute units and wait for the rest
+}
+
+bool HipEngine::persist_possible(int lanes, int nblocks, bool fused, bool plane) const
+{
+    static const bool trace = std::getenv("VISMA_ICP_PERSIST_TRACE") != nullptr;
+    auto no = [&](const char *why) {
+        if (trace) std::fprintf(stderr, "[visma_icp] no persistent launch: %s\n", why);
+        return false;
+    };
+    if (!persist_enabled_) return no("switched off");
+    if (!fused || tshard_ || comm_ || ipc_n_ > 1 || minreduce_) return no("sharded ranks / fold in a second launch");
+    if (lanes != kCoopLanes || !coop_ok() || !pos_fresh_) return no("not a pass of the certificate kernel");
+    if (grid_lanes_ > 0 && grid_lanes_ != kCoopLanes) return no("lanes forced");
+    if (std::getenv("VISMA_ICP_COOP_KERNEL")) return no("kernel forced");       // (A/B runs of the two one-pass kernels)
+    // one query per lane, every workgroup resident at once
+    if ((int64_t)nblocks * kBlock < ns_) return no("several queries per lane");
+    const int cap = coop_persist_capacity(plane ? 1 : 0);
+    if (trace) std::fprintf(stderr, "[visma_icp] persistent launch: %d workgroups, device holds %d\n", nblocks, cap);
+    return nblocks <= cap;
+}
+
+int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3], unsigned long long seq, int, bool prof)
+{
+    if (device_ < 0 || device_ >= 64) return VISMA_ICP_OK;
+    int expect = 0;
+    if (!g_persist_slot[device_].compare_exchange_strong(expect, 1)) return VISMA_ICP_OK;   // somebody else's turn: ordinary launches
+    sess_dev_slot_ = device_;
+    sess_live_ = true;
+    sess_pass_ = 0;
+    sess_max_ = std::min(loop_budget_, 1 << 20);
+    sess_tag0_ = cmd_tag_ + 1u;
+    if (sess_tag0_ == 0u || sess_tag0_ + (unsigned)sess_max_ < sess_tag0_) { cmd_tag_ = 0u; sess_tag0_ = 1u; }   // (tags never 0, never wrap inside a session)
+    cmd_tag_ = sess_tag0_ - 1u;
+    sess_seq0_ = seq;
+    sess_plane_ = plane;
+    sess_prof_ = prof;
+    sess_r2f_ = r2f_;
+    for (int a = 0; a < 3; a++) sess_off_[a] = offset[a];
+    sess_e0_ = -1;
+    reinterpret_cast<volatile unsigned *>(h_cmd_ + 32)[0] = 0u;
+    persist_sessions_++;
+    return VISMA_ICP_OK;
+}
+
+// the next command, word by word: every word carries the tag, so the device accepts the block when all words show it
+void HipEngine::post_command(const Xform64 &T64, unsigned cmd)
+{
+    const unsigned tag = ++cmd_tag_;
+    volatile unsigned long long *c = h_cmd_;
+    const unsigned long long t = (unsigned long long)tag << 32;
+    for (int k = 0; k < 12; k++) {
+        unsigned long long b;
+        std::memcpy(&b, &T64.m[k], sizeof(b));
+        c[2 * k] = (b & 0xFFFFFFFFull) | t;
+        c[2 * k + 1] = (b >> 32) | t;
+    }
+    c[kPersistWords - 1] = (unsigned long long)cmd | t;
+    std::atomic_thread_fence(std::memory_order_release);
+}
+
+void HipEngine::finish_session()
+{
+    if (!sess_live_) return;
+    sess_live_ = false;
+    if (sess_e0_ >= 0) sess_pending_.push_back({sess_e0_, std::max(sess_pass_, 1)});
+    sess_e0_ = -1;
+    if (sess_dev_slot_ >= 0) g_persist_slot[sess_dev_slot_].store(0);
+    sess_dev_slot_ = -1;
+}
+
+// STOP to a launch that still waits for a command (one that has run its last pass ends by itself), then its end
+int HipEngine::end_session()
+{
+    if (!sess_live_) return VISMA_ICP_OK;
+    if (sess_pass_ >= 1 && sess_pass_ < sess_max_) {
+        Xform64 none{};
+        post_command(none, kPersistStop);
+    }
+    hipError_t e = hipStreamSynchronize(stream_);
+    finish_session();
+    if (e != hipSuccess) { err_ = std::string("persistent launch: ") + hipGetErrorString(e); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
+    return VISMA_ICP_OK;
 }
 
 int HipEngine::get_correspondences(int32_t *idx, float *d2)

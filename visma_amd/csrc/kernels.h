@@ -69,6 +69,25 @@ struct FoldArgs {
     long long ipc_spins;
 };
 
+// The PERSISTENT form of the certificate kernel (grid_coop.hip, round 4b): ONE launch runs up to max_passes ICP
+// passes of one registration.  After a pass the workgroup that finished the fold (and published the statistics to
+// the host) polls a command block in mapped host memory for the next transform, re-publishes it in device memory
+// (relay) for the other workgroups, and everybody runs the next pass -- no relaunch, no dispatch ramp, source and
+// state re-read from a warm L2.  Command block / relay: kPersistWords 8-byte words {low or high half of a double |
+// tag << 32}, each word validating itself (no fence anywhere): words 0..23 = the 3 x 4 transform, word 24 = command.
+// Every wait is bounded by the 100 MHz wall clock: a launch whose host went away ends by itself.
+constexpr int kPersistWords = 25;
+constexpr unsigned kPersistGo = 1u, kPersistStop = 2u, kPersistAbort = 3u;
+struct PersistArgs {
+    const unsigned long long *host_cmd;   // mapped, coherent host memory (device pointer), kPersistWords words
+    unsigned long long *relay;            // device memory, kPersistWords words
+    unsigned *host_flag;                  // mapped host memory: set to the pass count reached when a wait ran out
+    int max_passes;                       // passes this launch may run (>= 1); the first needs no command
+    unsigned tag0;                        // the command for pass p (1-based after the first) carries tag0 + p - 1
+    long long poll_ticks;                 // budget of the poller's wait, in wall_clock64 ticks (100 MHz)
+    long long wait_ticks;                 // ... of everybody else's (longer: the poller gives up first and says so)
+};
+
 struct NNLaunch {
     int src_tiles;
     int tgt_splits;
@@ -307,7 +326,10 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  const Pt64 *src64 = nullptr, const Pt64 *sorted64 = nullptr,
                                  double r2d = 0.0, const Pt64 *nrm64 = nullptr, int exact = 0,
                                  const FoldArgs *fold = nullptr, double *d64_out = nullptr,
-                                 Pt64 *wst_io = nullptr, int warm = 0, const Xform64 *Tprev = nullptr);
+                                 Pt64 *wst_io = nullptr, int warm = 0, const Xform64 *Tprev = nullptr,
+                                 const PersistArgs *persist = nullptr);
+// persist: run the launch as the persistent certificate kernel (one problem, one query per lane, fused fold with
+// host publication; hipErrorInvalidValue where that does not apply -- ask coop_persist_capacity first).
 // wst_io (one Pt64 per query, laid out like idx_out): the exact searches leave their winners there (f64 point,
 // original index | LB << 32 -- see grid_coop.hip; NaN coordinates = none, all bits set = nothing known); the
 // warm-started search (kCoopLanes) reads them when `warm & 1`, and with Tprev (the transform of the pass that left
@@ -329,7 +351,9 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
                           const FoldArgs &fold, double *d64_out, Pt64 *wst_io, int warm, hipStream_t stream,
-                          const Xform64 *Tprev = nullptr);
+                          const Xform64 *Tprev = nullptr, const PersistArgs *persist = nullptr);
+// workgroups of the persistent kernel the current device holds at once (0: none -- do not launch it)
+int coop_persist_capacity(int point_to_plane);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
 // offsets / grid / workgroup range; total_blocks = sum of descs[].nblocks.
 hipError_t launch_nn_grid_reduce_batch(const float4 *src, const float4 *sorted, const unsigned *start,
