@@ -449,15 +449,41 @@ def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=
     return T, last, elapsed, tm, setup
 
 
+def persistent_launches(roofline, tm):
+    """Persistent launches (round 4b: ONE launch of the certificate kernel runs the passes of a host loop, the next
+    transform handed over through mapped host memory): the timing counters hold whole launches -- the waits for the host
+    included -- and count their passes.  `achieved` = bytes per launch / launch duration is the same ratio either way;
+    the object says per LAUNCH what rocprofv3 sees (one long dispatch) and per PASS what an iteration costs."""
+    pl, pp = tm.get("persist_launches", 0.0), tm.get("persist_passes", 0.0)
+    if pl <= 0 or pp <= 0:
+        return roofline
+    per_pass_ms = roofline["avg_launch_ms"]
+    k = pp / pl
+    roofline["launch"] = {"persistent": True, "launches_timed": pl, "passes_timed": pp, "passes_per_launch": k,
+                          "avg_launch_ms": tm["persist_ms"] / pl, "ms_per_pass": tm["persist_ms"] / pp,
+                          "one_pass_launches_in_the_same_counters": tm["nn_launches"] - pp,
+                          "note": "the kernel-trace name is nn_coop_kernel_persist; a launch lasts as long as its loop: "
+                                  "its waits for the host's next transform (statistics out, solve, command back over "
+                                  "PCIe) are inside"}
+    if tm["nn_launches"] == pp:
+        roofline["avg_launch_ms"] = tm["persist_ms"] / pl
+        for key in ("alg_bytes_per_launch", "examined_bytes_per_launch"):
+            roofline[key.replace("_per_launch", "_per_pass")] = roofline[key]
+            roofline[key] = roofline[key] * k
+        roofline["ms_per_pass"] = per_pass_ms
+    return roofline
+
+
 def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None):
     """roofline object of the search kernel the context's last passes ran, from its event / candidate counters"""
     nl = max(tm["nn_launches"], 1)
     kind = ctx.search_kernel_used()
     key = {"warm": "grid_warm", "serial": "grid"}.get(kind, "grid")
-    return grid_roofline(ns_local, nt_local, tm["nn_ms"] / nl, tm["grid_candidates"] / nl,
-                         tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
-                         ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial",
-                         tm["grid_certified"] / nl)
+    r = grid_roofline(ns_local, nt_local, tm["nn_ms"] / nl, tm["grid_candidates"] / nl,
+                      tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
+                      ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial",
+                      tm["grid_certified"] / nl)
+    return persistent_launches(r, tm)
 
 
 def c4_variant(R, device, src, tgt, radius, T_gt, steps, what):
@@ -690,10 +716,11 @@ def run_c4(R, args):
                                      load_traffic("grid_warm" if kernel_kind == "warm" else "grid", ns_local, nt_local),
                                      exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial",
                                      tm["grid_certified"] / nl)
+            roofline = persistent_launches(roofline, tm)
         else:
             roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
-        roofline["launches_timed"] = tm["nn_launches"]
-        roofline["timed_every_nth_pass"] = prof_every
+        roofline["launches_timed"] = tm["nn_launches"] if "launch" not in roofline else roofline["launch"]["launches_timed"]
+        roofline["timed_every_nth_pass"] = prof_every if "launch" not in roofline else 1
         roofline["separate_fold_launch_avg_ms"] = tm["reduce_ms"] / max(tm["reduce_launches"], 1)
         par = ("source-sharded x%d, 1 all-reduce(38 f64)/iter via %s" % (R.world, comm_kind)
                if args.shard == "source" else

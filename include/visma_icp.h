@@ -113,6 +113,7 @@ typedef struct {
     double persist_launches;
     double persist_passes;
     double persist_ms;               /* their share of nn_ms */
+    double persist_aborts;           /* persistent launches that ended by themselves (no command in time); counted always */
 } visma_icp_timing;
 
 /* ---- lifetime ---------------------------------------------------------- */

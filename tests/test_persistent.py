@@ -1,0 +1,170 @@
+"""The PERSISTENT launch of a host loop (visma_amd/csrc/grid_coop.hip: nn_coop_kernel_persist): one
+launch of the certificate kernel runs the remaining passes of visma_icp_run / visma_icp_iterate, the next transform
+handed over through a command block in mapped host memory.  It must never change a result -- transformation,
+correspondences, distances, iteration counts BIT for bit against one launch per pass --, it must really run (or the
+test would pass on a library that never starts one), it must end when the loop stops early, start again for the next
+loop, refuse what it cannot do (several queries per lane), and when its host does not come back in time it must end by
+itself and the registration must carry on with ordinary launches to the same result."""
+import numpy as np
+import pytest
+
+from visma_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def pair_of_contexts(src, tgt, normals=False):
+    per_pass, persist = _lib.Context(0), _lib.Context(0)
+    per_pass.set_persistent(False)
+    persist.set_persistent(True)
+    nrm = persist.estimate_normals(tgt, knn=12) if normals else None
+    for c in (per_pass, persist):
+        c.set_nn_mode(_lib.NN_GRID)
+        c.set_clouds_f64(src, tgt)
+        if normals:
+            c.set_target_normals_f64(nrm)
+    return per_pass, persist
+
+
+def same_result(a, b):
+    assert np.array_equal(a.transformation_, b.transformation_)
+    assert a.num_correspondences == b.num_correspondences and a.iterations == b.iterations
+    assert a.fitness_ == b.fitness_ and a.inlier_rmse_ == b.inlier_rmse_
+
+
+CASES = [
+    # name, ns, nt, fraction of the source without a partner, persistent launches expected
+    ("5k-20k", 5000, 20000, 0.0, True),
+    ("partial overlap", 30000, 120000, 0.5, True),
+    ("all outside", 4000, 20000, 1.0, True),
+    ("64k-1M", 65536, 1048576, 0.3, True),
+    ("262144-1M: every compute unit", 262144, 1048576, 0.1, True),
+    ("several queries per lane", 600000, 1000000, 0.1, False),
+]
+
+
+@pytest.mark.parametrize("name,ns,nt,out_frac,expect", CASES, ids=[c[0] for c in CASES])
+def test_persistent_loop_equals_one_launch_per_pass_bit_for_bit(name, ns, nt, out_frac, expect):
+    rng = np.random.default_rng(ns + 3 * nt)
+    src, tgt, T_gt, r = synth.make_pair(ns, nt, seed_t=ns + 5, seed_s=nt + 7, motion="radius")
+    if out_frac > 0:
+        k = int(ns * out_frac)
+        sel = rng.permutation(ns)[:k]
+        src = src.copy()
+        src[sel[: k // 2]] += np.array([5.0, 0.0, 0.0])
+        src[sel[k // 2:]] += rng.standard_normal((k - k // 2, 3)) * 3.0 * r
+    a, b = pair_of_contexts(src, tgt)
+    b.set_profiling(1)
+    b.get_timing(reset=True)
+    # fixed iterations: 13 from the identity, then three blocks that carry on (each block: one persistent launch)
+    Ta, Tb = np.eye(4), np.eye(4)
+    for steps in (13, 5, 2, 9):
+        Ta, ra = a.iterate(Ta, r, steps)
+        Tb, rb = b.iterate(Tb, r, steps)
+        assert np.array_equal(Ta, Tb), (name, steps)
+        same_result(ra, rb)
+        for x, y in zip(a.get_correspondences(), b.get_correspondences()):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), (name, steps)
+    tm = b.get_timing(reset=True)
+    if expect:
+        # 13 steps: the first is the cold pass, 12 in ONE launch; the other blocks: one launch each
+        assert tm["persist_launches"] == 4 and tm["persist_passes"] == 12 + 5 + 2 + 9, tm
+        assert tm["persist_aborts"] == 0
+    else:
+        assert tm["persist_launches"] == 0 and tm["nn_launches"] == 29, tm
+    # whole registrations with the stop test on the host: the loop ends before its budget (STOP to the launch), the next
+    # registration starts its own; a radius change in between
+    for radius, tol in ((r, 1e-6), (1.7 * r, 1e-6), (r, 1e-3), (r, 0.0)):
+        for c in (a, b):
+            c.forget_winners()
+        same_result(a.run(None, radius, 40, tol, tol), b.run(None, radius, 40, tol, tol))
+        assert np.array_equal(a.correspondence_index(), b.correspondence_index())
+    tm = b.get_timing(reset=True)
+    assert (tm["persist_launches"] == 4) == expect and tm["persist_aborts"] == 0, tm
+    # the per-pass API between loops is untouched by all this
+    for c in (a, b):
+        c.nn_pass(T_gt, r)
+    assert np.array_equal(a.reduce().view(np.uint64), b.reduce().view(np.uint64))
+    a.close()
+    b.close()
+
+
+def test_persistent_point_to_plane_and_gauss_newton(lib):
+    src, tgt, T_gt, r = synth.make_pair(20000, 90000, seed_t=28, seed_s=29, motion="radius")
+    src = src.copy()
+    src[::4] += np.array([0.0, 3.0, 0.0])
+    a, b = pair_of_contexts(src, tgt, normals=True)
+    b.set_profiling(1)
+    b.get_timing(reset=True)
+    same_result(a.run_point_to_plane(None, r, 30, 1e-9, 1e-9), b.run_point_to_plane(None, r, 30, 1e-9, 1e-9))
+    for solver in (lib.SOLVER_KABSCH, lib.SOLVER_GN_EULER, lib.SOLVER_GN_EXPMAP):
+        for c in (a, b):
+            c.forget_winners()
+        same_result(a.run(None, r, 25, 1e-9, 1e-9, solver), b.run(None, r, 25, 1e-9, 1e-9, solver))
+    tm = b.get_timing(reset=True)
+    assert tm["persist_launches"] == 4 and tm["persist_aborts"] == 0, tm
+    a.close()
+    b.close()
+
+
+def test_a_launch_whose_host_stalls_ends_by_itself_and_the_loop_carries_on():
+    src, tgt, T_gt, r = synth.make_pair(40000, 200000, seed_t=38, seed_s=39, motion="radius")
+    a, b = pair_of_contexts(src, tgt)
+    b.set_persistent(True, timeout_ms=5.0)
+    b.get_timing(reset=True)
+    ra = a.run(None, r, 30, 0.0, 0.0)
+    b.test_stall_command(7, 60.0)                  # the 7th command comes 60 ms late: the launch waits 5 and leaves
+    rb = b.run(None, r, 30, 0.0, 0.0)
+    same_result(ra, rb)
+    assert np.array_equal(a.correspondence_index(), b.correspondence_index())
+    tm = b.get_timing(reset=True)
+    assert tm["persist_aborts"] == 1, tm
+    # persistent launches are off on this context from then on (until asked for again) ...
+    b.set_profiling(1)
+    for c in (a, b):
+        c.forget_winners()                         # (both start with the cold pass: its summation tree is another)
+    same_result(a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0))
+    assert b.get_timing(reset=True)["persist_launches"] == 0
+    # ... and work again when they are
+    b.set_persistent(True, timeout_ms=200.0)
+    for c in (a, b):
+        c.forget_winners()
+    same_result(a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0))
+    tm = b.get_timing(reset=True)
+    assert tm["persist_launches"] == 1 and tm["persist_passes"] == 12 and tm["persist_aborts"] == 0, tm
+    a.close()
+    b.close()
+
+
+def test_two_contexts_in_one_process_take_turns():
+    """One persistent launch per device at a time: a second context whose loop starts while the first one's launch is
+    alive (another host thread) runs ordinary launches -- both get the single-context results."""
+    import threading
+    src, tgt, T_gt, r = synth.make_pair(30000, 150000, seed_t=48, seed_s=49, motion="radius")
+    ref = _lib.Context(0)
+    ref.set_persistent(False)
+    ref.set_nn_mode(_lib.NN_GRID)
+    ref.set_clouds_f64(src, tgt)
+    want = ref.run(None, r, 30, 0.0, 0.0)
+    ctxs = [_lib.Context(0) for _ in range(3)]
+    for c in ctxs:
+        c.set_nn_mode(_lib.NN_GRID)
+        c.set_clouds_f64(src, tgt)
+    got = [None] * len(ctxs)
+
+    def work(i):
+        for _ in range(5):
+            ctxs[i].forget_winners()
+            got[i] = ctxs[i].run(None, r, 30, 0.0, 0.0)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for g in got:
+        same_result(want, g)
+    for c in ctxs:
+        assert c.get_timing()["persist_aborts"] == 0
+        c.close()
+    ref.close()

@@ -46,7 +46,8 @@ class CTiming(C.Structure):
                 ("tile_workgroups", C.c_double), ("tile_fallback_workgroups", C.c_double), ("tile_parts", C.c_double),
                 ("tile_points", C.c_double), ("tile_rows", C.c_double), ("f64_reranks", C.c_double),
                 ("tile_phase_cycles", C.c_double * 7), ("grid_certified", C.c_double),
-                ("persist_launches", C.c_double), ("persist_passes", C.c_double), ("persist_ms", C.c_double)]
+                ("persist_launches", C.c_double), ("persist_passes", C.c_double), ("persist_ms", C.c_double),
+                ("persist_aborts", C.c_double)]
 
 
 class CProblem(C.Structure):
@@ -182,6 +183,8 @@ def _bind(L):
     L.visma_icp_get_nn_mode_used.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     L.visma_icp_set_profiling.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_set_device_loop.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_set_persistent.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.visma_icp_test_stall_command.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_get_timing.argtypes = [C.c_void_p, C.POINTER(CTiming), C.c_int]
     L.visma_icp_get_tile_config.argtypes = [C.POINTER(C.c_int)] * 3
     L.visma_icp_get_launch_config.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -545,6 +548,13 @@ class Context:
     def forget_winners(self):
         """The next pass runs like the first of a new registration (no warm start)."""
         self._chk(self.L.visma_icp_forget_winners(self._h))
+
+    def set_persistent(self, on=True, timeout_ms=0.0):
+        """the persistent launch of a host loop (default on); timeout_ms > 0: the launch's patience"""
+        self._chk(self.L.visma_icp_set_persistent(self._h, int(bool(on)), float(timeout_ms)))
+
+    def test_stall_command(self, nth, ms):
+        self._chk(self.L.visma_icp_test_stall_command(self._h, int(nth), float(ms)))
 
     def set_device_loop(self, on=True):
         """True: on-device loop, False: host loop, None: automatic (default)."""

@@ -1008,6 +1008,21 @@ int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled)
     return VISMA_ICP_OK;
 }
 
+int visma_icp_set_persistent(visma_icp_ctx *ctx, int enabled, double timeout_ms)
+{
+    CTX_CHECK();
+    ctx->eng->set_persistent(enabled, timeout_ms);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_test_stall_command(visma_icp_ctx *ctx, int nth, double ms)
+{
+    CTX_CHECK();
+    if (nth < 0 || !(ms >= 0.0) || ms > 10000.0) return ctx->fail(VISMA_ICP_ERR_INVALID, "bad stall arguments");
+    ctx->eng->stall_command(nth, ms);
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled)
 {
     CTX_CHECK();

@@ -256,6 +256,8 @@ public:
     // The host loop of ONE registration announces itself: between loop_begin(n) and loop_end() the caller runs at most
     // n passes (nn_pass + reduce, nothing else) -- an engine may then keep ONE launch alive across them (HipEngine:
     // the persistent certificate kernel).  loop_end() must follow on every path; LoopScope does that.
+    virtual void set_persistent(int /*enabled*/, double /*timeout_ms*/) {}
+    virtual void stall_command(int /*nth*/, double /*ms*/) {}
     virtual void loop_begin(int /*max_passes*/) {}
     virtual int loop_end() { return VISMA_ICP_OK; }
     struct LoopScope {

@@ -236,6 +236,12 @@ public:
     int get_correspondences(int32_t *idx, float *d2) override;
 
     // ---- the persistent launch of a host loop (kernels.h: PersistArgs; grid_coop.hip: nn_coop_kernel_persist)
+    void set_persistent(int enabled, double timeout_ms) override
+    {
+        persist_enabled_ = enabled != 0;
+        if (timeout_ms >= 0.5 && timeout_ms <= 5000.0) persist_timeout_ms_ = timeout_ms;
+    }
+    void stall_command(int nth, double ms) override { stall_nth_ = nth; stall_ms_ = ms; }
     void loop_begin(int max_passes) override
     {
         loop_scope_ = true;
@@ -620,6 +626,8 @@ private:
     unsigned long long *h_cmd_ = nullptr, *h_cmd_dev_ = nullptr;   // kPersistWords command words; word 32: the kernel's flag
     void *d_relay_ = nullptr;
     int persist_sessions_ = 0, persist_aborts_ = 0;
+    int stall_nth_ = 0;              // (tests) sleep stall_ms_ before the stall_nth_-th command from now
+    double stall_ms_ = 0.0;
     bool persist_possible(int lanes, int nblocks, bool fused, bool plane) const;
     int start_session(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, int nblocks, bool prof);
     void post_command(const Xform64 &T64, unsigned cmd);

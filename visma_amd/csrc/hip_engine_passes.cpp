@@ -72,6 +72,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     const bool ipc = ipc_n_ > 1;
     bool ipc_done = false;                           // the exchange ran inside the search launch
     bool in_session = false;                         // this pass runs inside a persistent launch (see hip_engine.hpp)
+    bool posted = false;                             // ... as a command to a launch that was already running
     double *pub = (comm_ || ipc) ? nullptr : h_stats_dev_;
 #ifdef VISMA_WITH_TILE
     if (use_tile()) {
@@ -115,8 +116,8 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 post_command(T64, kPersistGo);
                 sess_pass_++;
                 in_session = true;
+                posted = true;                               // (its transform becomes "the previous one" once the pass has run)
                 last_kernel_ = 2;
-                note_state_pass(T64);
             } else {
                 int rc = end_session();
                 if (rc) return rc;
@@ -208,6 +209,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         seen = all_tagged();
         if (!seen) {
             persist_aborts_++;
+            timing_.persist_aborts += 1.0;
             if (std::getenv("VISMA_ICP_PERSIST_TRACE"))
                 std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
                              reinterpret_cast<volatile unsigned *>(h_cmd_ + 32)[0], cmd_tag_, sess_tag0_);
@@ -220,6 +222,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
             seen = wait_published();
         }
     }
+    if (in_session && seen && posted) note_state_pass(T64);
     if (in_session && seen && sess_live_ && sess_pass_ >= sess_max_) finish_session();   // (its last pass: the launch ends by itself)
     if (!seen) {
         HIP_TRY(hipStreamSynchronize(stream_));   // surfaces a kernel fault, if any
@@ -336,6 +339,8 @@ int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3]
 // the next command, word by word: every word carries the tag, so the device accepts the block when all words show it
 void HipEngine::post_command(const Xform64 &T64, unsigned cmd)
 {
+    if (stall_nth_ > 0 && --stall_nth_ == 0)             // (tests: a host thread that does not come back in time)
+        std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(stall_ms_));
     const unsigned tag = ++cmd_tag_;
     volatile unsigned long long *c = h_cmd_;
     const unsigned long long t = (unsigned long long)tag << 32;
