@@ -112,7 +112,7 @@ __device__ __forceinline__ bool coop_body(
     const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,
     int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,
     const Pt64 *__restrict__ nrm64, const FoldArgs &fold, double *__restrict__ d64_out,
-    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev)
+    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev, unsigned *work_out = nullptr)
 {
     constexpr int NACC = Acc<PLANE>::N;
     const P12 *s12 = reinterpret_cast<const P12 *>(s12f);
@@ -506,6 +506,7 @@ __device__ __forceinline__ bool coop_body(
                 if (w < wave) off_q += c;                    // ... in the workgroup's list
                 m_all += c;
             }
+            if (work_out) *work_out = nq_all | (m_all << 12);    // (measurement: queued queries, chunks listed)
             // the two best chunks (minimum, first slot, flag byte) and the third chunk minimum
             float gh0 = INFINITY, gh1 = INFINITY, gh2 = INFINITY;
             float gsec = INFINITY;                           // best candidate outside the rounding band of its chunk's minimum
@@ -865,9 +866,10 @@ __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa
     unsigned long long w = 0ull;
     const long long t0 = (long long)wall_clock64();
     const long long budget = poller ? pa.poll_ticks : pa.wait_ticks;
+    const bool direct = pa.direct != 0;                      // the command block lies in device memory: everybody reads it
     for (;;) {
         if (mine) {
-            if (poller) w = __hip_atomic_load(pa.host_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (poller || direct) w = __hip_atomic_load(pa.host_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             else w = __hip_atomic_load(pa.relay + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool ok = !mine || (unsigned)(w >> 32) == tag;
@@ -878,9 +880,9 @@ __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa
             if (poller && lane == 0) __hip_atomic_store(pa.host_flag, (unsigned)pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
-        if (poller) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(4);
+        if (poller) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(3);
     }
-    if (poller && mine) __hip_atomic_store(pa.relay + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (poller && mine && !direct) __hip_atomic_store(pa.relay + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return w;
 }
 
@@ -931,6 +933,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         asm volatile("" : "+s"(kp));                         // (nothing read through it is loop-invariant to the compiler)
         // (member by member: scalar loads straight into registers; the fold's ipc fields stay zero: no exchange)
 #define VISMA_KARG(F_) ld_karg(&kp->F_)
+        const unsigned long long t_begin = VISMA_KARG(pa.timeline) ? wall_clock64() : 0ull;
+        unsigned work = 0u;
         const int cur = (pass - 1) & 1;
         Xform64 Tc, Tp;
 #pragma unroll
@@ -953,9 +957,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const bool published = coop_body<PLANE, true, kBlock, true>(
             VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
             VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
-            nullptr, 1, VISMA_KARG(src64), VISMA_KARG(sorted64), VISMA_KARG(nrm64), f, nullptr, VISMA_KARG(wst_io), w, Tp);
+            nullptr, 1, VISMA_KARG(src64), VISMA_KARG(sorted64), VISMA_KARG(nrm64), f, nullptr, VISMA_KARG(wst_io), w, Tp,
+            t_begin ? &work : nullptr);
         const PersistArgs pa = VISMA_KARG(pa);
 #undef VISMA_KARG
+        if (pa.timeline && pass <= pa.timeline_passes && thread_number<true>() == 0) {
+            // (measurement runs only) [pass][workgroup]{begin, body done}; the begin of pass 1 is the launch's
+            unsigned long long *slot = pa.timeline + ((unsigned long long)(pass - 1) * gridDim.x + blockIdx.x) * 2ull;
+            slot[0] = t_begin;
+            // (the clock's low 44 bits -- 48 hours at 100 MHz -- and above them: queued queries, chunks listed)
+            slot[1] = (wall_clock64() & 0xFFFFFFFFFFFull) | ((unsigned long long)work << 44);
+        }
         if (pass >= pa.max_passes) break;
         const int tidx = thread_number<true>();
         if (tidx < 64) {

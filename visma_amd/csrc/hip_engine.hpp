@@ -39,8 +39,10 @@ public:
         if (sess_live_) (void)end_session();
         if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
-        if (h_cmd_) (void)hipHostFree(h_cmd_);
-        free_dev(d_relay_);
+        if (h_cmd_ && !cmd_direct_) (void)hipHostFree(h_cmd_);
+        if (d_cmd_block_) (void)hipFree(d_cmd_block_);
+        if (h_flag_) (void)hipHostFree(h_flag_);
+        free_dev(d_relay_); free_dev(d_timeline_);
         pool_trim(0);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -625,7 +627,16 @@ private:
     std::vector<std::pair<int, int>> sess_pending_;   // (event pair, passes run) of finished sessions
     unsigned long long *h_cmd_ = nullptr, *h_cmd_dev_ = nullptr;   // kPersistWords command words; word 32: the kernel's flag
     void *d_relay_ = nullptr;
+    bool cmd_direct_ = false;        // h_cmd_ is fine-grained DEVICE memory, stored to through the PCIe BAR (large-BAR systems)
+    void *d_cmd_block_ = nullptr;
+    unsigned *h_flag_ = nullptr, *h_flag_dev_ = nullptr;   // the launch's "gave up" word, always in mapped host memory
     int persist_sessions_ = 0, persist_aborts_ = 0;
+    std::chrono::steady_clock::time_point t_stats_seen_{};   // (VISMA_ICP_PERSIST_TRACE: statistics seen -> next command posted)
+    double host_gap_us_ = 0.0, wait_us_ = 0.0;
+    int host_gaps_ = 0;
+    void *d_timeline_ = nullptr;     // VISMA_ICP_PERSIST_TIMELINE=<file>: per pass and workgroup clocks of every session, appended
+    int timeline_passes_ = 0, timeline_blocks_ = 0;
+    std::string timeline_path_;
     int stall_nth_ = 0;              // (tests) sleep stall_ms_ before the stall_nth_-th command from now
     double stall_ms_ = 0.0;
     bool persist_possible(int lanes, int nblocks, bool fused, bool plane) const;

@@ -53,9 +53,34 @@ int HipEngine::init()
     HIP_TRY(hipHostGetDevicePointer((void **)&h_stats_dev_, h_stats_, 0));
     if (const char *e = std::getenv("VISMA_ICP_PERSIST")) persist_enabled_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMEOUT_MS")) { const double v = std::atof(e); if (v >= 1.0 && v <= 5000.0) persist_timeout_ms_ = v; }
-    HIP_TRY(hipHostMalloc((void **)&h_cmd_, sizeof(unsigned long long) * 64, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(h_cmd_, 0, sizeof(unsigned long long) * 64);
-    HIP_TRY(hipHostGetDevicePointer((void **)&h_cmd_dev_, h_cmd_, 0));
+    if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMELINE")) timeline_path_ = e;
+    // The command block of the persistent launch.  On a large-BAR system it lies in fine-grained DEVICE memory the host
+    // stores into through the BAR (write-combining: post_command ends with a store fence): every workgroup polls it
+    // where it is -- no PCIe read per poll, no relay through a poller (tools/ubench/device_mailbox.hip: 2.3 us host ->
+    // wave -> host against 2.7 with the block in host memory, and the relay hop on top of that).  Otherwise, or with
+    // VISMA_ICP_PERSIST_CMD=host: mapped host memory, polled by the workgroup that published, relayed to the others.
+    {
+        int large_bar = 0;
+        if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device_) != hipSuccess) { (void)hipGetLastError(); large_bar = 0; }
+        const char *e = std::getenv("VISMA_ICP_PERSIST_CMD");
+        const bool want_direct = e ? (e[0] == 'd') : large_bar != 0;
+        if (want_direct && large_bar &&
+            hipExtMallocWithFlags(&d_cmd_block_, sizeof(unsigned long long) * 64, hipDeviceMallocFinegrained) == hipSuccess) {
+            HIP_TRY(hipMemset(d_cmd_block_, 0, sizeof(unsigned long long) * 64));
+            HIP_TRY(hipDeviceSynchronize());
+            h_cmd_ = h_cmd_dev_ = (unsigned long long *)d_cmd_block_;
+            cmd_direct_ = true;
+        } else {
+            (void)hipGetLastError();
+            d_cmd_block_ = nullptr;
+            HIP_TRY(hipHostMalloc((void **)&h_cmd_, sizeof(unsigned long long) * 64, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(h_cmd_, 0, sizeof(unsigned long long) * 64);
+            HIP_TRY(hipHostGetDevicePointer((void **)&h_cmd_dev_, h_cmd_, 0));
+        }
+        HIP_TRY(hipHostMalloc((void **)&h_flag_, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(h_flag_, 0, 64);
+        HIP_TRY(hipHostGetDevicePointer((void **)&h_flag_dev_, h_flag_, 0));
+    }
     HIP_TRY(hipMalloc(&d_relay_, sizeof(unsigned long long) * 64));
     HIP_TRY(hipMemset(d_relay_, 0, sizeof(unsigned long long) * 64));
     inited_ = true;

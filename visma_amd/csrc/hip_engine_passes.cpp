@@ -1,6 +1,8 @@
 // hip_engine_passes.cpp -- HipEngine: the per-pass launches (brute force / lane-serial grid / warm-started grid), the fused fold, the device-resident loops (single problem, sweeps, batches of problems with their own clouds).
 #include "hip_engine.hpp"
 
+#include <immintrin.h>
+
 namespace visma {
 namespace drv {
 
@@ -113,7 +115,13 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                               o[2] == sess_off_[2] && sess_pass_ < sess_max_ && seq == sess_seq0_ + (unsigned long long)sess_pass_ &&
                               lanes == kCoopLanes;
             if (same) {
+                static const bool trace = std::getenv("VISMA_ICP_PERSIST_TRACE") != nullptr;
+                if (trace) {
+                    host_gap_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_stats_seen_).count();
+                    host_gaps_++;
+                }
                 post_command(T64, kPersistGo);
+                if (trace) t_stats_seen_ = std::chrono::steady_clock::now();   // (re-used: command posted -> statistics seen)
                 sess_pass_++;
                 in_session = true;
                 posted = true;                               // (its transform becomes "the previous one" once the pass has run)
@@ -132,11 +140,23 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 if (rc == VISMA_ICP_OK && sess_live_) {
                     pa.host_cmd = h_cmd_dev_;
                     pa.relay = (unsigned long long *)d_relay_;
-                    pa.host_flag = reinterpret_cast<unsigned *>(h_cmd_dev_ + 32);
+                    pa.direct = cmd_direct_ ? 1 : 0;
+                    pa.host_flag = h_flag_dev_;
                     pa.max_passes = sess_max_;
                     pa.tag0 = sess_tag0_;
                     pa.poll_ticks = (long long)(persist_timeout_ms_ * 1e5);     // (100 MHz)
                     pa.wait_ticks = 2 * pa.poll_ticks;
+                    if (!timeline_path_.empty()) {
+                        // (measurement: clocks of up to 64 passes of this launch, read back when it has ended)
+                        if (!d_timeline_) HIP_TRY(hipMalloc(&d_timeline_, sizeof(unsigned long long) * 2 * 64 * 1024));
+                        if (nb <= 1024) {
+                            HIP_TRY(hipMemsetAsync(d_timeline_, 0, sizeof(unsigned long long) * 2 * 64 * 1024, stream_));
+                            pa.timeline = (unsigned long long *)d_timeline_;
+                            pa.timeline_passes = std::min(64, sess_max_);
+                            timeline_passes_ = pa.timeline_passes;
+                            timeline_blocks_ = nb;
+                        }
+                    }
                     pp = &pa;
                 }
             }
@@ -212,7 +232,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
             timing_.persist_aborts += 1.0;
             if (std::getenv("VISMA_ICP_PERSIST_TRACE"))
                 std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
-                             reinterpret_cast<volatile unsigned *>(h_cmd_ + 32)[0], cmd_tag_, sess_tag0_);
+                             *reinterpret_cast<volatile unsigned *>(h_flag_), cmd_tag_, sess_tag0_);
             finish_session();
             persist_enabled_ = 0;
             in_session = false;
@@ -223,6 +243,14 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         }
     }
     if (in_session && seen && posted) note_state_pass(T64);
+    if (in_session && seen) {
+        static const bool trace = std::getenv("VISMA_ICP_PERSIST_TRACE") != nullptr;
+        if (trace) {
+            const auto now = std::chrono::steady_clock::now();
+            if (posted) wait_us_ += std::chrono::duration<double, std::micro>(now - t_stats_seen_).count();
+            t_stats_seen_ = now;
+        }
+    }
     if (in_session && seen && sess_live_ && sess_pass_ >= sess_max_) finish_session();   // (its last pass: the launch ends by itself)
     if (!seen) {
         HIP_TRY(hipStreamSynchronize(stream_));   // surfaces a kernel fault, if any
@@ -331,7 +359,7 @@ int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3]
     sess_r2f_ = r2f_;
     for (int a = 0; a < 3; a++) sess_off_[a] = offset[a];
     sess_e0_ = -1;
-    reinterpret_cast<volatile unsigned *>(h_cmd_ + 32)[0] = 0u;
+    *reinterpret_cast<volatile unsigned *>(h_flag_) = 0u;
     persist_sessions_++;
     return VISMA_ICP_OK;
 }
@@ -352,12 +380,31 @@ void HipEngine::post_command(const Xform64 &T64, unsigned cmd)
     }
     c[kPersistWords - 1] = (unsigned long long)cmd | t;
     std::atomic_thread_fence(std::memory_order_release);
+    if (cmd_direct_) _mm_sfence();                       // (the BAR is write-combining: the stores leave the core now, not when its buffers fill)
 }
 
 void HipEngine::finish_session()
 {
     if (!sess_live_) return;
     sess_live_ = false;
+    if (host_gaps_ > 0) {
+        std::fprintf(stderr, "[visma_icp] persistent launch: %d passes; host: statistics seen -> command posted %.2f us, command posted -> statistics seen %.2f us (averages)\n",
+                     sess_pass_, host_gap_us_ / host_gaps_, wait_us_ / host_gaps_);
+        host_gap_us_ = wait_us_ = 0.0;
+        host_gaps_ = 0;
+    }
+    if (d_timeline_ && timeline_passes_ > 0 && !timeline_path_.empty()) {
+        // record: {passes recorded, workgroups, passes run}, then [pass][workgroup]{begin, body done} (100 MHz ticks)
+        if (hipStreamSynchronize(stream_) == hipSuccess) {
+            const size_t n = (size_t)2 * timeline_passes_ * timeline_blocks_;
+            std::vector<unsigned long long> buf(n + 3);
+            buf[0] = (unsigned long long)timeline_passes_; buf[1] = (unsigned long long)timeline_blocks_; buf[2] = (unsigned long long)sess_pass_;
+            if (hipMemcpy(buf.data() + 3, d_timeline_, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE *f = std::fopen(timeline_path_.c_str(), "ab")) { std::fwrite(buf.data(), sizeof(unsigned long long), buf.size(), f); std::fclose(f); }
+        }
+        (void)hipGetLastError();
+        timeline_passes_ = 0;
+    }
     if (sess_e0_ >= 0) sess_pending_.push_back({sess_e0_, std::max(sess_pass_, 1)});
     sess_e0_ = -1;
     if (sess_dev_slot_ >= 0) g_persist_slot[sess_dev_slot_].store(0);

@@ -79,13 +79,18 @@ struct FoldArgs {
 constexpr int kPersistWords = 25;
 constexpr unsigned kPersistGo = 1u, kPersistStop = 2u, kPersistAbort = 3u;
 struct PersistArgs {
-    const unsigned long long *host_cmd;   // mapped, coherent host memory (device pointer), kPersistWords words
+    const unsigned long long *host_cmd;   // mapped, coherent host memory (device pointer), kPersistWords words -- or, `direct`,
+                                          // fine-grained DEVICE memory the host stores into through the PCIe BAR: then every
+                                          // workgroup polls it itself (no PCIe read per poll, no relay hop)
+    int direct;
     unsigned long long *relay;            // device memory, kPersistWords words
     unsigned *host_flag;                  // mapped host memory: set to the pass count reached when a wait ran out
     int max_passes;                       // passes this launch may run (>= 1); the first needs no command
     unsigned tag0;                        // the command for pass p (1-based after the first) carries tag0 + p - 1
     long long poll_ticks;                 // budget of the poller's wait, in wall_clock64 ticks (100 MHz)
     long long wait_ticks;                 // ... of everybody else's (longer: the poller gives up first and says so)
+    unsigned long long *timeline;         // measurement (VISMA_ICP_PERSIST_TIMELINE), else NULL: per pass and workgroup the
+    int timeline_passes;                  // 100 MHz clock when the pass began and when its body (fold ticket included) was done
 };
 
 struct NNLaunch {
