@@ -294,12 +294,12 @@ def cpu_baseline_c4(src, tgt, radius, iters, repeats):
 # ------------------------------------------------------------------------------------------
 # rooflines
 # ------------------------------------------------------------------------------------------
-def load_traffic(kind, ns_local, nt):
+def load_traffic(kind, ns_local, nt, field="hbm_bytes_per_nn_launch"):
     """HBM bytes per launch from the PMC passes of a PROFILED run of this same command (profiles/traffic.json);
     not collected in this run."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        return tj.get("%s:%dx%d" % (kind, ns_local, nt), {}).get("hbm_bytes_per_nn_launch")
+        return tj.get("%s:%dx%d" % (kind, ns_local, nt), {}).get(field)
     except Exception:
         return None
 
@@ -449,7 +449,7 @@ def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=
     return T, last, elapsed, tm, setup
 
 
-def persistent_launches(roofline, tm):
+def persistent_launches(roofline, tm, queries=0, nt=0):
     """Persistent launches (round 4b: ONE launch of the certificate kernel runs the passes of a host loop, the next
     transform handed over through mapped host memory): the timing counters hold whole launches -- the waits for the host
     included -- and count their passes.  `achieved` = bytes per launch / launch duration is the same ratio either way;
@@ -466,6 +466,14 @@ def persistent_launches(roofline, tm):
                                   "its waits for the host's next transform (statistics out, solve, command back over "
                                   "PCIe) are inside"}
     if tm["nn_launches"] == pp:
+        per_pass_traffic = load_traffic("grid_persist", int(queries), int(nt), "hbm_bytes_per_pass") if queries else None
+        if per_pass_traffic:
+            roofline["traffic"] = per_pass_traffic * k
+            roofline["traffic_per_pass"] = per_pass_traffic
+            roofline["traffic_frac"] = per_pass_traffic / (per_pass_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
+        elif roofline.get("traffic"):
+            roofline["traffic_per_pass"] = roofline["traffic"]      # (the one-pass kernel's PMC figure)
+            roofline["traffic"] = roofline["traffic"] * k
         roofline["avg_launch_ms"] = tm["persist_ms"] / pl
         for key in ("alg_bytes_per_launch", "examined_bytes_per_launch"):
             roofline[key.replace("_per_launch", "_per_pass")] = roofline[key]
@@ -483,7 +491,7 @@ def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None):
                       tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
                       ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial",
                       tm["grid_certified"] / nl)
-    return persistent_launches(r, tm)
+    return persistent_launches(r, tm, ns_local if traffic_kind != "none" else 0, nt_local)
 
 
 def c4_variant(R, device, src, tgt, radius, T_gt, steps, what):
@@ -716,7 +724,7 @@ def run_c4(R, args):
                                      load_traffic("grid_warm" if kernel_kind == "warm" else "grid", ns_local, nt_local),
                                      exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial",
                                      tm["grid_certified"] / nl)
-            roofline = persistent_launches(roofline, tm)
+            roofline = persistent_launches(roofline, tm, ns_local, nt_local)
         else:
             roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
         roofline["launches_timed"] = tm["nn_launches"] if "launch" not in roofline else roofline["launch"]["launches_timed"]

@@ -16,7 +16,9 @@ pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.j
          ("stats_c4/c4_kernel_stats.csv", "%s_bench_c4_kernel_stats.csv"), ("stats_c3/c3_kernel_stats.csv", "%s_bench_c3_kernel_stats.csv"),
          ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv"),
          ("pmc_traffic_saturated_summary.csv", "%s_4m_queries_traffic_pmc_summary.csv"),
-         ("pmc_kernel_summary.csv", "%s_c4_kernel_pmc_summary.csv")]
+         ("pmc_kernel_summary.csv", "%s_c4_kernel_pmc_summary.csv"),
+         ("persist_timeline.txt", "%s_persist_timeline.txt"), ("persist_host_gaps.txt", "%s_persist_host_gaps.txt"),
+         ("persist_probe.jsonl", "%s_persist_probe.jsonl"), ("mailbox_ubench.txt", "%s_mailbox_ubench.txt")]
 for a, b in pairs:
     p = os.path.join(src, a)
     if os.path.exists(p):
@@ -48,12 +50,12 @@ p = os.path.join(src, "pmc_traffic_summary.csv")
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 for key, match, label in (("grid:262144x4194304", "nn_grid_reduce_kernel", "nn_grid_reduce_kernel<false,1,8,true,false,true> (lane-serial exact search: first pass of a registration; fold fused)"),
-                          ("grid_warm:262144x4194304", "nn_coop_kernel", "nn_coop_kernel_one<false> (warm-started exact search with certificates, passes 28..47 of a registration; fold fused)")):
+                          ("grid_warm:262144x4194304", "nn_coop_kernel_one", "nn_coop_kernel_one<false> (warm-started exact search with certificates, passes 28..47 of a registration; fold fused)")):
     vals = {}
     if os.path.exists(p):
         for r in csv.DictReader(open(p)):
             # (the warm kernel: its last 20 dispatches -- the converged passes bench.py's `value` times)
-            if match in r["kernel"] and (("[last" in r["kernel"]) == (match == "nn_coop_kernel")):
+            if match in r["kernel"] and (("[last" in r["kernel"]) == (match == "nn_coop_kernel_one")):
                 vals[r["counter"]] = float(r["mean_per_dispatch"])
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         tj[key] = {
@@ -64,6 +66,25 @@ for key, match, label in (("grid:262144x4194304", "nn_grid_reduce_kernel", "nn_g
             "kernel": label,
             "source": "profiles/%s_c4_traffic_pmc_summary.csv (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % tag}
         print("traffic.json %s: %.1f MB per launch" % (key, tj[key]["hbm_bytes_per_nn_launch"] / 1e6))
+# the persistent launch of the last 20 passes (one dispatch): per launch and per pass
+vals = {}
+if os.path.exists(p):
+    for r in csv.DictReader(open(p)):
+        if "nn_coop_kernel_persist" in r["kernel"] and "[last dispatch" in r["kernel"]:
+            vals[r["counter"]] = float(r["mean_per_dispatch"])
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    tj["grid_persist:262144x4194304"] = {
+        "hbm_bytes_per_nn_launch": b, "passes_per_launch": 20, "hbm_bytes_per_pass": b / 20.0,
+        "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+        "correction": "FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE "
+                      "uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB; the polls of the command block (every "
+                      "workgroup's first wave, system-scope loads of fine-grained device memory while the host solves) are in it"
+                      % (vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
+        "kernel": "nn_coop_kernel_persist<false> (ONE launch running passes 28..47 of a registration: certificates, fold fused, "
+                  "next transform through the command block)",
+        "source": "profiles/%s_c4_traffic_pmc_summary.csv (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % tag}
+    print("traffic.json grid_persist: %.1f MB per launch of 20 passes = %.1f MB per pass" % (b / 1e6, b / 20e6))
 # ... and with 4 M queries per launch
 p = os.path.join(src, "pmc_traffic_saturated_summary.csv")
 vals = {}

@@ -19,6 +19,10 @@ for (f, k, c), v in rows.items():
     if len(v) > LAST:
         for _, x in v[-LAST:]:
             acc[(k + " [last %d dispatches]" % LAST, c)][0] += x; acc[(k + " [last %d dispatches]" % LAST, c)][1] += 1
+    if "persist" in k:
+        # a persistent launch runs a whole host loop: the LAST dispatch is the loop of the last 20 passes
+        # (tools/run_c4_iterations.py), the regime `value` is timed in
+        acc[(k + " [last dispatch = 20 passes]", c)][0] += v[-1][1]; acc[(k + " [last dispatch = 20 passes]", c)][1] += 1
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
 for (k, c), (s, n) in sorted(acc.items()):

@@ -25,4 +25,8 @@ python tools/pmc_summarize.py $out/pmc_sat nn_ > $out/pmc_traffic_saturated_summ
 # instruction mix / L1 / wait counters of the default kernel (every pass under its own timeout)
 tools/pmc_quick.sh $out/pmc_kernel > $out/pmc_kernel_summary.txt 2>&1
 python tools/pmc_summarize.py $out/pmc_kernel nn_ > $out/pmc_kernel_summary.csv
+# the persistent launch: per-pass / per-workgroup clocks, host-side gaps, the two mailbox round trips
+( VISMA_ICP_PERSIST_TRACE=1 VISMA_ICP_PERSIST_TIMELINE=/tmp/tl_$tag.bin timeout 300 python tools/persist_probe.py 4194304 262144 5000 > $out/persist_probe_traced.jsonl 2> $out/persist_host_gaps.txt; python tools/persist_timeline.py /tmp/tl_$tag.bin > $out/persist_timeline.txt 2>&1 )
+timeout 300 python tools/persist_probe.py 4194304 262144 131072 65536 5000 > $out/persist_probe.jsonl 2>&1
+( timeout 60 tools/ubench/_build/host_mailbox; timeout 120 tools/ubench/_build/device_mailbox ) > $out/mailbox_ubench.txt 2>&1
 ls $out
