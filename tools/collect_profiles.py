@@ -44,6 +44,24 @@ if os.path.exists(kt):
     csv.writer(open(os.path.join(dst, "%s_bench_c4_search_kernels_by_launch_size.csv" % tag), "w")).writerows(rows)
     print("wrote %s_bench_c4_search_kernels_by_launch_size.csv" % tag)
 
+# Persistent launches last as long as their host loop (5-pass warm-up, the seven timed 20-pass blocks, 19-pass loops from
+# the identity, ...): every launch of the C4 size in dispatch order, so that the seven the roofline object times -- the
+# 2nd to 8th at 262,144 threads: they follow the warm-up's -- can be compared with its avg_launch_ms.
+if os.path.exists(kt):
+    rows = [("order_at_this_size", "grid_threads", "start_ns_since_first", "duration_ns")]
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        if "nn_coop_kernel_persist" in r["Kernel_Name"]:
+            per[int(r["Grid_Size_X"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    for g in sorted(per, reverse=True):
+        v = sorted(per[g])
+        for i, (t, d) in enumerate(v):
+            rows.append((i + 1, g, t - v[0][0], d))
+    csv.writer(open(os.path.join(dst, "%s_bench_c4_persistent_launches_in_order.csv" % tag), "w")).writerows(rows)
+    c4 = [d for _, d in sorted(per.get(262144, []))]
+    if len(c4) >= 8:
+        print("wrote %s_bench_c4_persistent_launches_in_order.csv; launches 2..8 at 262,144 threads: average %.1f us" % (tag, sum(c4[1:8]) / 7e3))
+
 # traffic of the C4 kernels: FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md, HBM) + WRITE_SIZE, KiB -> bytes.
 # tools/run_c4_iterations.py runs one cold pass (lane-serial kernel) and five warm-started ones.
 p = os.path.join(src, "pmc_traffic_summary.csv")
