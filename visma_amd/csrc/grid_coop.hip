@@ -856,17 +856,24 @@ __global__ __launch_bounds__(kBlock) void nn_coop_kernel_many(VISMA_COOP_PARAMS)
 //   * the other waves sleep in the barrier.
 // A word is accepted when it carries the tag of the pass that is due: nothing orders the words among themselves, so
 // no fence (an agent- or system-scope release would write the launch's megabytes of dirty state back first).
-// Every wait gives up after its budget of 100 MHz ticks; the poller then says so in host memory and hands the others
-// an ABORT, so a launch whose host process stopped, or whose workgroups were not all resident after all, ends by
-// itself: between passes the state in memory is exactly what the last completed pass left, and the host goes on
-// with ordinary launches.
+// The HOST keeps the patience: a thread that comes back later than VISMA_ICP_PERSIST_TIMEOUT_MS after it saw the
+// statistics posts STOP instead of the transform and runs the pass as an ordinary launch.  The launch itself only
+// protects the GPU against a host that never comes back: after the publication of a pass's statistics every
+// workgroup waits four times that patience for a command (so no GO can arrive while some have already left), then
+// leaves; before the publication -- the pass is still running somewhere -- it waits as long as the pass takes (a cap
+// of a minute that only a lost workgroup could reach).  A launch that ended that way leaves the host a pass without
+// statistics: it forgets the winners, re-arms the fold and carries on with ordinary launches.
 __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa, unsigned tag, bool poller, int pass, int lane)
 {
     const bool mine = lane < kPersistWords;
     unsigned long long w = 0ull;
-    const long long t0 = (long long)wall_clock64();
-    const long long budget = poller ? pa.poll_ticks : pa.wait_ticks;
     const bool direct = pa.direct != 0;                      // the command block lies in device memory: everybody reads it
+    // the workgroup that published says so (the others' patience counts from there: until then the pass is still
+    // running somewhere, for as long as it takes)
+    if (poller && lane == 0)
+        __hip_atomic_store(pa.relay + kPersistPublished, (unsigned long long)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long t_ref = (long long)wall_clock64();
+    bool published = poller;
     for (;;) {
         if (mine) {
             if (poller || direct) w = __hip_atomic_load(pa.host_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -874,7 +881,12 @@ __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa
         }
         const bool ok = !mine || (unsigned)(w >> 32) == tag;
         if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
-        if ((long long)wall_clock64() - t0 > budget) {
+        const long long now = (long long)wall_clock64();
+        if (!published) {
+            const unsigned long long m = __hip_atomic_load(pa.relay + kPersistPublished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)m == tag) { published = true; t_ref = now; }
+        }
+        if (now - t_ref > (published ? pa.wait_ticks : pa.hard_ticks)) {
             // nothing came: everybody leaves (the command word decides; the transform words are not looked at)
             w = ((unsigned long long)tag << 32) | (lane == kPersistWords - 1 ? kPersistAbort : 0u);
             if (poller && lane == 0) __hip_atomic_store(pa.host_flag, (unsigned)pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -114,14 +114,26 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
             const bool same = plane == sess_plane_ && r2f_ == sess_r2f_ && o[0] == sess_off_[0] && o[1] == sess_off_[1] &&
                               o[2] == sess_off_[2] && sess_pass_ < sess_max_ && seq == sess_seq0_ + (unsigned long long)sess_pass_ &&
                               lanes == kCoopLanes;
+            bool patient = true;
             if (same) {
-                static const bool trace = std::getenv("VISMA_ICP_PERSIST_TRACE") != nullptr;
-                if (trace) {
-                    host_gap_us_ += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_stats_seen_).count();
+                if (stall_nth_ > 0 && --stall_nth_ == 0)   // (tests: a host thread that does not come back in time)
+                    std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(stall_ms_));
+                // The host keeps the patience: whoever comes back this late posts STOP, not the transform -- the launch
+                // waits four times as long before it gives up by itself, so a GO never meets a half-empty launch.
+                const double gap_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_stats_seen_).count();
+                patient = gap_us <= persist_timeout_ms_ * 1e3;
+                if (!patient) {
+                    persist_aborts_++;
+                    timing_.persist_aborts += 1.0;
+                    persist_enabled_ = 0;                    // (until visma_icp_set_persistent asks again)
+                } else if (trace_persist()) {
+                    host_gap_us_ += gap_us;
                     host_gaps_++;
                 }
+            }
+            if (same && patient) {
                 post_command(T64, kPersistGo);
-                if (trace) t_stats_seen_ = std::chrono::steady_clock::now();   // (re-used: command posted -> statistics seen)
+                if (trace_persist()) t_posted_ = std::chrono::steady_clock::now();
                 sess_pass_++;
                 in_session = true;
                 posted = true;                               // (its transform becomes "the previous one" once the pass has run)
@@ -144,8 +156,9 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                     pa.host_flag = h_flag_dev_;
                     pa.max_passes = sess_max_;
                     pa.tag0 = sess_tag0_;
-                    pa.poll_ticks = (long long)(persist_timeout_ms_ * 1e5);     // (100 MHz)
-                    pa.wait_ticks = 2 * pa.poll_ticks;
+                    pa.poll_ticks = 0;
+                    pa.wait_ticks = (long long)(4.0 * persist_timeout_ms_ * 1e5) + 1000000ll;   // (100 MHz; host patience x 4 + 10 ms)
+                    pa.hard_ticks = 60ll * 100000000ll;
                     if (!timeline_path_.empty()) {
                         // (measurement: clocks of up to 64 passes of this launch, read back when it has ended)
                         if (!d_timeline_) HIP_TRY(hipMalloc(&d_timeline_, sizeof(unsigned long long) * 2 * 64 * 1024));
@@ -210,12 +223,12 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     };
     bool seen = false;
     auto wait_published = [&]() {
-        for (long long spin = 0; spin < 400000000ll; ++spin) {
+        // (inside a persistent launch: for as long as the launch lives -- a pass of a pathological configuration may take
+        //  seconds, and a host that stopped looking would leave the launch waiting for a command until its patience ends)
+        for (long long spin = 0; in_session || spin < 400000000ll; ++spin) {
             if (all_tagged()) return true;
-            // (in a session the launch ends by itself when its patience runs out: look more often)
-            if ((spin & (in_session ? 0xFFFFll : 0xFFFFFll)) == (in_session ? 0xFFFFll : 0xFFFFFll) &&
-                hipStreamQuery(stream_) != hipErrorNotReady)
-                return all_tagged();
+            const long long every = in_session ? 0xFFFFll : 0xFFFFFll;
+            if ((spin & every) == every && hipStreamQuery(stream_) != hipErrorNotReady) return all_tagged();
         }
         return false;
     };
@@ -230,12 +243,17 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         if (!seen) {
             persist_aborts_++;
             timing_.persist_aborts += 1.0;
-            if (std::getenv("VISMA_ICP_PERSIST_TRACE"))
+            if (trace_persist())
                 std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
                              *reinterpret_cast<volatile unsigned *>(h_flag_), cmd_tag_, sess_tag0_);
             finish_session();
             persist_enabled_ = 0;
             in_session = false;
+            // Whatever made it leave (the host thread away for longer than four times its patience, a command that
+            // arrived torn over more than that): some workgroups may have begun the pass and others not.  Nothing of a
+            // half-run pass is kept: the fold's tickets are re-armed and the winners forgotten -- the pass runs cold.
+            if (d_tickets_ && tickets_cap_ > 0) HIP_TRY(hipMemsetAsync(d_tickets_, 0, sizeof(unsigned) * tickets_cap_, stream_));
+            { int irc = invalidate_pos(); if (irc) return irc; }
             int nblocks = 1;
             int rc = launch_grid_pass(T64, plane, offset, seq, false, nullptr, &nblocks, &ipc_done);
             if (rc) return rc;
@@ -244,12 +262,9 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     }
     if (in_session && seen && posted) note_state_pass(T64);
     if (in_session && seen) {
-        static const bool trace = std::getenv("VISMA_ICP_PERSIST_TRACE") != nullptr;
-        if (trace) {
-            const auto now = std::chrono::steady_clock::now();
-            if (posted) wait_us_ += std::chrono::duration<double, std::micro>(now - t_stats_seen_).count();
-            t_stats_seen_ = now;
-        }
+        const auto now = std::chrono::steady_clock::now();
+        if (posted && trace_persist()) wait_us_ += std::chrono::duration<double, std::micro>(now - t_posted_).count();
+        t_stats_seen_ = now;                                 // (the host's patience with itself counts from here)
     }
     if (in_session && seen && sess_live_ && sess_pass_ >= sess_max_) finish_session();   // (its last pass: the launch ends by itself)
     if (!seen) {
@@ -367,8 +382,6 @@ int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3]
 // the next command, word by word: every word carries the tag, so the device accepts the block when all words show it
 void HipEngine::post_command(const Xform64 &T64, unsigned cmd)
 {
-    if (stall_nth_ > 0 && --stall_nth_ == 0)             // (tests: a host thread that does not come back in time)
-        std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(stall_ms_));
     const unsigned tag = ++cmd_tag_;
     volatile unsigned long long *c = h_cmd_;
     const unsigned long long t = (unsigned long long)tag << 32;

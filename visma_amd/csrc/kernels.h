@@ -77,6 +77,7 @@ struct FoldArgs {
 // tag << 32}, each word validating itself (no fence anywhere): words 0..23 = the 3 x 4 transform, word 24 = command.
 // Every wait is bounded by the 100 MHz wall clock: a launch whose host went away ends by itself.
 constexpr int kPersistWords = 25;
+constexpr int kPersistPublished = 31;   // relay word: the tag of the pass whose statistics have been published
 constexpr unsigned kPersistGo = 1u, kPersistStop = 2u, kPersistAbort = 3u;
 struct PersistArgs {
     const unsigned long long *host_cmd;   // mapped, coherent host memory (device pointer), kPersistWords words -- or, `direct`,
@@ -87,8 +88,13 @@ struct PersistArgs {
     unsigned *host_flag;                  // mapped host memory: set to the pass count reached when a wait ran out
     int max_passes;                       // passes this launch may run (>= 1); the first needs no command
     unsigned tag0;                        // the command for pass p (1-based after the first) carries tag0 + p - 1
-    long long poll_ticks;                 // budget of the poller's wait, in wall_clock64 ticks (100 MHz)
-    long long wait_ticks;                 // ... of everybody else's (longer: the poller gives up first and says so)
+    long long poll_ticks;                 // (unused since the host keeps the patience: see wait_ticks)
+    long long wait_ticks;                 // how long a workgroup waits for a command AFTER the pass's statistics were published
+                                          // (wall_clock64 ticks, 100 MHz).  The HOST never posts GO later than a quarter of
+                                          // this after it saw the statistics (it posts STOP and carries on with ordinary
+                                          // launches), so no command can arrive while some workgroups have given up already
+    long long hard_ticks;                 // ... and before that publication (the pass is still running somewhere): a cap that
+                                          // only a lost workgroup could reach
     unsigned long long *timeline;         // measurement (VISMA_ICP_PERSIST_TIMELINE), else NULL: per pass and workgroup the
     int timeline_passes;                  // 100 MHz clock when the pass began and when its body (fold ticket included) was done
 };
