@@ -168,3 +168,52 @@ def test_two_contexts_in_one_process_take_turns():
         assert c.get_timing()["persist_aborts"] == 0
         c.close()
     ref.close()
+
+
+def _racing_process(rank, barrier, q):
+    import numpy as np
+    from visma_amd import _lib, synth
+    src, tgt, T_gt, r = synth.make_pair(262144, 600000, seed_t=58, seed_s=59, motion="radius")
+    c = _lib.Context(0)
+    c.set_persistent(True, timeout_ms=20.0)
+    c.set_nn_mode(_lib.NN_GRID)
+    c.set_clouds_f64(src, tgt)
+    c.run(None, r, 2, 0.0, 0.0)
+    barrier.wait()
+    out = None
+    for _ in range(4):
+        c.forget_winners()
+        out = c.run(None, r, 25, 0.0, 0.0)
+    tm = c.get_timing()
+    q.put((rank, out.transformation_, out.num_correspondences, tm["persist_aborts"]))
+    c.close()
+
+
+def test_two_processes_whose_launches_want_every_compute_unit_both_finish():
+    """Two processes start 1,024-workgroup persistent launches on the same GPU at the same moment: each may get a part of
+    the compute units and wait for the rest.  Neither may hang: a launch that sees its own workgroups missing gives up
+    after its patience, the registration restarts the pass cold with ordinary launches -- both end with the registration's
+    result (to rounding: a cold pass sums along another tree)."""
+    import multiprocessing as mp
+    import time
+    src, tgt, T_gt, r = synth.make_pair(262144, 600000, seed_t=58, seed_s=59, motion="radius")
+    ref = _lib.Context(0)
+    ref.set_persistent(False)
+    ref.set_nn_mode(_lib.NN_GRID)
+    ref.set_clouds_f64(src, tgt)
+    want = ref.run(None, r, 25, 0.0, 0.0)
+    ref.close()
+    ctx = mp.get_context("spawn")
+    barrier, q = ctx.Barrier(2), ctx.Queue()
+    ps = [ctx.Process(target=_racing_process, args=(i, barrier, q)) for i in range(2)]
+    t0 = time.time()
+    for p in ps:
+        p.start()
+    got = [q.get(timeout=240) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert time.time() - t0 < 200
+    for rank, T, k, aborts in got:
+        assert k == want.num_correspondences
+        assert synth.rel_frobenius(T, want.transformation_) < 1e-9, (rank, aborts)

@@ -882,14 +882,24 @@ __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa
         const bool ok = !mine || (unsigned)(w >> 32) == tag;
         if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
         const long long now = (long long)wall_clock64();
+        bool all_here = true, dead = false;
         if (!published) {
             const unsigned long long m = __hip_atomic_load(pa.relay + kPersistPublished, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((unsigned)m == tag) { published = true; t_ref = now; }
+            else {
+                all_here = __hip_atomic_load(pa.relay + kPersistStarted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned long long)gridDim.x;
+                // (somebody left early -- its workgroups were not all running in time --: no fold of this launch can
+                //  complete any more, whatever the others of us still do)
+                dead = __hip_atomic_load(pa.relay + kPersistDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+            }
         }
-        if (now - t_ref > (published ? pa.wait_ticks : pa.hard_ticks)) {
+        if (dead || now - t_ref > ((published || !all_here) ? pa.wait_ticks : pa.hard_ticks)) {
             // nothing came: everybody leaves (the command word decides; the transform words are not looked at)
             w = ((unsigned long long)tag << 32) | (lane == kPersistWords - 1 ? kPersistAbort : 0u);
-            if (poller && lane == 0) __hip_atomic_store(pa.host_flag, (unsigned)pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (lane == 0) {
+                __hip_atomic_store(pa.relay + kPersistDead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pa.host_flag, (unsigned)pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             break;
         }
         if (poller) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(3);
@@ -930,6 +940,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __shared__ unsigned s_tw[2][24];
     __shared__ unsigned s_cmdw;
     if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(P.pa.relay + kPersistStarted, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (this workgroup runs)
 #pragma unroll
         for (int k = 0; k < 12; k++) {
             const unsigned long long c = (unsigned long long)__double_as_longlong(P.T64.m[k]);

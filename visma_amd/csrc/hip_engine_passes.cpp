@@ -159,6 +159,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                     pa.poll_ticks = 0;
                     pa.wait_ticks = (long long)(4.0 * persist_timeout_ms_ * 1e5) + 1000000ll;   // (100 MHz; host patience x 4 + 10 ms)
                     pa.hard_ticks = 60ll * 100000000ll;
+                    HIP_TRY(hipMemsetAsync((unsigned long long *)d_relay_ + kPersistDead, 0, 2 * sizeof(unsigned long long), stream_));   // (dead, started)
                     if (!timeline_path_.empty()) {
                         // (measurement: clocks of up to 64 passes of this launch, read back when it has ended)
                         if (!d_timeline_) HIP_TRY(hipMalloc(&d_timeline_, sizeof(unsigned long long) * 2 * 64 * 1024));

@@ -78,6 +78,8 @@ struct FoldArgs {
 // Every wait is bounded by the 100 MHz wall clock: a launch whose host went away ends by itself.
 constexpr int kPersistWords = 25;
 constexpr int kPersistPublished = 31;   // relay word: the tag of the pass whose statistics have been published
+constexpr int kPersistDead = 29;        // relay word: nonzero once a workgroup of this launch has left early (the launch can never fold again)
+constexpr int kPersistStarted = 30;     // relay word: workgroups of this launch that have begun (zeroed on the stream before the launch)
 constexpr unsigned kPersistGo = 1u, kPersistStop = 2u, kPersistAbort = 3u;
 struct PersistArgs {
     const unsigned long long *host_cmd;   // mapped, coherent host memory (device pointer), kPersistWords words -- or, `direct`,
@@ -94,7 +96,9 @@ struct PersistArgs {
                                           // this after it saw the statistics (it posts STOP and carries on with ordinary
                                           // launches), so no command can arrive while some workgroups have given up already
     long long hard_ticks;                 // ... and before that publication (the pass is still running somewhere): a cap that
-                                          // only a lost workgroup could reach
+                                          // only a lost workgroup could reach -- unless not every workgroup of the launch has
+                                          // begun by then (another process's persistent launch holds the rest of the compute
+                                          // units and waits for ours): then wait_ticks
     unsigned long long *timeline;         // measurement (VISMA_ICP_PERSIST_TIMELINE), else NULL: per pass and workgroup the
     int timeline_passes;                  // 100 MHz clock when the pass began and when its body (fold ticket included) was done
 };
