@@ -18,6 +18,8 @@ def main(rank, world, conn, device, device_loop):
     conn.send(ctx.comm_ipc_export())
     handles = conn.recv()
     ctx.comm_ipc_init(rank, world, handles)
+    ctx.set_profiling(1)                          # (counts the persistent launches, if any ran)
+    ctx.get_timing(reset=True)
     res = ctx.run(None, r, 12, 0.0, 0.0)
     # registrations that STOP EARLY (loose stop test), again and again: in the device loop the launches
     # queued after convergence return without exchanging -- they must not use up exchange numbers, or the
@@ -27,7 +29,8 @@ def main(rank, world, conn, device, device_loop):
         e = ctx.run(None, r, 3 + 2 * k, 3e-2, 3e-2)
         early.append((int(e.iterations), int(e.num_correspondences), np.asarray(e.transformation_)))
     T2, last = ctx.iterate(np.eye(4), r, 5)
+    tm = ctx.get_timing()
     conn.send((np.asarray(res.transformation_), int(res.num_correspondences), float(res.fitness_),
-               float(res.inlier_rmse_), np.asarray(T2), early))
+               float(res.inlier_rmse_), np.asarray(T2), early, (tm["persist_launches"], tm["persist_passes"], tm["persist_aborts"])))
     conn.recv()                                   # keep the mailbox alive until every rank is done
     ctx.close()

@@ -13,8 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 
-def _run(world, device_loop):
+def _run(world, device_loop, persist_on_shared_gpu=False):
     import ipc_worker
+    # (ranks that share a device never keep persistent launches alive side by side -- except when a test says its clouds
+    #  are small enough for all of them to be resident together)
+    if persist_on_shared_gpu:
+        os.environ["VISMA_ICP_PERSIST_SHARED_GPU"] = "1"
+    else:
+        os.environ.pop("VISMA_ICP_PERSIST_SHARED_GPU", None)
     from visma_amd import _lib, synth
     ndev = int(os.environ.get("VISMA_TEST_NDEV", "0")) or 1
     ndev = max(ndev, _lib.device_count())
@@ -40,6 +46,7 @@ def _run(world, device_loop):
         for a in pipes:
             a.send(b"bye")
     finally:
+        os.environ.pop("VISMA_ICP_PERSIST_SHARED_GPU", None)
         for p in procs:
             p.join(30)
             if p.is_alive():
@@ -54,10 +61,18 @@ def _run(world, device_loop):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,device_loop", [(2, False), (3, False), (2, True)])
-def test_ranks_in_processes_hold_the_single_gpu_result(lib, world, device_loop):
+@pytest.mark.parametrize("world,device_loop,persist", [(2, False, False), (3, False, False), (2, True, False), (2, False, True), (3, False, True)])
+def test_ranks_in_processes_hold_the_single_gpu_result(lib, world, device_loop, persist):
+    """persist: the ranks' host loops each keep ONE launch alive across their passes (what one rank per GPU does; here
+    the ranks share GPU 0 and say so is fine): the folding workgroup of every launch exchanges with the peers' launches
+    through the mailboxes pass after pass -- same results, and the launches must really have run."""
     from visma_amd import synth
-    outs, w = _run(world, device_loop)
+    outs, w = _run(world, device_loop, persist)
+    for o in outs:
+        launches, passes, aborts = o[6]
+        assert aborts == 0
+        assert (launches > 0 and passes > launches) if persist else launches == 0, o[6]
+    outs = [o[:6] for o in outs]
     for T, k, fit, rmse, T2, early in outs:
         assert k == w.num_correspondences
         assert synth.rel_frobenius(T, w.transformation_) < 1e-12

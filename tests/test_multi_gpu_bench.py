@@ -80,6 +80,21 @@ def test_two_source_sharded_ranks_on_one_gpu(lib, one_rank, comm, want):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(1800)
+def test_two_source_sharded_ranks_keep_their_launches_alive(lib, one_rank):
+    """What one rank per GPU does since round 4b: every rank's host loop keeps ONE launch of the certificate kernel alive,
+    the folding workgroups of the ranks' launches exchange through the mailboxes pass after pass.  Ranks that share a GPU do
+    not (their launches would wait for each other's compute units) unless told that they fit side by side: 2 x 128
+    workgroups here."""
+    two = _bench(["--shard", "source", "--no-weak", "--no-extras"],
+                 {"VISMA_BENCH_COMM": "ipc", "VISMA_TEST_SHARE_GPU": "1", "VISMA_ICP_PERSIST_SHARED_GPU": "1"}, 2)
+    _same_registration(one_rank, two)
+    assert "hipipc" in two["config"]["parallelism"].lower()
+    launch = two["roofline"].get("launch", {})
+    assert launch.get("persistent") is True and launch["passes_per_launch"] > 1, two["roofline"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
 def test_two_target_sharded_ranks_on_one_gpu(lib, one_rank):
     """north_star's decomposition: each rank holds half of the target; per pass a MIN exchange of the f64
     distances, a MIN exchange of the claimed indices, then the 38-double sum (host callbacks on one GPU)."""

@@ -367,10 +367,16 @@ __device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
     return v;
 }
 
+// TABLE: the mailboxes come from `table` (device memory) instead of `peers` (a by-value argument)
+template <bool TABLE = false>
 __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeers &peers, int rank, int nranks,
                                                unsigned long long seq, int *timeout_flag, long long max_spins,
-                                               bool &late)
+                                               bool &late, void *const *table = nullptr)
 {
+    auto box = [&](int r) -> void * {
+        if constexpr (TABLE) return table[r];
+        else return peers.box[r];
+    };
     // granule = {value bits 0..31, tag, value bits 32..63, tag} with tag = the low 32 bits of the call count:
     // each 8-byte half validates itself, so the protocol only needs 8-byte stores to arrive whole (the
     // 16-byte store may be split in two on its way through the fabric)
@@ -383,8 +389,12 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
         g.z = (unsigned)(v >> 32); g.w = tag;
         const size_t half = (size_t)(seq & 1ull) * kIpcMaxRanks * kNStats;
         for (int p = 0; p < nranks; p++)
-            __builtin_nontemporal_store(g, reinterpret_cast<u4_t *>(peers.box[p]) + half + rank * kNStats + a);
-        const u4_t *own = reinterpret_cast<const u4_t *>(peers.box[rank]) + half;
+        {
+            u4_t *dst = reinterpret_cast<u4_t *>(box(p)) + half + rank * kNStats + a;
+            if constexpr (TABLE) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(g) : "memory");   // (the launch goes on: written through now)
+            else __builtin_nontemporal_store(g, dst);
+        }
+        const u4_t *own = reinterpret_cast<const u4_t *>(box(rank)) + half;
         for (int r = 0; r < nranks; r++) {
             u4_t w;
             long long spins = 0;
@@ -515,7 +525,7 @@ __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *part
     __shared__ double f_stats[kNStats + 2];
     if (tid == 0) expand_moments<PLANE>(f_tot, f_stats);
     __syncthreads();
-    if (!LOOPED && f.ipc_n > 1) {
+    if (f.ipc_n > 1) {
         // source-sharded ranks: this workgroup's first wave exchanges the statistics with the peers
         // (remote stores over xGMI, rank-ordered sum) before anything is published
         // the number of THIS exchange: kept in device memory, advanced by the one workgroup that exchanges
@@ -528,8 +538,9 @@ __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *part
         __syncthreads();
         if (tid < 64) {
             bool late = false;
-            const double sum = ipc_exchange(tid, tid < kNStats ? f_stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n,
-                                            f_seq, f.ipc_flag, f.ipc_spins, late);
+            // (inside the persistent kernel the mailboxes are read from the table in device memory)
+            const double sum = ipc_exchange<LOOPED>(tid, tid < kNStats ? f_stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n,
+                                                    f_seq, f.ipc_flag, f.ipc_spins, late, f.peer_table);
             if (tid < kNStats) f_stats[tid] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
             if (late) f_flag[0] = 1;
         }

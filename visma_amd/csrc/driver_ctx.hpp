@@ -86,7 +86,9 @@ struct visma_icp_ctx {
     bool use_device_loop_batched() const { return loop_mode != 0 && device_loop_possible(); }
     // one rank, nothing summed on the host between a pass and the next: the engine may keep one launch alive across
     // the passes of a loop (ranks that share a GPU would wait for each other's workgroups)
-    bool solo() const { return !host_allreduce && nranks == 1 && !target_sharded; }
+    // (source-sharded ranks that exchange through their peer-to-peer mailboxes, one rank per GPU: the exchange happens
+    //  inside the launch, so it may stay alive there too -- the engine knows whether the ranks share a device)
+    bool solo() const { return !host_allreduce && !target_sharded && (nranks == 1 || eng->loop_across_ranks_ok()); }
     static bool wants_world_frame(int solver, bool plane) { return plane || solver != VISMA_ICP_SOLVER_KABSCH; }
 
     // T_centred <- update o T_centred, with the update expressed in `world` or centred frame

@@ -258,6 +258,7 @@ public:
     // the persistent certificate kernel).  loop_end() must follow on every path; LoopScope does that.
     virtual void set_persistent(int /*enabled*/, double /*timeout_ms*/) {}
     virtual void stall_command(int /*nth*/, double /*ms*/) {}
+    virtual bool loop_across_ranks_ok() const { return false; }   // source-sharded ranks may keep a launch alive across passes too
     virtual void loop_begin(int /*max_passes*/) {}
     virtual int loop_end() { return VISMA_ICP_OK; }
     struct LoopScope {

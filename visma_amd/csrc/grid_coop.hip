@@ -954,7 +954,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     for (int pass = 1;; pass++) {
         KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));                         // (nothing read through it is loop-invariant to the compiler)
-        // (member by member: scalar loads straight into registers; the fold's ipc fields stay zero: no exchange)
+        // (member by member: scalar loads straight into registers)
 #define VISMA_KARG(F_) ld_karg(&kp->F_)
         const unsigned long long t_begin = VISMA_KARG(pa.timeline) ? wall_clock64() : 0ull;
         unsigned work = 0u;
@@ -977,6 +977,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         f.ticket_stride = VISMA_KARG(fold.ticket_stride); f.stats_out = VISMA_KARG(fold.stats_out);
         f.stats_stride = VISMA_KARG(fold.stats_stride); f.host_out = VISMA_KARG(fold.host_out);
         f.seq = VISMA_KARG(fold.seq) + (unsigned long long)(pass - 1);
+        // (source-sharded ranks, one per GPU: the folding workgroup exchanges with the peers through their mailboxes, read
+        //  from the table in device memory)
+        f.ipc_n = VISMA_KARG(fold.ipc_n); f.ipc_rank = VISMA_KARG(fold.ipc_rank); f.ipc_seq_dev = VISMA_KARG(fold.ipc_seq_dev);
+        f.ipc_flag = VISMA_KARG(fold.ipc_flag); f.ipc_spins = VISMA_KARG(fold.ipc_spins); f.peer_table = VISMA_KARG(fold.peer_table);
         const bool published = coop_body<PLANE, true, kBlock, true>(
             VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
             VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
@@ -1032,7 +1036,7 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
     if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
     if (persist) {
         // one registration, one query per lane, the fold and its publication inside the launch, everybody resident
-        if (descs || nprob != 1 || !one || st || !fold.tickets || !fold.host_out || fold.ipc_n > 1 || d64_out ||
+        if (descs || nprob != 1 || !one || st || !fold.tickets || !fold.host_out || (fold.ipc_n > 1 && !fold.peer_table) || d64_out ||
             persist->max_passes < 1 || !persist->host_cmd || !persist->relay || !persist->host_flag ||
             total_blocks > coop_persist_capacity(point_to_plane))
             return hipErrorInvalidValue;

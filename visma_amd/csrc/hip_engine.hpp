@@ -42,7 +42,7 @@ public:
         if (h_cmd_ && !cmd_direct_) (void)hipHostFree(h_cmd_);
         if (d_cmd_block_) (void)hipFree(d_cmd_block_);
         if (h_flag_) (void)hipHostFree(h_flag_);
-        free_dev(d_relay_); free_dev(d_timeline_);
+        free_dev(d_relay_); free_dev(d_timeline_); free_dev(d_peer_table_);
         pool_trim(0);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -249,6 +249,7 @@ public:
         loop_scope_ = true;
         loop_budget_ = max_passes;
     }
+    bool loop_across_ranks_ok() const override { return persist_ranks_ok(); }
     int loop_end() override
     {
         loop_scope_ = false;
@@ -596,6 +597,7 @@ private:
     void add_ipc(FoldArgs *fa)
     {
         fa->peers = peers_;
+        fa->peer_table = (void *const *)d_peer_table_;
         fa->ipc_rank = ipc_rank_;
         fa->ipc_n = ipc_n_;
         fa->ipc_seq_dev = ipc_seq_dev();
@@ -627,6 +629,14 @@ private:
     std::vector<std::pair<int, int>> sess_pending_;   // (event pair, passes run) of finished sessions
     unsigned long long *h_cmd_ = nullptr, *h_cmd_dev_ = nullptr;   // kPersistWords command words; word 32: the kernel's flag
     void *d_relay_ = nullptr;
+    void *d_peer_table_ = nullptr;   // peers_ in device memory (the persistent kernel's fold reads the mailboxes from there)
+    bool peers_share_device_ = true; // some peer of the IPC ring sits on THIS device (tests): no persistent launch then --
+                                     // the ranks' launches would each hold a part of the compute units and wait for the rest
+    bool persist_ranks_ok() const
+    {
+        static const bool shared_ok = std::getenv("VISMA_ICP_PERSIST_SHARED_GPU") != nullptr;   // (tests with small clouds)
+        return ipc_n_ > 1 && d_peer_table_ && !comm_ && (!peers_share_device_ || shared_ok);
+    }
     bool cmd_direct_ = false;        // h_cmd_ is fine-grained DEVICE memory, stored to through the PCIe BAR (large-BAR systems)
     void *d_cmd_block_ = nullptr;
     unsigned *h_flag_ = nullptr, *h_flag_dev_ = nullptr;   // the launch's "gave up" word, always in mapped host memory

@@ -224,6 +224,47 @@ int HipEngine::ipc_init(int rank, int nranks, const void *handles)
                         : std::string("peer-to-peer handshake: wrong sum");
             return VISMA_ICP_ERR_HIP;
         }
+        // Who sits where: a second all-reduce in which every rank contributes the PCI address of its device in its own
+        // slot.  Ranks that share a device (tests run two on one GPU) must not keep persistent launches alive side by
+        // side; one rank per GPU may (hip_engine.hpp: persist_ranks_ok).
+        {
+            int dom = 0, bus = 0, dev = 0;
+            (void)hipDeviceGetAttribute(&dom, hipDeviceAttributePciDomainID, device_);
+            (void)hipDeviceGetAttribute(&bus, hipDeviceAttributePciBusId, device_);
+            (void)hipDeviceGetAttribute(&dev, hipDeviceAttributePciDeviceId, device_);
+            (void)hipGetLastError();
+            const double me = 1.0 + (double)(((long long)dom << 16) | ((long long)bus << 8) | (long long)dev);
+            for (int a = 0; a < kNStats; a++) hs[(size_t)a] = a == rank ? me : 0.0;
+            double *d_id = nullptr;
+            peers_share_device_ = true;
+            if (hipMalloc((void **)&d_id, sizeof(double) * kNStats) == hipSuccess) {
+                hipError_t e2 = hipMemcpyAsync(d_id, hs.data(), sizeof(double) * kNStats, hipMemcpyHostToDevice, stream_);
+                if (e2 == hipSuccess)
+                    e2 = launch_ipc_allreduce(d_id, d_id, peers_, ipc_rank_, ipc_n_, ipc_seq_dev(), nullptr, 0, (int *)d_ipc_flag_,
+                                              stream_, kIpcHandshakeSpins);
+                if (e2 == hipSuccess) e2 = hipMemcpyAsync(hs.data(), d_id, sizeof(double) * kNStats, hipMemcpyDeviceToHost, stream_);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream_);
+                (void)hipFree(d_id);
+                if (e2 == hipSuccess) {
+                    bool shared = false;
+                    for (int r = 0; r < nranks; r++) shared = shared || (r != rank && hs[(size_t)r] == me) || hs[(size_t)r] < 1.0;
+                    peers_share_device_ = shared;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        // the mailboxes as a table in device memory (what the persistent kernel's fold indexes)
+        free_dev(d_peer_table_);
+        if (hipMalloc(&d_peer_table_, sizeof(void *) * kIpcMaxRanks) == hipSuccess) {
+            if (hipMemcpy(d_peer_table_, peers_.box, sizeof(void *) * kIpcMaxRanks, hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipGetLastError();
+                free_dev(d_peer_table_);
+            }
+        } else {
+            (void)hipGetLastError();
+            d_peer_table_ = nullptr;
+        }
     }
     return VISMA_ICP_OK;
 }

@@ -137,6 +137,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 sess_pass_++;
                 in_session = true;
                 posted = true;                               // (its transform becomes "the previous one" once the pass has run)
+                ipc_done = true;                             // (ranks: the folding workgroup exchanges inside the launch)
                 last_kernel_ = 2;
             } else {
                 int rc = end_session();
@@ -346,7 +347,7 @@ bool HipEngine::persist_possible(int lanes, int nblocks, bool fused, bool plane)
         return false;
     };
     if (!persist_enabled_) return no("switched off");
-    if (!fused || tshard_ || comm_ || ipc_n_ > 1 || minreduce_) return no("sharded ranks / fold in a second launch");
+    if (!fused || tshard_ || comm_ || minreduce_ || (ipc_n_ > 1 && !persist_ranks_ok())) return no("sharded ranks / fold in a second launch");
     if (lanes != kCoopLanes || !coop_ok() || !pos_fresh_) return no("not a pass of the certificate kernel");
     if (grid_lanes_ > 0 && grid_lanes_ != kCoopLanes) return no("lanes forced");
     if (std::getenv("VISMA_ICP_COOP_KERNEL")) return no("kernel forced");       // (A/B runs of the two one-pass kernels)

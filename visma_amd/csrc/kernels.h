@@ -67,6 +67,8 @@ struct FoldArgs {
                                        // must not burn a number: the two mailbox halves alternate by it)
     int *ipc_flag;
     long long ipc_spins;
+    void *const *peer_table;           // the same mailboxes as `peers`, as a table in DEVICE memory: what the persistent
+                                       // kernel's fold reads (a by-value table indexed in a loop would live in scratch there)
 };
 
 // The PERSISTENT form of the certificate kernel (grid_coop.hip, round 4b): ONE launch runs up to max_passes ICP
