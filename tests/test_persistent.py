@@ -89,6 +89,38 @@ def test_persistent_loop_equals_one_launch_per_pass_bit_for_bit(name, ns, nt, ou
     b.close()
 
 
+def test_command_block_in_host_memory_is_polled_by_the_publisher_and_relayed():
+    """Without a large PCIe BAR (forced here: VISMA_ICP_PERSIST_CMD=host) the command block lies in mapped host memory:
+    only the workgroup that published polls it, the others take the words from its relay in device memory."""
+    import os
+    src, tgt, T_gt, r = synth.make_pair(65536, 400000, seed_t=68, seed_s=69, motion="radius")
+    a = _lib.Context(0)
+    a.set_persistent(False)
+    old = os.environ.get("VISMA_ICP_PERSIST_CMD")
+    os.environ["VISMA_ICP_PERSIST_CMD"] = "host"
+    try:
+        b = _lib.Context(0)
+    finally:
+        if old is None:
+            os.environ.pop("VISMA_ICP_PERSIST_CMD", None)
+        else:
+            os.environ["VISMA_ICP_PERSIST_CMD"] = old
+    for c in (a, b):
+        c.set_nn_mode(_lib.NN_GRID)
+        c.set_clouds_f64(src, tgt)
+    b.set_profiling(1)
+    b.get_timing(reset=True)
+    same_result(a.run(None, r, 30, 0.0, 0.0), b.run(None, r, 30, 0.0, 0.0))
+    Ta, _ = a.iterate(None, r, 11)
+    Tb, _ = b.iterate(None, r, 11)
+    assert np.array_equal(Ta, Tb)
+    assert np.array_equal(a.correspondence_index(), b.correspondence_index())
+    tm = b.get_timing(reset=True)
+    assert tm["persist_launches"] == 2 and tm["persist_passes"] == 30 + 11 and tm["persist_aborts"] == 0, tm
+    a.close()
+    b.close()
+
+
 def test_persistent_point_to_plane_and_gauss_newton(lib):
     src, tgt, T_gt, r = synth.make_pair(20000, 90000, seed_t=28, seed_s=29, motion="radius")
     src = src.copy()

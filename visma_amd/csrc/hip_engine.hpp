@@ -276,7 +276,12 @@ public:
     }
     int nn_mode_used() const override { return use_grid_ ? VISMA_ICP_NN_GRID : VISMA_ICP_NN_BRUTE; }
     int search_kernel_used() const override { return use_grid_ ? last_kernel_ : 0; }
-    int forget_winners() override { HIP_TRY(hipSetDevice(device_)); return invalidate_pos(); }
+    int forget_winners() override
+    {
+        HIP_TRY(hipSetDevice(device_));
+        if (sess_live_) { int rc = end_session(); if (rc) return rc; }
+        return invalidate_pos();
+    }
 
     int set_target_shard(int64_t offset, int64_t global_nt) override;
     void set_minreduce(visma_icp_minreduce_fn fn, void *user) override { minreduce_ = fn; minreduce_user_ = user; }

@@ -68,6 +68,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     int e0 = -1;
     // profiling level n > 1: time (and count candidates on) every n-th pass only --
     // four event records per iteration cost ~14 us of the ~75 they measure
+    if (sess_live_ && !use_grid_) { int src = end_session(); if (src) return src; }   // (the search changed under a live launch)
     const bool prof = profiling_ > 0 && (++prof_tick_ % profiling_) == 0;
     // without RCCL the fold kernel publishes to mapped host memory itself
     const unsigned long long seq = ++pub_seq_;
@@ -443,6 +444,7 @@ int HipEngine::end_session()
 int HipEngine::get_correspondences(int32_t *idx, float *d2)
 {
     HIP_TRY(hipSetDevice(device_));
+    if (sess_live_) { int src = end_session(); if (src) return src; }   // (never behind a launch that waits for this thread)
     if (!have_pass_) { err_ = "no nn_pass yet"; return VISMA_ICP_ERR_STATE; }
 #ifdef VISMA_WITH_TILE
     if (use_grid_ && grid_pending_ && use_tile()) {
@@ -493,6 +495,7 @@ int HipEngine::get_correspondences(int32_t *idx, float *d2)
 int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopResult *out)
 {
     HIP_TRY(hipSetDevice(device_));
+    if (sess_live_) { int src = end_session(); if (src) return src; }
     if (nprob < 1) { err_ = "nprob < 1"; return VISMA_ICP_ERR_INVALID; }
     if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
     if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
@@ -673,6 +676,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
 int HipEngine::run_loop_batch(const LoopParams &lp, const std::vector<BatchProblem> &pb, LoopResult *out)
 {
     HIP_TRY(hipSetDevice(device_));
+    if (sess_live_) { int src = end_session(); if (src) return src; }
     const int B = (int)pb.size();
     if (B < 1) return VISMA_ICP_OK;
     if (comm_) { err_ = "batched loop is single-GPU"; return VISMA_ICP_ERR_STATE; }
