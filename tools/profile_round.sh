@@ -28,5 +28,9 @@ python tools/pmc_summarize.py $out/pmc_kernel nn_ > $out/pmc_kernel_summary.csv
 # the persistent launch: per-pass / per-workgroup clocks, host-side gaps, the two mailbox round trips
 ( VISMA_ICP_PERSIST_TRACE=1 VISMA_ICP_PERSIST_TIMELINE=/tmp/tl_$tag.bin timeout 300 python tools/persist_probe.py 4194304 262144 5000 > $out/persist_probe_traced.jsonl 2> $out/persist_host_gaps.txt; python tools/persist_timeline.py /tmp/tl_$tag.bin > $out/persist_timeline.txt 2>&1 )
 timeout 300 python tools/persist_probe.py 4194304 262144 131072 65536 5000 > $out/persist_probe.jsonl 2>&1
+mkdir -p tools/ubench/_build
+for u in host_mailbox device_mailbox; do
+  [ -x tools/ubench/_build/$u ] || hipcc --offload-arch=gfx950 -O3 tools/ubench/$u.hip -o tools/ubench/_build/$u 2> /dev/null
+done
 ( timeout 60 tools/ubench/_build/host_mailbox; timeout 120 tools/ubench/_build/device_mailbox ) > $out/mailbox_ubench.txt 2>&1
 ls $out
