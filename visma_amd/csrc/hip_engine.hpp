@@ -645,7 +645,6 @@ private:
     bool cmd_direct_ = false;        // h_cmd_ is fine-grained DEVICE memory, stored to through the PCIe BAR (large-BAR systems)
     void *d_cmd_block_ = nullptr;
     unsigned *h_flag_ = nullptr, *h_flag_dev_ = nullptr;   // the launch's "gave up" word, always in mapped host memory
-    int persist_sessions_ = 0, persist_aborts_ = 0;
     std::chrono::steady_clock::time_point t_stats_seen_{}, t_posted_{};   // when the host saw a pass's statistics / posted a command
     static bool trace_persist() { static const bool t = std::getenv("VISMA_ICP_PERSIST_TRACE") != nullptr; return t; }
     double host_gap_us_ = 0.0, wait_us_ = 0.0;

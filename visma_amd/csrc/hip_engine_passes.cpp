@@ -124,7 +124,6 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 const double gap_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_stats_seen_).count();
                 patient = gap_us <= persist_timeout_ms_ * 1e3;
                 if (!patient) {
-                    persist_aborts_++;
                     timing_.persist_aborts += 1.0;
                     persist_enabled_ = 0;                    // (until visma_icp_set_persistent asks again)
                 } else if (trace_persist()) {
@@ -158,7 +157,6 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                     pa.host_flag = h_flag_dev_;
                     pa.max_passes = sess_max_;
                     pa.tag0 = sess_tag0_;
-                    pa.poll_ticks = 0;
                     pa.wait_ticks = (long long)(4.0 * persist_timeout_ms_ * 1e5) + 1000000ll;   // (100 MHz; host patience x 4 + 10 ms)
                     pa.hard_ticks = 60ll * 100000000ll;
                     HIP_TRY(hipMemsetAsync((unsigned long long *)d_relay_ + kPersistDead, 0, 2 * sizeof(unsigned long long), stream_));   // (dead, started)
@@ -244,7 +242,6 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         HIP_TRY(hipStreamSynchronize(stream_));
         seen = all_tagged();
         if (!seen) {
-            persist_aborts_++;
             timing_.persist_aborts += 1.0;
             if (trace_persist())
                 std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
@@ -378,7 +375,6 @@ int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3]
     for (int a = 0; a < 3; a++) sess_off_[a] = offset[a];
     sess_e0_ = -1;
     *reinterpret_cast<volatile unsigned *>(h_flag_) = 0u;
-    persist_sessions_++;
     return VISMA_ICP_OK;
 }
 

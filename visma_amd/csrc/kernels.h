@@ -92,7 +92,6 @@ struct PersistArgs {
     unsigned *host_flag;                  // mapped host memory: set to the pass count reached when a wait ran out
     int max_passes;                       // passes this launch may run (>= 1); the first needs no command
     unsigned tag0;                        // the command for pass p (1-based after the first) carries tag0 + p - 1
-    long long poll_ticks;                 // (unused since the host keeps the patience: see wait_ticks)
     long long wait_ticks;                 // how long a workgroup waits for a command AFTER the pass's statistics were published
                                           // (wall_clock64 ticks, 100 MHz).  The HOST never posts GO later than a quarter of
                                           // this after it saw the statistics (it posts STOP and carries on with ordinary
