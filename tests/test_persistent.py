@@ -250,3 +250,26 @@ def test_two_processes_whose_launches_want_every_compute_unit_both_finish():
     for rank, T, k, aborts in got:
         assert k == want.num_correspondences
         assert synth.rel_frobenius(T, want.transformation_) < 1e-9, (rank, aborts)
+
+
+def test_short_loops_and_tiny_clouds():
+    """The budget edges of a host loop (0, 1, 2, 3 iterations: no launch to keep alive, a launch of one pass, ...) and clouds
+    of a handful of points (one workgroup, lanes without a query)."""
+    rng = np.random.default_rng(7)
+    for ns, nt in ((1, 50), (3, 3), (70, 1000), (257, 5000)):
+        tgt = rng.standard_normal((nt, 3))
+        src = tgt[rng.integers(0, nt, ns)] + rng.standard_normal((ns, 3)) * 0.01
+        a, b = pair_of_contexts(src, tgt)
+        for max_iter in (0, 1, 2, 3, 7):
+            for c in (a, b):
+                c.forget_winners()
+            same_result(a.run(None, 0.3, max_iter, 0.0, 0.0), b.run(None, 0.3, max_iter, 0.0, 0.0))
+        Ta, Tb = np.eye(4), np.eye(4)
+        for steps in (1, 1, 2, 3, 1):
+            Ta, ra = a.iterate(Ta, 0.3, steps)
+            Tb, rb = b.iterate(Tb, 0.3, steps)
+            assert np.array_equal(Ta, Tb), (ns, nt, steps)
+            same_result(ra, rb)
+        assert b.get_timing()["persist_aborts"] == 0
+        a.close()
+        b.close()
