@@ -120,7 +120,11 @@ int HipEngine::set_target_f64(const double *xyz, int64_t nt, int stride, double 
         struct Piece { int64_t lo, hi; bool f32; };
         std::vector<Piece> pieces;
         bool try32 = true;
+        static const bool trace_pieces = std::getenv("VISMA_ICP_UPLOAD_TRACE") != nullptr;
+        const auto t_up0 = std::chrono::steady_clock::now();
+        double stage_ms = 0.0;
         for (int64_t lo = 0; lo < nt; lo += piece) {
+            const auto t_p0 = std::chrono::steady_clock::now();
             const int64_t hi = std::min(nt, lo + piece);
             const int64_t nch = (hi - lo + kHostChunk - 1) / kHostChunk;      // (piece is a multiple of kHostChunk)
             std::atomic<bool> exact(true);
@@ -169,6 +173,7 @@ int HipEngine::set_target_f64(const double *xyz, int64_t nt, int stride, double 
                 as32 = false;                                // a value fp32 cannot hold: this piece again, as f64
                 try32 = false;
             }
+            stage_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_p0).count();
             // (an fp32 piece of a LATER upload may still be in flight from this area: the stream is in order,
             //  and the previous upload ended with a synchronise)
             if (as32)
@@ -202,6 +207,13 @@ int HipEngine::set_target_f64(const double *xyz, int64_t nt, int stride, double 
             }
         for (int k = 0; k < 3; k++) { host_mn_[k] = (float)(lo3[k] - c[k]); host_mx_[k] = (float)(hi3[k] - c[k]); }
         host_box_valid_ = std::isfinite(host_mn_[0] + host_mn_[1] + host_mn_[2] + host_mx_[0] + host_mx_[1] + host_mx_[2]);
+        if (trace_pieces) {
+            const double enq = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count();
+            (void)hipStreamSynchronize(stream_);
+            const double all = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up0).count();
+            std::fprintf(stderr, "target upload trace: %lld points in %d pieces: staging %.3f ms of %.3f ms on the host, %.3f ms until the stream is idle\n",
+                         (long long)nt, (int)pieces.size(), stage_ms, enq, all);
+        }
     } else if (compute_centre) {
         c[0] = c[1] = c[2] = 0.0;
     }
