@@ -116,7 +116,13 @@ int HipEngine::set_target_f64(const double *xyz, int64_t nt, int stride, double 
         // bounding box of the caller's values, per chunk (the grid build then needs no kernel and no round trip
         // for it: x -> (float)(x - c) is monotone, so the box of the fp32 target is the image of this one)
         std::vector<double> lohi((size_t)nch_all * 6);
-        const int64_t piece = 1 << 20;                       // (a parallel_for starts its threads anew)
+        // (pieces of 1 M points: each is staged by the host threads and goes out while the next one is staged;
+        //  VISMA_ICP_UPLOAD_PIECE = another multiple of 16,384 for experiments)
+        static const int64_t piece = [] {
+            const char *e = std::getenv("VISMA_ICP_UPLOAD_PIECE");
+            const long long v = e ? std::atoll(e) : 0;
+            return (v >= kHostChunk && v % kHostChunk == 0) ? (int64_t)v : (int64_t)1 << 20;
+        }();
         struct Piece { int64_t lo, hi; bool f32; };
         std::vector<Piece> pieces;
         bool try32 = true;
