@@ -419,7 +419,7 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
 // every storing wave drains, one relaxed agent atomic as the ticket, one acquire by the reader.
 // tickets: ticket_stride words per problem, zero before the first launch (the last arrivers
 // re-arm them); [0] = level 2, [1 + g] = level 1 of group g.
-constexpr int kFoldGroup = 32;
+// (kFoldGroup: kernels.h -- the host sizes the ticket and level-2 buffers by it)
 constexpr int kFoldSingle = 256;      // up to this many rows: one level
 // Returns true on the ONE workgroup of the problem that finished the fold and published the statistics.
 // LOOPED: called from the loop of the persistent kernel (no exchange with peers there; opaque thread number).

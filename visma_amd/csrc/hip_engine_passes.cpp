@@ -82,7 +82,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         // ONE launch: streamed search + exact re-rank + moments + fused fold + publication
         const int cfg = tile_config(ns_);
         const int nblocks = tile_blocks(ns_, cfg);
-        const size_t tstride = 1 + (size_t)(nblocks + 31) / 32;
+        const size_t tstride = 1 + (size_t)(nblocks + kFoldGroup - 1) / kFoldGroup;
         int rc = ensure_tile_buffers((size_t)nblocks, tstride);
         if (rc) return rc;
         TileArgs ta = tile_args(T64, offset, prof);
@@ -911,7 +911,7 @@ int HipEngine::run_loop_batch(const LoopParams &lp, const std::vector<BatchProbl
     if (fused_fold_) {
         int max_nb = 1;
         for (int b = 0; b < B; b++) max_nb = std::max(max_nb, descs[b].nblocks);
-        const size_t tstride = 1 + (size_t)(max_nb + 31) / 32;
+        const size_t tstride = 1 + (size_t)(max_nb + kFoldGroup - 1) / kFoldGroup;
         int rc2 = ensure_tile_buffers((size_t)total_blocks, tstride * B);
         if (rc2) return rc2;
         bfa.tickets = (unsigned *)d_tickets_;
@@ -973,7 +973,7 @@ int HipEngine::run_loop_batch(const LoopParams &lp, const std::vector<BatchProbl
 int HipEngine::make_fold(int bpp, int nprob, double *stats_out, long long stats_stride, double *host_out,
               unsigned long long seq, FoldArgs *out)
 {
-    const size_t tstride = 1 + (size_t)(bpp + 31) / 32;
+    const size_t tstride = 1 + (size_t)(bpp + kFoldGroup - 1) / kFoldGroup;
     int rc = ensure_tile_buffers((size_t)bpp * nprob, tstride * nprob);
     if (rc) return rc;
     out->tickets = (unsigned *)d_tickets_;

@@ -45,6 +45,14 @@ struct DevIcpState {
 };
 
 // The fold of the partial rows inside the search launch (device_common.h: fused_fold).
+// Rows per first-level group (launches of more than kFoldSingle rows fold in two levels).  16 since the end of round 4
+// (32 before): the last arrivers of the groups -- the slowest workgroups of a launch by construction -- sum half as many
+// rows, and the level-2 sum of 64 rows is still one batch of eight loads per thread: C4 22.2 vs 24.2 us per iteration
+// in the persistent launch, 25.9 vs 27.8 with one launch per pass (64: 26.4 in the persistent launch; 8: as 16).
+#ifndef VISMA_FOLD_GROUP
+#define VISMA_FOLD_GROUP 16
+#endif
+constexpr int kFoldGroup = VISMA_FOLD_GROUP;
 constexpr int kIpcMaxRanks = 16;
 constexpr long long kIpcSpinLimit = 200000000ll;    // polls of the own mailbox before a peer counts as lost (minutes)
 constexpr long long kIpcHandshakeSpins = 15000000ll;  // ... in the handshake of visma_icp_comm_ipc_init (tens of seconds)
