@@ -420,7 +420,10 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
 // tickets: ticket_stride words per problem, zero before the first launch (the last arrivers
 // re-arm them); [0] = level 2, [1 + g] = level 1 of group g.
 // (kFoldGroup: kernels.h -- the host sizes the ticket and level-2 buffers by it)
-constexpr int kFoldSingle = 256;      // up to this many rows: one level
+#ifndef VISMA_FOLD_SINGLE
+#define VISMA_FOLD_SINGLE 256
+#endif
+constexpr int kFoldSingle = VISMA_FOLD_SINGLE;      // up to this many rows: one level
 // Returns true on the ONE workgroup of the problem that finished the fold and published the statistics.
 // LOOPED: called from the loop of the persistent kernel (no exchange with peers there; opaque thread number).
 template <bool PLANE, int NTH, bool LOOPED = false>
