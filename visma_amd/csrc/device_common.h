@@ -420,8 +420,10 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
 // tickets: ticket_stride words per problem, zero before the first launch (the last arrivers
 // re-arm them); [0] = level 2, [1 + g] = level 1 of group g.
 // (kFoldGroup: kernels.h -- the host sizes the ticket and level-2 buffers by it)
+// (128 since the end of round 4, 256 before: 65,536 queries = 256 rows fold 0.8 us faster in two levels of 16 x 16 than
+//  with four batches of loads at one level -- 17.3 vs 18.1 us per iteration; 64: 128- and 79-row launches lose 0.5-1.2 us)
 #ifndef VISMA_FOLD_SINGLE
-#define VISMA_FOLD_SINGLE 256
+#define VISMA_FOLD_SINGLE 128
 #endif
 constexpr int kFoldSingle = VISMA_FOLD_SINGLE;      // up to this many rows: one level
 // Returns true on the ONE workgroup of the problem that finished the fold and published the statistics.
