@@ -902,7 +902,10 @@ __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa
             }
             break;
         }
-        if (poller) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(3);
+#ifndef VISMA_PERSIST_SLEEP
+#define VISMA_PERSIST_SLEEP 3
+#endif
+        if (poller) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(VISMA_PERSIST_SLEEP);
     }
     if (poller && mine && !direct) __hip_atomic_store(pa.relay + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return w;
