@@ -66,9 +66,9 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     Xform64 T64;
     for (int i = 0; i < 12; i++) T64.m[i] = Tc.m[i];
     int e0 = -1;
+    if (sess_live_ && !use_grid_) { int src = end_session(); if (src) return src; }   // (the search changed under a live launch)
     // profiling level n > 1: time (and count candidates on) every n-th pass only --
     // four event records per iteration cost ~14 us of the ~75 they measure
-    if (sess_live_ && !use_grid_) { int src = end_session(); if (src) return src; }   // (the search changed under a live launch)
     const bool prof = profiling_ > 0 && (++prof_tick_ % profiling_) == 0;
     // without RCCL the fold kernel publishes to mapped host memory itself
     const unsigned long long seq = ++pub_seq_;
@@ -235,10 +235,9 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
     };
     seen = wait_published();
     if (!seen && in_session) {
-        // The persistent launch ended without running this pass: it waited for the command longer than its patience
-        // (a stopped or descheduled host thread; workgroups that were not all resident after all).  Nothing of the
-        // pass has happened -- the state in memory is what the last completed pass left -- so it runs as an
-        // ordinary launch, and so do the passes after it.
+        // The stream is idle and the pass this thread asked for has not been published: the persistent launch ended by
+        // itself (its workgroups were not all resident in time -- another process's launch held the rest of the compute
+        // units --, or no command reached it within four times the host's patience).
         HIP_TRY(hipStreamSynchronize(stream_));
         seen = all_tagged();
         if (!seen) {
