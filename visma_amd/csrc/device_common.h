@@ -240,8 +240,19 @@ __device__ __forceinline__ int thread_number()
     return t;
 }
 
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+// a double as a granule {low half, tag, high half, tag}: each 8-byte half validates itself
+__device__ __forceinline__ void store_granule_agent(u4_t *dst, double v, unsigned tag)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    u4_t g;
+    g.x = (unsigned)b; g.y = tag; g.z = (unsigned)(b >> 32); g.w = tag;
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(g) : "memory");
+}
+
 template <int NACC, int NWAVES = kBlock / 64, bool OPAQUE_TID = false>
-__device__ __forceinline__ void block_reduce_store(double *acc, double *partials, bool agent = false)
+__device__ __forceinline__ void block_reduce_store(double *acc, double *partials, bool agent = false, void *tagged_row = nullptr,
+                                                   unsigned tag = 0u)
 {
     __shared__ double wsum[NWAVES][NACC];
     const int tidx = thread_number<OPAQUE_TID, NWAVES * 64>();
@@ -254,9 +265,15 @@ __device__ __forceinline__ void block_reduce_store(double *acc, double *partials
         double v = wsum[0][tidx];
 #pragma unroll
         for (int w = 1; w < NWAVES; w++) v += wsum[w][tidx];
-        double *dst = partials + (long long)blockIdx.x * kReduceAcc + tidx;
-        if (agent) store_agent_f64(dst, v);
-        else *dst = v;
+        if (tagged_row) {
+            // (persistent launches, polled fold: the row as self-validating granules, written through -- nobody waits for
+            //  an acknowledgement, the group's reducer polls for the tag)
+            store_granule_agent(reinterpret_cast<u4_t *>(tagged_row) + (long long)blockIdx.x * 32 + tidx, v, tag);
+        } else {
+            double *dst = partials + (long long)blockIdx.x * kReduceAcc + tidx;
+            if (agent) store_agent_f64(dst, v);
+            else *dst = v;
+        }
     }
 }
 
@@ -358,8 +375,6 @@ __device__ __forceinline__ void publish_tagged_stats(const double *stats, double
 // rank order.  The mailbox has two halves used alternately (call count parity): a rank can only start
 // call k+2 after every peer has SENT call k+1, which a peer does only after it has finished reading call
 // k, so a granule is never overwritten before its reader has seen it.
-typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
-
 __device__ __forceinline__ u4_t load_granule_sys(const u4_t *p)
 {
     u4_t v;
@@ -571,6 +586,136 @@ __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *part
             } else {
                 __builtin_nontemporal_store(g, dst);
             }
+        }
+    }
+    return true;
+}
+
+// ---- The POLLED fold of a persistent launch.  Every workgroup of the launch is resident, so nobody needs a ticket to
+// learn that it is the last: the rows are granules that validate themselves with the pass's tag, the FIRST workgroup of
+// every group of kFoldGroup rows polls its group's rows and writes the group row, workgroup 0 polls the group rows, sums,
+// expands and publishes.  Behind the slowest workgroup that is two store-to-poll latencies instead of two acknowledged
+// stores, two ticket round trips and two loads.  Sums in the order of fused_fold (rows sg, sg + NG, ... per thread, then
+// the thread groups in order): the statistics are bit-identical to its.  A reducer whose rows do not come (the launch
+// is dead: somebody left) gives up with everybody else.  Returns true on the workgroup that published.
+template <bool PLANE, int NTH>
+__device__ __forceinline__ bool polled_fold(const FoldArgs &f, int lb, int bpp, unsigned tag)
+{
+    constexpr int NACC = Acc<PLANE>::N;
+    constexpr int NG = NTH / 32;
+    __shared__ double p_part[NG][33];
+    __shared__ double p_tot[32];
+    __shared__ int p_dead;
+    const int tid = thread_number<true, NTH>();
+    const bool single = bpp <= kFoldSingle;
+    const int ngroups = single ? 1 : (bpp + kFoldGroup - 1) / kFoldGroup;
+    const int grp = single ? 0 : lb / kFoldGroup;
+    if (lb != grp * kFoldGroup) return false;                // (not the first of its group: the row is out, done)
+    const int gsize = single ? bpp : min(kFoldGroup, bpp - grp * kFoldGroup);
+    const int sa = tid & 31, sg = tid >> 5;
+    if (tid == 0) p_dead = 0;
+    __syncthreads();
+    const long long t0 = (long long)wall_clock64();
+    // the sum of `count` granule rows starting at `rows` (32 granules per row), rows sg, sg + NG, ... on this thread
+    auto poll_sum = [&](const u4_t *rows, int count) {
+        double v = 0.0;
+        if (sa < NACC)
+            for (int r0 = sg; r0 < count; r0 += 8 * NG) {
+                double w[8];
+                unsigned pending = 0u;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    w[u] = 0.0;
+                    if (r0 + u * NG < count) pending |= 1u << u;
+                }
+                while (pending) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (pending & (1u << u)) {
+                            const u4_t g = load_granule_sys(rows + (long long)(r0 + u * NG) * 32 + sa);
+                            if (g.y == tag && g.w == tag) {
+                                w[u] = __longlong_as_double((long long)(((unsigned long long)g.z << 32) | g.x));
+                                pending &= ~(1u << u);
+                            }
+                        }
+                    if (pending) {
+                        const bool gone = __hip_atomic_load(f.dead_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull ||
+                                          (long long)wall_clock64() - t0 > f.poll_ticks;
+                        if (gone) { p_dead = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) v += w[u];
+            }
+        return v;
+    };
+    p_part[sg][sa] = poll_sum(reinterpret_cast<const u4_t *>(f.rows_tagged) + (long long)grp * kFoldGroup * 32, gsize);
+    __syncthreads();
+    if (p_dead) {
+        if (tid == 0) __hip_atomic_store(f.dead_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    if (tid < 32) {
+        double t = 0.0;
+#pragma unroll
+        for (int gg = 0; gg < NG; gg++) t += p_part[gg][tid];
+        if (single) p_tot[tid] = t;
+        else if (tid < NACC) store_granule_agent(reinterpret_cast<u4_t *>(f.rows2_tagged) + (long long)grp * 32 + tid, t, tag);
+    }
+    if (!single) {
+        if (lb != 0) return false;
+        __syncthreads();
+        p_part[sg][sa] = poll_sum(reinterpret_cast<const u4_t *>(f.rows2_tagged), ngroups);
+        __syncthreads();
+        if (p_dead) {
+            if (tid == 0) __hip_atomic_store(f.dead_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        if (tid < 32) {
+            double t = 0.0;
+#pragma unroll
+            for (int gg = 0; gg < NG; gg++) t += p_part[gg][tid];
+            p_tot[tid] = t;
+        }
+    }
+    __syncthreads();
+    // the statistics: expanded, exchanged with the peers (source-sharded ranks), published -- as fused_fold does
+    double *stats = f.stats_out;
+    __shared__ double p_stats[kNStats + 2];
+    __shared__ unsigned long long p_seq;
+    if (tid == 0) expand_moments<PLANE>(p_tot, p_stats);
+    __syncthreads();
+    if (f.ipc_n > 1) {
+        if (tid == 0) {
+            p_dead = 0;
+            p_seq = __hip_atomic_load(f.ipc_seq_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+            __hip_atomic_store(f.ipc_seq_dev, p_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            bool late = false;
+            const double sum = ipc_exchange<true>(tid, tid < kNStats ? p_stats[tid] : 0.0, f.peers, f.ipc_rank, f.ipc_n, p_seq,
+                                                  f.ipc_flag, f.ipc_spins, late, f.peer_table);
+            if (tid < kNStats) p_stats[tid] = late ? __longlong_as_double(0x7ff8000000000000ll) : sum;
+            if (late) p_dead = 1;
+        }
+        __syncthreads();
+        if (p_dead) {                                      // a peer was lost: nothing is published
+            if (tid < kNStats) stats[tid] = p_stats[tid];
+            return true;
+        }
+    }
+    if (tid < kNStats) {
+        const double sv = p_stats[tid];
+        stats[tid] = sv;
+        if (f.host_out) {
+            const unsigned long long v = (unsigned long long)__double_as_longlong(sv);
+            u4_t g;
+            g.x = (unsigned)v; g.y = (unsigned)(v >> 32);
+            g.z = (unsigned)f.seq; g.w = (unsigned)(f.seq >> 32);
+            u4_t *dst = reinterpret_cast<u4_t *>(f.host_out) + tid;
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(g) : "memory");
         }
     }
     return true;

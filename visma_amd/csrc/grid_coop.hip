@@ -811,10 +811,19 @@ __device__ __forceinline__ bool coop_body(
     }
     COOP_MARK(6);                                            // outputs + moments
     COOP_WAVE_DONE();
-    block_reduce_store<NACC, NW, PERSIST>(acc, partials, fold.tickets != nullptr);
-    COOP_MARK(7);                                            // workgroup's partial row stored
     bool published = false;
-    if (fold.tickets) published = fused_fold<PLANE, NTH, PERSIST>(fold, partials, row0, lb, bpp, prob);
+    if constexpr (PERSIST) {
+        // persistent launch: rows as tagged granules, the fold by polling (device_common.h: polled_fold; the launcher
+        // refuses a persistent launch without the granule buffers)
+        const unsigned tag = (unsigned)fold.seq;
+        block_reduce_store<NACC, NW, true>(acc, partials, true, fold.rows_tagged, tag);
+        COOP_MARK(7);
+        published = polled_fold<PLANE, NTH>(fold, lb, bpp, tag);
+    } else {
+        block_reduce_store<NACC, NW, false>(acc, partials, fold.tickets != nullptr);
+        COOP_MARK(7);                                        // workgroup's partial row stored
+        if (fold.tickets) published = fused_fold<PLANE, NTH, false>(fold, partials, row0, lb, bpp, prob);
+    }
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
     return published;
 }
@@ -984,6 +993,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         //  from the table in device memory)
         f.ipc_n = VISMA_KARG(fold.ipc_n); f.ipc_rank = VISMA_KARG(fold.ipc_rank); f.ipc_seq_dev = VISMA_KARG(fold.ipc_seq_dev);
         f.ipc_flag = VISMA_KARG(fold.ipc_flag); f.ipc_spins = VISMA_KARG(fold.ipc_spins); f.peer_table = VISMA_KARG(fold.peer_table);
+        f.rows_tagged = VISMA_KARG(fold.rows_tagged); f.rows2_tagged = VISMA_KARG(fold.rows2_tagged);
+        f.dead_flag = VISMA_KARG(fold.dead_flag); f.poll_ticks = VISMA_KARG(fold.poll_ticks);
         const bool published = coop_body<PLANE, true, kBlock, true>(
             VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
             VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
@@ -1039,7 +1050,8 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
     if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
     if (persist) {
         // one registration, one query per lane, the fold and its publication inside the launch, everybody resident
-        if (descs || nprob != 1 || !one || st || !fold.tickets || !fold.host_out || (fold.ipc_n > 1 && !fold.peer_table) || d64_out ||
+        if (descs || nprob != 1 || !one || st || !fold.rows_tagged || !fold.rows2_tagged || !fold.dead_flag || !fold.host_out ||
+            (fold.ipc_n > 1 && !fold.peer_table) || d64_out ||
             persist->max_passes < 1 || !persist->host_cmd || !persist->relay || !persist->host_flag ||
             total_blocks > coop_persist_capacity(point_to_plane))
             return hipErrorInvalidValue;

@@ -42,7 +42,7 @@ public:
         if (h_cmd_ && !cmd_direct_) (void)hipHostFree(h_cmd_);
         if (d_cmd_block_) (void)hipFree(d_cmd_block_);
         if (h_flag_) (void)hipHostFree(h_flag_);
-        free_dev(d_relay_); free_dev(d_timeline_); free_dev(d_peer_table_);
+        free_dev(d_relay_); free_dev(d_timeline_); free_dev(d_peer_table_); free_dev(d_fold_tag_);
         pool_trim(0);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
@@ -634,6 +634,7 @@ private:
     std::vector<std::pair<int, int>> sess_pending_;   // (event pair, passes run) of finished sessions
     unsigned long long *h_cmd_ = nullptr, *h_cmd_dev_ = nullptr;   // kPersistWords command words; word 32: the kernel's flag
     void *d_relay_ = nullptr;
+    void *d_fold_tag_ = nullptr;     // the polled fold's granule rows (2,048 rows + 256 group rows of 32 granules)
     void *d_peer_table_ = nullptr;   // peers_ in device memory (the persistent kernel's fold reads the mailboxes from there)
     bool peers_share_device_ = true; // some peer of the IPC ring sits on THIS device (tests): no persistent launch then --
                                      // the ranks' launches would each hold a part of the compute units and wait for the rest

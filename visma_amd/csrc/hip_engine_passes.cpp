@@ -302,6 +302,19 @@ int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double off
                            ipc ? h_stats_dev_ : pub, seq, &fa);
         if (rc) return rc;
         if (ipc) { add_ipc(&fa); *ipc_done = true; }
+        if (persist) {
+            // the persistent launch folds by polling: rows and group rows as tagged granules (no tickets)
+            constexpr size_t kRows = 2048, kGroups = 256, kRowBytes = 32 * 16;
+            if (!d_fold_tag_) {
+                HIP_TRY(hipMalloc(&d_fold_tag_, (kRows + kGroups) * kRowBytes));
+                HIP_TRY(hipMemsetAsync(d_fold_tag_, 0, (kRows + kGroups) * kRowBytes, stream_));
+            }
+            if ((size_t)grid_launch_blocks(ns_, lanes, grid_blocks()) > kRows) { err_ = "persistent launch larger than its fold rows"; return VISMA_ICP_ERR_STATE; }
+            fa.rows_tagged = d_fold_tag_;
+            fa.rows2_tagged = (char *)d_fold_tag_ + kRows * kRowBytes;
+            fa.dead_flag = (unsigned long long *)d_relay_ + kPersistDead;
+            fa.poll_ticks = persist->hard_ticks;
+        }
     }
     if (prof) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
     HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),

@@ -77,6 +77,11 @@ struct FoldArgs {
     long long ipc_spins;
     void *const *peer_table;           // the same mailboxes as `peers`, as a table in DEVICE memory: what the persistent
                                        // kernel's fold reads (a by-value table indexed in a loop would live in scratch there)
+    // the POLLED fold of persistent launches (device_common.h: polled_fold): rows and group rows as self-validating
+    // granules {low half, tag, high half, tag}, 32 per row; NULL = the ticket fold
+    void *rows_tagged, *rows2_tagged;
+    unsigned long long *dead_flag;     // the launch's "somebody left" word (kernels.h: kPersistDead)
+    long long poll_ticks;              // how long a reducer waits for a row (wall_clock64 ticks) before it gives the launch up
 };
 
 // The PERSISTENT form of the certificate kernel (grid_coop.hip, round 4b): ONE launch runs up to max_passes ICP
