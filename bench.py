@@ -32,9 +32,11 @@ steps are always run after the timed region and reported under `brute_force`.
 
 Prints ONE JSON line on rank 0 (contract in the task description), with the extra objects
 `roofline` (dominant kernel = NN correspondence) and `cpu_baseline` (the reference itself,
-oracle/_ref, timed on this host).  c4 also carries: `blocks` (the K-step block is timed 7 times, each between a
-barrier + synchronize pair; `value` is the MEDIAN block, min / max beside it), `from_initial_pose` (iterations
-1..K of a fresh registration: first pass cold, the rest warm-started), `end_to_end` (host arrays in ->
+oracle/_ref, timed on this host).  c4: `value` = K iterations of a FRESH registration from T = I (the
+reference's loop, Registration.cpp:167-185: first pass cold, the rest warm-started while the pose moves), timed
+`--blocks` times (default 7), each between a barrier + synchronize pair, winners forgotten before each: the MEDIAN,
+min / max in `blocks`; `value_converged` / `converged` = the registration carried on past its convergence (what
+rounds 1-4 reported as `value`: no caller gets there); `end_to_end` (host arrays in ->
 transformation out: upload, grid build, 31 passes; the PCIe-inclusive rate -- never `value`),
 `roofline_saturated` (the same kernel and target with 1 M and 4 M queries per launch: the chip refilled many
 times over, no single-round latency chain) and `scaling_workloads` (what N = 1, 2, 4, 8 runs of this command
@@ -423,13 +425,41 @@ def timed_block(R, ctx, T, radius, steps):
     return T, last, R.reduce_max(time.perf_counter() - t0)
 
 
-def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=1):
-    """W untimed iterations, then `blocks` blocks of K timed iterations each (the pose carries on from block to
-    block).  Returns the elapsed time of every block."""
+def timed_registrations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=5):
+    """SURVEY 8d's registration, `blocks` times: W untimed iterations (grid build, buffers, code objects), then every
+    block a FRESH registration -- nothing remembered from earlier passes -- of K timed iterations from T = I: the first
+    pass cold, the rest warm-started while the pose moves (Registration.cpp:167-185 under criteria (0, 0, K)).  Each
+    block between two barrier + synchronize pairs.  Returns the final transform of the last block and every elapsed time."""
     from visma_amd import _lib
     ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID, "brute": _lib.NN_BRUTE}[nn_mode])
     ctx.set_profiling(prof_every)
-    T = np.eye(4)
+    ctx.get_timing(reset=True)
+    if warmup > 0:
+        ctx.iterate(np.eye(4), radius, warmup)      # also builds the grid (one-off)
+    setup = ctx.get_timing(reset=True)
+    elapsed, last, T = [], None, np.eye(4)
+    for _ in range(max(blocks, 1)):
+        ctx.forget_winners()
+        ctx.get_timing()                            # (drains the stream: the reset of the winners is not in the block)
+        T, last, el = timed_block(R, ctx, np.eye(4), radius, steps)
+        elapsed.append(el)
+    tm = ctx.get_timing(reset=True)
+    if tm["nn_launches"] == 0:
+        ctx.set_profiling(1)
+        ctx.forget_winners()
+        ctx.iterate(np.eye(4), radius, 3)
+        tm = ctx.get_timing(reset=True)
+    ctx.set_profiling(0)
+    return T, last, elapsed, tm, setup
+
+
+def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=1, T0=None):
+    """W untimed iterations, then `blocks` blocks of K timed iterations each (the pose carries on from block to
+    block; T0: carry on from there).  Returns the elapsed time of every block."""
+    from visma_amd import _lib
+    ctx.set_nn_mode({"auto": _lib.NN_AUTO, "grid": _lib.NN_GRID, "brute": _lib.NN_BRUTE}[nn_mode])
+    ctx.set_profiling(prof_every)
+    T = np.eye(4) if T0 is None else T0
     ctx.get_timing(reset=True)
     if warmup > 0:
         T, _ = ctx.iterate(T, radius, warmup)       # also builds the grid (one-off)
@@ -449,7 +479,7 @@ def timed_iterations(R, ctx, radius, warmup, steps, nn_mode, prof_every, blocks=
     return T, last, elapsed, tm, setup
 
 
-def persistent_launches(roofline, tm, queries=0, nt=0):
+def persistent_launches(roofline, tm, queries=0, nt=0, traffic_key="grid_persist"):
     """Persistent launches (round 4b: ONE launch of the certificate kernel runs the passes of a host loop, the next
     transform handed over through mapped host memory): the timing counters hold whole launches -- the waits for the host
     included -- and count their passes.  `achieved` = bytes per launch / launch duration is the same ratio either way;
@@ -466,7 +496,7 @@ def persistent_launches(roofline, tm, queries=0, nt=0):
                                   "its waits for the host's next transform (statistics out, solve, command back over "
                                   "PCIe) are inside"}
     if tm["nn_launches"] == pp:
-        per_pass_traffic = load_traffic("grid_persist", int(queries), int(nt), "hbm_bytes_per_pass") if queries else None
+        per_pass_traffic = load_traffic(traffic_key, int(queries), int(nt), "hbm_bytes_per_pass") if queries else None
         if per_pass_traffic:
             roofline["traffic"] = per_pass_traffic * k
             roofline["traffic_per_pass"] = per_pass_traffic
@@ -597,7 +627,9 @@ def run_c4(R, args):
     #  kernel on three extra passes afterwards)
     prof_every = 1 if args.nn == "brute" else (4 if args.steps >= 8 else 0)
     blocks = 1 if args.nn == "brute" else max(args.blocks, 1)
-    T, last, elapsed_all, tm, setup = timed_iterations(R, ctx, radius, args.warmup, args.steps, args.nn, prof_every, blocks)
+    # `value` (since round 5): SURVEY 8d's registration as the reference runs it -- K iterations from T = I, the cold
+    # first pass included (Registration.cpp:167-185) --, the median of `blocks` fresh registrations
+    T, last, elapsed_all, tm, setup = timed_registrations(R, ctx, radius, args.warmup, args.steps, args.nn, prof_every, blocks)
     elapsed = float(np.median(elapsed_all))
     mode = "grid" if ctx.nn_mode_used() == _lib.NN_GRID else "brute"
     search = ctx.search_mode_used()
@@ -614,21 +646,17 @@ def run_c4(R, args):
     nn_ms = R.reduce_max(tm["nn_ms"] / nl)
     cand = tm["grid_candidates"] / nl
 
-    # iterations 1..K of a FRESH registration (what the winners of the passes so far would not be there for):
-    # first pass on the lane-serial kernel, the rest warm-started while the pose still moves
-    initial = None
+    # the regime rounds 1-4 reported as `value`: the registration carried on past its convergence (2K more iterations
+    # untimed, then `blocks` blocks of K continuing at the converged pose: nearly every query certified) -- no caller of
+    # the reference gets there (its default criteria stop a C4 registration at iteration 29); kept as `value_converged`
+    converged = None
     if mode == "grid" and not args.no_extras:
-        ctx.forget_winners()
-        ctx.iterate(np.eye(4), radius, args.steps)                  # throw-away
-        els = []
-        for _ in range(3):
-            ctx.forget_winners()
-            _, li, el = timed_block(R, ctx, np.eye(4), radius, args.steps)
-            els.append(el)
-        initial = {"steps": args.steps, "ms_per_step": float(np.median(els)) / args.steps * 1e3,
-                   "icp_iterations_per_sec": args.steps / float(np.median(els)), "median_of": 3,
-                   "note": "identity start, nothing remembered from earlier passes; `value` above times iterations "
-                           "%d..%d continuing at the converged pose" % (args.warmup + 1, args.warmup + args.steps * blocks)}
+        Tcv, lastc, el_c, tm_c, _ = timed_iterations(R, ctx, radius, 2 * args.steps, args.steps, args.nn, prof_every, blocks, T0=T)
+        e_c = float(np.median(el_c))
+        converged = {"steps": args.steps, "ms_per_step": e_c / args.steps * 1e3, "icp_iterations_per_sec": args.steps / e_c,
+                     "blocks": [args.steps / e for e in el_c], "median_of": len(el_c),
+                     "iterations": "%d..%d of one registration" % (3 * args.steps + 1, (3 + len(el_c)) * args.steps),
+                     "tm": tm_c, "fitness": lastc.fitness_, "err_vs_T_gt": synth.rel_frobenius(Tcv, T_gt)}
 
     # north_star's brute-force kernel on the same (sharded) problem, outside the timed region: collective timing
     brute = None
@@ -720,16 +748,20 @@ def run_c4(R, args):
         tile = _lib.tile_config()
         exact = search != "f32"
         if mode == "grid":
+            # (traffic: PMC passes of tools/run_c4_iterations.py in ITS regime -- fresh registrations from the identity;
+            #  the converged regime's counters belong to `converged.roofline`)
             roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, tm["grid_candidates_27cell"] / nl,
-                                     load_traffic("grid_warm" if kernel_kind == "warm" else "grid", ns_local, nt_local),
+                                     load_traffic("grid_initial", ns_local, nt_local, "hbm_bytes_per_pass"),
                                      exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial",
                                      tm["grid_certified"] / nl)
-            roofline = persistent_launches(roofline, tm, ns_local, nt_local)
+            roofline = persistent_launches(roofline, tm, ns_local, nt_local, "grid_persist_initial")
         else:
             roofline = brute_roofline(ns_local, nt_local, nn_ms, tile, load_traffic("brute", ns_local, nt_local))
         roofline["launches_timed"] = tm["nn_launches"] if "launch" not in roofline else roofline["launch"]["launches_timed"]
         roofline["timed_every_nth_pass"] = prof_every if "launch" not in roofline else 1
         roofline["separate_fold_launch_avg_ms"] = tm["reduce_ms"] / max(tm["reduce_launches"], 1)
+        roofline["regime"] = "the timed region: %d fresh registrations of %d iterations from T = I (cold pass + warm passes)" % (
+            len(elapsed_all), args.steps)
         par = ("source-sharded x%d, 1 all-reduce(38 f64)/iter via %s" % (R.world, comm_kind)
                if args.shard == "source" else
                "target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter via %s" % (R.world, ns, comm_kind))
@@ -741,13 +773,16 @@ def run_c4(R, args):
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations, nn=%s, "
-                                   "search=%s" % (ns, nt, args.steps, mode, search),
+            "config": {"workload": "C4 S-surf %d-pt source -> %d-pt target, %d fixed ICP iterations from T = I (a fresh "
+                                   "registration: cold first pass + warm passes; median of %d), nn=%s, search=%s" % (
+                                       ns, nt, args.steps, len(elapsed_all), mode, search),
                        "ns": ns, "nt": nt, "radius": radius, "solver": "kabsch", "nn": mode, "search": search,
                        "search_kernel": kernel_kind,
                        "arithmetic": "fp32 candidate ranking, f64 re-rank of the rounding band, f64 statistics",
                        "parallelism": par},
-            "blocks": {"timed": len(elapsed_all), "steps_each": args.steps, "value_is": "median block",
+            "blocks": {"timed": len(elapsed_all), "steps_each": args.steps,
+                       "value_is": "median over fresh registrations of K iterations from the identity (SURVEY 8d; "
+                                   "Registration.cpp:167-185), winners forgotten before each",
                        "iterations_per_sec": [args.steps / e for e in elapsed_all],
                        "min": args.steps / max(elapsed_all), "max": args.steps / min(elapsed_all)},
             "candidates_evaluated_per_sec": cand * R.world * args.steps / elapsed if mode == "grid" else float(ns) * nt * args.steps / elapsed,
@@ -758,14 +793,22 @@ def run_c4(R, args):
             "setup_ms": {"grid_build_kernels": setup["aux_ms"]},
             "roofline": roofline,
         }
-        if initial is not None:
-            out["from_initial_pose"] = initial
-            # (first-class: a registration as its caller starts it, next to `value`, which continues at the converged pose)
-            out["value_from_initial_pose"] = initial["icp_iterations_per_sec"]
-            out["config"]["workload"] += "; value = iterations %d..%d continuing at the converged pose (%.0f it/s), " \
-                                         "iterations 1..%d from the identity: %.0f it/s" % (
-                                             args.warmup + 1, args.warmup + args.steps * blocks, args.steps / elapsed,
-                                             args.steps, initial["icp_iterations_per_sec"])
+        # (continuity with rounds 3-4, where this regime was an extra key and `value` the converged one)
+        out["value_from_initial_pose"] = out["value"]
+        if converged is not None:
+            tm_c = converged.pop("tm")
+            nlc = max(tm_c["nn_launches"], 1)
+            rc = grid_roofline(ns_local, nt_local, R.reduce_max(tm_c["nn_ms"] / nlc), tm_c["grid_candidates"] / nlc,
+                               tm_c["grid_candidates_27cell"] / nlc, load_traffic("grid_warm", ns_local, nt_local), exact,
+                               kernel_kind if kernel_kind in ("warm", "serial") else "serial", tm_c["grid_certified"] / nlc)
+            rc = persistent_launches(rc, tm_c, ns_local, nt_local)
+            rc.pop("note", None)
+            converged["roofline"] = rc
+            out["converged"] = converged
+            out["value_converged"] = converged["icp_iterations_per_sec"]
+            out["config"]["workload"] += "; value_converged = iterations %s, continuing at the converged pose: %.0f it/s " \
+                                         "(what rounds 1-4 reported as value)" % (converged["iterations"],
+                                                                                converged["icp_iterations_per_sec"])
         if R.world == 1 and not args.no_extras and mode == "grid":
             # what the reference's callers register: a model against a PARTIAL scan (fitness ~0.5: half of the queries
             # find nothing within the radius, every pass), same sizes, same radius rule, same motion
@@ -774,8 +817,9 @@ def run_c4(R, args):
                                                 "C4 sizes, the whole model against a scan of half of its surface "
                                                 "(synth.make_partial_pair; the compiled reference's result on it: "
                                                 "tests/golden/c4_partial_ref.npz)")
-            out["value_partial_overlap"] = out["partial_overlap"]["continuing"]["icp_iterations_per_sec"]
-            out["value_partial_overlap_from_initial_pose"] = out["partial_overlap"]["from_initial_pose"]["icp_iterations_per_sec"]
+            out["value_partial_overlap"] = out["partial_overlap"]["from_initial_pose"]["icp_iterations_per_sec"]
+            out["value_partial_overlap_converged"] = out["partial_overlap"]["continuing"]["icp_iterations_per_sec"]
+            out["value_partial_overlap_from_initial_pose"] = out["value_partial_overlap"]
             del psrc, ptgt
             # SURVEY 8d's literal ground truth (5 deg yaw, 1 deg pitch, ~3 cm) needs a radius of 0.15 m to converge:
             # twelve point spacings at 65,536 target points -- at 4,194,304 points that radius holds 15,000 points

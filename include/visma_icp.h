@@ -405,6 +405,44 @@ VISMA_ICP_API int visma_icp_get_nn_mode_used(visma_icp_ctx *ctx, int *nn_mode);
 VISMA_ICP_API int visma_icp_set_profiling(visma_icp_ctx *ctx, int enabled);
 VISMA_ICP_API int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out,
                                        int reset);
+/* The same for callers compiled against another revision of this header: at most `struct_size` bytes of the
+ * structure are written (the structure only ever grows at its end; round 4 added persist_* -- a caller built against
+ * round 3's header passes ITS sizeof and is not overrun).  visma_icp_get_timing(ctx, out, reset) is
+ * visma_icp_get_timing_sized(ctx, out, sizeof(visma_icp_timing) OF THE LIBRARY'S BUILD, reset). */
+VISMA_ICP_API int visma_icp_get_timing_sized(visma_icp_ctx *ctx, void *out, size_t struct_size, int reset);
+
+/* ---- the persistent launch of a host loop -------------------------------------------------------------------------
+ * visma_icp_run / visma_icp_iterate on one GPU (and source-sharded ranks on their own GPUs) keep ONE launch of the
+ * search kernel alive for the passes of their loop: the next transform goes to the launch through a command block, the
+ * statistics come back as always -- same results as one launch per pass, bit for bit.  Such a launch
+ * needs every one of its workgroups resident at once and SPINS between passes: while a loop runs, the compute units it
+ * holds are not available to other streams or processes.  An integrator decides with these three calls (they replace
+ * nothing in the reference, which has no device to share):
+ *  visma_icp_set_persistent(ctx, enabled, timeout_ms): 1 (default) / 0 = one launch per pass on this context (also
+ *    VISMA_ICP_PERSIST=0).  timeout_ms > 0: how long the launch waits for the host's next command before it ends by
+ *    itself (default 200; the loop then carries on with ordinary launches, same results, and the context stops
+ *    starting persistent launches until they are enabled again).
+ *  visma_icp_set_persistent_cu_share(share): PER PROCESS, 0 < share <= 1 (default 1; also VISMA_ICP_PERSIST_CU_SHARE):
+ *    the largest part of a device's workgroup slots a persistent launch may hold.  A loop whose launch would need
+ *    more runs one launch per pass, which other streams' kernels interleave with (a 262,144-point source needs all
+ *    slots of an MI355X; 65,536 points a quarter).  Queue workers of visma_icp_run_corpus / batches never start
+ *    persistent launches.
+ *  visma_icp_get_persistent_info(ctx, out): what happened so far on this context. */
+typedef struct {
+    int struct_size;               /* in: sizeof(visma_icp_persistent_info) of the caller's build */
+    int enabled;                   /* persistent launches are allowed on this context right now (0 after an abort) */
+    int last_loop_persistent;      /* the last finished host loop ran (part of) its passes in a persistent launch */
+    int last_loop_passes;          /* ... that many of them */
+    double launches, passes;       /* persistent launches / passes inside them since the context was created */
+    double aborts;                 /* launches that ended by themselves or whose host came back too late */
+    double timeout_ms;             /* the patience in force */
+    double cu_share;               /* the process-wide share in force */
+    int device_slots;              /* workgroups of this kernel the device holds at once (0: not asked yet) */
+    int reserved;
+} visma_icp_persistent_info;
+VISMA_ICP_API int visma_icp_set_persistent(visma_icp_ctx *ctx, int enabled, double timeout_ms);
+VISMA_ICP_API int visma_icp_set_persistent_cu_share(double share);
+VISMA_ICP_API int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_persistent_info *out);
 
 /* ---- multi-GPU (one process per GPU; source-sharded) -------------------- */
 

@@ -51,15 +51,10 @@ VISMA_ICP_API int visma_icp_forget_winners(visma_icp_ctx *ctx);
  * iteration.  Results agree to rounding. */
 VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
 
-/* The PERSISTENT launch of a host loop (visma_icp_run / visma_icp_iterate on one GPU; visma_amd/csrc/grid_coop.hip:
- * nn_coop_kernel_persist): one launch of the certificate kernel runs the remaining passes of the loop, each next
- * transform handed over through a command block in mapped host memory; same results as one launch per pass, bit for
- * bit.  enabled: 1 (default) / 0 = one launch per pass (A/B timing; also VISMA_ICP_PERSIST=0).  timeout_ms > 0: how
- * long the launch waits for a command before it ends by itself (default 200; the host then carries on with ordinary
- * launches and stops starting persistent ones on this context until they are enabled again).
- * visma_icp_test_stall_command: (tests) the host sleeps `ms` before it posts its `nth` command from now (1 = the
- * next) -- a stalled host thread, as seen from the device.  Replaces nothing in the reference. */
-VISMA_ICP_API int visma_icp_set_persistent(visma_icp_ctx *ctx, int enabled, double timeout_ms);
+/* (visma_icp_set_persistent, visma_icp_set_persistent_cu_share, visma_icp_get_persistent_info: product API since
+ *  round 5, visma_icp.h.)
+ * visma_icp_test_stall_command: (tests) the host sleeps `ms` before it posts its `nth` command to a persistent launch
+ * from now (1 = the next) -- a stalled host thread, as seen from the device.  Replaces nothing in the reference. */
 VISMA_ICP_API int visma_icp_test_stall_command(visma_icp_ctx *ctx, int nth, double ms);
 
 /* Compile-time tile constants, for roofline accounting: S_TILE source points

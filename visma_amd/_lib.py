@@ -50,6 +50,12 @@ class CTiming(C.Structure):
                 ("persist_aborts", C.c_double)]
 
 
+class CPersistentInfo(C.Structure):
+    _fields_ = [("struct_size", C.c_int), ("enabled", C.c_int), ("last_loop_persistent", C.c_int), ("last_loop_passes", C.c_int),
+                ("launches", C.c_double), ("passes", C.c_double), ("aborts", C.c_double), ("timeout_ms", C.c_double),
+                ("cu_share", C.c_double), ("device_slots", C.c_int), ("reserved", C.c_int)]
+
+
 class CProblem(C.Structure):
     _fields_ = [("src_xyz", _dp), ("ns", C.c_int64), ("tgt_xyz", _dp), ("nt", C.c_int64),
                 ("init", C.c_double * 16), ("max_dist", C.c_double)]
@@ -185,6 +191,9 @@ def _bind(L):
     L.visma_icp_set_device_loop.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_set_persistent.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_test_stall_command.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.visma_icp_set_persistent_cu_share.argtypes = [C.c_double]
+    L.visma_icp_get_persistent_info.argtypes = [C.c_void_p, C.POINTER(CPersistentInfo)]
+    L.visma_icp_get_timing_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     L.visma_icp_get_timing.argtypes = [C.c_void_p, C.POINTER(CTiming), C.c_int]
     L.visma_icp_get_tile_config.argtypes = [C.POINTER(C.c_int)] * 3
     L.visma_icp_get_launch_config.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -553,6 +562,13 @@ class Context:
         """the persistent launch of a host loop (default on); timeout_ms > 0: the launch's patience"""
         self._chk(self.L.visma_icp_set_persistent(self._h, int(bool(on)), float(timeout_ms)))
 
+    def persistent_info(self):
+        """what the persistent launches of this context's host loops did so far (visma_icp_get_persistent_info)"""
+        t = CPersistentInfo()
+        t.struct_size = C.sizeof(CPersistentInfo)
+        self._chk(self.L.visma_icp_get_persistent_info(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in CPersistentInfo._fields_ if k != "reserved"}
+
     def test_stall_command(self, nth, ms):
         self._chk(self.L.visma_icp_test_stall_command(self._h, int(nth), float(ms)))
 
@@ -672,6 +688,13 @@ def run_batch_multi(ctxs, problems, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6
     if rc != 0:
         raise IcpError(rc, err.value.decode(errors="replace"))
     return [Result(out[i]) for i in range(n)]
+
+
+def set_persistent_cu_share(share):
+    """per process: the largest part of a device's workgroup slots a persistent launch may hold (0 < share <= 1)"""
+    rc = load().visma_icp_set_persistent_cu_share(float(share))
+    if rc != 0:
+        raise IcpError(rc, "visma_icp_set_persistent_cu_share(%r)" % (share,))
 
 
 def device_count():

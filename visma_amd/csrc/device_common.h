@@ -11,6 +11,7 @@
 
 #include "kernels.h"
 #include "so3.h"
+#include "icp_state.h"
 
 namespace visma {
 
@@ -443,7 +444,9 @@ __device__ __forceinline__ double ipc_exchange(int a, double mine, const IpcPeer
 constexpr int kFoldSingle = VISMA_FOLD_SINGLE;      // up to this many rows: one level
 // Returns true on the ONE workgroup of the problem that finished the fold and published the statistics.
 // LOOPED: called from the loop of the persistent kernel (no exchange with peers there; opaque thread number).
-template <bool PLANE, int NTH, bool LOOPED = false>
+// SOLVE: the kernel honours FoldArgs::solve -- the publishing workgroup advances the problem's device-resident state
+// (closed-form update, compose, stop test) right behind its fold, one thread on a copy of the state in LDS.
+template <bool PLANE, int NTH, bool LOOPED = false, bool SOLVE = false>
 __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *partials, long long row0, int lb,
                                            int bpp, int prob)
 {
@@ -588,6 +591,25 @@ __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *part
             }
         }
     }
+    if constexpr (SOLVE) {
+        if (f.solve && f.ipc_n <= 1) {                       // (workgroup-uniform)
+            // Every workgroup of this problem has delivered its row -- each read the state when it began --, so the state
+            // may move on now: the whole workgroup brings it into LDS (one round trip instead of one per field), the
+            // statistics come from where the fold left them, thread 0 solves, the workgroup writes it back.  What
+            // solve_state_kernel did in a launch of its own between every two search launches (18 % of config 3's GPU time).
+            static_assert(sizeof(DevIcpState) % 8 == 0 && offsetof(DevIcpState, stats) % 8 == 0, "state copied as 8-byte words");
+            constexpr int kWords = (int)(sizeof(DevIcpState) / 8), kStatsWord = (int)(offsetof(DevIcpState, stats) / 8);
+            __shared__ unsigned long long f_sst[kWords];
+            unsigned long long *gs = reinterpret_cast<unsigned long long *>(f.solve + prob);
+            for (int k = tid; k < kWords; k += NTH)
+                f_sst[k] = (k >= kStatsWord && k < kStatsWord + kNStats) ? (unsigned long long)__double_as_longlong(f_stats[k - kStatsWord])
+                                                                         : gs[k];
+            __syncthreads();
+            if (tid == 0) advance_state<true>(reinterpret_cast<DevIcpState *>(f_sst));
+            __syncthreads();
+            for (int k = tid; k < kWords; k += NTH) gs[k] = f_sst[k];
+        }
+    }
     return true;
 }
 
@@ -609,8 +631,21 @@ __device__ __forceinline__ bool polled_fold(const FoldArgs &f, int lb, int bpp, 
     const int tid = thread_number<true, NTH>();
     const bool single = bpp <= kFoldSingle;
     const int ngroups = single ? 1 : (bpp + kFoldGroup - 1) / kFoldGroup;
-    const int grp = single ? 0 : lb / kFoldGroup;
-    if (lb != grp * kFoldGroup) return false;                // (not the first of its group: the row is out, done)
+    // Who reduces group g: workgroup g -- the lowest-numbered workgroups are the OLDEST waves of their SIMDs (blocks 0..255
+    // are the first resident workgroup of every compute unit), which the instruction arbiter serves first: their bodies are
+    // done 3 us before the youngest workgroups' (tools/persist_timeline.py, round 5: four plateaus by residency slot), and
+    // their polls are not starved by three older waves.  (Until round 5: the first workgroup of each group, slots 0..3 alike.)
+#ifndef VISMA_FOLD_REDUCERS_FIRST
+#define VISMA_FOLD_REDUCERS_FIRST 1
+#endif
+    int grp;
+    if (VISMA_FOLD_REDUCERS_FIRST) {
+        if (lb >= ngroups) return false;                     // (not a reducer: the row is out, done)
+        grp = lb;
+    } else {
+        grp = single ? 0 : lb / kFoldGroup;
+        if (lb != grp * kFoldGroup) return false;
+    }
     const int gsize = single ? bpp : min(kFoldGroup, bpp - grp * kFoldGroup);
     const int sa = tid & 31, sg = tid >> 5;
     if (tid == 0) p_dead = 0;

@@ -1015,6 +1015,26 @@ int visma_icp_set_persistent(visma_icp_ctx *ctx, int enabled, double timeout_ms)
     return VISMA_ICP_OK;
 }
 
+int visma_icp_set_persistent_cu_share(double share)
+{
+    if (!(share > 0.0) || share > 1.0) return VISMA_ICP_ERR_INVALID;
+    persist_cu_share_ref().store(share);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_persistent_info *out)
+{
+    CTX_CHECK();
+    if (!out || out->struct_size < (int)sizeof(visma_icp_persistent_info))
+        return ctx->fail(VISMA_ICP_ERR_INVALID, "visma_icp_persistent_info: set struct_size = sizeof(visma_icp_persistent_info)");
+    const int sz = out->struct_size;
+    std::memset(out, 0, sizeof(*out));
+    out->struct_size = sz;
+    out->cu_share = 1.0;
+    ctx->eng->get_persistent_info(out);
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_test_stall_command(visma_icp_ctx *ctx, int nth, double ms)
 {
     CTX_CHECK();
@@ -1035,6 +1055,16 @@ int visma_icp_get_timing(visma_icp_ctx *ctx, visma_icp_timing *out, int reset)
     CTX_CHECK();
     if (!out) return ctx->fail(VISMA_ICP_ERR_INVALID, "out is NULL");
     ctx->eng->get_timing(out, reset != 0);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_timing_sized(visma_icp_ctx *ctx, void *out, size_t struct_size, int reset)
+{
+    CTX_CHECK();
+    if (!out) return ctx->fail(VISMA_ICP_ERR_INVALID, "out is NULL");
+    visma_icp_timing t;
+    ctx->eng->get_timing(&t, reset != 0);
+    std::memcpy(out, &t, struct_size < sizeof(t) ? struct_size : sizeof(t));
     return VISMA_ICP_OK;
 }
 

@@ -186,6 +186,26 @@ private:
     size_t workers_ = 0;
 };
 
+// the process-wide cap on the part of a device's workgroup slots a persistent launch may hold
+// (visma_icp_set_persistent_cu_share; VISMA_ICP_PERSIST_CU_SHARE)
+inline std::atomic<double> &persist_cu_share_ref()
+{
+    static std::atomic<double> share([] {
+        const char *e = std::getenv("VISMA_ICP_PERSIST_CU_SHARE");
+        const double v = e ? std::atof(e) : 1.0;
+        return (v > 0.0 && v <= 1.0) ? v : 1.0;
+    }());
+    return share;
+}
+
+// (one flag for every instantiation of parallel_for below: a pass started from inside a pass with ANOTHER functor type
+//  must be seen as nested too -- a flag inside the template is per functor type)
+inline bool &parallel_for_inside()
+{
+    static thread_local bool inside = false;
+    return inside;
+}
+
 // Run fn(i) for i in [0, n) on a few host threads (packing / ordering of clouds).
 template <typename F>
 void parallel_for(int64_t n, int64_t min_per_thread, F fn)
@@ -196,7 +216,7 @@ void parallel_for(int64_t n, int64_t min_per_thread, F fn)
     if (n / (min_per_thread > 0 ? min_per_thread : 1) < nt) nt = std::max<int64_t>(1, n / (min_per_thread > 0 ? min_per_thread : 1));
     // (a pass started from inside a pass -- fn itself calling parallel_for -- runs on the calling thread: the pools'
     //  run mutex is not recursive)
-    static thread_local bool inside = false;
+    bool &inside = parallel_for_inside();
     if (nt <= 1 || inside) { for (int64_t i = 0; i < n; i++) fn(i); return; }
     struct Guard { bool &f; explicit Guard(bool &x) : f(x) { f = true; } ~Guard() { f = false; } } guard(inside);
     HostPool::instance(0);                                         // (starts the pools in the first process that asks)
@@ -257,6 +277,7 @@ public:
     // n passes (nn_pass + reduce, nothing else) -- an engine may then keep ONE launch alive across them (HipEngine:
     // the persistent certificate kernel).  loop_end() must follow on every path; LoopScope does that.
     virtual void set_persistent(int /*enabled*/, double /*timeout_ms*/) {}
+    virtual void get_persistent_info(visma_icp_persistent_info *out) const { (void)out; }
     virtual void stall_command(int /*nth*/, double /*ms*/) {}
     virtual bool loop_across_ranks_ok() const { return false; }   // source-sharded ranks may keep a launch alive across passes too
     virtual void loop_begin(int /*max_passes*/) {}

@@ -60,8 +60,14 @@ namespace visma {
 namespace {
 
 struct P12 { float x, y, z; };                // fp32 rounding of a cell-sorted f64 target point
-constexpr int kCoopCap = 384;                 // chunk descriptors per wave and list window (3 KiB; a wave of 64 searched
-                                              // queries lists ~250-300 chunks while the pose still moves, fewer later)
+#ifndef VISMA_COOP_CAP
+#define VISMA_COOP_CAP 352
+#endif
+constexpr int kCoopCap = VISMA_COOP_CAP;      // chunk descriptors per wave and list window (1,408 per workgroup: 16.5 KiB with the
+                                              // side array; a workgroup of 170 queued queries -- the second pass of a C4
+                                              // registration -- lists ~850 chunks: at 768 it took two windows and 5-9 us more).
+                                              // 384 until round 5: the persistent kernel keeps every query's source point and
+                                              // state in LDS now (and re-derives the transformed query instead of keeping it)
 #ifndef VISMA_COOP_DEPTH
 #define VISMA_COOP_DEPTH 7
 #endif
@@ -103,6 +109,35 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int)
 
 }  // namespace
 
+// The PERSISTENT launch keeps the state a query carries from pass to pass in LDS (round 5): the winner's f64 point,
+// index and LB.  The first pass of a launch reads it from global memory, the passes after it do not touch it there: a
+// certified query reads its source point (32 B, from a warm L2) and writes nothing, and nothing of a pass is written
+// back until the launch ends (its last lines).  The one-pass kernels pass nullptrs.
+// (Measured, round 5: the source points in LDS as well -- no global access at all for a certified query -- left no room
+//  for the transformed queries, which every user then re-derived: 24 more scalar registers live across the search, 26 of
+//  them spilled, and the chunk-list window had to shrink; 0.5-1 us slower per pass than this.)
+struct CoopRes {
+    double (*q64)[3];      // [NTH] state: the winner's f64 point (NaN: none)            } = the s_q64 / s_dprev slots the
+    float *idx;            // [NTH] state: the winner's original index (bits; ~0: none)  } passes hand their results over in
+    float *lb;             // [NTH] state: LB
+    int first;             // this pass is the launch's first: source and state come from global memory
+};
+
+// the query of thread `tid` of workgroup `lb` of a problem of `bpp` workgroups (the query -> lane map of
+// nn_grid_reduce_kernel<G = 1>: XCD-aware chunking of the Morton order)
+template <int NTH>
+__device__ __forceinline__ void coop_query_range(int ns, int bpp, int lb, int tid, int &vb, int &per_group, long long &i_begin,
+                                                 long long &i_end)
+{
+    vb = lb;
+    if ((bpp & 7) == 0) vb = (lb & 7) * (bpp >> 3) + (lb >> 3);
+    const int total_groups = bpp * NTH;
+    per_group = (ns + total_groups - 1) / total_groups;
+    const int gid = vb * NTH + tid;
+    i_begin = (long long)gid * per_group;
+    i_end = i_begin + per_group < ns ? i_begin + per_group : ns;
+}
+
 // Returns true on the one workgroup that finished the fold and published the statistics (fused fold only).
 template <bool PLANE, bool ONE, int NTH, bool PERSIST = false>
 __device__ __forceinline__ bool coop_body(
@@ -112,7 +147,7 @@ __device__ __forceinline__ bool coop_body(
     const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,
     int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,
     const Pt64 *__restrict__ nrm64, const FoldArgs &fold, double *__restrict__ d64_out,
-    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev, unsigned *work_out = nullptr)
+    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev, unsigned *work_out = nullptr, const CoopRes res = CoopRes{})
 {
     constexpr int NACC = Acc<PLANE>::N;
     const P12 *s12 = reinterpret_cast<const P12 *>(s12f);
@@ -185,31 +220,38 @@ __device__ __forceinline__ bool coop_body(
     constexpr int NW = NTH / 64;                             // waves of the workgroup
     constexpr unsigned kCapAll = (unsigned)(NW * kCoopCap);  // chunk descriptors of the workgroup's list window
     // the query -> lane map of nn_grid_reduce_kernel<G = 1> (XCD-aware chunking of the Morton order)
-    int vb = lb;
-    if ((bpp & 7) == 0) vb = (lb & 7) * (bpp >> 3) + (lb >> 3);
-    const int total_groups = bpp * NTH;
-    const int per_group = (ns + total_groups - 1) / total_groups;
-    const int gid = vb * NTH + tid;
-    const long long i_begin = (long long)gid * per_group;
-    const long long i_end = i_begin + per_group < ns ? i_begin + per_group : ns;
+    int vb, per_group;
+    long long i_begin, i_end;
+    coop_query_range<NTH>(ns, bpp, lb, tid, vb, per_group, i_begin, i_end);
 
     __shared__ float4 s_qp[NTH];                            // (px, py, pz, W) of the query each SEARCHER thread took over
     __shared__ uint2 s_item[kCapAll];                       // the workgroup's chunk descriptors, completed by chunk results
     __shared__ float s_sec[kCapAll];                        // per chunk: its best candidate OUTSIDE the rounding band
     __shared__ double s_p64[NTH][3];                        // the transformed query of every HOME lane, f64 (what a searcher
                                                             // takes over instead of loading and transforming the source again)
-    __shared__ double s_q64[NTH][3];                        // the partner of every home lane's query: the certified winner
-                                                            // (phase A) or what the query's searcher found (phase B)
-    __shared__ float s_dprev[NTH];                          // home lane's squared fp32 distance to its previous winner (NaN:
-                                                            // none) for the searcher; then the partner's index (bits; ~0: none)
+    // the partner of every home lane's query: the certified winner (phase A) or what the query's searcher found
+    // (phase B); and the home lane's squared fp32 distance to its previous winner (NaN: none) for the searcher, then the
+    // partner's index (bits; ~0: none).  In the persistent launch these slots ARE the state the next pass starts from.
+    __shared__ double s_q64_own[PERSIST ? 1 : NTH][3];
+    __shared__ float s_dprev_own[PERSIST ? 1 : NTH];
+    double (*s_q64)[3] = s_q64_own;
+    float *s_dprev = s_dprev_own;
+    if constexpr (PERSIST) { s_q64 = res.q64; s_dprev = res.idx; }
     __shared__ unsigned short s_home[NTH];                  // the home thread of the query each searcher thread took over
     __shared__ unsigned s_need[NW];                         // queries queued by each wave this round (see `round` below)
     __shared__ unsigned s_m[NW];                            // chunks listed by each wave's searchers
     __shared__ unsigned short s_queue[NW][64];              // the queued queries' home threads
 
     // outputs of one query: the correspondence and the state for the next pass
-    auto emit = [&](long long i, bool cert, double bd, unsigned bidx, bool found, double qx, double qy, double qz,
+    // (`ht`: the query's home thread)
+    auto emit = [&](long long i, unsigned ht, bool cert, double bd, unsigned bidx, bool found, double qx, double qy, double qz,
                     float lb_new) {
+        if constexpr (PERSIST) {
+            // the winner's point and index are handed over / stay in the home lane's slots; the rest of the state:
+            // (the distance is re-derived when the launch ends: coop_flush)
+            res.lb[ht] = lb_new;
+            return;
+        }
         const unsigned long long lbw = (unsigned long long)__float_as_uint(lb_new) << 32;
         idx_out[i] = found ? (int)bidx : -1;                 // (also when certified: later stages may reuse the array)
         if (cert) {
@@ -225,6 +267,8 @@ __device__ __forceinline__ bool coop_body(
         d2_out[i] = (float)bd;
         if (d64_out) d64_out[i] = bd;                        // (target-sharded ranks compare shards in f64)
     };
+    // the transformed query of home thread h (f64)
+    auto query_p = [&](unsigned h, double (&out)[3]) { out[0] = s_p64[h][0]; out[1] = s_p64[h][1]; out[2] = s_p64[h][2]; };
     // the Jacobian / residual moments of one correspondence (p, q), on the query's HOME lane
     auto moments = [&](double pxd, double pyd, double pzd, unsigned bidx, double qx, double qy, double qz) {
         double nx = 0.0, ny = 0.0, nz = 0.0;
@@ -355,7 +399,17 @@ __device__ __forceinline__ bool coop_body(
         w8.w = ~0ull;
         if (active) {
             s8 = src64[i];
-            if (warm & 1) w8 = wst_io[i];
+            if constexpr (PERSIST) {
+                if (res.first) {
+                    if (warm & 1) w8 = wst_io[i];
+                } else {
+                    // the state the pass before left in this lane's slots
+                    w8.x = s_q64[tid][0]; w8.y = s_q64[tid][1]; w8.z = s_q64[tid][2];
+                    w8.w = (unsigned long long)__float_as_uint(s_dprev[tid]) | ((unsigned long long)__float_as_uint(res.lb[tid]) << 32);
+                }
+            } else {
+                if (warm & 1) w8 = wst_io[i];
+            }
         }
         // (se3_act: the restatement of SE3Type's action on a point, core/se3.h:103-106 -- same products, same order)
         double hp[3];
@@ -398,7 +452,7 @@ __device__ __forceinline__ bool coop_body(
             } else {
                 cert = active && widx == 0xFFFFFFFFu && t > tlim * (1.0f + 1e-6f);
             }
-            if (cert) emit(i, true, has_w ? d2w : r2d, widx, has_w, w8.x, w8.y, w8.z, t);
+            if (cert) emit(i, (unsigned)tid, true, has_w ? d2w : r2d, widx, has_w, w8.x, w8.y, w8.z, t);
         }
         const bool need = active && !cert;
         const bool cfound = cert && has_w;                   // certified WITH a partner: (hp, w8) is the correspondence
@@ -451,7 +505,9 @@ __device__ __forceinline__ bool coop_body(
             if (searching) {
                 s_home[tid] = (unsigned short)home;          // (read back at the end: nothing is carried across the search)
                 // the query as its home lane transformed it (phase A), and its distance to the previous winner
-                const double pxd = s_p64[home][0], pyd = s_p64[home][1], pzd = s_p64[home][2];
+                double hq[3];
+                query_p(home, hq);
+                const double pxd = hq[0], pyd = hq[1], pzd = hq[2];
                 const float dprev = sact ? s_dprev[home] : __uint_as_float(~0u);
                 const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
                 COOP_MARK(0);                                // the query taken over from its home lane
@@ -777,18 +833,21 @@ __device__ __forceinline__ bool coop_body(
                 COOP_MARK(5);                                // f64 winner arrived and ranked
                 if (active) {
                     const long long i = (long long)(vb * NTH + (int)s_home[tid]) * per_group + it;   // its home thread's query of the round
-                    emit(i, false, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
+                    emit(i, (unsigned)s_home[tid], false, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
                 }
-                        // the hand-over to the query's home lane (phase C): the winner's f64 point and index
+                        // the hand-over to the query's home lane (phase C): the winner's f64 point (NaN: none) and index
                 if (active) {
                     const unsigned h = s_home[tid];
-                    s_q64[h][0] = bq.x; s_q64[h][1] = bq.y; s_q64[h][2] = bq.z;
+                    const double none = __longlong_as_double(-1ll);
+                    s_q64[h][0] = found ? bq.x : none; s_q64[h][1] = found ? bq.y : none; s_q64[h][2] = found ? bq.z : none;
                     s_dprev[h] = __uint_as_float(found ? bidx : 0xFFFFFFFFu);
                 }
                 };   // tail
                 const float4 me = s_qp[tid];
                 const unsigned h = s_home[tid];
-                tail(s_p64[h][0], s_p64[h][1], s_p64[h][2], me.x, me.y, me.z, me.w);
+                double hq[3];
+                query_p(h, hq);
+                tail(hq[0], hq[1], hq[2], me.x, me.y, me.z, me.w);
                 COOP_MARK(11);                               // search done
             }
         }
@@ -798,8 +857,11 @@ __device__ __forceinline__ bool coop_body(
         // them was kept across the search, where the kernel sits at the 128 registers it may use: 4 waves per SIMD)
         {
             const unsigned pidx = __float_as_uint(s_dprev[tid]);
-            if (active && pidx != 0xFFFFFFFFu)
-                moments(s_p64[tid][0], s_p64[tid][1], s_p64[tid][2], pidx, s_q64[tid][0], s_q64[tid][1], s_q64[tid][2]);
+            if (active && pidx != 0xFFFFFFFFu) {
+                double hq[3];
+                query_p((unsigned)tid, hq);
+                moments(hq[0], hq[1], hq[2], pidx, s_q64[tid][0], s_q64[tid][1], s_q64[tid][2]);
+            }
         }
         if constexpr (!ONE) __syncthreads();                 // (the next round re-uses the slots, the list and the queue)
     };
@@ -815,14 +877,14 @@ __device__ __forceinline__ bool coop_body(
     if constexpr (PERSIST) {
         // persistent launch: rows as tagged granules, the fold by polling (device_common.h: polled_fold; the launcher
         // refuses a persistent launch without the granule buffers)
-        const unsigned tag = (unsigned)fold.seq;
+        const unsigned tag = fold_row_tag(fold.seq);
         block_reduce_store<NACC, NW, true>(acc, partials, true, fold.rows_tagged, tag);
         COOP_MARK(7);
         published = polled_fold<PLANE, NTH>(fold, lb, bpp, tag);
     } else {
         block_reduce_store<NACC, NW, false>(acc, partials, fold.tickets != nullptr);
         COOP_MARK(7);                                        // workgroup's partial row stored
-        if (fold.tickets) published = fused_fold<PLANE, NTH, false>(fold, partials, row0, lb, bpp, prob);
+        if (fold.tickets) published = fused_fold<PLANE, NTH, false, true>(fold, partials, row0, lb, bpp, prob);
     }
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
     return published;
@@ -951,6 +1013,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // doubles, two slots used alternately) and become scalars at the top of every pass.
     __shared__ unsigned s_tw[2][24];
     __shared__ unsigned s_cmdw;
+    // what the queries carry from pass to pass (CoopRes): read from global memory by the first pass, written back once
+    __shared__ double r_q64[kBlock][3];
+    __shared__ float r_idx[kBlock], r_lb[kBlock];
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(P.pa.relay + kPersistStarted, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (this workgroup runs)
 #pragma unroll
@@ -999,9 +1064,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
             VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
             nullptr, 1, VISMA_KARG(src64), VISMA_KARG(sorted64), VISMA_KARG(nrm64), f, nullptr, VISMA_KARG(wst_io), w, Tp,
-            t_begin ? &work : nullptr);
+            t_begin ? &work : nullptr, CoopRes{r_q64, r_idx, r_lb, pass == 1 ? 1 : 0});
         const PersistArgs pa = VISMA_KARG(pa);
-#undef VISMA_KARG
         if (pa.timeline && pass <= pa.timeline_passes && thread_number<true>() == 0) {
             // (measurement runs only) [pass][workgroup]{begin, body done}; the begin of pass 1 is the launch's
             unsigned long long *slot = pa.timeline + ((unsigned long long)(pass - 1) * gridDim.x + blockIdx.x) * 2ull;
@@ -1009,18 +1073,58 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             // (the clock's low 44 bits -- 48 hours at 100 MHz -- and above them: queued queries, chunks listed)
             slot[1] = (wall_clock64() & 0xFFFFFFFFFFFull) | ((unsigned long long)work << 44);
         }
-        if (pass >= pa.max_passes) break;
-        const int tidx = thread_number<true>();
-        if (tidx < 64) {
-            const bool poller = __builtin_amdgcn_readfirstlane((int)published) != 0;     // (the same on every lane: scalar)
-            const unsigned long long cw = persist_wait(pa, pa.tag0 + (unsigned)(pass - 1), poller, pass, tidx);
-            // the new transform takes the slot of the one before the pass that just ran
-            if (tidx < 24) s_tw[cur ^ 1][tidx] = (unsigned)cw;
-            if (tidx == kPersistWords - 1) s_cmdw = (unsigned)cw;
+        bool last = pass >= pa.max_passes;
+        if (!last) {
+            const int tidx = thread_number<true>();
+            if (tidx < 64) {
+                const bool poller = __builtin_amdgcn_readfirstlane((int)published) != 0;     // (the same on every lane: scalar)
+                const unsigned long long cw = persist_wait(pa, pa.tag0 + (unsigned)(pass - 1), poller, pass, tidx);
+                // the new transform takes the slot of the one before the pass that just ran
+                if (tidx < 24) s_tw[cur ^ 1][tidx] = (unsigned)cw;
+                if (tidx == kPersistWords - 1) s_cmdw = (unsigned)cw;
+            }
+            __syncthreads();
+            const unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cmdw);
+            last = cmd != kPersistGo;
         }
-        __syncthreads();
-        const unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cmdw);
-        if (cmd != kPersistGo) break;
+        if (last) {
+            // The launch ends (its last pass, STOP, nobody came): what the last completed pass left goes back to memory --
+            // correspondence and state of every query, exactly what a one-pass launch of that pass would have written.
+            const int tidx = thread_number<true>();
+            const int bpp = VISMA_KARG(bpp);
+            int vb, per_group;
+            long long i_begin, i_end;
+            coop_query_range<kBlock>(VISMA_KARG(ns), bpp, (int)blockIdx.x % bpp, tidx, vb, per_group, i_begin, i_end);
+            if (i_begin < i_end) {
+                const unsigned pid = __float_as_uint(r_idx[tidx]);
+                Pt64 o8;
+                o8.x = r_q64[tidx][0]; o8.y = r_q64[tidx][1]; o8.z = r_q64[tidx][2];      // (NaN, all bits set: no partner)
+                o8.w = (unsigned long long)pid | ((unsigned long long)__float_as_uint(r_lb[tidx]) << 32);
+                // the squared distance of the last pass's correspondence, as that pass computed it: its transform (still
+                // in its slot), the products of se3_act, flann's sum (dist.h:159-176)
+                float d2 = VISMA_KARG(r2f);
+                if (pid != 0xFFFFFFFFu) {
+                    double Tl[12];
+#pragma unroll
+                    for (int k = 0; k < 12; k++)
+                        Tl[k] = __longlong_as_double((long long)(((unsigned long long)s_tw[cur][2 * k + 1] << 32) | s_tw[cur][2 * k]));
+                    const Pt64 s8 = VISMA_KARG(src64)[i_begin];
+                    const double sv[3] = {s8.x, s8.y, s8.z};
+                    double hp[3];
+                    se3_act(Tl, sv, hp);
+                    const double dx = o8.x - hp[0], dy = o8.y - hp[1], dz = o8.z - hp[2];
+                    double d = dx * dx;
+                    d += dy * dy;
+                    d += dz * dz;
+                    d2 = (float)d;
+                }
+                VISMA_KARG(idx_out)[i_begin] = (int)pid;                                // (~0 = -1: none)
+                VISMA_KARG(d2_out)[i_begin] = d2;
+                VISMA_KARG(wst_io)[i_begin] = o8;
+            }
+            break;
+        }
+#undef VISMA_KARG
     }
 }
 #undef VISMA_COOP_PARAMS

@@ -22,6 +22,7 @@ public:
             if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
         free_dev(d_mbox_); free_dev(d_ipc_flag_); free_dev(d_raw_); free_dev(d_sorted12_); free_dev(bt_sorted12_);
         free_dev(d_pend_count_); free_dev(d_pend_q32_); free_dev(d_pend_q64_); free_dev(d_pend_best_); free_dev(d_pend_idx_);
+        if (sess_live_) (void)end_session();     // (first: nothing is freed under a launch that still polls for a command)
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
         free_dev(d_claim_); free_dev(d_d64_);
@@ -36,7 +37,6 @@ public:
         free_dev(bt_nrm_); free_dev(bt_nrm64_); free_dev(bt_raw_);
         free_dev(bt_src64_); free_dev(bt_tgt64_); free_dev(bt_sorted64_);
         free_dev(bt_cell_of_); free_dev(bt_count_); free_dev(bt_start_); free_dev(bt_bsum_); free_dev(bt_descs_);
-        if (sess_live_) (void)end_session();
         if (h_state_) (void)hipHostFree(h_state_);
         if (h_stats_) (void)hipHostFree(h_stats_);
         if (h_cmd_ && !cmd_direct_) (void)hipHostFree(h_cmd_);
@@ -243,18 +243,33 @@ public:
         persist_enabled_ = enabled != 0;
         if (timeout_ms >= 0.5 && timeout_ms <= 5000.0) persist_timeout_ms_ = timeout_ms;
     }
+    void get_persistent_info(visma_icp_persistent_info *out) const override
+    {
+        out->enabled = persist_enabled_ ? 1 : 0;
+        out->last_loop_persistent = last_loop_persist_passes_ > 0 ? 1 : 0;
+        out->last_loop_passes = last_loop_persist_passes_;
+        out->launches = timing_persist_launches_total_;
+        out->passes = timing_persist_passes_total_;
+        out->aborts = persist_aborts_total_;
+        out->timeout_ms = persist_timeout_ms_;
+        out->cu_share = persist_cu_share();
+        out->device_slots = persist_slots_seen_;
+    }
     void stall_command(int nth, double ms) override { stall_nth_ = nth; stall_ms_ = ms; }
     void loop_begin(int max_passes) override
     {
         loop_scope_ = true;
         loop_budget_ = max_passes;
+        loop_persist_passes_ = 0;
     }
     bool loop_across_ranks_ok() const override { return persist_ranks_ok(); }
     int loop_end() override
     {
         loop_scope_ = false;
         loop_budget_ = 0;
-        return sess_live_ ? end_session() : VISMA_ICP_OK;
+        const int rc = sess_live_ ? end_session() : VISMA_ICP_OK;
+        last_loop_persist_passes_ = loop_persist_passes_;
+        return rc;
     }
 
     bool supports_device_loop() const override { return true; }
@@ -502,8 +517,16 @@ private:
     {
         if (grid_lanes_ > 0) return grid_lanes_;
         if (coop_ok() && pos_fresh_) return kCoopLanes;
+        // the FIRST pass of a large registration inside the persistent launch of its host loop (round 5): the certificate
+        // kernel started cold (no winner known: every query searches against the radius) costs about what the
+        // lane-serial kernel costs at these sizes, and the loop saves a launch, a drain and a host round trip
+        if (nprob == 1 && cold_in_launch_ && ns_ >= cold_in_launch_min_ns_ && loop_scope_ && loop_budget_ >= 2 && coop_ok() &&
+            persist_static_ok())
+            return kCoopLanes;
         return grid_lanes(nprob);
     }
+    int cold_in_launch_ = 1;                 // VISMA_ICP_COLD_IN_LAUNCH=0: the first pass always on the lane-serial kernel
+    int64_t cold_in_launch_min_ns_ = 131072; // VISMA_ICP_COLD_IN_LAUNCH_MIN_NS (below: lane-serial 20 us vs 29 at 5 k)
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes(int nprob = 1) const
     {
@@ -611,6 +634,13 @@ private:
     }
     int make_fold(int bpp, int nprob, double *stats_out, long long stats_stride, double *host_out,
                   unsigned long long seq, FoldArgs *out);
+    // device-resident loops: the problem's state advances in the fold epilogue of the search launch (FoldArgs::solve) --
+    // the closed-form update on one GPU; Gauss-Newton / point-to-plane loops and ranks keep solve_state_kernel
+    int solve_in_fold_ = 1;          // VISMA_ICP_SOLVE_IN_FOLD=0: the solve in a launch of its own, as until round 4 (A/B)
+    bool solve_in_fold(const LoopParams &lp) const
+    {
+        return solve_in_fold_ && fused_fold_ && !lp.plane && lp.solver == VISMA_ICP_SOLVER_KABSCH && !tshard_ && !comm_ && ipc_n_ <= 1;
+    }
     int ensure_f64_views();
 
     // ---- persistent sessions: ONE launch of the certificate kernel runs the remaining passes of the host loop that
@@ -619,6 +649,13 @@ private:
     // fit (another radius, plane, frame) posts STOP and waits for the launch to end.  The launch gives up by itself
     // when no command arrives in time (the host then finds the stream idle and goes on with ordinary launches).
     int persist_enabled_ = 1;        // VISMA_ICP_PERSIST=0: one launch per pass
+    // what visma_icp_get_persistent_info reports (never reset)
+    int loop_persist_passes_ = 0, last_loop_persist_passes_ = 0;
+    double timing_persist_launches_total_ = 0.0, timing_persist_passes_total_ = 0.0, persist_aborts_total_ = 0.0;
+    mutable int persist_slots_seen_ = 0;
+    // the process-wide cap on the part of a device's workgroup slots a persistent launch may hold
+    // (visma_icp_set_persistent_cu_share; VISMA_ICP_PERSIST_CU_SHARE)
+    static double persist_cu_share() { return persist_cu_share_ref().load(); }
     double persist_timeout_ms_ = 200.0;   // VISMA_ICP_PERSIST_TIMEOUT_MS: the poller's patience
     bool loop_scope_ = false;
     int loop_budget_ = 0;            // passes the announced loop may still run
@@ -656,6 +693,13 @@ private:
     int stall_nth_ = 0;              // (tests) sleep stall_ms_ before the stall_nth_-th command from now
     double stall_ms_ = 0.0;
     bool persist_possible(int lanes, int nblocks, bool fused, bool plane) const;
+    // what a persistent launch needs of the context, whatever the pass (persist_possible adds the launch's shape)
+    bool persist_static_ok() const
+    {
+        static const bool forced = std::getenv("VISMA_ICP_COOP_KERNEL") != nullptr;       // (A/B runs of the two one-pass kernels)
+        return persist_enabled_ && fused_fold_ && !tshard_ && !comm_ && !minreduce_ && (ipc_n_ <= 1 || persist_ranks_ok()) &&
+               !(grid_lanes_ > 0 && grid_lanes_ != kCoopLanes) && !forced && ns_ <= (int64_t)grid_blocks() * kBlock;
+    }
     int start_session(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, int nblocks, bool prof);
     void post_command(const Xform64 &T64, unsigned cmd);
     int end_session();

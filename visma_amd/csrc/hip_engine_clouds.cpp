@@ -47,11 +47,14 @@ int HipEngine::init()
     if (const char *e = std::getenv("VISMA_ICP_TILE_FALLBACK")) tile_fallback_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_TILE_FOLD")) tile_fused_fold_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_FUSED_FOLD")) fused_fold_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_SOLVE_IN_FOLD")) solve_in_fold_ = std::atoi(e) != 0;
     HIP_TRY(hipHostMalloc(&h_stats_, sizeof(double) * 2 * kNStats,     // {value, tag} granules
                           hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(h_stats_, 0, sizeof(double) * 2 * kNStats);
     HIP_TRY(hipHostGetDevicePointer((void **)&h_stats_dev_, h_stats_, 0));
     if (const char *e = std::getenv("VISMA_ICP_PERSIST")) persist_enabled_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH")) cold_in_launch_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH_MIN_NS")) cold_in_launch_min_ns_ = std::max<long long>(0, std::atoll(e));
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMEOUT_MS")) { const double v = std::atof(e); if (v >= 1.0 && v <= 5000.0) persist_timeout_ms_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMELINE")) timeline_path_ = e;
     // The command block of the persistent launch.  On a large-BAR system it lies in fine-grained DEVICE memory the host

@@ -235,19 +235,23 @@ int HipEngine::ipc_init(int rank, int nranks, const void *handles)
             (void)hipGetLastError();
             const double me = 1.0 + (double)(((long long)dom << 16) | ((long long)bus << 8) | (long long)dev);
             for (int a = 0; a < kNStats; a++) hs[(size_t)a] = a == rank ? me : 0.0;
-            double *d_id = nullptr;
             peers_share_device_ = true;
-            if (hipMalloc((void **)&d_id, sizeof(double) * kNStats) == hipSuccess) {
+            // (the exchange runs in the statistics buffer every context owns: no allocation that could fail on one rank
+            //  only -- a rank that skipped this collective would leave the mailbox call count, and with it the half in use,
+            //  out of step with its peers for every later pass)
+            double *d_id = (double *)d_stats_;
+            {
                 hipError_t e2 = hipMemcpyAsync(d_id, hs.data(), sizeof(double) * kNStats, hipMemcpyHostToDevice, stream_);
                 if (e2 == hipSuccess)
                     e2 = launch_ipc_allreduce(d_id, d_id, peers_, ipc_rank_, ipc_n_, ipc_seq_dev(), nullptr, 0, (int *)d_ipc_flag_,
                                               stream_, kIpcHandshakeSpins);
                 if (e2 == hipSuccess) e2 = hipMemcpyAsync(hs.data(), d_id, sizeof(double) * kNStats, hipMemcpyDeviceToHost, stream_);
                 if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream_);
-                (void)hipFree(d_id);
                 if (e2 == hipSuccess) {
+                    // anything but a proper address in a slot (a late peer leaves NaN, a silent one 0) counts as shared:
+                    // persistent launches across ranks only where every peer is KNOWN to sit elsewhere
                     bool shared = false;
-                    for (int r = 0; r < nranks; r++) shared = shared || (r != rank && hs[(size_t)r] == me) || hs[(size_t)r] < 1.0;
+                    for (int r = 0; r < nranks; r++) shared = shared || !(hs[(size_t)r] >= 1.0) || (r != rank && hs[(size_t)r] == me);
                     peers_share_device_ = shared;
                 } else {
                     (void)hipGetLastError();

@@ -1,7 +1,13 @@
 // hip_engine_passes.cpp -- HipEngine: the per-pass launches (brute force / lane-serial grid / warm-started grid), the fused fold, the device-resident loops (single problem, sweeps, batches of problems with their own clouds).
 #include "hip_engine.hpp"
 
+#if defined(__x86_64__) || defined(_M_X64)
 #include <immintrin.h>
+#define VISMA_STORE_FENCE() _mm_sfence()
+#else
+// (no write-combining BAR stores elsewhere: the command block then lies in host memory, hip_engine_clouds.cpp)
+#define VISMA_STORE_FENCE() std::atomic_thread_fence(std::memory_order_seq_cst)
+#endif
 
 namespace visma {
 namespace drv {
@@ -124,7 +130,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 const double gap_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_stats_seen_).count();
                 patient = gap_us <= persist_timeout_ms_ * 1e3;
                 if (!patient) {
-                    timing_.persist_aborts += 1.0;
+                    timing_.persist_aborts += 1.0; persist_aborts_total_ += 1.0;
                     persist_enabled_ = 0;                    // (until visma_icp_set_persistent asks again)
                 } else if (trace_persist()) {
                     host_gap_us_ += gap_us;
@@ -135,6 +141,8 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 post_command(T64, kPersistGo);
                 if (trace_persist()) t_posted_ = std::chrono::steady_clock::now();
                 sess_pass_++;
+                loop_persist_passes_++;
+                timing_persist_passes_total_ += 1.0;
                 in_session = true;
                 posted = true;                               // (its transform becomes "the previous one" once the pass has run)
                 ipc_done = true;                             // (ranks: the folding workgroup exchanges inside the launch)
@@ -176,7 +184,12 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
             }
             int rc = launch_grid_pass(T64, plane, offset, seq, pp ? sess_prof_ : prof, pp, &nblocks, &ipc_done);
             if (rc) { if (pp) finish_session(); return rc; }
-            if (pp) { sess_pass_ = 1; in_session = true; }
+            if (pp) {
+                sess_pass_ = 1; in_session = true;
+                loop_persist_passes_++;
+                timing_persist_launches_total_ += 1.0;
+                timing_persist_passes_total_ += 1.0;
+            }
         }
         if (loop_budget_ > 0) loop_budget_--;
         (void)nblocks;
@@ -241,7 +254,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         HIP_TRY(hipStreamSynchronize(stream_));
         seen = all_tagged();
         if (!seen) {
-            timing_.persist_aborts += 1.0;
+            timing_.persist_aborts += 1.0; persist_aborts_total_ += 1.0;
             if (trace_persist())
                 std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
                              *reinterpret_cast<volatile unsigned *>(h_flag_), cmd_tag_, sess_tag0_);
@@ -304,12 +317,17 @@ int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double off
         if (ipc) { add_ipc(&fa); *ipc_done = true; }
         if (persist) {
             // the persistent launch folds by polling: rows and group rows as tagged granules (no tickets)
-            constexpr size_t kRows = 2048, kGroups = 256, kRowBytes = 32 * 16;
+            constexpr size_t kRows = 2048, kGroups = (kRows + kFoldGroup - 1) / kFoldGroup, kRowBytes = 32 * 16;
+            static_assert(kFoldGroup >= 1 && kGroups <= kRows, "group rows of the polled fold");
             if (!d_fold_tag_) {
                 HIP_TRY(hipMalloc(&d_fold_tag_, (kRows + kGroups) * kRowBytes));
                 HIP_TRY(hipMemsetAsync(d_fold_tag_, 0, (kRows + kGroups) * kRowBytes, stream_));
             }
             if ((size_t)grid_launch_blocks(ns_, lanes, grid_blocks()) > kRows) { err_ = "persistent launch larger than its fold rows"; return VISMA_ICP_ERR_STATE; }
+            // (the rows validate themselves with fold_row_tag(sequence number): when a session's numbers run through the
+            //  tag's wrap, the buffer is cleared first -- a row of 2^32 - 1 passes ago must not validate)
+            if (seq % kFoldTagPeriod + (unsigned long long)persist->max_passes >= kFoldTagPeriod)
+                HIP_TRY(hipMemsetAsync(d_fold_tag_, 0, (kRows + kGroups) * kRowBytes, stream_));
             fa.rows_tagged = d_fold_tag_;
             fa.rows2_tagged = (char *)d_fold_tag_ + kRows * kRowBytes;
             fa.dead_flag = (unsigned long long *)d_relay_ + kPersistDead;
@@ -358,14 +376,18 @@ bool HipEngine::persist_possible(int lanes, int nblocks, bool fused, bool plane)
     };
     if (!persist_enabled_) return no("switched off");
     if (!fused || tshard_ || comm_ || minreduce_ || (ipc_n_ > 1 && !persist_ranks_ok())) return no("sharded ranks / fold in a second launch");
-    if (lanes != kCoopLanes || !coop_ok() || !pos_fresh_) return no("not a pass of the certificate kernel");
+    if (lanes != kCoopLanes || !coop_ok()) return no("not a pass of the certificate kernel");   // (pass_lanes: warm, or cold in a loop)
     if (grid_lanes_ > 0 && grid_lanes_ != kCoopLanes) return no("lanes forced");
     if (std::getenv("VISMA_ICP_COOP_KERNEL")) return no("kernel forced");       // (A/B runs of the two one-pass kernels)
     // one query per lane, every workgroup resident at once
     if ((int64_t)nblocks * kBlock < ns_) return no("several queries per lane");
     const int cap = coop_persist_capacity(plane ? 1 : 0);
-    if (trace) std::fprintf(stderr, "[visma_icp] persistent launch: %d workgroups, device holds %d\n", nblocks, cap);
-    return nblocks <= cap;
+    persist_slots_seen_ = cap;
+    // (the process's share of the device: a launch that needs more runs one launch per pass, which the kernels of other
+    //  streams interleave with -- a persistent launch holds its slots, spinning, for the length of the loop)
+    const int allowed = (int)((double)cap * persist_cu_share());
+    if (trace) std::fprintf(stderr, "[visma_icp] persistent launch: %d workgroups, device holds %d, this process may hold %d\n", nblocks, cap, allowed);
+    return nblocks <= allowed;
 }
 
 int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3], unsigned long long seq, int, bool prof)
@@ -404,7 +426,7 @@ void HipEngine::post_command(const Xform64 &T64, unsigned cmd)
     }
     c[kPersistWords - 1] = (unsigned long long)cmd | t;
     std::atomic_thread_fence(std::memory_order_release);
-    if (cmd_direct_) _mm_sfence();                       // (the BAR is write-combining: the stores leave the core now, not when its buffers fill)
+    if (cmd_direct_) VISMA_STORE_FENCE();                       // (the BAR is write-combining: the stores leave the core now, not when its buffers fill)
 }
 
 void HipEngine::finish_session()
@@ -584,7 +606,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
         for (int j = 0; j < n; j++) {
             int nblocks = 1, e0 = -1;
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-            bool fused = false;
+            bool fused = false, solved_in_fold = false;
             if (use_grid_) {
                 // fold inside the search launch: the statistics land in the problems' device state
                 FoldArgs fa{};
@@ -595,7 +617,11 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
                                    st->stats, (long long)(sizeof(DevIcpState) / sizeof(double)), nullptr, 0, &fa);
                     if (rc) return rc;
                     if (ipc_n_ > 1) add_ipc(&fa);      // (one problem per rank: ipc needs nprob == 1)
+                    // closed-form update on one GPU: the workgroup that completes a problem's fold advances its state
+                    // in the same launch (no solve_state_kernel between two search launches)
+                    if (solve_in_fold(lp)) fa.solve = st;
                 }
+                solved_in_fold = fused && fa.solve != nullptr;
                 HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
                                               (const unsigned *)d_start_, grid_, (const float4 *)d_nrm_,
                                               T32_, T64, nullptr, r2f_, plane, (int32_t *)d_idx_,
@@ -645,7 +671,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
                 }
                 HIP_TRY(launch_solve_state(st, 1, stream_));
             } else if (fused) {
-                HIP_TRY(launch_solve_state(st, nprob, stream_));
+                if (!solved_in_fold) HIP_TRY(launch_solve_state(st, nprob, stream_));
             } else {
                 HIP_TRY(launch_finalize_solve((const double *)d_partials_, nblocks, st, plane, nprob, stream_));
             }
@@ -931,6 +957,7 @@ int HipEngine::run_loop_batch(const LoopParams &lp, const std::vector<BatchProbl
         bfa.ticket_stride = (int)tstride;
         bfa.stats_out = st->stats;
         bfa.stats_stride = (long long)(sizeof(DevIcpState) / sizeof(double));
+        if (solve_in_fold(lp)) bfa.solve = st;               // (see run_loop)
     }
     const int chunk = lp.check_stop ? 8 : lp.passes;
     int done = 0;
@@ -957,7 +984,7 @@ int HipEngine::run_loop_batch(const LoopParams &lp, const std::vector<BatchProbl
             fresh = true;
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
-            if (fused_fold_) HIP_TRY(launch_solve_state(st, B, stream_));
+            if (fused_fold_) { if (!bfa.solve) HIP_TRY(launch_solve_state(st, B, stream_)); }
             else HIP_TRY(launch_finalize_solve_batch((const double *)d_partials_, (const ProbDesc *)bt_descs_, st, B, stream_, lp.plane ? 1 : 0));
             if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 1}); }
         }

@@ -205,6 +205,62 @@ VISMA_HD void project_so3(const double A[9], double R[9])
             R[i * 3 + j] = d.U[i * 3] * d.V[j * 3] + d.U[i * 3 + 1] * d.V[j * 3 + 1] + d.U[i * 3 + 2] * d.V[j * 3 + 2];
 }
 
+// The rotation nearest to A -- the orthogonal polar factor Q of A = Q H -- by Newton's iteration
+// X <- (X + X^-T) / 2 from X0 = A / |A|_F (Higham, "Computing the polar decomposition -- with applications", 1986):
+// the singular vectors of X never change, every singular value s goes to (s + 1/s) / 2 -> 1 quadratically, and
+// det X keeps its sign.  For det A > 0 that Q is exactly Umeyama's U S V^T (Umeyama.h:118-159: S = I when
+// det U det V > 0), with tr(Q^T A) the sum of A's singular values -- WITHOUT the one-sided Jacobi sweeps of svd3,
+// whose ~18 rotations are a chain of dependent f64 divisions and square roots: 9 us in one GPU thread (the solve
+// launch between every two search launches of a batch: 18 % of config 3's GPU time until round 5) against ~1 us
+// here (one division per step, 8-13 steps).  Only +, -, x, / in a fixed order: host and device agree bit for bit.
+// Returns false -- the caller then takes the SVD path -- for det A <= 0 (a reflection is nearest: Umeyama flips the
+// smallest singular direction, which only the SVD names), for a matrix too close to singular for the inverse to be
+// trusted (relative det below 1e-7: planar or collinear correspondences, a handful of pairs), and for non-finite input.
+VISMA_HD bool polar_rotation3(const double A[9], double Q[9])
+{
+    double f2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) f2 += A[i] * A[i];
+    if (!(f2 > 0.0) || !(f2 < 1e300)) return false;
+    const double inv_f = 1.0 / sqrt(f2);
+    double X[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) X[i] = A[i] * inv_f;
+    for (int it = 0; it < 64; it++) {
+        // cofactors: C = det(X) X^-T
+        double C[9];
+        C[0] = X[4] * X[8] - X[5] * X[7];
+        C[1] = X[5] * X[6] - X[3] * X[8];
+        C[2] = X[3] * X[7] - X[4] * X[6];
+        C[3] = X[2] * X[7] - X[1] * X[8];
+        C[4] = X[0] * X[8] - X[2] * X[6];
+        C[5] = X[1] * X[6] - X[0] * X[7];
+        C[6] = X[1] * X[5] - X[2] * X[4];
+        C[7] = X[2] * X[3] - X[0] * X[5];
+        C[8] = X[0] * X[4] - X[1] * X[3];
+        const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+        // (|X0|_F = 1: det X0 = s1 s2 s3 <= 3^-3/2; later iterates have every s >= 1)
+        if (!(det > (it == 0 ? 1e-7 : 0.5))) return false;
+        const double inv = 1.0 / det;
+        double d2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const double xn = 0.5 * (X[i] + C[i] * inv);
+            const double d = xn - X[i];
+            d2 += d * d;
+            X[i] = xn;
+        }
+        // quadratic convergence: a step below 1e-8 leaves an error of ~1e-16 -- one more step then changes nothing
+        // above rounding
+        if (d2 < 1e-16) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) Q[i] = X[i];
+            return true;
+        }
+    }
+    return false;
+}
+
 struct NormalEq {
     double K, r2;
     double JTJ[36];
@@ -243,20 +299,28 @@ VISMA_HD Mat4 kabsch_from_stats(const double *st, bool with_scaling)
     for (int a = 0; a < 3; a++) { pm[a] = P[a] * inv; qm[a] = Q[a] * inv; }
     for (int a = 0; a < 3; a++)
         for (int b = 0; b < 3; b++) sigma[a * 3 + b] = e.M[a * 3 + b] * inv - qm[a] * pm[b];
-    const Svd3 d = svd3(sigma);
-    double S[3] = {1.0, 1.0, 1.0};
-    if (det3(d.U) * det3(d.V) < 0.0) S[2] = -1.0;
-    double R[9];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++)
-            R[i * 3 + j] = d.U[i * 3] * S[0] * d.V[j * 3] + d.U[i * 3 + 1] * S[1] * d.V[j * 3 + 1] +
-                           d.U[i * 3 + 2] * S[2] * d.V[j * 3 + 2];
+    // R = U S V^T (Umeyama.h:139-152) and sum_i s_i S_i (:155-158): through the polar factor when det sigma > 0 and
+    // sigma is well conditioned (every registration of a real surface), else through the SVD
+    double R[9], strace;
+    if (polar_rotation3(sigma, R)) {
+        strace = 0.0;                                        // tr(R^T sigma) = s1 + s2 + s3
+        for (int i = 0; i < 9; i++) strace += R[i] * sigma[i];
+    } else {
+        const Svd3 d = svd3(sigma);
+        double S[3] = {1.0, 1.0, 1.0};
+        if (det3(d.U) * det3(d.V) < 0.0) S[2] = -1.0;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R[i * 3 + j] = d.U[i * 3] * S[0] * d.V[j * 3] + d.U[i * 3 + 1] * S[1] * d.V[j * 3 + 1] +
+                               d.U[i * 3 + 2] * S[2] * d.V[j * 3 + 2];
+        strace = d.s[0] * S[0] + d.s[1] * S[1] + d.s[2] * S[2];
+    }
     double c = 1.0;
     if (with_scaling) {
         // tr(sum(|p|^2 I - p p^T)) = 2 sum |p|^2
         const double sum_p2 = 0.5 * (e.JTJ[0] + e.JTJ[7] + e.JTJ[14]);
         const double var = sum_p2 * inv - (pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2]);
-        c = (d.s[0] * S[0] + d.s[1] * S[1] + d.s[2] * S[2]) / var;
+        c = strace / var;
     }
     Mat4 T = Mat4::identity();
     for (int i = 0; i < 3; i++) {

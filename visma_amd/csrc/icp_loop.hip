@@ -12,58 +12,9 @@
 // closed-form Kabsch/Umeyama from the reduced moments, or the 6x6 Gauss-Newton
 // step with Euler / exponential-map retraction.
 #include "device_common.h"
-#include "host_math.hpp"
+#include "icp_state.h"
 
 namespace visma {
-
-__device__ __forceinline__ void advance_state(DevIcpState *st)
-{
-    const double *stats = st->stats;
-    const double K = stats[0];
-    // fitness / rmse of the pass just finished (Registration.cpp:87-94)
-    double fit = 0.0, rmse = 0.0;
-    if (K > 0.0) {
-        fit = K / (double)st->ns_total;
-        rmse = sqrt(stats[1] / K);
-    }
-    st->K = K;
-    st->fit = fit;
-    st->rmse = rmse;
-    st->passes += 1;
-    bool stop = false;
-    if (st->check_stop && st->passes >= 2 && fabs(st->fit_prev - fit) < st->rel_fit &&
-        fabs(st->rmse_prev - rmse) < st->rel_rmse)
-        stop = true;                                   // Registration.cpp:179-183
-    if (st->iter >= st->max_iter) stop = true;         // loop bound, :169
-    if (stop) {
-        st->active = 0;
-        return;
-    }
-    // update = estimation.ComputeTransformation(...)  (:172-173), from the moments
-    Mat4 upd;
-    bool ok = true;
-    if (st->plane || st->solver == 1)
-        upd = gn_from_stats(stats, false, &ok);
-    else if (st->solver == 2)
-        upd = gn_from_stats(stats, true, &ok);
-    else
-        upd = kabsch_from_stats(stats, st->scaling != 0);
-    // transformation = update * transformation  (:174), in f64
-    Mat4 Tc = Mat4::identity();
-    for (int i = 0; i < 12; i++) Tc.m[i] = st->Tc[i];
-    Mat4 Tn;
-    if (st->world_frame)
-        Tn = to_centred(upd * from_centred(Tc, st->centre), st->centre);
-    else
-        Tn = upd * Tc;
-    // (the pose the pass just folded was searched at: what the next pass's certificates measure their motion from)
-    for (int i = 0; i < 12; i++) st->Tc_prev[i] = st->Tc[i];
-    st->have_prev = 1;
-    for (int i = 0; i < 12; i++) st->Tc[i] = Tn.m[i];
-    st->iter += 1;
-    st->fit_prev = fit;
-    st->rmse_prev = rmse;
-}
 
 // 256 threads, not the 1024 of the plain fold kernel: the one-thread solve below needs more
 // than the 128 VGPRs a 1024-thread workgroup leaves per lane (it spilled ~1500 scratch

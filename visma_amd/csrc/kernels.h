@@ -82,7 +82,21 @@ struct FoldArgs {
     void *rows_tagged, *rows2_tagged;
     unsigned long long *dead_flag;     // the launch's "somebody left" word (kernels.h: kPersistDead)
     long long poll_ticks;              // how long a reducer waits for a row (wall_clock64 ticks) before it gives the launch up
+    // device-resident loops with the closed-form (Kabsch) update (round 5): the workgroup that completes problem b's fold
+    // advances solve[b] right there (icp_state.h: advance_state<true>) -- no solve launch between two search launches.
+    // NULL: the statistics are left in the state and solve_state_kernel advances it (Gauss-Newton modes, point-to-plane,
+    // ranks that exchange first).  Honoured by the kernels batches and sweeps run (grid.hip, grid_wave.hip).
+    DevIcpState *solve;
 };
+
+// The tag the granule rows of the polled fold validate themselves with: the pass's sequence number folded into
+// 1 .. 2^32 - 1 -- never 0 (a cleared buffer validates nothing), the same value again only 2^32 - 1 passes later (the
+// host clears the rows before a session whose numbers run through that wrap: hip_engine_passes.cpp).
+constexpr unsigned long long kFoldTagPeriod = 0xFFFFFFFFull;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline unsigned fold_row_tag(unsigned long long seq) { return (unsigned)(seq % kFoldTagPeriod) + 1u; }
 
 // The PERSISTENT form of the certificate kernel (grid_coop.hip, round 4b): ONE launch runs up to max_passes ICP
 // passes of one registration.  After a pass the workgroup that finished the fold (and published the statistics to
