@@ -92,7 +92,7 @@ def parse():
     ap.add_argument("--no-weak", action="store_true", help="skip the weak-scaling line of c4 at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20)
-    ap.add_argument("--cpu-repeats", type=int, default=5)
+    ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=7, help="how many times the K-step block is timed (value = median)")
     ap.add_argument("--no-extras", action="store_true",
                     help="c4: skip from_initial_pose / end_to_end / roofline_saturated / scaling_workloads")
@@ -143,7 +143,9 @@ class Ranks:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
                 self.tdev = "cuda"
             else:
-                dist.init_process_group(backend=self.backend)
+                import datetime
+                dist.init_process_group(backend=self.backend, timeout=datetime.timedelta(
+                    seconds=float(os.environ.get("VISMA_BENCH_RENDEZVOUS_TIMEOUT_S", "300"))))
             self.dist = dist
             self.torch = torch
 
@@ -172,6 +174,33 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
+BRINGUP_TIMEOUT_S = float(os.environ.get("VISMA_BENCH_BRINGUP_TIMEOUT_S", "90"))
+
+
+def bounded(what, fn, *a):
+    """One bring-up step of a transport (hipIpcOpenMemHandle, ncclCommInitRank, ...) under a wall-clock limit: the
+    call runs on a helper thread (ctypes releases the GIL), and a call that has not returned after
+    VISMA_BENCH_BRINGUP_TIMEOUT_S counts as FAILED -- the rank goes on to the agreement with its peers (every step is
+    followed by a MIN over the ranks' flags) and everybody lands on the next transport together.  The stuck thread and
+    its context are abandoned, not joined: a hung driver call must not eat the lease."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["v"] = fn(*a)
+        except BaseException as e:      # noqa: BLE001
+            box["e"] = e
+    t = threading.Thread(target=run, daemon=True, name="bringup:" + what)
+    t.start()
+    t.join(BRINGUP_TIMEOUT_S)
+    if t.is_alive():
+        raise TimeoutError("%s did not return within %.0f s" % (what, BRINGUP_TIMEOUT_S))
+    if "e" in box:
+        raise box["e"]
+    return box.get("v")
+
+
 def attach_comm(R, ctx, make_ctx, args):
     """Bring up the library's all-reduce on every rank together.  Preference: the library's own RCCL
     communicator (ncclAllReduce of 38 f64 on the context's stream); should it fail to come up on this
@@ -187,7 +216,7 @@ def attach_comm(R, ctx, make_ctx, args):
             #  fall-back chain: every rank must land on the NEXT transport together, tests/test_multi_gpu_bench.py)
             if os.environ.get("VISMA_BENCH_FAIL_IPC_EXPORT_RANK") == str(R.rank):
                 raise RuntimeError("injected failure")
-            mine = ctx.comm_ipc_export()
+            mine = bounded("hipIpcGetMemHandle", ctx.comm_ipc_export)
         except Exception as e:      # noqa: BLE001
             print("bench: rank %d: mailbox export failed (%s)" % (R.rank, e), file=sys.stderr)
             mine, ok = bytes(_lib.IPC_HANDLE_BYTES), 0
@@ -200,7 +229,9 @@ def attach_comm(R, ctx, make_ctx, args):
             try:
                 if os.environ.get("VISMA_BENCH_FAIL_IPC_INIT_RANK") == str(R.rank):
                     raise RuntimeError("injected failure")
-                ctx.comm_ipc_init(R.rank, R.world, [bytes(x.cpu().tolist()) for x in lst])
+                if os.environ.get("VISMA_BENCH_HANG_IPC_INIT_RANK") == str(R.rank):
+                    bounded("hipIpcOpenMemHandle (injected hang)", time.sleep, 3600.0)      # (test: a driver call that never returns)
+                bounded("hipIpcOpenMemHandle + handshake", ctx.comm_ipc_init, R.rank, R.world, [bytes(x.cpu().tolist()) for x in lst])
             except Exception as e:      # noqa: BLE001
                 print("bench: rank %d: mailbox mapping failed (%s)" % (R.rank, e), file=sys.stderr)
                 ok = 0
@@ -215,7 +246,7 @@ def attach_comm(R, ctx, make_ctx, args):
     uid_bytes = bytes(_lib.UNIQUE_ID_BYTES)
     if R.rank == 0 and ok:
         try:
-            uid_bytes = _lib.comm_unique_id()
+            uid_bytes = bounded("ncclGetUniqueId", _lib.comm_unique_id)
         except Exception as e:      # noqa: BLE001
             print("bench: ncclGetUniqueId failed (%s)" % e, file=sys.stderr)
             ok = 0
@@ -226,7 +257,7 @@ def attach_comm(R, ctx, make_ctx, args):
     ok = int(flag.item())
     if ok:
         try:
-            ctx.comm_init(R.rank, R.world, bytes(uid.cpu().tolist()))
+            bounded("ncclCommInitRank", ctx.comm_init, R.rank, R.world, bytes(uid.cpu().tolist()))
         except Exception as e:      # noqa: BLE001
             print("bench: rank %d: ncclCommInitRank failed (%s)" % (R.rank, e), file=sys.stderr)
             ok = 0
@@ -302,6 +333,14 @@ def load_traffic(kind, ns_local, nt, field="hbm_bytes_per_nn_launch"):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         return tj.get("%s:%dx%d" % (kind, ns_local, nt), {}).get(field)
+    except Exception:
+        return None
+
+
+def batch_traffic(key):
+    """fabric bytes per launch of the batch kernel of config 3 / 5 (profiles/traffic.json; PMC passes of a profiled run)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}).get("hbm_bytes_per_nn_launch")
     except Exception:
         return None
 
@@ -512,7 +551,7 @@ def persistent_launches(roofline, tm, queries=0, nt=0, traffic_key="grid_persist
     return roofline
 
 
-def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None):
+def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None, persist_traffic_key="grid_persist"):
     """roofline object of the search kernel the context's last passes ran, from its event / candidate counters"""
     nl = max(tm["nn_launches"], 1)
     kind = ctx.search_kernel_used()
@@ -521,13 +560,14 @@ def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None):
                       tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
                       ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial",
                       tm["grid_certified"] / nl)
-    return persistent_launches(r, tm, ns_local if traffic_kind != "none" else 0, nt_local)
+    return persistent_launches(r, tm, ns_local if traffic_kind != "none" else 0, nt_local, persist_traffic_key)
 
 
-def c4_variant(R, device, src, tgt, radius, T_gt, steps, what):
+def c4_variant(R, device, src, tgt, radius, T_gt, steps, what, traffic_key=None):
     """One more C4-shaped registration measured like the headline, on its own context (rank 0, N = 1 only): iterations
-    1..K from the identity (first pass cold, the rest warm-started while the pose moves) and the K iterations after
-    2K more (the `value` regime), each the median of three, with the roofline object of the search kernel."""
+    1..K from the identity (first pass cold, the rest warm-started while the pose moves: the `value` regime, with the
+    roofline object of ITS launches -- traffic_key: its PMC entry in profiles/traffic.json) and the K iterations after 2K
+    more (converged), each the median of three."""
     from visma_amd import _lib, synth
     c = _lib.Context(device)
     c.set_clouds_f64(src, tgt)
@@ -535,10 +575,18 @@ def c4_variant(R, device, src, tgt, radius, T_gt, steps, what):
     c.iterate(np.eye(4), radius, 2)                                  # grid build, buffers
     first, cont = [], []
     T = np.eye(4)
+    c.set_profiling(4)
+    c.get_timing(reset=True)
     for _ in range(3):
         c.forget_winners()
+        c.get_timing()
         T, last, el = timed_block(R, c, np.eye(4), radius, steps)
         first.append(el)
+    tm_first = c.get_timing(reset=True)
+    c.set_profiling(0)
+    first_roofline = kernel_roofline(c, len(src), len(tgt), tm_first, traffic_kind="none" if traffic_key is None else "grid_initial",
+                                     persist_traffic_key=traffic_key or "grid_persist")
+    first_roofline.pop("note", None)
     T, _ = c.iterate(T, radius, steps)
     for _ in range(3):
         T, last, el = timed_block(R, c, T, radius, steps)
@@ -550,7 +598,7 @@ def c4_variant(R, device, src, tgt, radius, T_gt, steps, what):
     c.set_profiling(0)
     out = {"workload": what, "ns": len(src), "nt": len(tgt), "radius": radius, "steps": steps,
            "from_initial_pose": {"icp_iterations_per_sec": steps / float(np.median(first)),
-                                 "ms_per_step": float(np.median(first)) / steps * 1e3},
+                                 "ms_per_step": float(np.median(first)) / steps * 1e3, "roofline": first_roofline},
            "continuing": {"icp_iterations_per_sec": steps / float(np.median(cont)),
                           "ms_per_step": float(np.median(cont)) / steps * 1e3,
                           "iterations": "%d..%d" % (2 * steps + 1, 5 * steps)},
@@ -584,6 +632,32 @@ def c4_end_to_end(device, src, tgt, radius, iters=30, repeats=5):
             "upload_ms": u * 1e3, "grid_build_and_loop_ms": r * 1e3, "total_ms": (u + r) * 1e3,
             "pcie_inclusive_iterations_per_sec": iters / (u + r), "median_of": repeats,
             "fitness": res.fitness_, "K": res.num_correspondences}
+
+
+def yaw_sweep_end_to_end(device, src, tgt, radius, level=24, iters=30, repeats=5):
+    """What feh::RegisterModelToScene costs its caller (src/annotation.cpp:29-64): host arrays in, the best of `level`
+    yaw starts out -- both clouds up once, the `level` registrations advance together (one launch per pass for all)."""
+    from visma_amd import _lib
+    c = _lib.Context(device)
+    c.set_clouds_f64(src, tgt)
+    c.run_yaw_sweep(level, radius, iters, 1e-6, 1e-6)
+    up, run = [], []
+    its = 0
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        c.set_clouds_f64(src, tgt)
+        t1 = time.perf_counter()
+        best, which, per = c.run_yaw_sweep(level, radius, iters, 1e-6, 1e-6)
+        t2 = time.perf_counter()
+        up.append(t1 - t0)
+        run.append(t2 - t1)
+        its = sum(p.iterations for p in per)
+    c.close()
+    u, r = float(np.median(up)), float(np.median(run))
+    return {"ns": len(src), "nt": len(tgt), "yaw_starts": level, "max_iterations": iters, "iterations_run": its,
+            "upload_ms": u * 1e3, "sweep_ms": r * 1e3, "total_ms": (u + r) * 1e3, "best_start": which,
+            "best_fitness": best.fitness_, "median_of": repeats,
+            "pcie_inclusive_iterations_per_sec": its / (u + r)}
 
 
 def c4_saturated(device, tgt, nt, radius, ns_list=(1048576, 4194304), steps=5):
@@ -656,7 +730,9 @@ def run_c4(R, args):
         converged = {"steps": args.steps, "ms_per_step": e_c / args.steps * 1e3, "icp_iterations_per_sec": args.steps / e_c,
                      "blocks": [args.steps / e for e in el_c], "median_of": len(el_c),
                      "iterations": "%d..%d of one registration" % (3 * args.steps + 1, (3 + len(el_c)) * args.steps),
-                     "tm": tm_c, "fitness": lastc.fitness_, "err_vs_T_gt": synth.rel_frobenius(Tcv, T_gt)}
+                     "tm": tm_c, "fitness": lastc.fitness_, "err_vs_T_gt": synth.rel_frobenius(Tcv, T_gt),
+                     # (collective: every rank is here)
+                     "nn_ms": R.reduce_max(tm_c["nn_ms"] / max(tm_c["nn_launches"], 1))}
 
     # north_star's brute-force kernel on the same (sharded) problem, outside the timed region: collective timing
     brute = None
@@ -765,8 +841,14 @@ def run_c4(R, args):
         par = ("source-sharded x%d, 1 all-reduce(38 f64)/iter via %s" % (R.world, comm_kind)
                if args.shard == "source" else
                "target-sharded x%d, ncclAllReduce(min, %d u64) + ncclAllReduce(38 f64)/iter via %s" % (R.world, ns, comm_kind))
+        launch_mode = ("ONE persistent launch per host loop (passes inside it)" if tm.get("persist_passes", 0) > 0
+                       else "one launch per pass")
         if R.dist is not None:
-            par += "; ranks meet over torch.distributed/%s" % R.backend
+            par += "; launch mode: %s%s; ranks meet over torch.distributed/%s" % (
+                launch_mode, " (VISMA_ICP_PERSIST_RANKS=1)" if os.environ.get("VISMA_ICP_PERSIST_RANKS") == "1" else
+                " (default for ranks; VISMA_ICP_PERSIST_RANKS=1 keeps the ranks' launches alive across passes)", R.backend)
+        else:
+            par += "; launch mode: %s" % launch_mode
         out = {
             "metric": "icp_iterations_per_sec", "value": args.steps / elapsed,
             "unit": "ICP iterations/s", "n_gpus": R.world, "steps": args.steps,
@@ -798,7 +880,7 @@ def run_c4(R, args):
         if converged is not None:
             tm_c = converged.pop("tm")
             nlc = max(tm_c["nn_launches"], 1)
-            rc = grid_roofline(ns_local, nt_local, R.reduce_max(tm_c["nn_ms"] / nlc), tm_c["grid_candidates"] / nlc,
+            rc = grid_roofline(ns_local, nt_local, converged.pop("nn_ms"), tm_c["grid_candidates"] / nlc,
                                tm_c["grid_candidates_27cell"] / nlc, load_traffic("grid_warm", ns_local, nt_local), exact,
                                kernel_kind if kernel_kind in ("warm", "serial") else "serial", tm_c["grid_certified"] / nlc)
             rc = persistent_launches(rc, tm_c, ns_local, nt_local)
@@ -816,7 +898,8 @@ def run_c4(R, args):
             out["partial_overlap"] = c4_variant(R, R.local_rank, psrc, ptgt, pr, pT, args.steps,
                                                 "C4 sizes, the whole model against a scan of half of its surface "
                                                 "(synth.make_partial_pair; the compiled reference's result on it: "
-                                                "tests/golden/c4_partial_ref.npz)")
+                                                "tests/golden/c4_partial_ref.npz)",
+                                                traffic_key="grid_persist_partial_initial" if (ns, nt) == (NS_DEFAULT, NT_DEFAULT) else None)
             out["value_partial_overlap"] = out["partial_overlap"]["from_initial_pose"]["icp_iterations_per_sec"]
             out["value_partial_overlap_converged"] = out["partial_overlap"]["continuing"]["icp_iterations_per_sec"]
             out["value_partial_overlap_from_initial_pose"] = out["value_partial_overlap"]
@@ -858,6 +941,7 @@ def run_c4(R, args):
         if R.world == 1 and not args.no_extras and mode == "grid":
             out["end_to_end"] = {"c4": c4_end_to_end(R.local_rank, src, tgt, radius),
                                  "c2_5k_20k": c4_end_to_end(R.local_rank, *synth.make_pair(5000, 20000)[:2], 0.075, iters=20),
+                                 "c2_5k_20k_yaw_sweep_24": yaw_sweep_end_to_end(R.local_rank, *synth.make_pair(5000, 20000)[:2], 0.075),
                                  "note": "host arrays in -> transformation out on a context whose buffers exist: both "
                                          "clouds cross PCIe as the caller's f64 values; never `value`"}
             out["roofline_saturated"] = c4_saturated(R.local_rank, tgt, nt, radius)
@@ -866,8 +950,52 @@ def run_c4(R, args):
             Tg = ctx.run(None, radius, 1 + args.cpu_iters, 0.0, 0.0)       # parity on this workload, same iteration count
             cb["gpu_vs_cpu_rel_frobenius"] = synth.rel_frobenius(Tg.transformation_, np.array(cb.pop("T")))
             out["cpu_baseline"] = cb
+    # N > 1, opt-in mode: the ranks' launches kept alive across passes (VISMA_ICP_PERSIST_RANKS=1: the folding workgroups
+    # of the ranks' persistent launches meet in the mailboxes pass after pass) -- measured AFTER `value`, which uses the
+    # default (one launch per pass), under a watchdog: should this mode hang on first contact with real peers, rank 0
+    # still prints the line (with the error in it) and every rank leaves
+    if (R.dist is not None and args.shard == "source" and "mailboxes" in comm_kind and not args.no_extras
+            and os.environ.get("VISMA_ICP_PERSIST_RANKS") != "1" and mode == "grid"):
+        res = ranks_persistent_probe(R, args, src, tgt, ns, nt, radius, out)
+        if out is not None:
+            out["ranks_persistent"] = res
     ctx.close()
     return out
+
+
+def ranks_persistent_probe(R, args, src, tgt, ns, nt, radius, out):
+    import threading
+    limit = float(os.environ.get("VISMA_BENCH_RANKS_PERSIST_LIMIT_S", "60"))
+
+    def fire():
+        if R.rank == 0 and out is not None:
+            out["ranks_persistent"] = {"error": "no result within %.0f s: the watchdog printed this line and ended the ranks" % limit}
+            print(json.dumps(out), flush=True)
+        else:
+            time.sleep(2.0)
+        os._exit(0)
+    wd = threading.Timer(limit, fire)
+    wd.daemon = True
+    wd.start()
+    res = None
+    os.environ["VISMA_ICP_PERSIST_RANKS"] = "1"
+    try:
+        pctx, _, _ = c4_context(R, args, src, tgt, ns, nt)
+        pctx, kind = attach_comm(R, pctx, lambda: c4_context(R, args, src, tgt, ns, nt)[0], args)
+        _, plast, pel, ptm, _ = timed_registrations(R, pctx, radius, args.warmup, args.steps, args.nn, 4, 3)
+        pe = float(np.median(pel))
+        res = {"icp_iterations_per_sec": args.steps / pe, "ms_per_step": pe / args.steps * 1e3, "median_of": len(pel),
+               "transport": kind, "fitness": plast.fitness_,
+               "launch_mode": ("ONE persistent launch per host loop on every rank" if ptm.get("persist_passes", 0) > 0
+                               else "one launch per pass (the ranks share a device, or the launch did not fit)"),
+               "persist_passes_timed": ptm.get("persist_passes", 0), "persist_aborts": ptm.get("persist_aborts", 0)}
+        pctx.close()
+    except Exception as e:      # noqa: BLE001
+        res = {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        wd.cancel()
+        os.environ.pop("VISMA_ICP_PERSIST_RANKS", None)
+    return res
 
 
 # ------------------------------------------------------------------------------------------
@@ -935,8 +1063,11 @@ def run_c3(R, args):
     if R.rank == 0:
         queries = my_queries
         nt_total = sum(len(objs[i][1]) for i in mine)
-        roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl, None, True,
+        roofline = grid_roofline(queries, nt_total, nn_ms, tm["grid_candidates"] / nl, tm["grid_candidates_27cell"] / nl,
+                                 batch_traffic("c3:wave") if R.world == 1 else None, True,
                                  "wave" if ctx.search_kernel_used() == "warm" else "serial", 0.0)   # (batches: grid_wave.hip)
+        roofline["traffic_source"] = "profiles/traffic.json c3:wave (PMC passes of `bench.py --workload c3` with one worker context, all " \
+                                     "problems per launch; not this run)"
         roofline["launches_timed"] = tm["nn_launches"]
         out = {
             "metric": "icp_iterations_per_sec", "value": total_its / elapsed, "unit": "ICP iterations/s",
@@ -1109,9 +1240,17 @@ def run_c5(R, args, tag=""):
             roofline = {"kernel": "nn_wave_kernel (grid_wave.hip) after each batch's first pass (%d problems per launch: %d items x 24 starts, exact search, fold fused)" % (
                             C5_CHUNK * level, C5_CHUNK),
                         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
-                        "traffic": None, "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": b_alg / max(launches, 1),
+                        "traffic": batch_traffic("c5:wave") if R.world == 1 else None,
+                        "traffic_source": "profiles/traffic.json c5:wave (PMC passes of `bench.py --workload c5`, one worker context)",
+                        "avg_launch_ms": ms / max(launches, 1), "alg_bytes_per_launch": b_alg / max(launches, 1),
                         "compulsory_bytes": b_comp / max(launches, 1), "launches_timed": launches,
-                        "note": "small clouds: every launch is a few tens of microseconds"}
+                        "note": "small clouds (3k-12k sources against 15k-40k targets, 384 problems per launch): every "
+                                "launch is a hundred microseconds and its clouds stay in the L2 / Infinity Cache -- `achieved` "
+                                "and `frac` are the kernel-counted EXAMINED bytes over the launch time, i.e. cache-resident "
+                                "bandwidth quoted against the HBM peak, NOT HBM traffic; `traffic` / `traffic_frac` are what the "
+                                "fabric counters saw"}
+            if roofline["traffic"]:
+                roofline["traffic_frac"] = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS
     out = None
     if R.rank == 0:
         out = {

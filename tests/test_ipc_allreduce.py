@@ -17,10 +17,14 @@ def _run(world, device_loop, persist_on_shared_gpu=False):
     import ipc_worker
     # (ranks that share a device never keep persistent launches alive side by side -- except when a test says its clouds
     #  are small enough for all of them to be resident together)
+    # (round 5: ranks keep their launches alive only when asked to -- VISMA_ICP_PERSIST_RANKS=1 --, one launch per pass
+    #  with the exchange inside it is their default)
     if persist_on_shared_gpu:
         os.environ["VISMA_ICP_PERSIST_SHARED_GPU"] = "1"
+        os.environ["VISMA_ICP_PERSIST_RANKS"] = "1"
     else:
         os.environ.pop("VISMA_ICP_PERSIST_SHARED_GPU", None)
+        os.environ.pop("VISMA_ICP_PERSIST_RANKS", None)
     from visma_amd import _lib, synth
     ndev = int(os.environ.get("VISMA_TEST_NDEV", "0")) or 1
     ndev = max(ndev, _lib.device_count())
@@ -47,6 +51,7 @@ def _run(world, device_loop, persist_on_shared_gpu=False):
             a.send(b"bye")
     finally:
         os.environ.pop("VISMA_ICP_PERSIST_SHARED_GPU", None)
+        os.environ.pop("VISMA_ICP_PERSIST_RANKS", None)
         for p in procs:
             p.join(30)
             if p.is_alive():

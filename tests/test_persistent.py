@@ -275,3 +275,100 @@ def test_short_loops_and_tiny_clouds():
         assert b.get_timing()["persist_aborts"] == 0
         a.close()
         b.close()
+
+
+def test_the_product_api_of_persistent_launches_share_cap_and_info(lib):
+    """visma_icp.h since round 5: visma_icp_set_persistent / _set_persistent_cu_share / _get_persistent_info.  A process
+    that may hold half of the device's workgroup slots runs a 262,144-point loop (all slots) one launch per pass and a
+    65,536-point loop (a quarter) persistently -- same results either way; the info call says what happened."""
+    src, tgt, T_gt, r = synth.make_pair(262144, 1048576, seed_t=91, seed_s=92, motion="radius")
+    a, b = pair_of_contexts(src, tgt)
+    info = b.persistent_info()
+    assert info["enabled"] == 1 and info["launches"] == 0 and info["cu_share"] == 1.0 and info["timeout_ms"] == 200.0
+    try:
+        lib.set_persistent_cu_share(0.5)
+        with pytest.raises(lib.IcpError):
+            lib.set_persistent_cu_share(0.0)
+        ra, rb = a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0)
+        same_result(ra, rb)
+        info = b.persistent_info()
+        assert info["launches"] == 0 and info["last_loop_persistent"] == 0 and info["cu_share"] == 0.5, info
+        assert info["device_slots"] >= 1024, info
+        # a quarter of the slots: allowed
+        for c in (a, b):
+            c.set_clouds_f64(src[:65536], tgt)
+        same_result(a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0))
+        info = b.persistent_info()
+        assert info["launches"] == 1 and info["last_loop_persistent"] == 1 and info["last_loop_passes"] == 12, info
+        lib.set_persistent_cu_share(1.0)
+        for c in (a, b):
+            c.set_clouds_f64(src, tgt)
+        same_result(a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0))
+        info = b.persistent_info()
+        assert info["launches"] == 2 and info["last_loop_passes"] == 13 and info["aborts"] == 0, info   # (cold pass inside)
+        # switched off per context
+        b.set_persistent(False)
+        b.forget_winners()
+        a.forget_winners()
+        same_result(a.run(None, r, 5, 0.0, 0.0), b.run(None, r, 5, 0.0, 0.0))
+        info = b.persistent_info()
+        assert info["enabled"] == 0 and info["launches"] == 2 and info["last_loop_persistent"] == 0, info
+    finally:
+        lib.set_persistent_cu_share(1.0)
+    a.close()
+    b.close()
+
+
+def test_a_loop_under_a_cu_share_leaves_room_for_a_batch_on_another_context(lib):
+    """What the share is for: a C4-sized host loop and a batch of small registrations on two contexts of one process, at
+    the same time.  With the whole device allowed, the loop's persistent launch holds every workgroup slot for its
+    length and the batch's launches wait behind it; under a share of 1/2 the loop launches once per pass and the two
+    interleave.  Both finish with the results of their solo runs; the wall times are reported."""
+    import threading
+    import time
+    src, tgt, T_gt, r = synth.make_pair(262144, 1048576, seed_t=93, seed_s=94, motion="radius")
+    loop = _lib.Context(0)
+    loop.set_nn_mode(_lib.NN_GRID)
+    loop.set_clouds_f64(src, tgt)
+    probs = []
+    for k in range(24):
+        s, t, _, _ = synth.make_pair(6000 + 500 * (k % 5), 9000, seed_t=300 + k % 3, seed_s=400 + k)
+        probs.append((s, t, np.eye(4), 0.02))
+    batch = _lib.Context(0)
+
+    def run_loop(out):
+        t0 = time.perf_counter()
+        for _ in range(6):
+            loop.forget_winners()
+            out["T"] = loop.run(None, r, 30, 0.0, 0.0).transformation_
+        out["s"] = time.perf_counter() - t0
+
+    def run_batch(out):
+        t0 = time.perf_counter()
+        for _ in range(4):
+            out["res"] = [x.transformation_ for x in batch.run_batch(probs, max_iter=20)]
+        out["s"] = time.perf_counter() - t0
+    solo_l, solo_b = {}, {}
+    run_loop({}); run_batch({})                    # warm-up (buffers, grids)
+    run_loop(solo_l); run_batch(solo_b)
+    report = {}
+    try:
+        for share in (1.0, 0.5):
+            lib.set_persistent_cu_share(share)
+            l, b = {}, {}
+            th = [threading.Thread(target=run_loop, args=(l,)), threading.Thread(target=run_batch, args=(b,))]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert np.array_equal(l["T"], solo_l["T"])
+            assert all(np.array_equal(x, y) for x, y in zip(b["res"], solo_b["res"]))
+            report[share] = (l["s"] / solo_l["s"], b["s"] / solo_b["s"])
+    finally:
+        lib.set_persistent_cu_share(1.0)
+    print("loop / batch wall time relative to solo: share 1.0 -> %.2f / %.2f, share 0.5 -> %.2f / %.2f"
+          % (report[1.0] + report[0.5]))
+    # (both make progress whatever the share; the ratios depend on the box -- see DESIGN.md 4.1e for the measured ones)
+    assert all(v < 6.0 for pair in report.values() for v in pair), report
+    loop.close()
+    batch.close()

@@ -8,13 +8,17 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.json"), ("bench_c5.json", "%s_bench_c5.json"),
          ("bench_c4_under_rocprof.json", "%s_bench_c4_under_rocprof.json"),
          ("stats_c4/c4_kernel_stats.csv", "%s_bench_c4_kernel_stats.csv"), ("stats_c3/c3_kernel_stats.csv", "%s_bench_c3_kernel_stats.csv"),
          ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv"),
+         ("pmc_traffic_initial_summary.csv", "%s_c4_from_identity_traffic_pmc_summary.csv"),
+         ("pmc_traffic_partial_initial_summary.csv", "%s_c4_partial_overlap_from_identity_traffic_pmc_summary.csv"),
+         ("pmc_traffic_c3_summary.csv", "%s_c3_traffic_pmc_summary.csv"), ("pmc_traffic_c5_summary.csv", "%s_c5_traffic_pmc_summary.csv"),
+         ("cert_probe.txt", "%s_cert_probe.txt"),
          ("pmc_traffic_saturated_summary.csv", "%s_4m_queries_traffic_pmc_summary.csv"),
          ("pmc_kernel_summary.csv", "%s_c4_kernel_pmc_summary.csv"),
          ("persist_timeline.txt", "%s_persist_timeline.txt"), ("persist_host_gaps.txt", "%s_persist_host_gaps.txt"),
@@ -118,4 +122,50 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         "kernel": "nn_coop_kernel_one<false>, 4,194,304 queries per launch",
         "source": "profiles/%s_4m_queries_traffic_pmc_summary.csv" % tag}
     print("traffic.json grid_warm 4M: %.1f MB per launch" % (tj["grid_warm:4194304x4194304"]["hbm_bytes_per_nn_launch"] / 1e6))
+
+
+def summary_vals(path, match, suffix):
+    """{counter: mean per dispatch} of the rows of a pmc_summarize.py table whose kernel contains `match` and whose label
+    ends the way `suffix` says (None: the plain per-kernel rows)."""
+    vals = {}
+    if os.path.exists(path):
+        for r in csv.DictReader(l for l in open(path) if "," in l):
+            k = r.get("kernel", "")
+            if match in k and ((suffix is None and "[" not in k) or (suffix is not None and suffix in k)):
+                try:
+                    vals[r["counter"]] = float(r["mean_per_dispatch"])
+                except (KeyError, ValueError):
+                    pass
+    return vals
+
+
+# round 5: the regime `value` is timed in -- a fresh registration of 20 iterations from the identity, ONE dispatch of the
+# persistent kernel (cold pass inside) -- full overlap and partial overlap; and the batch kernels of config 3 / 5
+for key, fn, what in (("grid_persist_initial:262144x4194304", "pmc_traffic_initial_summary.csv",
+                       "ONE launch running a FRESH registration: 20 passes from the identity, cold pass inside (bench.py `value`)"),
+                      ("grid_persist_partial_initial:262144x4194304", "pmc_traffic_partial_initial_summary.csv",
+                       "the same on the partial-overlap pair (bench.py `partial_overlap.from_initial_pose`)")):
+    vals = summary_vals(os.path.join(src, fn), "nn_coop_kernel_persist", "[last dispatch")
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+        tj[key] = {"hbm_bytes_per_nn_launch": b, "passes_per_launch": 20, "hbm_bytes_per_pass": b / 20.0,
+                   "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+                   "correction": "FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE "
+                                 "uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB" % (vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
+                   "kernel": "nn_coop_kernel_persist<false>: " + what,
+                   "source": "profiles/%s (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % (
+                       {"pmc_traffic_initial_summary.csv": "%s_c4_from_identity_traffic_pmc_summary.csv",
+                        "pmc_traffic_partial_initial_summary.csv": "%s_c4_partial_overlap_from_identity_traffic_pmc_summary.csv"}[fn] % tag)}
+        print("traffic.json %s: %.1f MB per pass" % (key, b / 20e6))
+for key, fn, name in (("c3:wave", "pmc_traffic_c3_summary.csv", "%s_c3_traffic_pmc_summary.csv"),
+                      ("c5:wave", "pmc_traffic_c5_summary.csv", "%s_c5_traffic_pmc_summary.csv")):
+    vals = summary_vals(os.path.join(src, fn), "nn_wave_kernel_one", None)
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        tj[key] = {"hbm_bytes_per_nn_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+                   "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+                   "correction": "FETCH_SIZE x2, WRITE_SIZE uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB" % (
+                       vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
+                   "kernel": "nn_wave_kernel_one<false>: mean over every launch of one bench step (all problems of the batch per launch)",
+                   "source": "profiles/" + name % tag}
+        print("traffic.json %s: %.1f MB per launch" % (key, tj[key]["hbm_bytes_per_nn_launch"] / 1e6))
 json.dump(tj, open(tj_path, "w"), indent=1)

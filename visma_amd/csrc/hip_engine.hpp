@@ -290,7 +290,9 @@ public:
         return VISMA_ICP_OK;
     }
     int nn_mode_used() const override { return use_grid_ ? VISMA_ICP_NN_GRID : VISMA_ICP_NN_BRUTE; }
-    int search_kernel_used() const override { return use_grid_ ? last_kernel_ : 0; }
+    // (a batch runs the grid search whatever the context's own clouds last used)
+    int search_kernel_used() const override { return (use_grid_ || last_was_batch_) ? last_kernel_ : 0; }
+    bool last_was_batch_ = false;
     int forget_winners() override
     {
         HIP_TRY(hipSetDevice(device_));
@@ -636,7 +638,7 @@ private:
                   unsigned long long seq, FoldArgs *out);
     // device-resident loops: the problem's state advances in the fold epilogue of the search launch (FoldArgs::solve) --
     // the closed-form update on one GPU; Gauss-Newton / point-to-plane loops and ranks keep solve_state_kernel
-    int solve_in_fold_ = 1;          // VISMA_ICP_SOLVE_IN_FOLD=0: the solve in a launch of its own, as until round 4 (A/B)
+    int solve_in_fold_ = 0;          // VISMA_ICP_SOLVE_IN_FOLD=1: see DESIGN.md 4.4 -- measured SLOWER than the launch of its own (A/B knob)
     bool solve_in_fold(const LoopParams &lp) const
     {
         return solve_in_fold_ && fused_fold_ && !lp.plane && lp.solver == VISMA_ICP_SOLVER_KABSCH && !tshard_ && !comm_ && ipc_n_ <= 1;
@@ -675,10 +677,14 @@ private:
     void *d_peer_table_ = nullptr;   // peers_ in device memory (the persistent kernel's fold reads the mailboxes from there)
     bool peers_share_device_ = true; // some peer of the IPC ring sits on THIS device (tests): no persistent launch then --
                                      // the ranks' launches would each hold a part of the compute units and wait for the rest
+    // Source-sharded ranks keep their launches alive across passes only when ASKED (VISMA_ICP_PERSIST_RANKS=1, read when
+    // the context is created): until one run on two real devices has passed, the default for ranks is the path two and
+    // three processes on one GPU have exercised -- one launch per pass, the exchange through the mailboxes inside it.
+    int persist_ranks_ = 0;
     bool persist_ranks_ok() const
     {
         static const bool shared_ok = std::getenv("VISMA_ICP_PERSIST_SHARED_GPU") != nullptr;   // (tests with small clouds)
-        return ipc_n_ > 1 && d_peer_table_ && !comm_ && (!peers_share_device_ || shared_ok);
+        return persist_ranks_ && ipc_n_ > 1 && d_peer_table_ && !comm_ && (!peers_share_device_ || shared_ok);
     }
     bool cmd_direct_ = false;        // h_cmd_ is fine-grained DEVICE memory, stored to through the PCIe BAR (large-BAR systems)
     void *d_cmd_block_ = nullptr;

@@ -16,6 +16,7 @@ int HipEngine::nn_pass(const Mat4 &Tc, double max_dist)
 {
     HIP_TRY(hipSetDevice(device_));
     if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+    last_was_batch_ = false;
     if (sess_live_ && (float)(max_dist * max_dist) != sess_r2f_) {
         // (another radius: the grid may be rebuilt below -- not behind a launch that waits for this thread)
         int rc = end_session();
@@ -528,6 +529,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
     if (sess_live_) { int src = end_session(); if (src) return src; }
     if (nprob < 1) { err_ = "nprob < 1"; return VISMA_ICP_ERR_INVALID; }
     if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+    last_was_batch_ = false;
     if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
     int rc = choose_mode(lp.max_dist);
     if (rc) return rc;
@@ -714,6 +716,7 @@ int HipEngine::run_loop_batch(const LoopParams &lp, const std::vector<BatchProbl
     const int B = (int)pb.size();
     if (B < 1) return VISMA_ICP_OK;
     if (comm_) { err_ = "batched loop is single-GPU"; return VISMA_ICP_ERR_STATE; }
+    last_was_batch_ = true;
     StageTrace tr("batch/engine");
     // ---- layout of the concatenated arrays
     std::vector<ProbDesc> descs((size_t)B);
