@@ -534,20 +534,32 @@ def persistent_launches(roofline, tm, queries=0, nt=0, traffic_key="grid_persist
                           "note": "the kernel-trace name is nn_coop_kernel_persist; a launch lasts as long as its loop: "
                                   "its waits for the host's next transform (statistics out, solve, command back over "
                                   "PCIe) are inside"}
-    if tm["nn_launches"] == pp:
-        per_pass_traffic = load_traffic(traffic_key, int(queries), int(nt), "hbm_bytes_per_pass") if queries else None
-        if per_pass_traffic:
-            roofline["traffic"] = per_pass_traffic * k
-            roofline["traffic_per_pass"] = per_pass_traffic
-            roofline["traffic_frac"] = per_pass_traffic / (per_pass_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
-        elif roofline.get("traffic"):
-            roofline["traffic_per_pass"] = roofline["traffic"]      # (the one-pass kernel's PMC figure)
-            roofline["traffic"] = roofline["traffic"] * k
-        roofline["avg_launch_ms"] = tm["persist_ms"] / pl
-        for key in ("alg_bytes_per_launch", "examined_bytes_per_launch"):
-            roofline[key.replace("_per_launch", "_per_pass")] = roofline[key]
-            roofline[key] = roofline[key] * k
-        roofline["ms_per_pass"] = per_pass_ms
+    # The object describes the PERSISTENT launches (the dominant kernel): their duration, their passes.  One-pass launches
+    # the same counters hold -- the lane-serial first pass of every fresh registration -- are reported beside them.
+    others = tm["nn_launches"] - pp
+    per_pass_ms = tm["persist_ms"] / pp
+    if others > 0:
+        roofline["launch"]["one_pass_launch_avg_ms"] = (tm["nn_ms"] - tm["persist_ms"]) / others
+        roofline["launch"]["one_pass_launches_are"] = "the first (cold) pass of a registration: nn_grid_reduce_kernel, lane-serial"
+        # (achieved / frac were formed with the mean over ALL timed passes: re-form them for the persistent launches)
+        scale = roofline["avg_launch_ms"] / per_pass_ms
+        for key in ("achieved", "frac", "achieved_on_examined_bytes", "frac_on_examined_bytes", "frac_on_compulsory_bytes"):
+            if roofline.get(key) is not None:
+                roofline[key] = roofline[key] * scale
+    per_pass_traffic = load_traffic(traffic_key, int(queries), int(nt), "hbm_bytes_per_pass") if queries else None
+    if per_pass_traffic:
+        roofline["traffic"] = per_pass_traffic * k
+        roofline["traffic_per_pass"] = per_pass_traffic
+        roofline["traffic_frac"] = per_pass_traffic / (per_pass_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
+    elif roofline.get("traffic"):
+        roofline["traffic_per_pass"] = roofline["traffic"]      # (the one-pass kernel's PMC figure)
+        roofline["traffic_frac"] = roofline["traffic"] / (per_pass_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS
+        roofline["traffic"] = roofline["traffic"] * k
+    roofline["avg_launch_ms"] = tm["persist_ms"] / pl
+    for key in ("alg_bytes_per_launch", "examined_bytes_per_launch"):
+        roofline[key.replace("_per_launch", "_per_pass")] = roofline[key]
+        roofline[key] = roofline[key] * k
+    roofline["ms_per_pass"] = per_pass_ms
     return roofline
 
 
@@ -827,7 +839,7 @@ def run_c4(R, args):
             # (traffic: PMC passes of tools/run_c4_iterations.py in ITS regime -- fresh registrations from the identity;
             #  the converged regime's counters belong to `converged.roofline`)
             roofline = grid_roofline(ns_local, nt_local, nn_ms, cand, tm["grid_candidates_27cell"] / nl,
-                                     load_traffic("grid_initial", ns_local, nt_local, "hbm_bytes_per_pass"),
+                                     None,
                                      exact, kernel_kind if kernel_kind in ("warm", "serial") else "serial",
                                      tm["grid_certified"] / nl)
             roofline = persistent_launches(roofline, tm, ns_local, nt_local, "grid_persist_initial")

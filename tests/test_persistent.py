@@ -69,7 +69,8 @@ def test_persistent_loop_equals_one_launch_per_pass_bit_for_bit(name, ns, nt, ou
     if expect:
         # 13 steps: the first is the cold pass, 12 in ONE launch (sources of 131,072 points and more: the cold pass runs
         # inside the launch too, round 5); the other blocks: one launch each
-        cold_inside = 1 if ns >= 131072 else 0
+        import os
+        cold_inside = 1 if (ns >= 131072 and os.environ.get("VISMA_ICP_COLD_IN_LAUNCH") == "1") else 0
         assert tm["persist_launches"] == 4 and tm["persist_passes"] == cold_inside + 12 + 5 + 2 + 9, tm
         assert tm["persist_aborts"] == 0
     else:
@@ -305,7 +306,7 @@ def test_the_product_api_of_persistent_launches_share_cap_and_info(lib):
             c.set_clouds_f64(src, tgt)
         same_result(a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0))
         info = b.persistent_info()
-        assert info["launches"] == 2 and info["last_loop_passes"] == 13 and info["aborts"] == 0, info   # (cold pass inside)
+        assert info["launches"] == 2 and info["last_loop_passes"] == 12 and info["aborts"] == 0, info   # (the cold pass: its own launch)
         # switched off per context
         b.set_persistent(False)
         b.forget_winners()
@@ -372,3 +373,31 @@ def test_a_loop_under_a_cu_share_leaves_room_for_a_batch_on_another_context(lib)
     assert all(v < 6.0 for pair in report.values() for v in pair), report
     loop.close()
     batch.close()
+
+
+def test_cold_pass_inside_the_launch_is_the_same_registration(lib):
+    """VISMA_ICP_COLD_IN_LAUNCH=1 (opt-in, round 5): sources of 131,072 points and more run their FIRST pass inside the
+    persistent launch too -- the certificate kernel started cold.  Same registration bit for bit, one launch for all passes."""
+    import os
+    src, tgt, T_gt, r = synth.make_pair(150000, 600000, seed_t=95, seed_s=96, motion="radius")
+    src = src.copy()
+    src[::5] += np.array([0.0, 4.0, 0.0])                  # a fifth of the source without a partner
+    a = _lib.Context(0)
+    a.set_persistent(False)
+    os.environ["VISMA_ICP_COLD_IN_LAUNCH"] = "1"
+    try:
+        b = _lib.Context(0)
+    finally:
+        os.environ.pop("VISMA_ICP_COLD_IN_LAUNCH", None)
+    for c in (a, b):
+        c.set_nn_mode(_lib.NN_GRID)
+        c.set_clouds_f64(src, tgt)
+    b.set_profiling(1)
+    b.get_timing(reset=True)
+    same_result(a.run(None, r, 14, 0.0, 0.0), b.run(None, r, 14, 0.0, 0.0))
+    for x, y in zip(a.get_correspondences(), b.get_correspondences()):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    tm = b.get_timing(reset=True)
+    assert tm["persist_launches"] == 1 and tm["persist_passes"] == 15 and tm["persist_aborts"] == 0, tm
+    a.close()
+    b.close()

@@ -99,6 +99,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     tj["grid_persist:262144x4194304"] = {
         "hbm_bytes_per_nn_launch": b, "passes_per_launch": 20, "hbm_bytes_per_pass": b / 20.0,
         "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+        "write_bytes_per_pass": vals["WRITE_SIZE"] * 1024.0 / 20.0,
         "correction": "FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE "
                       "uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB; the polls of the command block (every "
                       "workgroup's first wave, system-scope loads of fine-grained device memory while the host solves) are in it"
@@ -139,24 +140,31 @@ def summary_vals(path, match, suffix):
     return vals
 
 
-# round 5: the regime `value` is timed in -- a fresh registration of 20 iterations from the identity, ONE dispatch of the
-# persistent kernel (cold pass inside) -- full overlap and partial overlap; and the batch kernels of config 3 / 5
+# round 5: the regime `value` is timed in -- a fresh registration of 20 iterations from the identity: the lane-serial cold
+# pass (its own launch: traffic.json "grid:...") and ONE dispatch of the persistent kernel running the 19 warm passes --
+# full overlap and partial overlap; and the batch kernels of config 3 / 5
+PASSES = 19
 for key, fn, what in (("grid_persist_initial:262144x4194304", "pmc_traffic_initial_summary.csv",
-                       "ONE launch running a FRESH registration: 20 passes from the identity, cold pass inside (bench.py `value`)"),
+                       "ONE launch running the %d warm passes of a FRESH registration from the identity (bench.py `value`)" % PASSES),
                       ("grid_persist_partial_initial:262144x4194304", "pmc_traffic_partial_initial_summary.csv",
                        "the same on the partial-overlap pair (bench.py `partial_overlap.from_initial_pose`)")):
     vals = summary_vals(os.path.join(src, fn), "nn_coop_kernel_persist", "[last dispatch")
+    cold = summary_vals(os.path.join(src, fn), "nn_grid_reduce_kernel", None)
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-        tj[key] = {"hbm_bytes_per_nn_launch": b, "passes_per_launch": 20, "hbm_bytes_per_pass": b / 20.0,
+        tj[key] = {"hbm_bytes_per_nn_launch": b, "passes_per_launch": PASSES, "hbm_bytes_per_pass": b / PASSES,
                    "fetch_size_kib_raw": vals["FETCH_SIZE"], "write_size_kib_raw": vals["WRITE_SIZE"],
+                   "write_bytes_per_pass": vals["WRITE_SIZE"] * 1024.0 / PASSES,
                    "correction": "FETCH_SIZE x2 (gfx950 wide-stream under-count, MI355X_MICROARCH.md HBM section); WRITE_SIZE "
                                  "uncorrected; cross-check TCC_MISS_sum x 128 B = %.1f MB" % (vals.get("TCC_MISS_sum", 0.0) * 128 / 1e6),
                    "kernel": "nn_coop_kernel_persist<false>: " + what,
                    "source": "profiles/%s (rocprofv3 --pmc, one pass per counter group, tools/profile_round.sh)" % (
                        {"pmc_traffic_initial_summary.csv": "%s_c4_from_identity_traffic_pmc_summary.csv",
                         "pmc_traffic_partial_initial_summary.csv": "%s_c4_partial_overlap_from_identity_traffic_pmc_summary.csv"}[fn] % tag)}
-        print("traffic.json %s: %.1f MB per pass" % (key, b / 20e6))
+        if "FETCH_SIZE" in cold and "WRITE_SIZE" in cold:
+            tj[key]["cold_pass_launch_bytes"] = (2.0 * cold["FETCH_SIZE"] + cold["WRITE_SIZE"]) * 1024.0
+        print("traffic.json %s: %.1f MB per pass (write %.2f MB per pass), cold pass launch %.1f MB" % (
+            key, b / PASSES / 1e6, tj[key]["write_bytes_per_pass"] / 1e6, tj[key].get("cold_pass_launch_bytes", 0.0) / 1e6))
 for key, fn, name in (("c3:wave", "pmc_traffic_c3_summary.csv", "%s_c3_traffic_pmc_summary.csv"),
                       ("c5:wave", "pmc_traffic_c5_summary.csv", "%s_c5_traffic_pmc_summary.csv")):
     vals = summary_vals(os.path.join(src, fn), "nn_wave_kernel_one", None)

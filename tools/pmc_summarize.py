@@ -22,7 +22,7 @@ for (f, k, c), v in rows.items():
     if "persist" in k:
         # a persistent launch runs a whole host loop: the LAST dispatch is the loop of the last 20 passes
         # (tools/run_c4_iterations.py), the regime `value` is timed in
-        acc[(k + " [last dispatch = 20 passes]", c)][0] += v[-1][1]; acc[(k + " [last dispatch = 20 passes]", c)][1] += 1
+        acc[(k + " [last dispatch = one host loop]", c)][0] += v[-1][1]; acc[(k + " [last dispatch = one host loop]", c)][1] += 1
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
 for (k, c), (s, n) in sorted(acc.items()):

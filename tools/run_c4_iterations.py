@@ -4,7 +4,8 @@ VISMA_REGIME=converged (default): one cold pass + VISMA_PASSES - 1 (default 46) 
   `value_converged`; tools/pmc_summarize.py tabulates the last dispatch separately).
 VISMA_REGIME=initial: bench.py's `value` since round 5 -- after 5 warm-up iterations, three FRESH registrations of 20
   iterations from the identity (winners forgotten before each): the last dispatch of nn_coop_kernel_persist is such a
-  registration (cold pass inside the launch at this size; with VISMA_ICP_COLD_IN_LAUNCH=0 the 19 warm passes).
+  registration's 19 warm passes (the cold pass is the lane-serial kernel's launch before it; with
+  VISMA_ICP_COLD_IN_LAUNCH=1 it runs inside the launch too: 20 passes).
 VISMA_PAIR=partial: the whole model against a scan of half of its surface (synth.make_partial_pair) instead of the
   full-overlap pair.  VISMA_NS overrides the source size (the saturated launches of bench.py's roofline_saturated;
   several queries per lane: one launch per pass)."""

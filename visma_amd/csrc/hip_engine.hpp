@@ -519,15 +519,18 @@ private:
     {
         if (grid_lanes_ > 0) return grid_lanes_;
         if (coop_ok() && pos_fresh_) return kCoopLanes;
-        // the FIRST pass of a large registration inside the persistent launch of its host loop (round 5): the certificate
-        // kernel started cold (no winner known: every query searches against the radius) costs about what the
-        // lane-serial kernel costs at these sizes, and the loop saves a launch, a drain and a host round trip
+        // the FIRST pass of a large registration inside the persistent launch of its host loop (round 5, OPT-IN:
+        // VISMA_ICP_COLD_IN_LAUNCH=1): the certificate kernel started cold (no winner known: every query searches against
+        // the radius) saves a launch, a drain and a host round trip, but its pass costs 82 us where the lane-serial
+        // kernel's costs 62 + the launch: measured on one box, us per iteration over 1..20 from the identity,
+        // 262,144 -> 4 M 32.9-33.3 inside vs 33.0 separate, 131,072 28.0-28.2 vs 27.5, partial overlap (half of the
+        // queries without a partner: every one of their 27 cells listed) 41.1-41.6 vs 39.3 -- no gain, so not the default
         if (nprob == 1 && cold_in_launch_ && ns_ >= cold_in_launch_min_ns_ && loop_scope_ && loop_budget_ >= 2 && coop_ok() &&
             persist_static_ok())
             return kCoopLanes;
         return grid_lanes(nprob);
     }
-    int cold_in_launch_ = 1;                 // VISMA_ICP_COLD_IN_LAUNCH=0: the first pass always on the lane-serial kernel
+    int cold_in_launch_ = 0;                 // VISMA_ICP_COLD_IN_LAUNCH=1: the first pass of large registrations inside the launch
     int64_t cold_in_launch_min_ns_ = 131072; // VISMA_ICP_COLD_IN_LAUNCH_MIN_NS (below: lane-serial 20 us vs 29 at 5 k)
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
     int grid_lanes(int nprob = 1) const
