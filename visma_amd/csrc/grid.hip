@@ -970,7 +970,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
                                  const Pt64 *sorted64, double r2d, const Pt64 *nrm64, int exact,
                                  const FoldArgs *fold, double *d64_out, Pt64 *prevq_io, int warm, const Xform64 *Tprev,
-                                 const PersistArgs *persist)
+                                 const PersistArgs *persist, Pt64 *ru_io)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     // (the persistent launch exists for the certificate kernel only)
@@ -991,7 +991,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
             hipError_t e = launch_nn_coop(nblocks * nprob, nblocks, nprob, nullptr, (int)ns, (const float *)sorted, start, g,
                                           tgt_normals, nrm64, T64, off, r2f, point_to_plane, one ? 1 : 0, idx_out, d2_out,
                                           partials, cand_count, st, (long long)out_stride, src64, sorted64, fa, d64_out,
-                                          prevq_io, warm, stream, Tprev, persist);
+                                          prevq_io, warm, stream, Tprev, persist, ru_io);
             if (nblocks_out) *nblocks_out = nblocks;
             return e;
         }

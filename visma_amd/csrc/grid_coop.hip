@@ -60,9 +60,29 @@ namespace visma {
 namespace {
 
 struct P12 { float x, y, z; };                // fp32 rounding of a cell-sorted f64 target point
-#ifndef VISMA_COOP_CAP
-#define VISMA_COOP_CAP 352
+#ifndef VISMA_COOP_RU
+#define VISMA_COOP_RU 0
 #endif
+#ifndef VISMA_COOP_CAP
+#define VISMA_COOP_CAP (VISMA_COOP_RU ? 344 : 352)
+#endif
+// RUNNER-UP-AWARE certificates (round 5b).  What limits the bound LB a search leaves is the runner-up: in 82-85 % of the
+// searched queries of a C4 registration the second-best examined candidate, on average 1.0 mm below what the cells not
+// listed would allow (tools/lb_probe.py, profiles/r05_lb_probe.txt).  So the state also keeps the RUNNER-UP u (f64 point and
+// index, 32 B per query in global memory: ru_io) and LB3, a lower bound of the distance to every target point but the
+// winner w and u.  When the winner-unchanged certificate fails (d_w >= LB - delta), both distances are evaluated exactly
+// (the reference's arithmetic): if the nearer of the two lies inside the radius and below LB3 - delta, it is the unique
+// nearest neighbour (lowest original index on an exact tie, as rank()) -- no search; w and u change places if u won.
+// MEASURED AND NOT ADOPTED (compiled out by default; -DVISMA_COOP_RU=1 builds it, VISMA_ICP_RUNNER_UP=0 then switches
+// it off at run time): it certifies what it promises -- 53 % of the queries at pass 2 of a C4 registration instead of 33 %,
+// 71 % at pass 10 instead of 56 %, 87 % at pass 20 instead of 75 % (profiles/r05_cert_probe_runner_up.txt), same results
+// bit for bit -- and the kernel gets SLOWER: it sits at the 128 registers four waves per SIMD allow, and the three best
+// candidates per chunk (one more octet minimum, a ballot, a packed side word), the side word through the merge and the
+// runner-up's choice behind the f64 winner cost 2.7 us per pass before a single query is certified by it (13 registers
+// spilled instead of 8 -- the first build, which also fetched the runner-up's point beside the winner's, spilled 29 and
+// lost 5 us); with it switched on, 35.7-36.0 us per iteration over 1..20 from the identity against 33.4-33.8 without the
+// code, 22.8 against 21.2-21.5 at the converged pose (tools/ab_probe.py, same box, alternating runs).
+constexpr bool kCoopRu = VISMA_COOP_RU != 0;
 constexpr int kCoopCap = VISMA_COOP_CAP;      // chunk descriptors per wave and list window (1,408 per workgroup: 16.5 KiB with the
                                               // side array; a workgroup of 170 queued queries -- the second pass of a C4
                                               // registration -- lists ~850 chunks: at 768 it took two windows and 5-9 us more).
@@ -94,6 +114,16 @@ __device__ __forceinline__ float octet_min(float d)
     return r;
 }
 
+// the side word of a chunk result (s_sec): both values are lower bounds after the truncation (d2 >= 0: sign bit clear)
+// (without the runner-up code the word is sec itself, unrounded)
+__device__ __forceinline__ unsigned pack_sec(float sec, float third, unsigned lane)
+{
+    if constexpr (!kCoopRu) return __float_as_uint(sec);
+    return (__float_as_uint(sec) & 0xFFFF0000u) | (((__float_as_uint(third) >> 18) & 0x1FFFu) << 3) | (lane & 7u);
+}
+__device__ __forceinline__ float sec_of(unsigned w) { return __uint_as_float(kCoopRu ? (w & 0xFFFF0000u) : w); }
+[[maybe_unused]] __device__ __forceinline__ float third_of(unsigned w) { return __uint_as_float(((w >> 3) & 0x1FFFu) << 18); }
+
 // inclusive prefix sum over the 64 lanes: DPP row shifts inside the 16-lane rows (absent lanes read 0), then the
 // last lane of row 0 / 2 broadcast into row 1 / 3 and lane 31 into the upper half -- no LDS round trips
 __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int)
@@ -120,6 +150,7 @@ struct CoopRes {
     double (*q64)[3];      // [NTH] state: the winner's f64 point (NaN: none)            } = the s_q64 / s_dprev slots the
     float *idx;            // [NTH] state: the winner's original index (bits; ~0: none)  } passes hand their results over in
     float *lb;             // [NTH] state: LB
+    float *lb3;            // [NTH] state: LB3 (the runner-up's point and index stay in global memory: ru_io)
     int first;             // this pass is the launch's first: source and state come from global memory
 };
 
@@ -147,7 +178,8 @@ __device__ __forceinline__ bool coop_body(
     const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,
     int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,
     const Pt64 *__restrict__ nrm64, const FoldArgs &fold, double *__restrict__ d64_out,
-    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev, unsigned *work_out = nullptr, const CoopRes res = CoopRes{})
+    Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev, Pt64 *__restrict__ ru_io, unsigned *work_out = nullptr,
+    const CoopRes res = CoopRes{})
 {
     constexpr int NACC = Acc<PLANE>::N;
     const P12 *s12 = reinterpret_cast<const P12 *>(s12f);
@@ -184,6 +216,7 @@ __device__ __forceinline__ bool coop_body(
         idx_out += d.out_off;
         d2_out += d.out_off;
         wst_io += d.out_off;
+        if (ru_io) ru_io += d.out_off;
     } else {
         prob = blockIdx.x / bpp;
         lb = blockIdx.x - prob * bpp;
@@ -209,6 +242,7 @@ __device__ __forceinline__ bool coop_body(
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
     wst_io += (long long)prob * out_stride;
+    if (ru_io) ru_io += (long long)prob * out_stride;
     double acc[NACC];
 #pragma unroll
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -226,7 +260,10 @@ __device__ __forceinline__ bool coop_body(
 
     __shared__ float4 s_qp[NTH];                            // (px, py, pz, W) of the query each SEARCHER thread took over
     __shared__ uint2 s_item[kCapAll];                       // the workgroup's chunk descriptors, completed by chunk results
-    __shared__ float s_sec[kCapAll];                        // per chunk: its best candidate OUTSIDE the rounding band
+    __shared__ unsigned s_sec[kCapAll];                     // per chunk: sec = its best candidate OUTSIDE the rounding band,
+                                                            // third = its best candidate but the flagged ones and sec, and sec's
+                                                            // lane: sec rounded DOWN to 7 mantissa bits << 16 | third rounded
+                                                            // down to 5 mantissa bits << 3 | lane (pack_sec / sec_of / third_of)
     __shared__ double s_p64[NTH][3];                        // the transformed query of every HOME lane, f64 (what a searcher
                                                             // takes over instead of loading and transforming the source again)
     // the partner of every home lane's query: the certified winner (phase A) or what the query's searcher found
@@ -266,6 +303,19 @@ __device__ __forceinline__ bool coop_body(
         }
         d2_out[i] = (float)bd;
         if (d64_out) d64_out[i] = bd;                        // (target-sharded ranks compare shards in f64)
+    };
+    // the runner-up half of the state: u's f64 point, its index | LB3 << 32 (all bits set: none) -- written through to
+    // global memory whenever it changes (a search, a change of places); LB3 also to the persistent launch's slot
+    auto emit_ru = [&](long long i, unsigned ht, bool have, double ux, double uy, double uz, unsigned uidx, float lb3) {
+        if constexpr (kCoopRu) {
+            if (!ru_io) return;
+            Pt64 o8;
+            o8.x = o8.y = o8.z = __longlong_as_double(-1ll);
+            o8.w = ~0ull;
+            if (have) { o8.x = ux; o8.y = uy; o8.z = uz; o8.w = (unsigned long long)uidx | ((unsigned long long)__float_as_uint(lb3) << 32); }
+            ru_io[i] = o8;
+            if constexpr (PERSIST) res.lb3[ht] = have ? lb3 : __uint_as_float(0xFFFFFFFFu);
+        }
     };
     // the transformed query of home thread h (f64)
     auto query_p = [&](unsigned h, double (&out)[3]) { out[0] = s_p64[h][0]; out[1] = s_p64[h][1]; out[2] = s_p64[h][2]; };
@@ -387,6 +437,20 @@ __device__ __forceinline__ bool coop_body(
     //  C  home lanes again: the moments of the round's correspondence (from registers when certified, from the
     //     searcher's hand-over in LDS otherwise) -- the query -> lane map and the summation tree of the lane-serial
     //     kernel (for NTH = kBlock), so the 38 statistics stay bit-identical to its.
+    // a searched query's runner-up on its way from the f64 array to the state (phase C -> behind the partial row)
+    Pt64 ru_pending = Pt64{0.0, 0.0, 0.0, 0ull};
+    float ru_lb3 = 0.f;
+    bool ru_have = false, ru_go = false;
+    int ru_it = 0;                                           // (the round: uniform; the query's index is re-derived -- kept
+                                                             //  across the search it was two more registers to spill)
+    auto ru_finish = [&]() {
+        if constexpr (kCoopRu) {
+            if (ru_go)
+                emit_ru((long long)(vb * NTH + tid) * per_group + ru_it, (unsigned)tid, ru_have, ru_pending.x, ru_pending.y,
+                        ru_pending.z, (unsigned)ru_pending.w, ru_lb3);
+            ru_go = false;
+        }
+    };
     auto round = [&](const int it) {
         const long long i = i_begin + it;
         const bool active = i < i_end;
@@ -417,9 +481,17 @@ __device__ __forceinline__ bool coop_body(
             const double sv[3] = {s8.x, s8.y, s8.z};
             se3_act(T64.m, sv, hp);
         }
+        // (the runner-up of the state: asked for now, with the source point -- 32 B per query from a warm L2 -- so that a
+        //  failed winner-unchanged certificate does not wait for it)
+        Pt64 u8;
+        u8.x = u8.y = u8.z = __longlong_as_double(-1ll);
+        u8.w = ~0ull;
+        if constexpr (kCoopRu) {
+            if (ru_io && active && (warm & 4)) u8 = ru_io[i];
+        }
         // ---- the certificate: has the query moved by less than the room its previous result left?
-        const unsigned widx = (unsigned)w8.w;
-        const bool has_w = w8.x == w8.x;                     // (NaN: no previous winner)
+        unsigned widx = (unsigned)w8.w;
+        bool has_w = w8.x == w8.x;                           // (NaN: no previous winner)
         bool cert = false;
         if (warm & 4) {
             const float hx = (float)hp[0], hy = (float)hp[1], hz = (float)hp[2];
@@ -439,7 +511,8 @@ __device__ __forceinline__ bool coop_body(
             //  rounding of this subtraction and the ~1e-16 |p| by which the f64 difference above can be off -- the band
             //  E itself was taken off once, when the bound was formed: taking it off every pass would wear a 1 mm gap
             //  down in a few hundred certified passes and send the query back to the search for nothing)
-            const float t = (__uint_as_float((unsigned)(w8.w >> 32)) - del) * (1.0f - 2.4e-7f);
+            const float lb_old = __uint_as_float((unsigned)(w8.w >> 32));
+            const float t = (lb_old - del) * (1.0f - 2.4e-7f);
             double d2w = r2d;                                // the previous winner's distance now (reference arithmetic)
             if (has_w) {
                 // flann L2 (dist.h:159-176), as rank() below
@@ -453,6 +526,51 @@ __device__ __forceinline__ bool coop_body(
                 cert = active && widx == 0xFFFFFFFFu && t > tlim * (1.0f + 1e-6f);
             }
             if (cert) emit(i, (unsigned)tid, true, has_w ? d2w : r2d, widx, has_w, w8.x, w8.y, w8.z, t);
+            if constexpr (kCoopRu) {
+                // ---- the runner-up's turn.  LB3 bounds every target point but w and u as the query stood; it moved by
+                // del, so everything else is still at least t3 away.  (lb_old > 0: the state was left by a search of this
+                // kernel or by a certificate -- the lane-serial and wave kernels write LB = 0 and no runner-up.)
+                const bool has_u = u8.x == u8.x;
+                float lb3 = __uint_as_float((unsigned)(u8.w >> 32));
+                if constexpr (PERSIST) { if (!res.first) lb3 = res.lb3[tid]; }
+                const float t3 = (lb3 - del) * (1.0f - 2.4e-7f);
+                if (ru_io && active && has_w && has_u) {
+                    if (cert) {
+                        // (winner unchanged: LB3 moves like LB)
+                        if constexpr (PERSIST) res.lb3[tid] = t3;
+                        else reinterpret_cast<unsigned *>(&ru_io[i].w)[1] = __float_as_uint(t3);
+                    } else if (lb_old > 0.f && t3 > 0.f) {
+                        const unsigned uidx = (unsigned)u8.w;
+                        const double dx = u8.x - hp[0], dy = u8.y - hp[1], dz = u8.z - hp[2];
+                        double d2u = dx * dx;                // flann L2 (dist.h:159-176), as for the winner
+                        d2u += dy * dy;
+                        d2u += dz * dz;
+                        const bool u_wins = d2u < d2w || (d2u == d2w && uidx < widx);   // (lowest original index on a tie: rank())
+                        const double dm = u_wins ? d2u : d2w, dother = u_wins ? d2w : d2u;
+                        if (dm < r2d && dm < (double)t3 * (double)t3 * (1.0 - 1e-6)) {
+                            // the nearer of the two is the unique nearest neighbour; everything but it is at least
+                            // min(the other's distance, t3) away
+                            cert = true;
+                            const float lbn = fminf(t3, sqrtf((float)dother) * (1.0f - 1e-6f));
+                            if (u_wins) {
+                                // they change places
+                                const Pt64 ow = w8;
+                                w8.x = u8.x; w8.y = u8.y; w8.z = u8.z;
+                                w8.w = (unsigned long long)uidx | ((unsigned long long)__float_as_uint(lbn) << 32);
+                                widx = uidx;
+                                emit_ru(i, (unsigned)tid, true, ow.x, ow.y, ow.z, (unsigned)ow.w, t3);
+                                if constexpr (!PERSIST) wst_io[i] = w8;
+                            } else {
+                                if constexpr (PERSIST) res.lb3[tid] = t3;
+                                else reinterpret_cast<unsigned *>(&ru_io[i].w)[1] = __float_as_uint(t3);
+                            }
+                            emit(i, (unsigned)tid, true, dm, widx, true, w8.x, w8.y, w8.z, lbn);
+                        }
+                    }
+                } else if (ru_io && active && cert) {
+                    if constexpr (PERSIST) res.lb3[tid] = __uint_as_float(0xFFFFFFFFu);
+                }
+            }
         }
         const bool need = active && !cert;
         const bool cfound = cert && has_w;                   // certified WITH a partner: (hp, w8) is the correspondence
@@ -539,11 +657,13 @@ __device__ __forceinline__ bool coop_body(
                         c += __shfl_down(c, o, 64);
                         ca += __shfl_down(ca, o, 64);
                     }
+#ifndef VISMA_COOP_LB_PROBE
                     if (lane == 0 && ca) {
                         unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
                         atomicAdd(slot, c);
                         atomicAdd(slot + 1, ca);
                     }
+#endif
                 }
                 COOP_MARK(1);                                // row bounds asked for, rows pruned
 #pragma unroll
@@ -567,7 +687,8 @@ __device__ __forceinline__ bool coop_body(
             float gh0 = INFINITY, gh1 = INFINITY, gh2 = INFINITY;
             float gsec = INFINITY;                           // best candidate outside the rounding band of its chunk's minimum
             unsigned gb0 = 0xFFFFFFFFu, gb1 = 0xFFFFFFFFu, gm0 = 0u, gm1 = 0u;
-            auto chunk_insert = [&](float m, unsigned b, unsigned flags) {
+            unsigned gs0 = 0x7F800000u | (0x1FE0u << 3);     // the side word of the best chunk (sec = third = +inf)
+            auto chunk_insert = [&](float m, unsigned b, unsigned flags, unsigned side) {
                 const bool c1 = m < gh0, c2 = m < gh1;
                 gh2 = __builtin_amdgcn_fmed3f(gh1, gh2, m);
                 gh1 = __builtin_amdgcn_fmed3f(gh0, gh1, m);
@@ -575,6 +696,7 @@ __device__ __forceinline__ bool coop_body(
                 gb1 = c2 ? b : gb1; gm1 = c2 ? flags : gm1;
                 gb1 = c1 ? gb0 : gb1; gm1 = c1 ? gm0 : gm1;
                 gb0 = c1 ? b : gb0; gm0 = c1 ? flags : gm0;
+                if constexpr (kCoopRu) gs0 = c1 ? side : gs0;
             };
             // -- B2: the list, one window at a time (one window unless the cloud is very dense).  A query's chunks take
             // CONSECUTIVE entries, row after row: the owner reads its results back as one short run.
@@ -626,13 +748,23 @@ __device__ __forceinline__ bool coop_body(
                         const bool fl = d <= m + p.w;
                         const unsigned long long bal = __builtin_amdgcn_ballot_w64(fl);
                         const unsigned flags = (unsigned)(bal >> (oct * 8)) & 0xFFu;
-                        // the chunk's best candidate that is NOT flagged (for the LB the query leaves behind)
-                        const float sec = octet_min(fl ? INFINITY : d);
+                        // the chunk's best candidate that is NOT flagged (for the LB the query leaves behind), its lane, and
+                        // the best of the rest (the runner-up's chunk: what bounds everything but winner and runner-up)
+                        const float dn = fl ? INFINITY : d;
+                        const float sec = octet_min(dn);
+                        unsigned secl = 0u;
+                        float third = INFINITY;
+                        if constexpr (kCoopRu) {
+                            const unsigned long long bs = __builtin_amdgcn_ballot_w64(dn == sec && sec < INFINITY);
+                            const unsigned b8 = (unsigned)(bs >> (oct * 8)) & 0xFFu;
+                            secl = b8 ? (unsigned)__builtin_ctz(b8) : 0u;
+                            third = octet_min((b8 != 0u && (unsigned)l8 == secl) ? INFINITY : dn);
+                        }
                         // the result takes the place of the descriptor's second word: the chunk minimum rounded DOWN to
                         // 16 mantissa bits | the flag byte (the first word, the chunk's position, stays)
                         if (l8 == 0 && mine) {
                             s_item[c].y = (__float_as_uint(m) & 0xFFFFFF00u) | flags;
-                            s_sec[c] = sec;
+                            s_sec[c] = pack_sec(sec, third, secl);
                         }
                     }
                 }
@@ -642,7 +774,7 @@ __device__ __forceinline__ bool coop_body(
                     // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
                     for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
                         uint2 r[4];
-                        float rs[4];
+                        unsigned rs[4];
                         bool in[4];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
@@ -653,14 +785,17 @@ __device__ __forceinline__ bool coop_body(
                         }
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            chunk_insert(in[u] ? __uint_as_float(r[u].y & 0xFFFFFF00u) : INFINITY, r[u].x, r[u].y & 0xFFu);
-                            gsec = fminf(gsec, in[u] ? rs[u] : INFINITY);
+                            chunk_insert(in[u] ? __uint_as_float(r[u].y & 0xFFFFFF00u) : INFINITY, r[u].x, r[u].y & 0xFFu, rs[u]);
+                            gsec = fminf(gsec, in[u] ? sec_of(rs[u]) : INFINITY);
                         }
                     }
                     COOP_MARK(4);                            // chunk results merged per query
                 }
                 if (w0 + kCapAll < m_all) __syncthreads();   // (the list is re-used by the next window)
             }
+            // (runner-up builds: the searchers hand slot and bound over through the chunk list's memory -- not before every
+            //  owner has read its last results from it)
+            if constexpr (kCoopRu) __syncthreads();
             // -- B3 (searchers): the f64 decision -- flagged candidates of the kept chunks inside g + W.
             // The query itself comes back from where it lies in LDS -- its f64 point from its home lane's slot, its
             // fp32 view and W from the searcher's, the band re-derived -- instead of occupying 17 registers across the
@@ -695,6 +830,9 @@ __device__ __forceinline__ bool coop_body(
                 //  the tests below stay on the safe side -- a chunk or candidate more is ranked in f64, never one less)
                 const float g_up = gh0 * (1.0f + 6.2e-5f);
                 int n = 0;                                           // candidates ranked in f64
+                // the runner-up the state will keep (kCoopRu): its slot, the squared bound of everything but it and the winner
+                unsigned rupos = 0xFFFFFFFFu;
+                float lb3_2 = 0.f;
                 // (chunk minima at or beyond L cannot be accepted in f64: such chunks only serve the LB)
                 if (need && gh0 < L) {
                     const float thr = g_up + W;
@@ -711,6 +849,24 @@ __device__ __forceinline__ bool coop_body(
                     };
                     add(gb0, gm0);
                     if (gh1 <= thr) add(gb1, gm1);
+                    if constexpr (kCoopRu) {
+                        // One flagged candidate in all (the usual case): it is THE candidate of the best chunk.  The
+                        // runner-up is the best of (A) that chunk's best candidate outside the band -- then every other
+                        // chunk is at least gh1 away and the rest of this one at least `third` -- and (B) the second-best
+                        // chunk's minimum, if that chunk flagged one candidate only -- then the rest of every chunk is at
+                        // least gsec away and every other chunk gh2.  (All values rounded down: lower bounds.)
+                        if (ru_io && n == 1 && !slow) {
+                            const float secA = sec_of(gs0);
+                            if (secA < INFINITY && secA <= gh1) {
+                                rupos = gb0 + (gs0 & 7u);
+                                lb3_2 = fminf(gh1, third_of(gs0));
+                            } else if (gh1 < INFINITY && __builtin_popcount(gm1) == 1) {
+                                rupos = gb1 + (unsigned)__builtin_ctz(gm1);
+                                lb3_2 = fminf(gh2, gsec);
+                            }
+                            lb3_2 = fminf(lb3_2, lbgeo2);
+                        }
+                    }
                     // (a second flagged candidate: one query in a thousand; a third: duplicated points)
                     Pt64 c8a = Pt64{0.0, 0.0, 0.0, 0ull}, c8b = c8a;
                     if (n > 0) c8a = sorted64[c[0]];
@@ -828,12 +984,35 @@ __device__ __forceinline__ bool coop_body(
                     // a near-tie (several candidates ranked in f64, a re-scan): the runner-up was not bounded
                     if (slow || n > 1) lb = 0.f;
                     lb_new = fminf(fmaxf(lb, 0.f), 3.0e38f);
+#ifdef VISMA_COOP_LB_PROBE
+                    // (tools/lb_probe.py, measurement build) what limits the bound a search leaves: the runner-up among the
+                    // examined candidates, or the cells that were not listed?  counter 0: sum over the candidate-limited
+                    // queries of (geometric bound - candidate bound) in micrometres; counter 1: their number
+                    if (cand_count && bpos != 0xFFFFFFFFu && !(slow || n > 1)) {
+                        const float cb = fminf(gh1, gsec);
+                        if (cb < lbgeo2) {
+                            unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
+                            atomicAdd(slot, (unsigned long long)((sqrtf(fminf(lbgeo2, 4.0f * r2f)) - sqrtf(cb)) * 1e6f));
+                            atomicAdd(slot + 1, 1ull);
+                        }
+                    }
+#endif
                 }
                 const bool found = bpos != 0xFFFFFFFFu;
                 COOP_MARK(5);                                // f64 winner arrived and ranked
                 if (active) {
                     const long long i = (long long)(vb * NTH + (int)s_home[tid]) * per_group + it;   // its home thread's query of the round
                     emit(i, (unsigned)s_home[tid], false, bd, bidx, found, bq.x, bq.y, bq.z, lb_new);
+                    if constexpr (kCoopRu) {
+                        // (examined candidates and slab bounds alike: the margins of LB)
+                        // The runner-up's f64 point is NOT fetched here, where the kernel has no register to spare (eight more
+                        // live across the re-scan loop spilled 21: ~3 us of scratch round trips per pass): slot and bound go
+                        // to the home lane through the chunk list's memory, which nobody needs any more this round, and
+                        // the home lane fetches the point in phase C, behind its moments.
+                        const float lb3 = sqrtf(lb3_2) * (1.0f - 1e-6f) - 4.0f * E;
+                        const bool have = found && rupos != 0xFFFFFFFFu && !(slow || n > 1) && lb3 > 0.f && lb_new > 0.f;
+                        if (ru_io) s_item[s_home[tid]] = make_uint2(have ? rupos : 0xFFFFFFFFu, __float_as_uint(fminf(lb3, 3.0e38f)));
+                    }
                 }
                         // the hand-over to the query's home lane (phase C): the winner's f64 point (NaN: none) and index
                 if (active) {
@@ -855,6 +1034,18 @@ __device__ __forceinline__ bool coop_body(
         COOP_MARK(12);
         // ---- C: the moments of the round's correspondence, on the home lane: query and partner from LDS (nothing of
         // them was kept across the search, where the kernel sits at the 128 registers it may use: 4 waves per SIMD)
+        if constexpr (kCoopRu) {
+            // (a searched query's runner-up: asked for now, stored behind the workgroup's partial row -- ru_finish)
+            ru_go = false;
+            if (ru_io && ((needers >> lane) & 1ull)) {
+                const uint2 h = s_item[tid];
+                ru_go = true;
+                ru_it = it;
+                ru_lb3 = __uint_as_float(h.y);
+                ru_have = h.x != 0xFFFFFFFFu;
+                if (ru_have) ru_pending = sorted64[h.x];
+            }
+        }
         {
             const unsigned pidx = __float_as_uint(s_dprev[tid]);
             if (active && pidx != 0xFFFFFFFFu) {
@@ -863,7 +1054,10 @@ __device__ __forceinline__ bool coop_body(
                 moments(hq[0], hq[1], hq[2], pidx, s_q64[tid][0], s_q64[tid][1], s_q64[tid][2]);
             }
         }
-        if constexpr (!ONE) __syncthreads();                 // (the next round re-uses the slots, the list and the queue)
+        if constexpr (!ONE) {
+            ru_finish();
+            __syncthreads();                                 // (the next round re-uses the slots, the list and the queue)
+        }
     };
     if constexpr (ONE) {
         round(0);
@@ -879,12 +1073,15 @@ __device__ __forceinline__ bool coop_body(
         // refuses a persistent launch without the granule buffers)
         const unsigned tag = fold_row_tag(fold.seq);
         block_reduce_store<NACC, NW, true>(acc, partials, true, fold.rows_tagged, tag);
+        ru_finish();
         COOP_MARK(7);
         published = polled_fold<PLANE, NTH>(fold, lb, bpp, tag);
     } else {
         block_reduce_store<NACC, NW, false>(acc, partials, fold.tickets != nullptr);
+        if constexpr (ONE) ru_finish();
         COOP_MARK(7);                                        // workgroup's partial row stored
-        if (fold.tickets) published = fused_fold<PLANE, NTH, false, true>(fold, partials, row0, lb, bpp, prob);
+        if (fold.tickets) published = fused_fold<PLANE, NTH, false, false>(fold, partials, row0, lb, bpp, prob);   // (no SOLVE epilogue here: the
+        // one-thread solve spilled 43 registers of this 128-register kernel; FoldArgs::solve is for grid.hip / grid_wave.hip)
     }
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
     return published;
@@ -897,10 +1094,10 @@ __device__ __forceinline__ bool coop_body(
         const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,   \
         int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,                            \
         const Pt64 *__restrict__ nrm64, const FoldArgs fold, double *__restrict__ d64_out,                       \
-        Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev
+        Pt64 *__restrict__ wst_io, int warm, Xform64 Tprev, Pt64 *__restrict__ ru_io
 #define VISMA_COOP_ARGS                                                                                          \
     ns, s12f, start, g, nrm, T64, off, r2f, idx_out, d2_out, partials, cand_count, st, bpp, out_stride, descs,   \
-        nprob, src64, sorted64, nrm64, fold, d64_out, wst_io, warm, Tprev
+        nprob, src64, sorted64, nrm64, fold, d64_out, wst_io, warm, Tprev, ru_io
 // One query per lane: C4's 262,144 queries are 4096 waves, all resident at once only at 4 waves per SIMD
 // (<= 128 VGPRs; the kernel needs 104).  Several queries per lane: the 23 / 29 f64 moments stay live across
 // the queries, so the compiler gets the registers it asks for (2 waves per SIMD; such launches have more
@@ -964,7 +1161,10 @@ __device__ __forceinline__ unsigned long long persist_wait(const PersistArgs &pa
                 dead = __hip_atomic_load(pa.relay + kPersistDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
             }
         }
-        if (dead || now - t_ref > ((published || !all_here) ? pa.wait_ticks : pa.hard_ticks)) {
+        // (published: a command is due within the host's patience x 4; not everybody has begun: the launch may never
+        //  be complete -- somebody else holds compute units -- and says so soon; else the pass is still running somewhere)
+        const long long limit = published ? pa.wait_ticks : (!all_here ? (pa.start_ticks > 0 ? pa.start_ticks : pa.wait_ticks) : pa.hard_ticks);
+        if (dead || now - t_ref > limit) {
             // nothing came: everybody leaves (the command word decides; the transform words are not looked at)
             w = ((unsigned long long)tag << 32) | (lane == kPersistWords - 1 ? kPersistAbort : 0u);
             if (lane == 0) {
@@ -990,6 +1190,7 @@ struct CoopPersistParams {
     int ns; const float *s12f; const unsigned *start; GridParams g; const float4 *nrm; Xform64 T64; Offset64 off; float r2f;
     int *idx_out; float *d2_out; double *partials; unsigned long long *cand_count; int bpp; const Pt64 *src64;
     const Pt64 *sorted64; const Pt64 *nrm64; FoldArgs fold; Pt64 *wst_io; int warm; Xform64 Tprev; PersistArgs pa;
+    Pt64 *ru_io;
 };
 
 // a (member of a) kernel argument read through the laundered kernarg pointer, word by word
@@ -1015,7 +1216,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __shared__ unsigned s_cmdw;
     // what the queries carry from pass to pass (CoopRes): read from global memory by the first pass, written back once
     __shared__ double r_q64[kBlock][3];
-    __shared__ float r_idx[kBlock], r_lb[kBlock];
+    __shared__ float r_idx[kBlock], r_lb[kBlock], r_lb3[kCoopRu ? kBlock : 1];
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(P.pa.relay + kPersistStarted, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (this workgroup runs)
 #pragma unroll
@@ -1064,7 +1265,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
             VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
             nullptr, 1, VISMA_KARG(src64), VISMA_KARG(sorted64), VISMA_KARG(nrm64), f, nullptr, VISMA_KARG(wst_io), w, Tp,
-            t_begin ? &work : nullptr, CoopRes{r_q64, r_idx, r_lb, pass == 1 ? 1 : 0});
+            VISMA_KARG(ru_io), t_begin ? &work : nullptr, CoopRes{r_q64, r_idx, r_lb, r_lb3, pass == 1 ? 1 : 0});
         const PersistArgs pa = VISMA_KARG(pa);
         if (pa.timeline && pass <= pa.timeline_passes && thread_number<true>() == 0) {
             // (measurement runs only) [pass][workgroup]{begin, body done}; the begin of pass 1 is the launch's
@@ -1121,6 +1322,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 VISMA_KARG(idx_out)[i_begin] = (int)pid;                                // (~0 = -1: none)
                 VISMA_KARG(d2_out)[i_begin] = d2;
                 VISMA_KARG(wst_io)[i_begin] = o8;
+                if constexpr (kCoopRu) {
+                    // (the runner-up's point and index were written through when they changed; LB3 moved with every pass)
+                    Pt64 *ru = VISMA_KARG(ru_io);
+                    if (ru) reinterpret_cast<unsigned *>(&ru[i_begin].w)[1] = __float_as_uint(r_lb3[tidx]);
+                }
             }
             break;
         }
@@ -1133,7 +1339,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #define VISMA_COOP_LAUNCH(KERNEL_)                                                                               \
     hipLaunchKernelGGL(KERNEL_, dim3(total_blocks), dim3(kBlock), 0, stream, ns, s12, start, g, nrm, T64, off,   \
                        r2f, idx_out, d2_out, partials, cand_count, st, bpp, out_stride, descs, nprob, src64,     \
-                       sorted64, nrm64, fold, d64_out, wst_io, warm, Tp)
+                       sorted64, nrm64, fold, d64_out, wst_io, warm, Tp, ru_io)
 
 // The warm-started, flattened exact search.  Shared clouds: `nprob` problems of `bpp` workgroups each
 // (descs == NULL); own clouds: descs[nprob], total_blocks workgroups.  `one`: at most one query per lane.
@@ -1149,7 +1355,7 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
                           const FoldArgs &fold, double *d64_out, Pt64 *wst_io, int warm, hipStream_t stream,
-                          const Xform64 *Tprev, const PersistArgs *persist)
+                          const Xform64 *Tprev, const PersistArgs *persist, Pt64 *ru_io)
 {
     if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
     if (persist) {
@@ -1164,7 +1370,7 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
         P.idx_out = idx_out; P.d2_out = d2_out; P.partials = partials; P.cand_count = cand_count; P.bpp = bpp;
         P.src64 = src64; P.sorted64 = sorted64; P.nrm64 = nrm64; P.fold = fold; P.wst_io = wst_io;
         if (Tprev) { P.Tprev = *Tprev; warm |= 4; } else warm &= ~4;
-        P.warm = warm; P.pa = *persist;
+        P.warm = warm; P.pa = *persist; P.ru_io = ru_io;
         if (point_to_plane) hipLaunchKernelGGL(nn_coop_kernel_persist<true>, dim3(total_blocks), dim3(kBlock), 0, stream, P);
         else hipLaunchKernelGGL(nn_coop_kernel_persist<false>, dim3(total_blocks), dim3(kBlock), 0, stream, P);
         return hipGetLastError();

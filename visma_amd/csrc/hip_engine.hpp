@@ -28,7 +28,7 @@ public:
         free_dev(d_claim_); free_dev(d_d64_);
         free_dev(d_src64_); free_dev(d_tgt64_); free_dev(d_sorted64_); free_dev(d_nrm64_);
         for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
-        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_partials_); free_dev(d_stats_);
+        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_ru_); free_dev(d_partials_); free_dev(d_stats_);
         if (d_vox_out_) (void)hipFree(d_vox_out_);
         free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
@@ -241,11 +241,12 @@ public:
     void set_persistent(int enabled, double timeout_ms) override
     {
         persist_enabled_ = enabled != 0;
+        persist_cooldown_ = 0;
         if (timeout_ms >= 0.5 && timeout_ms <= 5000.0) persist_timeout_ms_ = timeout_ms;
     }
     void get_persistent_info(visma_icp_persistent_info *out) const override
     {
-        out->enabled = persist_enabled_ ? 1 : 0;
+        out->enabled = (persist_enabled_ && persist_cooldown_ == 0) ? 1 : 0;
         out->last_loop_persistent = last_loop_persist_passes_ > 0 ? 1 : 0;
         out->last_loop_passes = last_loop_persist_passes_;
         out->launches = timing_persist_launches_total_;
@@ -261,6 +262,7 @@ public:
         loop_scope_ = true;
         loop_budget_ = max_passes;
         loop_persist_passes_ = 0;
+        if (persist_cooldown_ > 0) persist_cooldown_--;
     }
     bool loop_across_ranks_ok() const override { return persist_ranks_ok(); }
     int loop_end() override
@@ -490,6 +492,11 @@ private:
     // the warm-started kernel).
     void *d_pos_ = nullptr;
     bool pos_fresh_ = false;
+    // the runner-up half of that state (round 5b, grid_coop.hip: kCoopRu): per query the runner-up's f64 point, its
+    // index | LB3 << 32; all bits set = none; same size, same resets as d_pos_.  VISMA_ICP_RUNNER_UP=0: not used (A/B)
+    void *d_ru_ = nullptr;
+    int runner_up_ = 1;
+    Pt64 *ru_state() const { return runner_up_ ? (Pt64 *)d_ru_ : nullptr; }
     // the certificate of grid_coop.hip: the transform of the pass that left the state (host-driven passes over ONE
     // problem; device loops carry it in their DevIcpState and leave prev_T_valid_ false behind them)
     Xform64 prev_T_{};
@@ -504,6 +511,7 @@ private:
         pos_fresh_ = false;
         prev_T_valid_ = false;
         if (d_pos_ && aux_cap_ > 0) HIP_TRY(hipMemsetAsync(d_pos_, 0xFF, sizeof(Pt64) * (size_t)aux_cap_, stream_));
+        if (d_ru_ && aux_cap_ > 0) HIP_TRY(hipMemsetAsync(d_ru_, 0xFF, sizeof(Pt64) * (size_t)aux_cap_, stream_));
         return VISMA_ICP_OK;
     }
     bool coop_ok() const
@@ -642,8 +650,11 @@ private:
     // device-resident loops: the problem's state advances in the fold epilogue of the search launch (FoldArgs::solve) --
     // the closed-form update on one GPU; Gauss-Newton / point-to-plane loops and ranks keep solve_state_kernel
     int solve_in_fold_ = 0;          // VISMA_ICP_SOLVE_IN_FOLD=1: see DESIGN.md 4.4 -- measured SLOWER than the launch of its own (A/B knob)
-    bool solve_in_fold(const LoopParams &lp) const
+    // (`lanes`: the launch's lanes code -- the certificate kernels of grid_coop.hip do not carry the epilogue)
+    bool solve_in_fold(const LoopParams &lp, int lanes = 0, int nprob = 2) const
     {
+        static const bool forced = std::getenv("VISMA_ICP_COOP_KERNEL") != nullptr;
+        if (forced || (lanes == kCoopLanes && nprob == 1)) return false;
         return solve_in_fold_ && fused_fold_ && !lp.plane && lp.solver == VISMA_ICP_SOLVER_KABSCH && !tshard_ && !comm_ && ipc_n_ <= 1;
     }
     int ensure_f64_views();
@@ -654,6 +665,12 @@ private:
     // fit (another radius, plane, frame) posts STOP and waits for the launch to end.  The launch gives up by itself
     // when no command arrives in time (the host then finds the stream idle and goes on with ordinary launches).
     int persist_enabled_ = 1;        // VISMA_ICP_PERSIST=0: one launch per pass
+    // After a launch that gave up (its workgroups could not all become resident -- another stream held compute units --, or
+    // the host came back too late) the context's next loops launch once per pass; persistent launches are tried again after
+    // kPersistCooldownLoops loops (until round 5: never again unless visma_icp_set_persistent asked), or at once when asked.
+    static constexpr int kPersistCooldownLoops = 8;
+    int persist_cooldown_ = 0;
+    double persist_start_ms_ = 5.0;  // VISMA_ICP_PERSIST_START_MS: how long a launch waits for all of its workgroups to begin
     // what visma_icp_get_persistent_info reports (never reset)
     int loop_persist_passes_ = 0, last_loop_persist_passes_ = 0;
     double timing_persist_launches_total_ = 0.0, timing_persist_passes_total_ = 0.0, persist_aborts_total_ = 0.0;
@@ -706,7 +723,7 @@ private:
     bool persist_static_ok() const
     {
         static const bool forced = std::getenv("VISMA_ICP_COOP_KERNEL") != nullptr;       // (A/B runs of the two one-pass kernels)
-        return persist_enabled_ && fused_fold_ && !tshard_ && !comm_ && !minreduce_ && (ipc_n_ <= 1 || persist_ranks_ok()) &&
+        return persist_enabled_ && persist_cooldown_ == 0 && fused_fold_ && !tshard_ && !comm_ && !minreduce_ && (ipc_n_ <= 1 || persist_ranks_ok()) &&
                !(grid_lanes_ > 0 && grid_lanes_ != kCoopLanes) && !forced && ns_ <= (int64_t)grid_blocks() * kBlock;
     }
     int start_session(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, int nblocks, bool prof);

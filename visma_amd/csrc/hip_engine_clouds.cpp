@@ -38,6 +38,7 @@ int HipEngine::init()
     HIP_TRY(hipMemset(d_cand_, 0, 3 * 4096 * sizeof(unsigned long long)));
     if (const char *e = std::getenv("VISMA_ICP_COOP")) coop_enabled_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_CERT")) cert_enabled_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_RUNNER_UP")) runner_up_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_GRID_LANES")) {
         const int v = std::atoi(e);
         if (v > 0) grid_lanes_ = v;   // G + 100*U (lanes per query, loads in flight per lane)
@@ -57,6 +58,7 @@ int HipEngine::init()
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH")) cold_in_launch_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH_MIN_NS")) cold_in_launch_min_ns_ = std::max<long long>(0, std::atoll(e));
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMEOUT_MS")) { const double v = std::atof(e); if (v >= 1.0 && v <= 5000.0) persist_timeout_ms_ = v; }
+    if (const char *e = std::getenv("VISMA_ICP_PERSIST_START_MS")) { const double v = std::atof(e); if (v >= 0.0 && v <= 5000.0) persist_start_ms_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMELINE")) timeline_path_ = e;
     // The command block of the persistent launch.  On a large-BAR system it lies in fine-grained DEVICE memory the host
     // stores into through the BAR (write-combining: post_command ends with a store fence): every workgroup polls it
@@ -542,10 +544,11 @@ int HipEngine::ensure_target(int64_t nt)
 int HipEngine::ensure_aux(int64_t ns_pad)
 {
     if (ns_pad > aux_cap_) {
-        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_);
+        free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_ru_);
         HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * (ns_pad > 0 ? ns_pad : 1)));
         HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * (ns_pad > 0 ? ns_pad : 1)));
         HIP_TRY(hipMalloc(&d_pos_, sizeof(Pt64) * (ns_pad > 0 ? ns_pad : 1)));
+        HIP_TRY(hipMalloc(&d_ru_, sizeof(Pt64) * (ns_pad > 0 ? ns_pad : 1)));
         aux_cap_ = ns_pad;
         return invalidate_pos();
     }

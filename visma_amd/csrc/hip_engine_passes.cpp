@@ -132,7 +132,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 patient = gap_us <= persist_timeout_ms_ * 1e3;
                 if (!patient) {
                     timing_.persist_aborts += 1.0; persist_aborts_total_ += 1.0;
-                    persist_enabled_ = 0;                    // (until visma_icp_set_persistent asks again)
+                    persist_cooldown_ = kPersistCooldownLoops;   // (for the next loops, or until visma_icp_set_persistent asks again)
                 } else if (trace_persist()) {
                     host_gap_us_ += gap_us;
                     host_gaps_++;
@@ -168,6 +168,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                     pa.tag0 = sess_tag0_;
                     pa.wait_ticks = (long long)(4.0 * persist_timeout_ms_ * 1e5) + 1000000ll;   // (100 MHz; host patience x 4 + 10 ms)
                     pa.hard_ticks = 60ll * 100000000ll;
+                    pa.start_ticks = (long long)(persist_start_ms_ * 1e5);
                     HIP_TRY(hipMemsetAsync((unsigned long long *)d_relay_ + kPersistDead, 0, 2 * sizeof(unsigned long long), stream_));   // (dead, started)
                     if (!timeline_path_.empty()) {
                         // (measurement: clocks of up to 64 passes of this launch, read back when it has ended)
@@ -260,7 +261,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 std::fprintf(stderr, "[visma_icp] persistent launch gave up: pass %d of %d, its flag %u, tag %u (first %u)\n", sess_pass_, sess_max_,
                              *reinterpret_cast<volatile unsigned *>(h_flag_), cmd_tag_, sess_tag0_);
             finish_session();
-            persist_enabled_ = 0;
+            persist_cooldown_ = kPersistCooldownLoops;
             in_session = false;
             // Whatever made it leave (the host thread away for longer than four times its patience, a command that
             // arrived torn over more than that): some workgroups may have begun the pass and others not.  Nothing of a
@@ -343,7 +344,7 @@ int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double off
                                   &nblocks, lanes,
                                   prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                   1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1, cert_prev(), persist));
+                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1, cert_prev(), persist, ru_state()));
     last_kernel_ = pass_kernel(lanes);
     pos_fresh_ = d_pos_ != nullptr;
     note_state_pass(T64);
@@ -376,6 +377,7 @@ bool HipEngine::persist_possible(int lanes, int nblocks, bool fused, bool plane)
         return false;
     };
     if (!persist_enabled_) return no("switched off");
+    if (persist_cooldown_ > 0) return no("cooling down after a launch that gave up");
     if (!fused || tshard_ || comm_ || minreduce_ || (ipc_n_ > 1 && !persist_ranks_ok())) return no("sharded ranks / fold in a second launch");
     if (lanes != kCoopLanes || !coop_ok()) return no("not a pass of the certificate kernel");   // (pass_lanes: warm, or cold in a loop)
     if (grid_lanes_ > 0 && grid_lanes_ != kCoopLanes) return no("lanes forced");
@@ -500,7 +502,7 @@ int HipEngine::get_correspondences(int32_t *idx, float *d2)
                                       (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                       &nblocks, (last_kernel_ = pass_kernel(pass_lanes()), pass_lanes()), nullptr, nullptr, 1, 0, stream_,
                                       f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0,
-                                      nullptr, nullptr, (Pt64 *)d_pos_, 1, cert_prev()));
+                                      nullptr, nullptr, (Pt64 *)d_pos_, 1, cert_prev(), nullptr, ru_state()));
         pos_fresh_ = d_pos_ != nullptr;
         note_state_pass(T64);
         grid_pending_ = false;
@@ -621,7 +623,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
                     if (ipc_n_ > 1) add_ipc(&fa);      // (one problem per rank: ipc needs nprob == 1)
                     // closed-form update on one GPU: the workgroup that completes a problem's fold advances its state
                     // in the same launch (no solve_state_kernel between two search launches)
-                    if (solve_in_fold(lp)) fa.solve = st;
+                    if (solve_in_fold(lp, lanes, nprob)) fa.solve = st;
                 }
                 solved_in_fold = fused && fa.solve != nullptr;
                 HIP_TRY(launch_nn_grid_reduce((const float4 *)d_src_, ns_, search_sorted(),
@@ -632,7 +634,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
                                               profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
                                               nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
                                               exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr,
-                                              (Pt64 *)d_pos_, cert_enabled_ ? 1 : (1 | 8)));
+                                              (Pt64 *)d_pos_, cert_enabled_ ? 1 : (1 | 8), nullptr, nullptr, nprob == 1 ? ru_state() : nullptr));
                 last_kernel_ = pass_kernel(lanes);
                 pos_fresh_ = d_pos_ != nullptr;
                 prev_T_valid_ = false;                   // (the state's pose now lives in the device loop's state)

@@ -85,7 +85,8 @@ struct FoldArgs {
     // device-resident loops with the closed-form (Kabsch) update (round 5): the workgroup that completes problem b's fold
     // advances solve[b] right there (icp_state.h: advance_state<true>) -- no solve launch between two search launches.
     // NULL: the statistics are left in the state and solve_state_kernel advances it (Gauss-Newton modes, point-to-plane,
-    // ranks that exchange first).  Honoured by the kernels batches and sweeps run (grid.hip, grid_wave.hip).
+    // ranks that exchange first).  Honoured by the kernels batches and sweeps run (grid.hip, grid_wave.hip), NOT by
+    // the certificate kernels of grid_coop.hip (the host never sets it for them: HipEngine::solve_in_fold).
     DevIcpState *solve;
 };
 
@@ -123,6 +124,10 @@ struct PersistArgs {
                                           // (wall_clock64 ticks, 100 MHz).  The HOST never posts GO later than a quarter of
                                           // this after it saw the statistics (it posts STOP and carries on with ordinary
                                           // launches), so no command can arrive while some workgroups have given up already
+    long long start_ticks;                // how long a workgroup waits for the launch's OTHER workgroups to begin (round 5:
+                                          // 5 ms by default -- when another stream's kernels hold compute units the launch
+                                          // cannot complete its residency, and waiting the four patiences of wait_ticks for
+                                          // that cost 0.8 s per attempt); 0: wait_ticks
     long long hard_ticks;                 // ... and before that publication (the pass is still running somewhere): a cap that
                                           // only a lost workgroup could reach -- unless not every workgroup of the launch has
                                           // begun by then (another process's persistent launch holds the rest of the compute
@@ -370,7 +375,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  double r2d = 0.0, const Pt64 *nrm64 = nullptr, int exact = 0,
                                  const FoldArgs *fold = nullptr, double *d64_out = nullptr,
                                  Pt64 *wst_io = nullptr, int warm = 0, const Xform64 *Tprev = nullptr,
-                                 const PersistArgs *persist = nullptr);
+                                 const PersistArgs *persist = nullptr, Pt64 *ru_io = nullptr);
 // persist: run the launch as the persistent certificate kernel (one problem, one query per lane, fused fold with
 // host publication; hipErrorInvalidValue where that does not apply -- ask coop_persist_capacity first).
 // wst_io (one Pt64 per query, laid out like idx_out): the exact searches leave their winners there (f64 point,
@@ -394,7 +399,7 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
                           const FoldArgs &fold, double *d64_out, Pt64 *wst_io, int warm, hipStream_t stream,
-                          const Xform64 *Tprev = nullptr, const PersistArgs *persist = nullptr);
+                          const Xform64 *Tprev = nullptr, const PersistArgs *persist = nullptr, Pt64 *ru_io = nullptr);
 // workgroups of the persistent kernel the current device holds at once (0: none -- do not launch it)
 int coop_persist_capacity(int point_to_plane);
 // Batch of problems with different clouds: `descs` (device) gives every problem's
