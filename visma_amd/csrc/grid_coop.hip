@@ -451,7 +451,24 @@ __device__ __forceinline__ bool coop_body(
             ru_go = false;
         }
     };
+    // (experiment, persistent launches: warm bits 32 / 64 = VISMA_ICP_PERSIST_PRIO 1 / 2.  The arbiter serves the oldest wave
+    //  of a SIMD first and the pass waits for the youngest residency slot, DESIGN 4.1e: 1 = priorities reversed for the whole
+    //  body -- youngest slot highest --, 2 = reversed in every other phase)
+    auto set_phase_prio = [&](const int phase) {
+        if constexpr (PERSIST) {
+            const int mode = (warm >> 5) & 3;
+            if (mode != 0) {
+                const int slot = (int)((blockIdx.x * 4u) / gridDim.x);
+                const int p = mode == 1 ? slot : ((phase & 1) ? slot : 3 - slot);
+                if (p == 0) __builtin_amdgcn_s_setprio(0);
+                else if (p == 1) __builtin_amdgcn_s_setprio(1);
+                else if (p == 2) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(3);
+            }
+        }
+    };
     auto round = [&](const int it) {
+        set_phase_prio(0);
         const long long i = i_begin + it;
         const bool active = i < i_end;
         // ---- A: the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
@@ -604,6 +621,7 @@ __device__ __forceinline__ bool coop_body(
         COOP_MARK(9);                                        // phase A done
         __syncthreads();
         COOP_MARK(10);
+        set_phase_prio(1);
         unsigned nq_all = 0;                                 // (uniform values: scalar registers)
         unsigned home = 0;                                   // the home thread of the query this thread searches
 #pragma unroll
@@ -717,6 +735,7 @@ __device__ __forceinline__ bool coop_body(
                     COOP_MARK(2);                            // chunk list written
                 }
                 __syncthreads();
+                set_phase_prio(2);
                 // ---- ALL waves: the window's chunks, eight lanes per chunk, one candidate per lane, kCoopDepth chunks
                 // per lane octet in flight (every load of the list is independent)
                 const unsigned mw = min(m_all - w0, kCapAll);
@@ -770,6 +789,7 @@ __device__ __forceinline__ bool coop_body(
                 }
                 if (searching) COOP_MARK(3);                 // chunks worked off (this wave's share)
                 __syncthreads();
+                set_phase_prio(3);
                 if (searching) {
                     // the owner's run of results, four reads in flight (a lane past its run inserts +inf: no effect)
                     for (unsigned c0 = 0; __builtin_amdgcn_ballot_w64(c0 < nq) != 0ull; c0 += 4u) {
@@ -1032,6 +1052,7 @@ __device__ __forceinline__ bool coop_body(
         }
         __syncthreads();
         COOP_MARK(12);
+        set_phase_prio(4);
         // ---- C: the moments of the round's correspondence, on the home lane: query and partner from LDS (nothing of
         // them was kept across the search, where the kernel sits at the 128 registers it may use: 4 waves per SIMD)
         if constexpr (kCoopRu) {

@@ -670,6 +670,7 @@ private:
     // kPersistCooldownLoops loops (until round 5: never again unless visma_icp_set_persistent asked), or at once when asked.
     static constexpr int kPersistCooldownLoops = 8;
     int persist_cooldown_ = 0;
+    int persist_prio_ = 0;           // VISMA_ICP_PERSIST_PRIO: 0 none, 1 / 2 the wave-priority experiments of grid_coop.hip
     double persist_start_ms_ = 5.0;  // VISMA_ICP_PERSIST_START_MS: how long a launch waits for all of its workgroups to begin
     // what visma_icp_get_persistent_info reports (never reset)
     int loop_persist_passes_ = 0, last_loop_persist_passes_ = 0;

@@ -58,6 +58,7 @@ int HipEngine::init()
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH")) cold_in_launch_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH_MIN_NS")) cold_in_launch_min_ns_ = std::max<long long>(0, std::atoll(e));
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMEOUT_MS")) { const double v = std::atof(e); if (v >= 1.0 && v <= 5000.0) persist_timeout_ms_ = v; }
+    if (const char *e = std::getenv("VISMA_ICP_PERSIST_PRIO")) { const int v = std::atoi(e); if (v >= 0 && v <= 2) persist_prio_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_START_MS")) { const double v = std::atof(e); if (v >= 0.0 && v <= 5000.0) persist_start_ms_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_TIMELINE")) timeline_path_ = e;
     // The command block of the persistent launch.  On a large-BAR system it lies in fine-grained DEVICE memory the host

@@ -344,7 +344,7 @@ int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double off
                                   &nblocks, lanes,
                                   prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                   1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1, cert_prev(), persist, ru_state()));
+                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1 | (persist ? persist_prio_ << 5 : 0), cert_prev(), persist, ru_state()));
     last_kernel_ = pass_kernel(lanes);
     pos_fresh_ = d_pos_ != nullptr;
     note_state_pass(T64);
