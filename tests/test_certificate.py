@@ -88,9 +88,10 @@ def test_certified_passes_equal_searched_passes_bit_for_bit(lib, name, ns, nt, r
             assert np.array_equal(o[1], outs[0][1]), (name, which, p)
             if p > 0:                                             # (the cold pass may use more lanes per query)
                 assert np.array_equal(o[2], outs[0][2]), (name, which, p)
-    # passes 0 (lane-serial) and 1 (first warm pass: leaves the bounds) cannot certify; a standstill after two
-    # decaying steps certifies nearly everything that is not an exact tie
-    assert certified[0] == 0.0 and certified[1] == 0.0, certified
+    # pass 0 (lane-serial, nothing known) cannot certify; pass 1 may since round 5 (the lane-serial kernel leaves a bound
+    # too: runner-up, skipped rows, outside of the 27 cells); a standstill after two decaying steps certifies nearly
+    # everything that is not an exact tie
+    assert certified[0] == 0.0, certified
     if dup:
         assert max(certified) < 0.9, certified                    # duplicated points are exact ties: never certified
     else:

@@ -702,6 +702,10 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         // cursor, one batch per trip of a single loop.  (A loop nest "for row: for batch"
         // makes the wave run max-over-queries batches for EVERY row -- 4-5x more load
         // instructions than a query needs.)
+        // (round 5: the smallest bound among the rows SKIPPED -- with the runner-up and the outside of the 27 cells it is
+        //  the lower bound LB this pass leaves to the certificates of grid_coop.hip)
+        float lb_skip2 = INFINITY;
+        bool near_tie = false;
         auto walk = [&]() {
             int kk = 0;
             for (;;) {
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                     float gbest = best_f32();
 #pragma unroll
                     for (int m = G >> 1; m > 0; m >>= 1) gbest = fminf(gbest, __shfl_xor(gbest, m, 64));
-                    if (bound > gbest) continue;
+                    if (bound > gbest) { lb_skip2 = fminf(lb_skip2, bound); continue; }
                     base = nb;
                     e = ne;
                     if (cand_count && sub == 0) ncand += e - base;
@@ -811,6 +815,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
                 in[0] = true;
 #pragma unroll
                 for (int k = 1; k <= NT; k++) in[k] = in[k - 1] && top.h[k] <= s1sq;
+                near_tie = in[1];                            // (a second candidate inside the band: the runner-up is not bounded)
                 auto rank = [&](unsigned pos) {
                     const Pt64 c8 = sorted64[pos];
                     // flann L2 (dist.h:159-176): result += diff * diff over x, y, z
@@ -878,12 +883,29 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
         if (sub == 0) {
             if constexpr (HYB) {
                 if (prevq_out) {
-                    // the state of grid_coop.hip: the winner's f64 point, original index | LB << 32 with LB = 0
-                    // (this kernel bounds no runner-up: the next pass searches, and leaves a bound)
+                    // the state of grid_coop.hip: the winner's f64 point, original index | LB << 32.  LB (round 5; 0 before: the
+                    // first warm pass of every registration searched every query): what every target point but the winner is
+                    // at least away -- the second-best candidate examined (every row visited was examined whole), the rows
+                    // skipped, the outside of the 27 cells; margins and rounding band as grid_coop.hip forms its own.
+                    float lbv = 0.f;
+                    if (g.sub == 1 && VISMA_GRID_NTOP >= 2) {
+                        const float fx = (px - g.mn[0]) * g.inv_h - (float)cx;
+                        const float lo_x = fmaxf(fx - mgn, 0.f), hi_x = fmaxf(1.0f - fx - mgn, 0.f);
+                        const float face = fminf(fminf(fminf(lo_x, hi_x), fminf(lo_y, hi_y)), fminf(lo_z, hi_z));
+                        const float ux = fx + (float)cx, uy = fy + (float)cy, uz = fz + (float)cz;
+                        const float far = fmaxf(fmaxf(fmaxf(-ux, ux - (float)g.dim[0]), fmaxf(-uy, uy - (float)g.dim[1])),
+                                                fmaxf(-uz, uz - (float)g.dim[2])) - 2.0f * mgn;
+                        const float outc = fmaxf(1.0f + face, far);
+                        float lb2 = fminf(fminf(outc * outc * h2, lb_skip2), top.h[1]);
+                        if (bpos == 0xFFFFFFFFu) lb2 = fminf(lb2, top.h[0]);     // nothing accepted: the best candidate bounds like the rest
+                        const float lb = sqrtf(lb2) * (1.0f - 1e-6f) - 4.0f * hyb_E;
+                        lbv = near_tie ? 0.f : fminf(fmaxf(lb, 0.f), 3.0e38f);
+                    }
+                    const unsigned long long lbw = (unsigned long long)__float_as_uint(lbv) << 32;
                     Pt64 w8;
                     w8.x = w8.y = w8.z = __longlong_as_double(-1ll);
-                    w8.w = 0xFFFFFFFFull;
-                    if (bpos != 0xFFFFFFFFu) { w8 = sorted64[bpos]; w8.w &= 0xFFFFFFFFull; }
+                    w8.w = 0xFFFFFFFFull | lbw;
+                    if (bpos != 0xFFFFFFFFu) { w8 = sorted64[bpos]; w8.w = (w8.w & 0xFFFFFFFFull) | lbw; }
                     prevq_out[i] = w8;
                 }
             }
