@@ -73,8 +73,8 @@ struct P12 { float x, y, z; };                // fp32 rounding of a cell-sorted 
 // winner w and u.  When the winner-unchanged certificate fails (d_w >= LB - delta), both distances are evaluated exactly
 // (the reference's arithmetic): if the nearer of the two lies inside the radius and below LB3 - delta, it is the unique
 // nearest neighbour (lowest original index on an exact tie, as rank()) -- no search; w and u change places if u won.
-// MEASURED AND NOT ADOPTED (compiled out by default; -DVISMA_COOP_RU=1 builds it, VISMA_ICP_RUNNER_UP=0 then switches
-// it off at run time): it certifies what it promises -- 53 % of the queries at pass 2 of a C4 registration instead of 33 %,
+// MEASURED AND NOT ADOPTED (compiled out by default; -DVISMA_COOP_RU=1 builds it, and VISMA_ICP_RUNNER_UP=1 makes the
+// contexts of such a build allocate and pass the runner-up buffer): it certifies what it promises -- 53 % of the queries at pass 2 of a C4 registration instead of 33 %,
 // 71 % at pass 10 instead of 56 %, 87 % at pass 20 instead of 75 % (profiles/r05_cert_probe_runner_up.txt), same results
 // bit for bit -- and the kernel gets SLOWER: it sits at the 128 registers four waves per SIMD allow, and the three best
 // candidates per chunk (one more octet minimum, a ballot, a packed side word), the side word through the merge and the

@@ -493,9 +493,11 @@ private:
     void *d_pos_ = nullptr;
     bool pos_fresh_ = false;
     // the runner-up half of that state (round 5b, grid_coop.hip: kCoopRu): per query the runner-up's f64 point, its
-    // index | LB3 << 32; all bits set = none; same size, same resets as d_pos_.  VISMA_ICP_RUNNER_UP=0: not used (A/B)
+    // index | LB3 << 32; all bits set = none; same size, same resets as d_pos_.  The kernels are built WITHOUT that code
+    // by default (-DVISMA_COOP_RU=1 builds it: measured slower), so the buffer exists only when asked for:
+    // VISMA_ICP_RUNNER_UP=1 (read when the context is created) with such a build
     void *d_ru_ = nullptr;
-    int runner_up_ = 1;
+    int runner_up_ = 0;
     Pt64 *ru_state() const { return runner_up_ ? (Pt64 *)d_ru_ : nullptr; }
     // the certificate of grid_coop.hip: the transform of the pass that left the state (host-driven passes over ONE
     // problem; device loops carry it in their DevIcpState and leave prev_T_valid_ false behind them)

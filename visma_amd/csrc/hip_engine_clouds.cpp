@@ -549,7 +549,7 @@ int HipEngine::ensure_aux(int64_t ns_pad)
         HIP_TRY(hipMalloc(&d_idx_, sizeof(int32_t) * (ns_pad > 0 ? ns_pad : 1)));
         HIP_TRY(hipMalloc(&d_d2_, sizeof(float) * (ns_pad > 0 ? ns_pad : 1)));
         HIP_TRY(hipMalloc(&d_pos_, sizeof(Pt64) * (ns_pad > 0 ? ns_pad : 1)));
-        HIP_TRY(hipMalloc(&d_ru_, sizeof(Pt64) * (ns_pad > 0 ? ns_pad : 1)));
+        if (runner_up_) HIP_TRY(hipMalloc(&d_ru_, sizeof(Pt64) * (ns_pad > 0 ? ns_pad : 1)));
         aux_cap_ = ns_pad;
         return invalidate_pos();
     }
