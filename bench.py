@@ -52,6 +52,7 @@ import argparse
 import json
 import math
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -94,9 +95,120 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=20)
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=7, help="how many times the K-step block is timed (value = median)")
+    ap.add_argument("--extras-file", default=os.path.join(ROOT, "bench_extras.json"),
+                    help="side file for the full result: every extra workload and note (the line on stdout carries the "
+                         "contract's keys only and names this file)")
     ap.add_argument("--no-extras", action="store_true",
                     help="c4: skip from_initial_pose / end_to_end / roofline_saturated / scaling_workloads")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------
+# the ONE line: numbers and one-phrase strings, <= 4 KB; everything else goes to the side file
+# ------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data")
+ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac", "avg_launch_ms", "ms_per_pass",
+                 "passes_per_launch", "launches_timed", "alg_bytes_per_launch", "examined_bytes_per_launch",
+                 "alg_flops_per_launch", "frac_on_examined_bytes", "candidates_per_query", "certified_fraction",
+                 "cold_pass_avg_ms")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "ms_per_iter", "gpu_vs_cpu_rel_frobenius")
+CONFIG_KEYS = ("workload", "ns", "nt", "radius", "solver", "nn", "search", "problems", "work_items", "parallelism")
+SCALAR_EXTRAS = ("value_converged", "value_partial_overlap", "fitness", "inlier_rmse", "err_vs_T_gt",
+                 "ranks_hold_identical_transforms", "matched_corr_per_sec", "problems_per_sec", "registrations_per_sec")
+
+
+def _num(x):
+    """numbers to 7 significant digits (the side file keeps them in full); strict JSON: no NaN / Infinity"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    x = float(x)
+    if not math.isfinite(x):
+        return None
+    return float("%.7g" % x)
+
+
+def _phrase(s, limit=160):
+    s = " ".join(str(s).split())
+    return s if len(s) <= limit else s[:limit - 3] + "..."
+
+
+def kernel_trace_name(roofline):
+    """the name rocprofv3's kernel trace shows for the launches the roofline object describes (no prose)"""
+    if roofline.get("kernel_name"):
+        return roofline["kernel_name"]
+    k = str(roofline.get("kernel", ""))
+    if roofline.get("launch", {}).get("persistent"):
+        return "nn_coop_kernel_persist"
+    return re.split(r"[ (]", k, 1)[0] if k else None
+
+
+def compact_line(full, extras_path=None):
+    """The summary line of the contract from the full result: the required keys, `config` (one short phrase per key),
+    `roofline` and `cpu_baseline` as NUMBERS, a handful of scalar extras, and the path of the side file that holds the
+    rest (every other workload, every note).  Always strict JSON of at most LINE_LIMIT bytes."""
+    line = {k: _num(full.get(k)) for k in REQUIRED_KEYS}
+    cfg = full.get("config", {})
+    short = full.get("config_short", {})
+    line["config"] = {k: (_phrase(short.get(k, cfg[k]), 200 if k == "workload" else 120) if isinstance(short.get(k, cfg[k]), str)
+                          else _num(short.get(k, cfg[k]))) for k in CONFIG_KEYS if k in cfg or k in short}
+    r = full.get("roofline")
+    if r:
+        rl = {"kernel": kernel_trace_name(r)}
+        launch = r.get("launch", {})
+        for k in ROOFLINE_KEYS:
+            v = r.get(k, launch.get(k))
+            if v is not None or k == "traffic":
+                rl[k] = _num(v)
+        if "one_pass_launch_avg_ms" in launch:
+            rl["cold_pass_avg_ms"] = _num(launch["one_pass_launch_avg_ms"])
+        line["roofline"] = rl
+    c = full.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {k: (_phrase(c[k], 200) if isinstance(c[k], str) else _num(c[k])) for k in CPU_KEYS if k in c}
+    for k in SCALAR_EXTRAS:
+        if k in full and not isinstance(full[k], (dict, list)):
+            line[k] = _num(full[k])
+    if extras_path:
+        line["extras"] = extras_path
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    # (cannot happen with the key lists above; the contract matters more than any optional key)
+    for k in SCALAR_EXTRAS + ("extras",):
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(k, None)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > LINE_LIMIT:
+        raise RuntimeError("bench line of %d bytes" % len(text))
+    return text
+
+
+def emit(full, extras_path):
+    """Rank 0: the full result to the side file (indented JSON; NaN / Infinity become null), the compact line to stdout."""
+    def clean(o):
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, (np.floating, float)):
+            return float(o) if math.isfinite(float(o)) else None
+        if isinstance(o, np.integer):
+            return int(o)
+        if isinstance(o, np.ndarray):
+            return clean(o.tolist())
+        return o
+    full = clean(full)
+    shown = None
+    if extras_path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(extras_path)), exist_ok=True)
+            with open(extras_path, "w") as f:
+                json.dump(full, f, indent=1, allow_nan=False)
+            shown = os.path.relpath(extras_path, ROOT) if os.path.abspath(extras_path).startswith(ROOT + os.sep) else extras_path
+        except OSError as e:
+            print("bench: side file %s not written (%s)" % (extras_path, e), file=sys.stderr)
+    print(compact_line(full, shown), flush=True)
 
 
 # ------------------------------------------------------------------------------------------
@@ -316,9 +428,9 @@ def cpu_baseline_c4(src, tgt, radius, iters, repeats):
     return {
         "value": float(np.median(rates)), "unit": "ICP iterations/s", "cores": int(threads), "kind": kind,
         "sample": "same clouds %d->%d, r=%.4g: %d steady-state iterations (t[%d its]-t[1 it]), median of %d; "
-                  "KD-tree build + 2 passes %.2fs; %d OpenMP threads of %d logical CPUs, OMP_PROC_BIND=%s" % (
-                      len(src), len(tgt), radius, iters, iters + 1, repeats, float(np.median(t1s)), int(threads),
-                      os.cpu_count() or 0, os.environ.get("OMP_PROC_BIND", "unset")),
+                  "%d OpenMP threads of %d CPUs" % (len(src), len(tgt), radius, iters, iters + 1, repeats, int(threads),
+                                                    os.cpu_count() or 0),
+        "omp_proc_bind": os.environ.get("OMP_PROC_BIND", "unset"),
         "runs": [float(x) for x in rates], "ms_per_iter": 1e3 / float(np.median(rates)),
         "setup_plus_first_iter_s": float(np.median(t1s)), "T": np.asarray(res.T).tolist(),
     }
@@ -887,6 +999,12 @@ def run_c4(R, args):
             "setup_ms": {"grid_build_kernels": setup["aux_ms"]},
             "roofline": roofline,
         }
+        # one phrase per key for the line on stdout (the long forms above stay in the side file)
+        out["config_short"] = {
+            "workload": "C4 S-surf %d->%d, %d ICP iterations of a fresh registration from T=I (cold pass + warm passes), "
+                        "median of %d" % (ns, nt, args.steps, len(elapsed_all)),
+            "parallelism": ("1 GPU, %s" % launch_mode.split(" (")[0] if R.dist is None else
+                            "%s-sharded x%d, allreduce(38 f64)/iter via %s" % (args.shard, R.world, comm_kind.split(" (")[0]))}
         # (continuity with rounds 3-4, where this regime was an extra key and `value` the converged one)
         out["value_from_initial_pose"] = out["value"]
         if converged is not None:
@@ -982,7 +1100,7 @@ def ranks_persistent_probe(R, args, src, tgt, ns, nt, radius, out):
     def fire():
         if R.rank == 0 and out is not None:
             out["ranks_persistent"] = {"error": "no result within %.0f s: the watchdog printed this line and ended the ranks" % limit}
-            print(json.dumps(out), flush=True)
+            emit(out, args.extras_file)
         else:
             time.sleep(2.0)
         os._exit(0)
@@ -1092,6 +1210,7 @@ def run_c3(R, args):
                        "search": ctx.search_mode_used(),
                        "parallelism": "replicas only: objects dealt round-robin by size over %d rank(s) x %d worker context(s) "
                                       "per GPU (visma_icp_run_batch_multi: each its own stream and host thread, shares side by side), no collective" % (R.world, W)},
+            "config_short": {"parallelism": "replicas only: %d rank(s) x %d worker context(s) per GPU, no collective" % (R.world, W)},
             "problems_per_sec": len(probs) * args.steps / elapsed,
             "roofline": roofline,
         }
@@ -1313,7 +1432,7 @@ def main():
         R.dist.barrier()
     out = {"c4": run_c4, "c3": run_c3, "c5": run_c5}[args.workload](R, args)
     if R.rank == 0 and out is not None:
-        print(json.dumps(out), flush=True)
+        emit(out, args.extras_file)
     R.close()
 
 

@@ -420,8 +420,9 @@ VISMA_ICP_API int visma_icp_get_timing_sized(visma_icp_ctx *ctx, void *out, size
  * nothing in the reference, which has no device to share):
  *  visma_icp_set_persistent(ctx, enabled, timeout_ms): 1 (default) / 0 = one launch per pass on this context (also
  *    VISMA_ICP_PERSIST=0).  timeout_ms > 0: how long the launch waits for the host's next command before it ends by
- *    itself (default 200; the loop then carries on with ordinary launches, same results, and the context stops
- *    starting persistent launches until they are enabled again).
+ *    itself (default 200; the loop then carries on with ordinary launches, same results).  After such an abort the
+ *    context COOLS DOWN: its next 8 host loops launch once per pass, then persistent launches are tried again by
+ *    themselves; visma_icp_set_persistent(ctx, 1, ...) re-arms them at once.
  *  visma_icp_set_persistent_cu_share(share): PER PROCESS, 0 < share <= 1 (default 1; also VISMA_ICP_PERSIST_CU_SHARE):
  *    the largest part of a device's workgroup slots a persistent launch may hold.  A loop whose launch would need
  *    more runs one launch per pass, which other streams' kernels interleave with (a 262,144-point source needs all
@@ -430,7 +431,8 @@ VISMA_ICP_API int visma_icp_get_timing_sized(visma_icp_ctx *ctx, void *out, size
  *  visma_icp_get_persistent_info(ctx, out): what happened so far on this context. */
 typedef struct {
     int struct_size;               /* in: sizeof(visma_icp_persistent_info) of the caller's build */
-    int enabled;                   /* persistent launches are allowed on this context right now (0 after an abort) */
+    int enabled;                   /* the next host loop may start a persistent launch: the user's setting AND not cooling
+                                      down (0 during the 8 loops after an abort, although the setting is still 1) */
     int last_loop_persistent;      /* the last finished host loop ran (part of) its passes in a persistent launch */
     int last_loop_passes;          /* ... that many of them */
     double launches, passes;       /* persistent launches / passes inside them since the context was created */

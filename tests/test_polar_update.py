@@ -31,6 +31,18 @@ def cases(rng):
         p = rng.standard_normal((n, 3)) * np.array([1.0, 1.0, 10.0 ** rng.uniform(-9, -2)])   # nearly planar
         q = p @ synth.rot_y(0.3).T + rng.standard_normal((n, 3)) * 1e-4
         out.append(("thin %d" % k, p, q))
+    # thin sets in GENERAL position (walls and floors seen at an angle): the covariance's singular vectors are
+    # random on both sides and s3 / s1 runs from 1e-7 to 1e-3 -- where a Newton step from an ill-conditioned first iterate
+    # loses 2e-17 / (s3 / s1); the polar path must hand those to the SVD (first-iterate threshold in polar_rotation3)
+    for k in range(40):
+        n = 600
+        ratio = 10.0 ** rng.uniform(-7, -3)                                   # s3 / s1 of the covariance
+        A, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        B, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        B = B * np.sign(np.linalg.det(B))
+        p = (rng.standard_normal((n, 3)) * np.array([1.0, rng.uniform(0.3, 1.0), np.sqrt(ratio)])) @ A.T
+        q = p @ B.T + rng.standard_normal(3)
+        out.append(("thin oriented %d" % k, p, q))
     p = rng.standard_normal((300, 3)); p[:, 2] = 0.0
     out.append(("planar", p, p @ synth.rot_x(0.2).T + 0.1))
     t = rng.standard_normal((200, 1))

@@ -8,10 +8,12 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
-pairs = [("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.json"), ("bench_c5.json", "%s_bench_c5.json"),
+pairs = [("bench_c4_extras.json", "%s_bench_c4_extras.json"), ("bench_c3_extras.json", "%s_bench_c3_extras.json"), ("bench_c5_extras.json", "%s_bench_c5_extras.json"),
+         ("bench_c4_under_rocprof_extras.json", "%s_bench_c4_under_rocprof_extras.json"),
+         ("bench_c4.json", "%s_bench_c4.json"), ("bench_c3.json", "%s_bench_c3.json"), ("bench_c5.json", "%s_bench_c5.json"),
          ("bench_c4_under_rocprof.json", "%s_bench_c4_under_rocprof.json"),
          ("stats_c4/c4_kernel_stats.csv", "%s_bench_c4_kernel_stats.csv"), ("stats_c3/c3_kernel_stats.csv", "%s_bench_c3_kernel_stats.csv"),
          ("pmc_traffic_summary.csv", "%s_c4_traffic_pmc_summary.csv"),

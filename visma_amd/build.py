@@ -70,7 +70,7 @@ def build_experiments(force=False):
         fcntl.flock(lock, fcntl.LOCK_EX)                 # (several test processes may get here together)
         if force or not os.path.exists(EXPERIMENTS_LIB) or is_stale_against(EXPERIMENTS_LIB):
             tmp = EXPERIMENTS_LIB + ".tmp.so"
-            build_lib(force=True, defines=("VISMA_WITH_TILE", "VISMA_TEST_SEAMS"), out=tmp)
+            build_lib(force=True, defines=("VISMA_WITH_TILE", "VISMA_TEST_SEAMS", "VISMA_SOLVE_IN_FOLD=1"), out=tmp)
             os.replace(tmp, EXPERIMENTS_LIB)
     return EXPERIMENTS_LIB
 

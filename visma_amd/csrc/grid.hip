@@ -952,7 +952,7 @@ __global__ __launch_bounds__(kBlock) void nn_grid_reduce_kernel(
             atomicAdd(slot + 1, ca);
         }
     }
-    if (fold.tickets) fused_fold<PLANE, kBlock, false, true>(fold, partials, row0, lb, bpp, prob);
+    if (fold.tickets) fused_fold<PLANE, kBlock, false, kSolveInFold>(fold, partials, row0, lb, bpp, prob);
 }
 
 template <bool PLANE, int G, int U>

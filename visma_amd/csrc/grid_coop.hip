@@ -1380,6 +1380,9 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
 {
     if (!src64 || !sorted64 || !s12 || !wst_io) return hipErrorInvalidValue;
     if (persist) {
+        // (the certificate kernels carry no solve epilogue: a fold that asks for one would leave the state where it is,
+        //  silently -- refuse it here rather than trust the caller's predicate)
+        if (fold.solve) return hipErrorInvalidValue;
         // one registration, one query per lane, the fold and its publication inside the launch, everybody resident
         if (descs || nprob != 1 || !one || st || !fold.rows_tagged || !fold.rows2_tagged || !fold.dead_flag || !fold.host_out ||
             (fold.ipc_n > 1 && !fold.peer_table) || d64_out ||
@@ -1406,6 +1409,7 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
         return launch_nn_wave(total_blocks, bpp, nprob, descs, ns, s12, start, g, nrm, nrm64, T64, off, r2f, point_to_plane, one,
                               idx_out, d2_out, partials, cand_count, st, out_stride, src64, sorted64, fold, d64_out, wst_io,
                               warm & 3, stream);
+    if (fold.solve) return hipErrorInvalidValue;            // (as above: only launch_nn_wave's kernels honour it)
     Xform64 Tp{};
     if (Tprev) { Tp = *Tprev; warm |= 4; } else warm &= ~4;
     if (point_to_plane) {

@@ -566,7 +566,7 @@ __device__ __forceinline__ void wave_body(
             atomicAdd(slot + 1, ca);
         }
     }
-    if (fold.tickets) fused_fold<PLANE, kBlock, false, true>(fold, partials, row0, lb, bpp, prob);
+    if (fold.tickets) fused_fold<PLANE, kBlock, false, kSolveInFold>(fold, partials, row0, lb, bpp, prob);
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
 }
 

@@ -17,12 +17,14 @@ public:
     {
         if (!inited_) { (void)hipGetLastError(); return; }   // never touched the device
         (void)hipSetDevice(device_);
+        // first of all: a persistent launch that still polls for a command reads d_sorted12_, the pending-query buffers
+        // and (ranks) stores into the peers' mailboxes -- it must have ended before any of them is freed or unmapped
+        if (sess_live_) (void)end_session();
         if (comm_) g_rccl.CommDestroy(comm_);
         for (int r = 0; r < ipc_n_; r++)
             if (r != ipc_rank_ && peers_.box[r]) (void)hipIpcCloseMemHandle(peers_.box[r]);
         free_dev(d_mbox_); free_dev(d_ipc_flag_); free_dev(d_raw_); free_dev(d_sorted12_); free_dev(bt_sorted12_);
         free_dev(d_pend_count_); free_dev(d_pend_q32_); free_dev(d_pend_q64_); free_dev(d_pend_best_); free_dev(d_pend_idx_);
-        if (sess_live_) (void)end_session();     // (first: nothing is freed under a launch that still polls for a command)
         for (hipEvent_t e : ev_) (void)hipEventDestroy(e);
         free_dev(d_src_); free_dev(d_tgt_); free_dev(d_nrm_); free_dev(d_keys_); free_dev(d_gkeys_);
         free_dev(d_claim_); free_dev(d_d64_);
@@ -656,7 +658,7 @@ private:
     bool solve_in_fold(const LoopParams &lp, int lanes = 0, int nprob = 2) const
     {
         static const bool forced = std::getenv("VISMA_ICP_COOP_KERNEL") != nullptr;
-        if (forced || (lanes == kCoopLanes && nprob == 1)) return false;
+        if (!kSolveInFold || forced || (lanes == kCoopLanes && nprob == 1)) return false;
         return solve_in_fold_ && fused_fold_ && !lp.plane && lp.solver == VISMA_ICP_SOLVER_KABSCH && !tshard_ && !comm_ && ipc_n_ <= 1;
     }
     int ensure_f64_views();

@@ -215,7 +215,11 @@ VISMA_HD void project_so3(const double A[9], double R[9])
 // here (one division per step, 8-13 steps).  Only +, -, x, / in a fixed order: host and device agree bit for bit.
 // Returns false -- the caller then takes the SVD path -- for det A <= 0 (a reflection is nearest: Umeyama flips the
 // smallest singular direction, which only the SVD names), for a matrix too close to singular for the inverse to be
-// trusted (relative det below 1e-7: planar or collinear correspondences, a handful of pairs), and for non-finite input.
+// trusted, and for non-finite input.  "Too close": the first step inverts X0, and a Newton step from an X0 with singular
+// values s1 >= s2 >= s3 loses ~2e-17 / (s3 / s1) of the singular VECTORS for good (measured: |Q - U V^T| = 2e-12 at
+// s3 / s1 = 1e-5, 6e-11 at 3e-7 -- walls and floors seen at an angle land there).  The SVD path is good to
+// 1e-16 at any conditioning, so the Newton path is taken only from det X0 >= 1e-3 (|X0|_F = 1: s3 / s1 >~ 2e-3, error
+// <~ 1e-14) and everything thinner -- nearly planar, planar, collinear sets, a handful of pairs -- goes to svd3.
 VISMA_HD bool polar_rotation3(const double A[9], double Q[9])
 {
     double f2 = 0.0;
@@ -240,7 +244,7 @@ VISMA_HD bool polar_rotation3(const double A[9], double Q[9])
         C[8] = X[0] * X[4] - X[1] * X[3];
         const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
         // (|X0|_F = 1: det X0 = s1 s2 s3 <= 3^-3/2; later iterates have every s >= 1)
-        if (!(det > (it == 0 ? 1e-7 : 0.5))) return false;
+        if (!(det > (it == 0 ? 1e-3 : 0.5))) return false;
         const double inv = 1.0 / det;
         double d2 = 0.0;
 #pragma unroll

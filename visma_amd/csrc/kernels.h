@@ -86,9 +86,15 @@ struct FoldArgs {
     // advances solve[b] right there (icp_state.h: advance_state<true>) -- no solve launch between two search launches.
     // NULL: the statistics are left in the state and solve_state_kernel advances it (Gauss-Newton modes, point-to-plane,
     // ranks that exchange first).  Honoured by the kernels batches and sweeps run (grid.hip, grid_wave.hip), NOT by
-    // the certificate kernels of grid_coop.hip (the host never sets it for them: HipEngine::solve_in_fold).
+    // the certificate kernels of grid_coop.hip (launch_nn_coop refuses a fold that sets it for them).  Compiled in only
+    // with -DVISMA_SOLVE_IN_FOLD=1 (kSolveInFold): it measured slower than the solve launch and its
+    // inlined one-thread solve costs the default search kernels scratch and LDS -- default builds carry none of it.
     DevIcpState *solve;
 };
+#ifndef VISMA_SOLVE_IN_FOLD
+#define VISMA_SOLVE_IN_FOLD 0
+#endif
+constexpr bool kSolveInFold = VISMA_SOLVE_IN_FOLD != 0;
 
 // The tag the granule rows of the polled fold validate themselves with: the pass's sequence number folded into
 // 1 .. 2^32 - 1 -- never 0 (a cleared buffer validates nothing), the same value again only 2^32 - 1 passes later (the
