@@ -4,6 +4,7 @@ A sample of the corpus against the oracle, and the pull queue of `bench.py --wor
 import json
 import os
 import subprocess
+import tempfile
 import sys
 
 import numpy as np
@@ -47,13 +48,15 @@ def test_two_ranks_pull_the_corpus_from_one_counter(lib):
     env = dict(os.environ, VISMA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
+    side = os.path.join(tempfile.mkdtemp(prefix="visma_bench_"), "extras.json")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c5", "--steps", "2",
-                          "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True,
-                         timeout=800)
+                          "--warmup", "1", "--no-cpu-baseline", "--extras-file", side], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=800)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(line) == 1
-    d = json.loads(line[0])
+    assert len(line) == 1 and len(line[0]) < 4096
+    assert json.loads(line[0])["n_gpus"] == 2
+    d = json.load(open(side))                                # the full result: the side file the line names
     assert d["n_gpus"] == 2 and d["config"]["items"] == 192
     assert "no collective" in d["config"]["parallelism"]
     assert d["items_done_by_all_ranks"] == 2 * 192          # two timed passes: every item exactly once per pass
