@@ -152,6 +152,10 @@ struct CoopRes {
     float *lb;             // [NTH] state: LB
     float *lb3;            // [NTH] state: LB3 (the runner-up's point and index stay in global memory: ru_io)
     int first;             // this pass is the launch's first: source and state come from global memory
+    // (round 6) the lane's source point, asked for BEFORE the wait for this pass's command (the source never changes: the
+    // load's round trip -- the first thing every pass waited for -- lies under the fold and the host's turn-around)
+    double sx, sy, sz;
+    int have_src;
 };
 
 // the query of thread `tid` of workgroup `lb` of a problem of `bpp` workgroups (the query -> lane map of
@@ -479,7 +483,12 @@ __device__ __forceinline__ bool coop_body(
         w8.x = w8.y = w8.z = __longlong_as_double(-1ll);
         w8.w = ~0ull;
         if (active) {
-            s8 = src64[i];
+            if constexpr (PERSIST) {
+                if (res.have_src) { s8.x = res.sx; s8.y = res.sy; s8.z = res.sz; }
+                else s8 = src64[i];
+            } else {
+                s8 = src64[i];
+            }
             if constexpr (PERSIST) {
                 if (res.first) {
                     if (warm & 1) w8 = wst_io[i];
@@ -518,7 +527,17 @@ __device__ __forceinline__ bool coop_body(
             // delta = |T s - T_prev s|: same products, same order as the transform itself, so the two computed
             // points are the ones the bounds speak about; rounded up
             double pp[3];
-            {
+            bool pp_known = false;
+            if constexpr (PERSIST) {
+                // (round 6) inside a persistent launch the pass before left exactly that point in this lane's slot -- the
+                // same products in the same order, from the transform that is Tprev now: read back instead of 18 more
+                // f64 operations and Tprev's 24 scalar registers live through phase A
+#ifndef VISMA_PERSIST_PP_LDS
+#define VISMA_PERSIST_PP_LDS 1
+#endif
+                if (VISMA_PERSIST_PP_LDS && !res.first) { pp[0] = s_p64[tid][0]; pp[1] = s_p64[tid][1]; pp[2] = s_p64[tid][2]; pp_known = true; }
+            }
+            if (!pp_known) {
                 const double sv[3] = {s8.x, s8.y, s8.z};
                 se3_act(Tprev.m, sv, pp);
             }
@@ -1250,6 +1269,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
     __syncthreads();
     typedef const CoopPersistParams __attribute__((address_space(4))) *KernargPtr;
+    // the lane's source point for the NEXT pass, asked for before the wait for its command (VISMA_PERSIST_PREFETCH=0: not)
+#ifndef VISMA_PERSIST_PREFETCH
+#define VISMA_PERSIST_PREFETCH 1
+#endif
+    double nsx = 0.0, nsy = 0.0, nsz = 0.0;
     for (int pass = 1;; pass++) {
         KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));                         // (nothing read through it is loop-invariant to the compiler)
@@ -1264,9 +1288,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur][2 * k]);
             const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur][2 * k + 1]);
             Tc.m[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-            const unsigned plo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur ^ 1][2 * k]);
-            const unsigned phi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur ^ 1][2 * k + 1]);
-            Tp.m[k] = __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+            Tp.m[k] = 0.0;
+        }
+        // (the transform before this pass's: only the launch's first pass needs it as numbers -- later passes find the
+        //  point it gave, which is all the certificate wants of it, where the pass before left it: coop_body, phase A)
+        if (pass == 1 || !VISMA_PERSIST_PP_LDS) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const unsigned plo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur ^ 1][2 * k]);
+                const unsigned phi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_tw[cur ^ 1][2 * k + 1]);
+                Tp.m[k] = __longlong_as_double((long long)(((unsigned long long)phi << 32) | plo));
+            }
         }
         // (after the first pass: the state the pass before left is there, and so is its transform)
         int w = VISMA_KARG(warm);
@@ -1286,7 +1318,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), VISMA_KARG(nrm), Tc, VISMA_KARG(off), VISMA_KARG(r2f),
             VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials), VISMA_KARG(cand_count), nullptr, VISMA_KARG(bpp), 0ll,
             nullptr, 1, VISMA_KARG(src64), VISMA_KARG(sorted64), VISMA_KARG(nrm64), f, nullptr, VISMA_KARG(wst_io), w, Tp,
-            VISMA_KARG(ru_io), t_begin ? &work : nullptr, CoopRes{r_q64, r_idx, r_lb, r_lb3, pass == 1 ? 1 : 0});
+            VISMA_KARG(ru_io), t_begin ? &work : nullptr, CoopRes{r_q64, r_idx, r_lb, r_lb3, pass == 1 ? 1 : 0, nsx, nsy, nsz,
+                                                                        (VISMA_PERSIST_PREFETCH && pass > 1) ? 1 : 0});
         const PersistArgs pa = VISMA_KARG(pa);
         if (pa.timeline && pass <= pa.timeline_passes && thread_number<true>() == 0) {
             // (measurement runs only) [pass][workgroup]{begin, body done}; the begin of pass 1 is the launch's
@@ -1296,6 +1329,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             slot[1] = (wall_clock64() & 0xFFFFFFFFFFFull) | ((unsigned long long)work << 44);
         }
         bool last = pass >= pa.max_passes;
+        nsx = nsy = nsz = 0.0;                               // (dead across the body: assigned on every path)
+        if (VISMA_PERSIST_PREFETCH && !last) {
+            // the next pass's source point: the load is in flight while the fold completes and the host turns around
+            // (pinned below: the compiler would otherwise sink it to its use, behind the wait)
+            const int tidx = thread_number<true>();
+            const int bpp = VISMA_KARG(bpp);
+            int vb, per_group;
+            long long i_begin, i_end;
+            coop_query_range<kBlock>(VISMA_KARG(ns), bpp, (int)blockIdx.x % bpp, tidx, vb, per_group, i_begin, i_end);
+            if (i_begin < i_end) {
+                const Pt64 s8 = VISMA_KARG(src64)[i_begin];
+                nsx = s8.x; nsy = s8.y; nsz = s8.z;
+            }
+        }
         if (!last) {
             const int tidx = thread_number<true>();
             if (tidx < 64) {
@@ -1306,6 +1353,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 if (tidx == kPersistWords - 1) s_cmdw = (unsigned)cw;
             }
             __syncthreads();
+            asm volatile("" : "+v"(nsx), "+v"(nsy), "+v"(nsz));
             const unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)s_cmdw);
             last = cmd != kPersistGo;
         }
@@ -1408,7 +1456,7 @@ hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *
     if (forced == 2 || (forced == 0 && (descs || nprob > 1)))
         return launch_nn_wave(total_blocks, bpp, nprob, descs, ns, s12, start, g, nrm, nrm64, T64, off, r2f, point_to_plane, one,
                               idx_out, d2_out, partials, cand_count, st, out_stride, src64, sorted64, fold, d64_out, wst_io,
-                              warm & 3, stream);
+                              warm & (3 | 8), stream);       // (8: certificates off -- the wave kernel's no-partner one too)
     if (fold.solve) return hipErrorInvalidValue;            // (as above: only launch_nn_wave's kernels honour it)
     Xform64 Tp{};
     if (Tprev) { Tp = *Tprev; warm |= 4; } else warm &= ~4;
