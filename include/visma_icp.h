@@ -577,7 +577,8 @@ VISMA_ICP_API int visma_icp_measure_surface_error(visma_icp_ctx *ctx, const doub
  * Jacobian arguments may be NULL. */
 /* SE3Type of core/se3.h:79-169 as plain functions on g = [R | t], row-major 3x4: composition (:96-100),
  * action on a point (:103-106: what every search kernel applies to a source point), inverse (:108-110).
- * Host functions (visma_icp_testing.h: visma_icp_selftest_se3 runs the same code on the GPU). */
+ * Host functions (visma_icp_testing.h: visma_icp_selftest_se3 runs the same code on the GPU).  Pinned by the outputs of
+ * the reference header itself (tests/golden/se3.npz, oracle/ref_se3.cpp). */
 VISMA_ICP_API int visma_se3_compose(const double a[12], const double b[12], double out[12]);
 VISMA_ICP_API int visma_se3_act(const double g[12], const double v[3], double out[3]);
 VISMA_ICP_API int visma_se3_inv(const double g[12], double out[12]);

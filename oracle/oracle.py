@@ -545,3 +545,39 @@ class Ref:
         R = _f64(R, (9,)); w = np.empty(3); D = np.empty(27) if jac else None
         self.lib.ref_invrodrigues(_ptr(R, _dp), _ptr(w, _dp), _ptr(D, _dp))
         return w, (D.reshape(3, 9) if jac else None)
+
+    # ---- core/se3.h: the reference's own SE3Type / SO3Type (oracle/ref_se3.cpp); g = [R | t] row-major 3 x 4
+    def se3_compose(self, a, b):
+        a = _f64(a, (12,)); b = _f64(b, (12,)); o = np.empty(12)
+        self.lib.ref_se3_compose(_ptr(a, _dp), _ptr(b, _dp), _ptr(o, _dp))
+        return o.reshape(3, 4)
+
+    def se3_act(self, g, v):
+        g = _f64(g, (12,)); v = _f64(v, (3,)); o = np.empty(3)
+        self.lib.ref_se3_act(_ptr(g, _dp), _ptr(v, _dp), _ptr(o, _dp))
+        return o
+
+    def se3_inv(self, g):
+        g = _f64(g, (12,)); o = np.empty(12)
+        self.lib.ref_se3_inv(_ptr(g, _dp), _ptr(o, _dp))
+        return o.reshape(3, 4)
+
+    def se3_matrix(self, g):
+        g = _f64(g, (12,)); o = np.empty(16)
+        self.lib.ref_se3_matrix(_ptr(g, _dp), _ptr(o, _dp))
+        return o.reshape(4, 4)
+
+    def so3_exp(self, w):
+        w = _f64(w, (3,)); o = np.empty(9)
+        self.lib.ref_so3_exp(_ptr(w, _dp), _ptr(o, _dp))
+        return o.reshape(3, 3)
+
+    def so3_log(self, R):
+        R = _f64(R, (9,)); o = np.empty(3)
+        self.lib.ref_so3_log(_ptr(R, _dp), _ptr(o, _dp))
+        return o
+
+    def so3_axis_angle(self, axis, angle):
+        axis = _f64(axis, (3,)); o = np.empty(9)
+        self.lib.ref_so3_axis_angle(_ptr(axis, _dp), C.c_double(float(angle)), _ptr(o, _dp))
+        return o.reshape(3, 3)

@@ -1,10 +1,10 @@
 // ref_rodrigues.cpp -- C-ABI harness around the reference's header-only
 // SO(3) math (core/rodrigues.h).
 //
-// core/se3.h is NOT compiled: it does not build with g++ 11 (se3.h:142 lacks the
-// `template` disambiguator, se3.h:162 calls a constructor that cannot deduce),
-// so SE3Type compose/act/inv (se3.h:96-110) are restated in icp_oracle.c and
-// pinned by group-property tests only.
+// core/se3.h does not build with g++ 11 (se3.h:142 lacks the `template`
+// disambiguator): its harness is ref_se3.cpp, compiled with the image's clang
+// (round 6) -- SE3Type compose/act/inv (se3.h:96-110) are pinned by ITS outputs
+// (tests/golden/se3.npz) since then, not by the restatement alone.
 //
 // TEST INFRASTRUCTURE ONLY; contains no reference code.  Compiled as its own
 // translation unit WITH -DEIGEN_DEFAULT_TO_ROW_MAJOR, as VISMA's

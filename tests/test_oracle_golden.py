@@ -247,8 +247,8 @@ def test_rodrigues_properties(oracle):
 
 
 def test_se3_group_properties(oracle):
-    # core/se3.h:96-110 is restated without a compiled reference (it does not
-    # build with g++ 11): pin it by the group axioms instead.
+    # core/se3.h:96-110: the group axioms (the restatement against the reference header's own outputs:
+    # tests/test_so3.py::test_se3_oracle_restatement_matches_the_reference_header, tests/golden/se3.npz).
     rng = np.random.default_rng(9)
     Ra = oracle.rodrigues(rng.standard_normal(3))[0]; ta = rng.standard_normal(3)
     Rb = oracle.rodrigues(rng.standard_normal(3))[0]; tb = rng.standard_normal(3)

@@ -157,9 +157,51 @@ def _rand_g(rng, n):
     return g.reshape(n, 12)
 
 
+SE3G = np.load(os.path.join(HERE, "golden", "se3.npz"))
+
+
+def test_se3_host_functions_match_the_reference_header(lib):
+    """tests/golden/se3.npz: outputs of the reference's own SE3Type / SO3Type (core/se3.h:79-169, :10-76), the header
+    compiled as it is into oracle/_ref (oracle/ref_se3.cpp; generator tests/golden/gen_se3.py) -- composition, action on
+    a point, inverse, the 4 x 4 form; SO3Type::exp / log / (axis, angle) against visma_so3_rodrigues / _invrodrigues."""
+    L, P = _se3_lib()
+    g, h, v = SE3G["g"], SE3G["h"], SE3G["v"]
+    for k in range(len(g)):
+        gh, gv, gi = np.empty(12), np.empty(3), np.empty(12)
+        a, b = np.ascontiguousarray(g[k].reshape(12)), np.ascontiguousarray(h[k].reshape(12))
+        assert L.visma_se3_compose(P(a), P(b), P(gh)) == 0 and L.visma_se3_inv(P(a), P(gi)) == 0
+        assert L.visma_se3_act(P(a), P(np.ascontiguousarray(v[k])), P(gv)) == 0
+        scale = 1.0 + np.abs(g[k]).max() + np.abs(h[k]).max()
+        assert np.max(np.abs(gh.reshape(3, 4) - SE3G["gh"][k])) <= 4e-16 * scale * scale, k
+        assert np.max(np.abs(gv - SE3G["gv"][k])) <= 4e-16 * scale * (1.0 + np.abs(v[k]).max()), k
+        assert np.max(np.abs(gi.reshape(3, 4) - SE3G["ginv"][k])) <= 4e-16 * scale, k
+        # the 4 x 4 form (SE3Type::matrix) is [g; 0 0 0 1]
+        assert np.array_equal(SE3G["g44"][k][:3], g[k]) and np.array_equal(SE3G["g44"][k][3], [0, 0, 0, 1])
+    for k in range(len(SE3G["w"])):
+        R, _ = rodrigues(L, SE3G["w"][k])
+        assert np.max(np.abs(R - SE3G["expw"][k])) < 1e-14, k                # SO3Type::exp = rodrigues
+        w, _ = invrodrigues(L, SE3G["expw"][k])
+        assert np.max(np.abs(w - SE3G["logR"][k])) < 1e-12, k                # SO3Type::log = invrodrigues
+        ax = SE3G["axis"][k]
+        Ra, _ = rodrigues(L, ax / np.linalg.norm(ax) * SE3G["angle"][k])     # SO3Type(axis, angle), se3.h:23-24
+        assert np.max(np.abs(Ra - SE3G["axis_angle"][k])) < 1e-14, k
+
+
+def test_se3_oracle_restatement_matches_the_reference_header(oracle):
+    """the same vectors against oracle/icp_oracle.c: vo_se3_* (what the property tests and the device tests compare with)"""
+    for k in range(len(SE3G["g"])):
+        g, h, v = SE3G["g"][k], SE3G["h"][k], SE3G["v"][k]
+        scale = 1.0 + np.abs(g).max() + np.abs(h).max()
+        R, t = oracle.se3_compose(g[:, :3], g[:, 3], h[:, :3], h[:, 3])
+        assert np.max(np.abs(np.c_[R, t] - SE3G["gh"][k])) <= 4e-16 * scale * scale, k
+        assert np.max(np.abs(oracle.se3_act(g[:, :3], g[:, 3], v) - SE3G["gv"][k])) <= 4e-16 * scale * (1.0 + np.abs(v).max()), k
+        Ri, ti = oracle.se3_inv(g[:, :3], g[:, 3])
+        assert np.max(np.abs(np.c_[Ri, ti] - SE3G["ginv"][k])) <= 4e-16 * scale, k
+
+
 def test_se3_host_functions_equal_the_oracle_restatement_and_form_a_group(lib, oracle):
-    """The reference header does not compile with this g++ (core/se3.h:142), so the pins are the oracle's
-    line-by-line restatement (oracle/icp_oracle.c: vo_se3_*) and the group axioms."""
+    """Beside the reference's vectors above: the oracle's line-by-line restatement (oracle/icp_oracle.c: vo_se3_*) on
+    random elements, and the group axioms."""
     L, P = _se3_lib()
     rng = np.random.default_rng(4)
     G, H, K = _rand_g(rng, 50), _rand_g(rng, 50), _rand_g(rng, 50)
