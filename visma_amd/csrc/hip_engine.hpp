@@ -46,6 +46,8 @@ public:
         if (h_flag_) (void)hipHostFree(h_flag_);
         free_dev(d_relay_); free_dev(d_timeline_); free_dev(d_peer_table_); free_dev(d_fold_tag_);
         pool_trim(0);
+        if (d_raw_src_) (void)hipFree(d_raw_src_);
+        if (stream_src_) (void)hipStreamDestroy(stream_src_);
         if (stream_) (void)hipStreamDestroy(stream_);
     }
 
@@ -83,7 +85,7 @@ public:
         }
         return VISMA_ICP_OK;
     }
-    int finish_raw_source(int64_t ns, const double *c, std::vector<int32_t> &order);
+    int finish_raw_source(int64_t ns, const double *c, std::vector<int32_t> &order, const void *raw = nullptr, hipStream_t st = nullptr);
     int set_source_f64(const double *xyz, int64_t ns, int stride, const double *c, bool want64,
                        std::vector<int32_t> &order) override;
     int set_source_meshes_f64(const MeshSource *meshes, int n_meshes, int quirks, unsigned long long seed, const double *c,
@@ -393,6 +395,14 @@ private:
 
     int device_;
     hipStream_t stream_ = nullptr;
+    // (round 6) the raw SOURCE upload -- copy, Morton order on the device, the permutation back -- runs on a stream of its
+    // own, from a buffer of its own: it needs the target's centroid (known when the host has staged the last piece) and
+    // nothing else of the target, so it overlaps the tail of the target's copies and the grid build that prepare_search
+    // queued behind them (set_target_f64 no longer drains the stream on its way out).  VISMA_ICP_UPLOAD_OVERLAP=0: as before.
+    hipStream_t stream_src_ = nullptr;
+    void *d_raw_src_ = nullptr;
+    size_t raw_src_bytes_ = 0;
+    int upload_overlap_ = 1;
     void *d_src_ = nullptr, *d_tgt_ = nullptr, *d_nrm_ = nullptr, *d_keys_ = nullptr;
     void *d_idx_ = nullptr, *d_d2_ = nullptr, *d_partials_ = nullptr, *d_stats_ = nullptr;
     double *h_stats_ = nullptr, *h_stats_dev_ = nullptr;

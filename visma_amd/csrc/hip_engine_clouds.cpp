@@ -23,6 +23,8 @@ int HipEngine::init()
         return VISMA_ICP_ERR_NO_DEVICE;
     }
     HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&stream_src_, hipStreamNonBlocking));
+    if (const char *e = std::getenv("VISMA_ICP_UPLOAD_OVERLAP")) upload_overlap_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_GRID_SUB")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2) grid_sub_ = v;
@@ -106,6 +108,9 @@ int HipEngine::init()
 int HipEngine::set_target_f64(const double *xyz, int64_t nt, int stride, double *c, bool compute_centre, bool want64)
 {
     HIP_TRY(hipSetDevice(device_));
+    // (the pinned staging area and d_raw_ are about to be written: whatever an earlier upload still has in flight from
+    //  them must be through -- since round 6 an upload no longer drains the stream on its way out)
+    HIP_TRY(hipStreamSynchronize(stream_));
     raw_source_points_ = 0;                              // (d_raw_ is about to be reused)
     int rc = ensure_target(nt);
     if (rc) return rc;
@@ -230,7 +235,9 @@ int HipEngine::set_target_f64(const double *xyz, int64_t nt, int stride, double 
     } else if (compute_centre) {
         c[0] = c[1] = c[2] = 0.0;
     }
-    HIP_TRY(hipStreamSynchronize(stream_));
+    // (the copies and the expansion are queued; what follows -- the grid build, the passes -- is queued behind them on the
+    //  same stream, and the source upload on its own stream needs none of it: nobody has to wait here)
+    if (!upload_overlap_) HIP_TRY(hipStreamSynchronize(stream_));
     return VISMA_ICP_OK;
 }
 
@@ -345,19 +352,21 @@ int HipEngine::begin_raw_source(int64_t ns, bool want64, std::vector<int32_t> &o
 }
 
 // d_raw_ holds ns points (caller order): Morton order on the device, fp32 + f64 copies, the permutation back
-int HipEngine::finish_raw_source(int64_t ns, const double *c, std::vector<int32_t> &order)
+int HipEngine::finish_raw_source(int64_t ns, const double *c, std::vector<int32_t> &order, const void *raw, hipStream_t st)
 {
+    if (!raw) raw = d_raw_;
+    if (!st) st = stream_;
     void *scratch = nullptr, *d_order = nullptr;
     const size_t sb = order_source_scratch_bytes(ns);
     int rc = pool_alloc(&scratch, sb);
     if (rc) return rc;
     rc = pool_alloc(&d_order, sizeof(int32_t) * (size_t)ns);
     if (rc) { free_dev(scratch); return rc; }
-    hipError_t e = order_source_device((const double *)d_raw_, ns, c, (float4 *)d_src_, (Pt64 *)d_src64_,
-                                       (int32_t *)d_order, scratch, sb, stream_);
+    hipError_t e = order_source_device((const double *)raw, ns, c, (float4 *)d_src_, (Pt64 *)d_src64_,
+                                       (int32_t *)d_order, scratch, sb, st);
     if (e == hipSuccess)
-        e = hipMemcpyAsync(order.data(), d_order, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, stream_);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream_);
+        e = hipMemcpyAsync(order.data(), d_order, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     free_dev(scratch); free_dev(d_order);
     if (e != hipSuccess) { err_ = std::string("source ordering: ") + hipGetErrorString(e); (void)hipGetLastError(); return VISMA_ICP_ERR_HIP; }
     return VISMA_ICP_OK;
@@ -371,8 +380,24 @@ int HipEngine::set_source_f64(const double *xyz, int64_t ns, int stride, const d
     int rc = begin_raw_source(ns, want64, order);
     if (rc) return rc;
     if (ns > 0) {
-        rc = ensure_raw((size_t)ns);
-        if (rc) return rc;
+        void *raw = nullptr;
+        hipStream_t st = stream_;
+        if (upload_overlap_) {
+            // its own buffer, its own stream (hip_engine.hpp: stream_src_)
+            if ((size_t)ns * 24 > raw_src_bytes_) {
+                HIP_TRY(hipStreamSynchronize(stream_src_));
+                if (d_raw_src_) (void)hipFree(d_raw_src_);
+                d_raw_src_ = nullptr; raw_src_bytes_ = 0;
+                HIP_TRY(hipMalloc(&d_raw_src_, (size_t)ns * 24 + (size_t)ns * 6));
+                raw_src_bytes_ = (size_t)ns * 24 + (size_t)ns * 6;
+            }
+            raw = d_raw_src_;
+            st = stream_src_;
+        } else {
+            rc = ensure_raw((size_t)ns);
+            if (rc) return rc;
+            raw = d_raw_;
+        }
         double *pin = reinterpret_cast<double *>(staging(3, (size_t)ns * 6));
         parallel_for((ns + kHostChunk - 1) / kHostChunk, 1, [&](int64_t ch) {
             const int64_t a = ch * kHostChunk, b = std::min(ns, a + kHostChunk);
@@ -383,8 +408,8 @@ int HipEngine::set_source_f64(const double *xyz, int64_t ns, int stride, const d
                     pin[3 * j] = q[0]; pin[3 * j + 1] = q[1]; pin[3 * j + 2] = q[2];
                 }
         });
-        HIP_TRY(hipMemcpyAsync(d_raw_, pin, sizeof(double) * 3 * (size_t)ns, hipMemcpyHostToDevice, stream_));
-        rc = finish_raw_source(ns, c, order);
+        HIP_TRY(hipMemcpyAsync(raw, pin, sizeof(double) * 3 * (size_t)ns, hipMemcpyHostToDevice, st));
+        rc = finish_raw_source(ns, c, order, raw, st);
         if (rc) return rc;
     }
     return VISMA_ICP_OK;
