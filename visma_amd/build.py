@@ -27,7 +27,7 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_lib(force=False, verbose=False, defines=(), out=None):
+def build_lib(force=False, verbose=False, defines=(), out=None, extra_flags=()):
     """Compile visma_amd/lib/libvisma_icp.so for gfx950 (cross-compiles without a GPU).
     One hipcc process per source file, run side by side, then one link."""
     if out is None and not force and not is_stale():
@@ -36,8 +36,12 @@ def build_lib(force=False, verbose=False, defines=(), out=None):
     os.makedirs(LIB_DIR, exist_ok=True)
     obj_dir = os.path.join(LIB_DIR, "_obj" + ("" if out is None else "_" + os.path.basename(out)))
     os.makedirs(obj_dir, exist_ok=True)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall"]
-    flags += ["-D" + d for d in defines]
+    # -fno-slp-vectorize (round 6): packed fp32 VALU ops issue at half the rate of plain ones on gfx950 (tools/ubench/valu_rate:
+    # v_pk_fma_f32 4.9 cycles per wave against 2.6 for v_fma_f32 -- nothing to gain), and the register pairs they need cost the
+    # persistent search kernel spills: 8 -> 4 spilled VGPRs, 33.3 -> 32.9 us per iteration (profiles/r06_build_knobs_ab.txt)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden", "-Wall",
+             "-fno-slp-vectorize"]
+    flags += ["-D" + d for d in defines] + list(extra_flags)
     procs, objs = [], []
     sources = list(SOURCES) + (["tile.hip"] if "VISMA_WITH_TILE" in defines else [])
     for src in sources:

@@ -697,6 +697,12 @@ private:
     bool loop_scope_ = false;
     int loop_budget_ = 0;            // passes the announced loop may still run
     bool sess_live_ = false;         // a persistent launch is in flight
+    // (round 6) ... queued behind the registration's COLD pass while the host still waited for that pass's statistics: its
+    // first pass too is posted as a command (PersistArgs::wait_first).  Dispatch, ramp and the host's turn-around overlap:
+    // the 20-30 us between the end of the cold pass and the begin of the launch shrink to the turn-around.
+    // VISMA_ICP_PERSIST_EARLY=0: the launch starts with the first warm pass, as in rounds 4-5.
+    bool sess_early_ = false;
+    int persist_early_ = 1;
     int sess_pass_ = 0, sess_max_ = 0;
     unsigned sess_tag0_ = 0, cmd_tag_ = 0;
     unsigned long long sess_seq0_ = 0;
@@ -745,8 +751,9 @@ private:
     void post_command(const Xform64 &T64, unsigned cmd);
     int end_session();
     void finish_session();
+    void fill_persist_args(PersistArgs *pa);
     int launch_grid_pass(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, bool prof,
-                         const PersistArgs *persist, int *nblocks_out, bool *ipc_done);
+                         const PersistArgs *persist, int *nblocks_out, bool *ipc_done, bool early = false);
 };
 
 }  // namespace drv

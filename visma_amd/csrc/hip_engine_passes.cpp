@@ -160,15 +160,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
             if (loop_scope_ && loop_budget_ >= 2 && persist_possible(lanes, nb, fused, plane)) {
                 int rc = start_session(T64, plane, offset, seq, nb, profiling_ > 0);
                 if (rc == VISMA_ICP_OK && sess_live_) {
-                    pa.host_cmd = h_cmd_dev_;
-                    pa.relay = (unsigned long long *)d_relay_;
-                    pa.direct = cmd_direct_ ? 1 : 0;
-                    pa.host_flag = h_flag_dev_;
-                    pa.max_passes = sess_max_;
-                    pa.tag0 = sess_tag0_;
-                    pa.wait_ticks = (long long)(4.0 * persist_timeout_ms_ * 1e5) + 1000000ll;   // (100 MHz; host patience x 4 + 10 ms)
-                    pa.hard_ticks = 60ll * 100000000ll;
-                    pa.start_ticks = (long long)(persist_start_ms_ * 1e5);
+                    fill_persist_args(&pa);
                     HIP_TRY(hipMemsetAsync((unsigned long long *)d_relay_ + kPersistDead, 0, 2 * sizeof(unsigned long long), stream_));   // (dead, started)
                     if (!timeline_path_.empty()) {
                         // (measurement: clocks of up to 64 passes of this launch, read back when it has ended)
@@ -184,6 +176,12 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                     pp = &pa;
                 }
             }
+            // (a cold pass that a persistent launch will follow: the launch's "dead / started" words are cleared BEFORE the
+            //  cold pass, not between the two)
+            const bool early_hope = !pp && persist_early_ && loop_scope_ && loop_budget_ >= 3 && lanes != kCoopLanes && !ipc &&
+                                    !comm_ && !tshard_ && timeline_path_.empty() && d_relay_;
+            if (early_hope)
+                HIP_TRY(hipMemsetAsync((unsigned long long *)d_relay_ + kPersistDead, 0, 2 * sizeof(unsigned long long), stream_));
             int rc = launch_grid_pass(T64, plane, offset, seq, pp ? sess_prof_ : prof, pp, &nblocks, &ipc_done);
             if (rc) { if (pp) finish_session(); return rc; }
             if (pp) {
@@ -191,6 +189,32 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
                 loop_persist_passes_++;
                 timing_persist_launches_total_ += 1.0;
                 timing_persist_passes_total_ += 1.0;
+            } else if (early_hope && pass_lanes() == kCoopLanes) {
+                // ---- the EARLY persistent launch (hip_engine.hpp: sess_early_): this was the registration's cold pass, the
+                // passes after it run the certificate kernel -- queue their launch now, behind the cold pass, and let it wait
+                // for its first transform like for every later one.  (pass_lanes() speaks about the NEXT pass now: the cold
+                // launch left the per-query state behind.)
+                const int nb2 = grid_launch_blocks(ns_, kCoopLanes, grid_blocks());
+                if (persist_possible(kCoopLanes, nb2, fused, plane)) {
+                    const int budget = loop_budget_;
+                    loop_budget_ = budget - 1;                       // (what the launch may run: the passes after this one)
+                    int src = start_session(T64, plane, offset, seq + 1ull, nb2, profiling_ > 0);
+                    loop_budget_ = budget;
+                    if (src == VISMA_ICP_OK && sess_live_) {
+                        PersistArgs pe{};
+                        fill_persist_args(&pe);
+                        pe.wait_first = 1;
+                        int nb_unused = 1;
+                        bool ipc_unused = false;
+                        // (T64: the COLD pass's transform -- the launch takes it as "the transform before" its first pass,
+                        //  what that pass's certificates measure their motion from; its own arrives with the first command)
+                        src = launch_grid_pass(T64, plane, offset, seq + 1ull, sess_prof_, &pe, &nb_unused, &ipc_unused, true);
+                        if (src) { finish_session(); return src; }
+                        sess_early_ = true;
+                        sess_pass_ = 0;
+                        timing_persist_launches_total_ += 1.0;
+                    }
+                }
             }
         }
         if (loop_budget_ > 0) loop_budget_--;
@@ -275,6 +299,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         }
     }
     if (in_session && seen && posted) note_state_pass(T64);
+    if (!in_session && seen && sess_live_ && sess_early_) t_stats_seen_ = std::chrono::steady_clock::now();   // (the early launch waits from here)
     if (in_session && seen) {
         const auto now = std::chrono::steady_clock::now();
         if (posted && trace_persist()) wait_us_ += std::chrono::duration<double, std::micro>(now - t_posted_).count();
@@ -302,7 +327,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
 // One search launch over the resident clouds (lane-serial, certificate, or -- persist != NULL -- the persistent form
 // of the certificate kernel), with the fold inside the launch where that applies.
 int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double offset[3], unsigned long long seq, bool prof,
-                                const PersistArgs *persist, int *nblocks_out, bool *ipc_done)
+                                const PersistArgs *persist, int *nblocks_out, bool *ipc_done, bool early)
 {
     const bool ipc = ipc_n_ > 1;
     double *pub = (comm_ || ipc) ? nullptr : h_stats_dev_;
@@ -345,9 +370,12 @@ int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double off
                                   prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                   1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
                                   exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1 | (persist ? persist_prio_ << 5 : 0), cert_prev(), persist, ru_state()));
-    last_kernel_ = pass_kernel(lanes);
-    pos_fresh_ = d_pos_ != nullptr;
-    note_state_pass(T64);
+    if (!early) {
+        // (an early persistent launch has run nothing yet: what its first pass leaves is noted when that pass has been seen)
+        last_kernel_ = pass_kernel(lanes);
+        pos_fresh_ = d_pos_ != nullptr;
+        note_state_pass(T64);
+    }
     if (prof) {
         HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_));
         if (persist) sess_e0_ = e0;                          // (accounted when the session ends: its passes are known then)
@@ -393,6 +421,19 @@ bool HipEngine::persist_possible(int lanes, int nblocks, bool fused, bool plane)
     return nblocks <= allowed;
 }
 
+void HipEngine::fill_persist_args(PersistArgs *pa)
+{
+    pa->host_cmd = h_cmd_dev_;
+    pa->relay = (unsigned long long *)d_relay_;
+    pa->direct = cmd_direct_ ? 1 : 0;
+    pa->host_flag = h_flag_dev_;
+    pa->max_passes = sess_max_;
+    pa->tag0 = sess_tag0_;
+    pa->wait_ticks = (long long)(4.0 * persist_timeout_ms_ * 1e5) + 1000000ll;   // (100 MHz; host patience x 4 + 10 ms)
+    pa->hard_ticks = 60ll * 100000000ll;
+    pa->start_ticks = (long long)(persist_start_ms_ * 1e5);
+}
+
 int HipEngine::start_session(const Xform64 &, bool plane, const double offset[3], unsigned long long seq, int, bool prof)
 {
     if (device_ < 0 || device_ >= 64) return VISMA_ICP_OK;
@@ -436,6 +477,7 @@ void HipEngine::finish_session()
 {
     if (!sess_live_) return;
     sess_live_ = false;
+    sess_early_ = false;
     if (host_gaps_ > 0) {
         std::fprintf(stderr, "[visma_icp] persistent launch: %d passes; host: statistics seen -> command posted %.2f us, command posted -> statistics seen %.2f us (averages)\n",
                      sess_pass_, host_gap_us_ / host_gaps_, wait_us_ / host_gaps_);
@@ -464,7 +506,8 @@ void HipEngine::finish_session()
 int HipEngine::end_session()
 {
     if (!sess_live_) return VISMA_ICP_OK;
-    if (sess_pass_ >= 1 && sess_pass_ < sess_max_) {
+    // (an early launch waits for a command before its FIRST pass too)
+    if ((sess_pass_ >= 1 || sess_early_) && sess_pass_ < sess_max_) {
         Xform64 none{};
         post_command(none, kPersistStop);
     }

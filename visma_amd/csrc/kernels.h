@@ -140,6 +140,10 @@ struct PersistArgs {
                                           // units and waits for ours): then wait_ticks
     unsigned long long *timeline;         // measurement (VISMA_ICP_PERSIST_TIMELINE), else NULL: per pass and workgroup the
     int timeline_passes;                  // 100 MHz clock when the pass began and when its body (fold ticket included) was done
+    int wait_first;                       // (round 6) the launch was queued BEHIND the registration's cold pass, before its
+                                          // statistics were out: the transform of the launch's first pass is not in the
+                                          // kernel arguments -- it comes as a command with tag0 like every later one (which
+                                          // then carry tag0 + p instead of tag0 + p - 1), and the launch waits for it first
 };
 
 struct NNLaunch {
