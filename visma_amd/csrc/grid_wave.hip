@@ -585,8 +585,11 @@ __device__ __forceinline__ void wave_body(
 // (<= 128 VGPRs; the kernel needs 104).  Several queries per lane: the 23 / 29 f64 moments stay live across
 // the queries, so the compiler gets the registers it asks for (2 waves per SIMD; such launches have more
 // waves than the chip holds anyway).
+#ifndef VISMA_WAVE_WAVES
+#define VISMA_WAVE_WAVES 4
+#endif
 template <bool PLANE>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn_wave_kernel_one(VISMA_WAVE_PARAMS)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(VISMA_WAVE_WAVES, VISMA_WAVE_WAVES))) void nn_wave_kernel_one(VISMA_WAVE_PARAMS)
 {
     wave_body<PLANE, true>(VISMA_WAVE_ARGS);
 }
