@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-CANNED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_bench_c[345].json")))
+# (rounds 4-5: the line WAS the full result; round 6: the side file is)
+CANNED = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]_bench_c[345].json")) +
+                glob.glob(os.path.join(ROOT, "profiles", "r06_bench_c[345]_extras.json")))
 REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
 
