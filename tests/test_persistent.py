@@ -171,6 +171,36 @@ def test_a_launch_whose_host_stalls_ends_by_itself_and_the_loop_carries_on():
     b.close()
 
 
+def test_a_host_that_stalls_before_the_FIRST_command_of_an_early_launch():
+    """Round 6: the persistent launch is queued behind the registration's cold pass and waits for its first transform like
+    for every later one.  A host that comes back too late with that FIRST command posts STOP instead: the launch leaves
+    without having run a pass (nothing written), the loop carries on with ordinary launches -- same registration, bit for
+    bit, one abort on record."""
+    src, tgt, T_gt, r = synth.make_pair(40000, 200000, seed_t=41, seed_s=42, motion="radius")
+    a, b = pair_of_contexts(src, tgt)
+    b.set_persistent(True, timeout_ms=5.0)
+    for c in (a, b):
+        c.forget_winners()                         # (both start with the cold pass)
+    b.get_timing(reset=True)
+    ra = a.run(None, r, 20, 0.0, 0.0)
+    b.test_stall_command(1, 60.0)                  # the launch's first command comes 60 ms late
+    rb = b.run(None, r, 20, 0.0, 0.0)
+    same_result(ra, rb)
+    assert np.array_equal(a.correspondence_index(), b.correspondence_index())
+    tm = b.get_timing(reset=True)
+    assert tm["persist_aborts"] == 1, tm
+    # (and with the patience back, the next fresh registration runs all its warm passes inside ONE early launch)
+    b.set_persistent(True, timeout_ms=200.0)
+    b.set_profiling(1)
+    for c in (a, b):
+        c.forget_winners()
+    same_result(a.run(None, r, 12, 0.0, 0.0), b.run(None, r, 12, 0.0, 0.0))
+    tm = b.get_timing(reset=True)
+    assert tm["persist_aborts"] == 0 and tm["persist_launches"] == 1 and tm["persist_passes"] == 12, tm
+    a.close()
+    b.close()
+
+
 def test_two_contexts_in_one_process_take_turns():
     """One persistent launch per device at a time: a second context whose loop starts while the first one's launch is
     alive (another host thread) runs ordinary launches -- both get the single-context results."""
