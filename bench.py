@@ -1294,7 +1294,7 @@ def run_c5(R, args, tag=""):
     ctx = _lib.Context(R.local_rank)
     # queue workers per GPU (visma_icp_run_corpus takes any number of contexts; each has its own stream): while one
     # worker packs and uploads its next chunk -- and while its one-thread solves run -- the other's searches have the GPU
-    nctx = max(1, int(os.environ.get("VISMA_C5_WORKERS_PER_GPU", "3")))
+    nctx = max(1, int(os.environ.get("VISMA_C5_WORKERS_PER_GPU", "4")))
     ctxs = [ctx] + [_lib.Context(R.local_rank) for _ in range(nctx - 1)]
     corpus = _lib.Corpus([(cads[c], scenes[s]) for s, c in items], level=level, max_dist=radius, max_iter=iters,
                          rel_fitness=1e-6, rel_rmse=1e-6, chunk=C5_CHUNK)
