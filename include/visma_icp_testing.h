@@ -57,6 +57,12 @@ VISMA_ICP_API int visma_icp_set_device_loop(visma_icp_ctx *ctx, int enabled);
  * from now (1 = the next) -- a stalled host thread, as seen from the device.  Replaces nothing in the reference. */
 VISMA_ICP_API int visma_icp_test_stall_command(visma_icp_ctx *ctx, int nth, double ms);
 
+/* (round 6, measurement) the persistent SWEEP launch of device-resident loops over shared clouds (yaw sweeps, the device
+ * loop of one registration: every pass after the first inside ONE launch; VISMA_ICP_SWEEP_PERSIST=0 switches it off):
+ * launches started / launches that gave up (a wait ran out; the loop carried on with one launch per pass) since the
+ * context was created.  Either pointer may be NULL. */
+VISMA_ICP_API int visma_icp_get_sweep_info(visma_icp_ctx *ctx, double *launches, double *aborts);
+
 /* Compile-time tile constants, for roofline accounting: S_TILE source points
  * per workgroup, target chunk staged per LDS fill, workgroup size. */
 VISMA_ICP_API int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block);

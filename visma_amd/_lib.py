@@ -191,6 +191,7 @@ def _bind(L):
     L.visma_icp_set_device_loop.argtypes = [C.c_void_p, C.c_int]
     L.visma_icp_set_persistent.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_test_stall_command.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.visma_icp_get_sweep_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.visma_icp_set_persistent_cu_share.argtypes = [C.c_double]
     L.visma_icp_get_persistent_info.argtypes = [C.c_void_p, C.POINTER(CPersistentInfo)]
     L.visma_icp_get_timing_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -568,6 +569,12 @@ class Context:
         t.struct_size = C.sizeof(CPersistentInfo)
         self._chk(self.L.visma_icp_get_persistent_info(self._h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in CPersistentInfo._fields_ if k != "reserved"}
+
+    def sweep_info(self):
+        """persistent sweep launches of this context's device-resident loops: started / gave up (visma_icp_get_sweep_info)"""
+        a, b = C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.L.visma_icp_get_sweep_info(self._h, C.byref(a), C.byref(b)))
+        return {"launches": a.value, "aborts": b.value}
 
     def test_stall_command(self, nth, ms):
         self._chk(self.L.visma_icp_test_stall_command(self._h, int(nth), float(ms)))

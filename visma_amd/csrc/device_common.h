@@ -446,6 +446,10 @@ constexpr int kFoldSingle = VISMA_FOLD_SINGLE;      // up to this many rows: one
 // LOOPED: called from the loop of the persistent kernel (no exchange with peers there; opaque thread number).
 // SOLVE: the kernel honours FoldArgs::solve -- the publishing workgroup advances the problem's device-resident state
 // (closed-form update, compose, stop test) right behind its fold, one thread on a copy of the state in LDS.
+// (the persistent sweep launch: the one-thread closed-form update OUT of line -- inlined it spilled 150 registers of the
+//  128-register search kernel around it; out of line it has an allocation of its own and the search path none of its cost)
+__device__ __attribute__((noinline)) void advance_state_kabsch_outlined(DevIcpState *s) { advance_state<true>(s); }
+
 template <bool PLANE, int NTH, bool LOOPED = false, bool SOLVE = false>
 __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *partials, long long row0, int lb,
                                            int bpp, int prob)
@@ -601,13 +605,64 @@ __device__ __forceinline__ bool fused_fold(const FoldArgs &f, const double *part
             constexpr int kWords = (int)(sizeof(DevIcpState) / 8), kStatsWord = (int)(offsetof(DevIcpState, stats) / 8);
             __shared__ unsigned long long f_sst[kWords];
             unsigned long long *gs = reinterpret_cast<unsigned long long *>(f.solve + prob);
-            for (int k = tid; k < kWords; k += NTH)
-                f_sst[k] = (k >= kStatsWord && k < kStatsWord + kNStats) ? (unsigned long long)__double_as_longlong(f_stats[k - kStatsWord])
-                                                                         : gs[k];
+            if constexpr (LOOPED) {
+                // (the persistent sweep launch: the workgroup that advanced this state in the pass before may sit on
+                //  another XCD -- the words come from and go to memory, past the L2s)
+                // (f.sweep_passes: the pass counter this state must show -- what the pass before left; a state still on its
+                //  way from that pass's folding workgroup shows an older one: read again.  The words of one state are stored
+                //  by one workgroup in one go; the counter lies behind the transform and the bookkeeping in the struct, and a
+                //  torn read -- new counter, old words before it -- is excluded by reading the counter LAST)
+                constexpr int kPassWord = (int)(offsetof(DevIcpState, passes) / 8);
+                static_assert(offsetof(DevIcpState, passes) % 8 == 4 || offsetof(DevIcpState, passes) % 8 == 0, "passes inside one word");
+                for (int guard = 0; guard < (1 << 20); guard++) {
+                    for (int k = tid; k < kWords; k += NTH)
+                        if (k != kPassWord)
+                            f_sst[k] = (k >= kStatsWord && k < kStatsWord + kNStats) ? (unsigned long long)__double_as_longlong(f_stats[k - kStatsWord])
+                                                                                     : __hip_atomic_load(gs + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) f_sst[kPassWord] = __hip_atomic_load(gs + kPassWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __syncthreads();
+                    if (reinterpret_cast<const DevIcpState *>(f_sst)->passes == f.sweep_passes) break;
+                    __syncthreads();
+                }
+            } else {
+                for (int k = tid; k < kWords; k += NTH)
+                    f_sst[k] = (k >= kStatsWord && k < kStatsWord + kNStats) ? (unsigned long long)__double_as_longlong(f_stats[k - kStatsWord])
+                                                                             : gs[k];
+            }
             __syncthreads();
-            if (tid == 0) advance_state<true>(reinterpret_cast<DevIcpState *>(f_sst));
+            if constexpr (LOOPED) { if (tid == 0) advance_state_kabsch_outlined(reinterpret_cast<DevIcpState *>(f_sst)); }
+            else { if (tid == 0) advance_state<true>(reinterpret_cast<DevIcpState *>(f_sst)); }
             __syncthreads();
-            for (int k = tid; k < kWords; k += NTH) gs[k] = f_sst[k];
+            if constexpr (LOOPED) {
+                // the problem's other workgroups first: they wait for nothing but these 25 words.  The state follows; the
+                // workgroup that folds the NEXT pass (a pass later, possibly on another XCD) validates what it reads by the
+                // pass counter it expects and reads again until it sees it (above).
+                if (f.sweep_relay && tid < kPersistWords) {
+                    const DevIcpState *ns_ = reinterpret_cast<const DevIcpState *>(f_sst);
+                    unsigned long long w;
+                    if (tid < 24) {
+                        const unsigned long long b = (unsigned long long)__double_as_longlong(ns_->Tc[tid >> 1]);
+                        w = (tid & 1) ? (b >> 32) : (b & 0xFFFFFFFFull);
+                    } else {
+                        w = ns_->active ? kPersistGo : kPersistStop;
+                    }
+                    __hip_atomic_store(f.sweep_relay + 32ll * prob + tid, w | ((unsigned long long)f.sweep_tag << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                {
+                    // (the word with the pass counter goes LAST, when the others are in memory: whoever reads it reads them)
+                    constexpr int kPassWordW = (int)(offsetof(DevIcpState, passes) / 8);
+                    for (int k = tid; k < kWords; k += NTH)
+                        if (k != kPassWordW) __hip_atomic_store(gs + k, f_sst[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(gs + kPassWordW, f_sst[kPassWordW], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                for (int k = tid; k < kWords; k += NTH) gs[k] = f_sst[k];
+            }
         }
     }
     return true;

@@ -1035,6 +1035,13 @@ int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_persistent_info 
     return VISMA_ICP_OK;
 }
 
+int visma_icp_get_sweep_info(visma_icp_ctx *ctx, double *launches, double *aborts)
+{
+    CTX_CHECK();
+    ctx->eng->get_sweep_info(launches, aborts);
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_test_stall_command(visma_icp_ctx *ctx, int nth, double ms)
 {
     CTX_CHECK();

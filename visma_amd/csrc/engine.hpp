@@ -278,6 +278,7 @@ public:
     // the persistent certificate kernel).  loop_end() must follow on every path; LoopScope does that.
     virtual void set_persistent(int /*enabled*/, double /*timeout_ms*/) {}
     virtual void get_persistent_info(visma_icp_persistent_info *out) const { (void)out; }
+    virtual void get_sweep_info(double *launches, double *aborts) const { if (launches) *launches = 0.0; if (aborts) *aborts = 0.0; }
     virtual void stall_command(int /*nth*/, double /*ms*/) {}
     virtual bool loop_across_ranks_ok() const { return false; }   // source-sharded ranks may keep a launch alive across passes too
     virtual void loop_begin(int /*max_passes*/) {}

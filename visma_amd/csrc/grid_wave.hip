@@ -95,15 +95,36 @@ __device__ __forceinline__ unsigned wave_scan_incl(unsigned v, int)
 
 }  // namespace
 
-template <bool PLANE, bool ONE>
-__device__ __forceinline__ void wave_body(
+// Everything the launch is given, as ONE by-value argument read from the kernarg segment at the top of EVERY pass through a
+// pointer the compiler cannot see through (grid_coop.hip's persistent kernel does the same): with ordinary arguments the loop
+// around the pass had every invariant of the body hoisted out of it and spilled.
+struct SweepParams {
+    int ns; const float *s12f; const unsigned *start; GridParams g; float r2f; int *idx_out; float *d2_out; double *partials;
+    unsigned long long *cand_count; DevIcpState *st; int bpp; long long out_stride; int nprob; const Pt64 *src64;
+    const Pt64 *sorted64; FoldArgs fold; Pt64 *prevq_io; SweepArgs sa;
+};
+template <class T>
+__device__ __forceinline__ T ld_karg_w(const T __attribute__((address_space(4))) *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "words");
+    constexpr int N = (int)(sizeof(T) / 4);
+    union U { T v; unsigned w[N]; __device__ U() {} } u;
+    typedef const unsigned __attribute__((address_space(4))) *WordPtr;
+    const WordPtr pw = (WordPtr)p;
+#pragma unroll
+    for (int k = 0; k < N; k++) u.w[k] = pw[k];
+    return u.v;
+}
+
+template <bool PLANE, bool ONE, bool SWEEP = false>
+__device__ __forceinline__ bool wave_body(
     int ns, const float *__restrict__ s12f, const unsigned *__restrict__ start, GridParams g,
     const float4 *__restrict__ nrm, Xform64 T64, Offset64 off, float r2f, int *__restrict__ idx_out,
     float *__restrict__ d2_out, double *__restrict__ partials, unsigned long long *__restrict__ cand_count,
     const DevIcpState *__restrict__ st, int bpp, long long out_stride, const ProbDesc *__restrict__ descs,
     int nprob, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64,
     const Pt64 *__restrict__ nrm64, const FoldArgs &fold, double *__restrict__ d64_out,
-    Pt64 *__restrict__ prevq_io, int warm)
+    Pt64 *__restrict__ prevq_io, int warm, int sweep_pass = 0)
 {
     constexpr int NACC = Acc<PLANE>::N;
     const P12 *s12 = reinterpret_cast<const P12 *>(s12f);
@@ -148,7 +169,7 @@ __device__ __forceinline__ void wave_body(
     if (st) st += prob;
     {
         Xform32 T32_unused;
-        if (!load_loop_state(st, T32_unused, T64, off, r2f)) return;
+        if (!load_loop_state(st, T32_unused, T64, off, r2f)) return false;
     }
     const double r2d = (double)r2f;                         // (double)(float)(r*r): KDTreeFlann.cpp:184-185
     COOP_PROBE_BEGIN();
@@ -160,7 +181,8 @@ __device__ __forceinline__ void wave_body(
     for (int a = 0; a < NACC; a++) acc[a] = 0.0;
     unsigned ncand = 0, ncand_all = 0;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (inside the persistent sweep's loop: opaque, or everything derived from the thread's number is hoisted out and spilled)
+    const int tid = thread_number<SWEEP, kBlock>(), lane = tid & 63, wave = tid >> 6;
     const int oct = lane >> 3, l8 = lane & 7;
     // the query -> lane map of nn_grid_reduce_kernel<G = 1> (XCD-aware chunking of the Morton order)
     int vb = lb;
@@ -551,7 +573,7 @@ __device__ __forceinline__ void wave_body(
     }
     COOP_MARK(6);                                            // outputs + moments
     COOP_WAVE_DONE();
-    block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
+    block_reduce_store<NACC, kBlock / 64, SWEEP>(acc, partials, SWEEP || fold.tickets != nullptr);   // (rows read by another workgroup: past the L2)
     COOP_MARK(7);                                            // workgroup's partial row stored
     if (cand_count) {
         unsigned long long c = ncand, ca = ncand_all;
@@ -560,14 +582,34 @@ __device__ __forceinline__ void wave_body(
             c += __shfl_down(c, o, 64);
             ca += __shfl_down(ca, o, 64);
         }
-        if ((threadIdx.x & 63) == 0 && ca) {
+        if (lane == 0 && ca) {
             unsigned long long *slot = cand_count + 2 * (blockIdx.x & 4095);
             atomicAdd(slot, c);
             atomicAdd(slot + 1, ca);
         }
     }
-    if (fold.tickets) fused_fold<PLANE, kBlock, false, kSolveInFold>(fold, partials, row0, lb, bpp, prob);
+    bool published = false;
+    if constexpr (SWEEP) {
+        // (the persistent sweep launch: fold, closed-form update, compose, stop test and the hand-over of the next transform
+        //  by the workgroup that completes the problem's fold)
+        // (the fold's arguments are read from the kernarg segment HERE, not carried across the search)
+        typedef const SweepParams __attribute__((address_space(4))) *KernargPtr;
+        KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        FoldArgs f{};
+        f.tickets = ld_karg_w(&kp->fold.tickets); f.partials2 = ld_karg_w(&kp->fold.partials2);
+        f.ticket_stride = ld_karg_w(&kp->fold.ticket_stride); f.stats_out = ld_karg_w(&kp->fold.stats_out);
+        f.stats_stride = ld_karg_w(&kp->fold.stats_stride);
+        f.solve = ld_karg_w(&kp->st);
+        f.sweep_relay = ld_karg_w(&kp->sa.relay);
+        f.sweep_tag = ld_karg_w(&kp->sa.tag0) + (unsigned)sweep_pass + 1u;
+        f.sweep_passes = ld_karg_w(&kp->sa.passes0) + sweep_pass;
+        published = fused_fold<PLANE, kBlock, true, true>(f, ld_karg_w(&kp->partials), row0, lb, bpp, prob);
+    } else {
+        if (fold.tickets) published = fused_fold<PLANE, kBlock, false, kSolveInFold>(fold, partials, row0, lb, bpp, prob);
+    }
     COOP_MARK(8);                                            // fold (most workgroups: just the ticket)
+    return published;
 }
 
 #define VISMA_WAVE_PARAMS                                                                                         \
@@ -600,6 +642,126 @@ __global__ __launch_bounds__(kBlock) void nn_wave_kernel_many(VISMA_WAVE_PARAMS)
 }
 #undef VISMA_WAVE_PARAMS
 #undef VISMA_WAVE_ARGS
+
+// ---- The PERSISTENT SWEEP launch (round 6): the warm passes of nprob registrations over SHARED clouds -- the 24 yaw starts of
+// feh::RegisterModelToScene (src/annotation.cpp:35-61), a device-resident loop of one problem -- inside ONE launch.  Until now
+// every pass was a search launch plus a one-thread solve launch (5 k -> 20 k, 24 starts: 27 us per pass for 20 us of kernels).
+// Here a workgroup runs its problem's passes back to back: search and block reduction as in nn_wave_kernel_one, the ticket
+// fold of its problem, and the workgroup that completes the fold advances the problem's state (advance_state: the code of
+// solve_state_kernel) and hands the next transform to the problem's other workgroups through 25 self-validating words in
+// device memory (kernels.h: FoldArgs::sweep_relay) -- nobody fences, every wait is bounded by the wall clock.  Problems
+// advance independently; a problem that stops frees its workgroups.  Same results as one launch per pass, bit for bit (same
+// search, same fold order, same solve).  Needs every workgroup resident (the launcher's caller checks the capacity); a wait
+// that runs out sets *dead and everybody leaves: the states hold what was completed, the host carries on with launches.
+template <bool PLANE>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void nn_wave_kernel_sweep(const SweepParams P)
+{
+    // the transform of the pass that is due: 32-bit halves of its 12 doubles + the command word, in LDS
+    __shared__ unsigned s_w[32];
+    const int prob = (int)blockIdx.x / P.bpp;
+    {
+        // pass 0: the state as the launches before this one left it
+        const DevIcpState *sp = P.st + prob;
+        if (!sp->active) return;
+        if (threadIdx.x < 12) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(sp->Tc[threadIdx.x]);
+            s_w[2 * threadIdx.x] = (unsigned)b;
+            s_w[2 * threadIdx.x + 1] = (unsigned)(b >> 32);
+        }
+    }
+    __syncthreads();
+    typedef const SweepParams __attribute__((address_space(4))) *KernargPtr;
+    for (int pass = 0;; pass++) {
+        KernargPtr kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));                         // (nothing read through it is loop-invariant to the compiler)
+#define VISMA_KARG(F_) ld_karg_w(&kp->F_)
+        Xform64 T64;
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)s_w[2 * k]);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)s_w[2 * k + 1]);
+            T64.m[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+        DevIcpState *st = VISMA_KARG(st);
+        const int bpp = VISMA_KARG(bpp);
+        const int pr = (int)blockIdx.x / bpp;
+        Offset64 off;
+        {
+            const DevIcpState *sp = st + pr;                 // (constants of the loop: never written after its start)
+#pragma unroll
+            for (int a = 0; a < 3; a++) off.v[a] = sp->world_frame ? sp->centre[a] : 0.0;
+        }
+        const FoldArgs nofold{};                             // (wave_body reads the fold's arguments itself: SWEEP)
+        (void)wave_body<PLANE, true, true>(VISMA_KARG(ns), VISMA_KARG(s12f), VISMA_KARG(start), VISMA_KARG(g), nullptr, T64, off,
+                                           VISMA_KARG(r2f), VISMA_KARG(idx_out), VISMA_KARG(d2_out), VISMA_KARG(partials),
+                                           VISMA_KARG(cand_count), nullptr, bpp, VISMA_KARG(out_stride), nullptr, VISMA_KARG(nprob),
+                                           VISMA_KARG(src64), VISMA_KARG(sorted64), nullptr, nofold, nullptr, VISMA_KARG(prevq_io), 1,
+                                           pass);
+        kp = (KernargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        const SweepArgs sa = VISMA_KARG(sa);
+#undef VISMA_KARG
+        if (pass + 1 >= sa.max_passes) break;
+        // ---- the problem's next transform: the first wave polls the problem's 25 words for the tag of the pass that is due
+        __syncthreads();                                     // (everybody has read s_w)
+        if (threadIdx.x < 64) {
+            const int lane = (int)threadIdx.x;
+            const unsigned tag = sa.tag0 + (unsigned)pass + 1u;
+            unsigned long long w = 0ull;
+            const long long t0 = (long long)wall_clock64();
+            const int pr2 = (int)blockIdx.x / ld_karg_w(&kp->bpp);
+            for (;;) {
+                if (lane < kPersistWords) w = __hip_atomic_load(sa.relay + 32ll * pr2 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool ok = lane >= kPersistWords || (unsigned)(w >> 32) == tag;
+                if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+                const bool dead = __hip_atomic_load(sa.dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+                if (dead || (long long)wall_clock64() - t0 > sa.wait_ticks) {
+                    // (somebody's workgroups are not running, or left: no fold of this launch can complete any more)
+                    if (lane == 0) __hip_atomic_store(sa.dead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    w = (unsigned long long)kPersistAbort;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane < 32) s_w[lane] = (unsigned)w;
+        }
+        __syncthreads();
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)s_w[kPersistWords - 1]) != kPersistGo) break;
+    }
+}
+
+int nn_wave_sweep_capacity()
+{
+    static int cap[64];
+    static bool known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 0; }
+    if (!known[dev]) {
+        int per_cu = 0, cus = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nn_wave_kernel_sweep<false>, kBlock, 0);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) { (void)hipGetLastError(); per_cu = 0; cus = 0; }
+        cap[dev] = per_cu * cus;
+        known[dev] = true;
+    }
+    return cap[dev];
+}
+
+hipError_t launch_nn_wave_sweep(int bpp, int nprob, int ns, const float *s12, const unsigned *start, const GridParams &g,
+                                float r2f, int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
+                                DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
+                                const FoldArgs &fold, Pt64 *prevq_io, const SweepArgs &sa, hipStream_t stream)
+{
+    if (!src64 || !sorted64 || !s12 || !prevq_io || !st || !fold.tickets || !sa.relay || !sa.dead || sa.max_passes < 1 ||
+        bpp < 1 || nprob < 1 || (long long)bpp * kBlock < ns || bpp * nprob > nn_wave_sweep_capacity())
+        return hipErrorInvalidValue;
+    SweepParams P{};
+    P.ns = ns; P.s12f = s12; P.start = start; P.g = g; P.r2f = r2f; P.idx_out = idx_out; P.d2_out = d2_out; P.partials = partials;
+    P.cand_count = cand_count; P.st = st; P.bpp = bpp; P.out_stride = out_stride; P.nprob = nprob; P.src64 = src64;
+    P.sorted64 = sorted64; P.fold = fold; P.prevq_io = prevq_io; P.sa = sa;
+    hipLaunchKernelGGL(nn_wave_kernel_sweep<false>, dim3(bpp * nprob), dim3(kBlock), 0, stream, P);
+    return hipGetLastError();
+}
 
 #define VISMA_WAVE_LAUNCH(KERNEL_)                                                                               \
     hipLaunchKernelGGL(KERNEL_, dim3(total_blocks), dim3(kBlock), 0, stream, ns, s12, start, g, nrm, T64, off,   \

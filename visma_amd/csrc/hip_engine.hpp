@@ -45,6 +45,7 @@ public:
         if (d_cmd_block_) (void)hipFree(d_cmd_block_);
         if (h_flag_) (void)hipHostFree(h_flag_);
         free_dev(d_relay_); free_dev(d_timeline_); free_dev(d_peer_table_); free_dev(d_fold_tag_);
+        if (d_sweep_relay_) (void)hipFree(d_sweep_relay_);
         pool_trim(0);
         if (d_raw_src_) (void)hipFree(d_raw_src_);
         if (stream_src_) (void)hipStreamDestroy(stream_src_);
@@ -247,6 +248,11 @@ public:
         persist_enabled_ = enabled != 0;
         persist_cooldown_ = 0;
         if (timeout_ms >= 0.5 && timeout_ms <= 5000.0) persist_timeout_ms_ = timeout_ms;
+    }
+    void get_sweep_info(double *launches, double *aborts) const override
+    {
+        if (launches) *launches = sweep_launches_total_;
+        if (aborts) *aborts = sweep_aborts_total_;
     }
     void get_persistent_info(visma_icp_persistent_info *out) const override
     {
@@ -703,6 +709,15 @@ private:
     // VISMA_ICP_PERSIST_EARLY=0: the launch starts with the first warm pass, as in rounds 4-5.
     bool sess_early_ = false;
     int persist_early_ = 1;
+    // (round 6) the persistent SWEEP launch of device-resident loops over shared clouds (grid_wave.hip: nn_wave_kernel_sweep):
+    // after the first (cold) pass, ONE launch runs the remaining passes of every problem -- search, fold, closed-form update,
+    // stop test inside it.  Closed-form point-to-point loops on one GPU whose workgroups all fit the device at once;
+    // VISMA_ICP_SWEEP_PERSIST=0: one search launch + one solve launch per pass, as before.
+    int sweep_persist_ = 1;
+    void *d_sweep_relay_ = nullptr;      // 32 words per problem + the "dead" word behind them
+    int sweep_relay_cap_ = 0;
+    unsigned sweep_tag_ = 0;
+    double sweep_launches_total_ = 0.0, sweep_aborts_total_ = 0.0;
     int sess_pass_ = 0, sess_max_ = 0;
     unsigned sess_tag0_ = 0, cmd_tag_ = 0;
     unsigned long long sess_seq0_ = 0;

@@ -57,6 +57,7 @@ int HipEngine::init()
     HIP_TRY(hipHostGetDevicePointer((void **)&h_stats_dev_, h_stats_, 0));
     if (const char *e = std::getenv("VISMA_ICP_PERSIST")) persist_enabled_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_EARLY")) persist_early_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_SWEEP_PERSIST")) sweep_persist_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_RANKS")) persist_ranks_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH")) cold_in_launch_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH_MIN_NS")) cold_in_launch_min_ns_ = std::max<long long>(0, std::atoll(e));

@@ -648,8 +648,80 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
     // after convergence are no-ops (the kernels return on !active)
     const int chunk = lp.check_stop ? 8 : lp.passes;
     int done = 0;
+    bool sweep_tried = false;
+    // (a loop the persistent sweep launch may take over runs its first pass alone: the launch starts behind it)
+    const bool sweep_candidate = sweep_persist_ && use_grid_ && fused_fold_ && !tshard_ && !comm_ && ipc_n_ <= 1 && !lp.plane &&
+                                 lp.solver == VISMA_ICP_SOLVER_KABSCH && lp.passes >= 3;
     while (done < lp.passes) {
-        const int n = std::min(chunk, lp.passes - done);
+        int n = std::min(chunk, lp.passes - done);
+        if (done == 0 && sweep_candidate) n = 1;
+        // ---- the persistent sweep launch (hip_engine.hpp: sweep_persist_): every pass after the first of every problem in ONE
+        // launch.  Tried once per loop; a launch that gave up (a wait ran out: its workgroups were not all resident) leaves the
+        // states where they got to, and the loop carries on below with one launch per pass.
+        if (done >= 1 && !sweep_tried && sweep_candidate && pass_lanes(nprob) == kCoopLanes && coop_ok() && device_ >= 0 && device_ < 64 &&
+            !std::getenv("VISMA_ICP_COOP_KERNEL")) {
+            sweep_tried = true;
+            const int nb = grid_launch_blocks(ns_, kCoopLanes, reduce_max_blocks());
+            const int cap = nn_wave_sweep_capacity();
+            int expect = 0;
+            if ((int64_t)nb * kBlock >= ns_ && (int64_t)nb * nprob <= (int64_t)((double)cap * persist_cu_share()) &&
+                g_persist_slot[device_].compare_exchange_strong(expect, 1)) {
+                struct SlotGuard { int d; ~SlotGuard() { g_persist_slot[d].store(0); } } guard{device_};
+                if (nprob > sweep_relay_cap_) {
+                    if (d_sweep_relay_) (void)hipFree(d_sweep_relay_);
+                    d_sweep_relay_ = nullptr; sweep_relay_cap_ = 0;
+                    HIP_TRY(hipMalloc(&d_sweep_relay_, sizeof(unsigned long long) * (32 * (size_t)nprob + 8)));
+                    sweep_relay_cap_ = nprob;
+                    sweep_tag_ = 0;
+                }
+                const int rem = lp.passes - done;
+                if (sweep_tag_ == 0u || sweep_tag_ + (unsigned)rem + 2u < sweep_tag_) {
+                    // (tags never 0, never wrap inside a launch: a cleared relay validates nothing)
+                    HIP_TRY(hipMemsetAsync(d_sweep_relay_, 0, sizeof(unsigned long long) * (32 * (size_t)sweep_relay_cap_ + 8), stream_));
+                    sweep_tag_ = 1u;
+                }
+                unsigned long long *dead = (unsigned long long *)d_sweep_relay_ + 32 * (size_t)sweep_relay_cap_;
+                HIP_TRY(hipMemsetAsync(dead, 0, sizeof(unsigned long long), stream_));
+                FoldArgs fa{};
+                rc = make_fold(nb, nprob, st->stats, (long long)(sizeof(DevIcpState) / sizeof(double)), nullptr, 0, &fa);
+                if (rc) return rc;
+                SweepArgs sa{};
+                sa.relay = (unsigned long long *)d_sweep_relay_;
+                sa.dead = dead;
+                sa.max_passes = rem;
+                sa.tag0 = sweep_tag_;
+                sa.passes0 = done;                             // (every problem still active has run `done` passes)
+                sa.wait_ticks = (long long)(50.0 * 1e5);      // 50 ms (100 MHz): a pass of a resident launch takes microseconds
+                sweep_tag_ += (unsigned)rem + 1u;
+                int e0 = -1;
+                if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }
+                HIP_TRY(launch_nn_wave_sweep(nb, nprob, (int)ns_, (const float *)d_sorted12_, (const unsigned *)d_start_, grid_, r2f_,
+                                             (int32_t *)d_idx_, (float *)d_d2_, (double *)d_partials_,
+                                             profiling_ ? (unsigned long long *)d_cand_ : nullptr, st, loop_out_stride_,
+                                             (const Pt64 *)d_src64_, (const Pt64 *)d_sorted64_, fa, (Pt64 *)d_pos_, sa, stream_));
+                if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 0}); }
+                last_kernel_ = 2;
+                pos_fresh_ = d_pos_ != nullptr;
+                prev_T_valid_ = false;
+                unsigned long long dead_h = 0ull;
+                HIP_TRY(hipMemcpyAsync(h_state_, d_state_, sizeof(DevIcpState) * nprob, hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipMemcpyAsync(&dead_h, dead, sizeof(dead_h), hipMemcpyDeviceToHost, stream_));
+                HIP_TRY(hipStreamSynchronize(stream_));
+                sweep_launches_total_ += 1.0;
+                rc = maybe_collect_timing();
+                if (rc) return rc;
+                if (!dead_h) { done = lp.passes; break; }
+                // gave up: every problem is at least where its slowest state says; carry on from there with launches
+                sweep_aborts_total_ += 1.0;
+                int least = lp.passes;
+                bool any = false;
+                for (int b = 0; b < nprob; b++)
+                    if (h_state_[b].active) { any = true; least = std::min(least, h_state_[b].passes); }
+                if (!any) break;
+                done = std::max(done, std::min(least, lp.passes - 1));
+                n = std::min(chunk, lp.passes - done);
+            }
+        }
         for (int j = 0; j < n; j++) {
             int nblocks = 1, e0 = -1;
             if (profiling_) { e0 = next_event_pair(); HIP_TRY(hipEventRecord(ev_[e0], stream_)); }

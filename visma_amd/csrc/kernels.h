@@ -90,6 +90,13 @@ struct FoldArgs {
     // with -DVISMA_SOLVE_IN_FOLD=1 (kSolveInFold): it measured slower than the solve launch and its
     // inlined one-thread solve costs the default search kernels scratch and LDS -- default builds carry none of it.
     DevIcpState *solve;
+    // (round 6) the PERSISTENT SWEEP launch (grid_wave.hip: nn_wave_kernel_sweep): the workgroup that completes problem b's
+    // fold advances solve[b] and hands the next pass's transform to the problem's other workgroups through
+    // sweep_relay + 32 b: kPersistWords 8-byte words {half of a double | tag << 32} + the command word (GO / STOP), every
+    // word carrying sweep_tag -- the tag of the pass that is due next.  NULL: not that launch.
+    unsigned long long *sweep_relay;
+    unsigned sweep_tag;
+    int sweep_passes;                  // DevIcpState::passes of solve[b] before this pass's update (validates the state read)
 };
 #ifndef VISMA_SOLVE_IN_FOLD
 #define VISMA_SOLVE_IN_FOLD 0
@@ -403,6 +410,26 @@ hipError_t launch_nn_wave(int total_blocks, int bpp, int nprob, const ProbDesc *
                           int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
                           const DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
                           const FoldArgs &fold, double *d64_out, Pt64 *prevq_io, int warm, hipStream_t stream);
+// The persistent form of the batch / sweep search over SHARED clouds (grid_wave.hip, round 6): ONE launch runs up to
+// max_passes warm passes of nprob problems of bpp workgroups each -- search, fold, closed-form update, compose and stop
+// test inside the launch (fused_fold<..., LOOPED, SOLVE>), the next transform handed to the problem's workgroups through
+// `relay` (32 words per problem, device memory, zeroed by the caller).  Every workgroup must be resident at once
+// (nn_wave_sweep_capacity()).  `dead`: one word, zeroed by the caller; nonzero afterwards = a wait ran out (somebody's
+// workgroups were not resident): the states hold what was completed, the caller carries on with ordinary launches.
+struct SweepArgs {
+    unsigned long long *relay;
+    unsigned long long *dead;
+    int max_passes;
+    unsigned tag0;             // the command for pass p (p >= 1) carries tag0 + p; pass 0 reads the state itself
+    int passes0;               // DevIcpState::passes of every problem when the launch begins (its first pass makes it passes0 + 1)
+    long long wait_ticks;      // how long a workgroup waits for its problem's next transform (100 MHz ticks)
+};
+int nn_wave_sweep_capacity();
+hipError_t launch_nn_wave_sweep(int bpp, int nprob, int ns, const float *s12, const unsigned *start, const GridParams &g,
+                                float r2f, int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
+                                DevIcpState *st, long long out_stride, const Pt64 *src64, const Pt64 *sorted64,
+                                const FoldArgs &fold, Pt64 *prevq_io, const SweepArgs &sa, hipStream_t stream);
+
 hipError_t launch_nn_coop(int total_blocks, int bpp, int nprob, const ProbDesc *descs, int ns, const float *s12,
                           const unsigned *start, const GridParams &g, const float4 *nrm, const Pt64 *nrm64,
                           const Xform64 &T64, const Offset64 &off, float r2f, int point_to_plane, int one,
