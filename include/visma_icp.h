@@ -446,6 +446,21 @@ VISMA_ICP_API int visma_icp_set_persistent(visma_icp_ctx *ctx, int enabled, doub
 VISMA_ICP_API int visma_icp_set_persistent_cu_share(double share);
 VISMA_ICP_API int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_persistent_info *out);
 
+/* ---- radii that are large against the target's point spacing --------------------------------------------------------
+ * The grid search lists the 27 radius-sized cells around a query (KDTreeFlann.cpp:164-189 asks for the nearest point
+ * within the radius).  When such a cell holds hundreds of points -- a radius of tens of point spacings -- the library builds
+ * cells of a few point spacings instead and searches them in rings of rows around the query, nearest first, bounded by the
+ * best candidate so far and, after the first pass, by the previous winner (grid_ring.hip): the same correspondences, bit
+ * for bit; the cost of a query follows the number of points nearer than its nearest neighbour, not the radius.
+ *  visma_icp_set_ring_search(ctx, mode): -1 (default) by the occupancy of the radius-sized cells (>= 256 points per
+ *    occupied cell; VISMA_ICP_RING_OCCUPANCY), 0 never, 1 whenever the f64 views exist and a finer table fits (also
+ *    VISMA_ICP_RING=0/1 when the context is created).  Takes effect at the next grid build (new target or radius).
+ *  visma_icp_get_ring_search(ctx, ...): what the current grid is: *rings > 0 = ring search with that many rings at most,
+ *    *cell = the cell edge, *occupancy = points per occupied radius-sized cell as counted (0 = not counted).  Any pointer may
+ *    be NULL.  Replaces nothing in the reference (FLANN's KD-tree has no such regime change). */
+VISMA_ICP_API int visma_icp_set_ring_search(visma_icp_ctx *ctx, int mode);
+VISMA_ICP_API int visma_icp_get_ring_search(visma_icp_ctx *ctx, int *rings, double *cell, double *occupancy);
+
 /* ---- multi-GPU (one process per GPU; source-sharded) -------------------- */
 
 #define VISMA_ICP_UNIQUE_ID_BYTES 128

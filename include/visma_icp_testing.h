@@ -35,7 +35,8 @@ VISMA_ICP_API int visma_icp_create_with_engine(visma_icp_ctx **out,
 /* Which kernel the last grid pass ran: 0 brute force, 1 the lane-serial grid search (first pass of a
  * registration: progressive pruning, nothing known about the queries), 2 the warm-started wave-cooperative
  * search (visma_amd/csrc/grid_coop.hip: every later pass; each query starts from its previous winner, which
- * bounds it before anything is gathered).  Same results, bit for bit.
+ * bounds it before anything is gathered), 3 the ring search over cells smaller than the radius (grid_ring.hip: radii
+ * that are large against the point spacing, visma_icp_set_ring_search).  Same results, bit for bit.
  * visma_icp_forget_winners drops what the passes so far remembered (the library does so itself whenever the
  * source, the target or the radius changes): the next pass then runs like the first of a new registration.
  * Replaces nothing in the reference (KDTreeFlann keeps no state between searches, KDTreeFlann.cpp:164-189). */

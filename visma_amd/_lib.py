@@ -192,6 +192,8 @@ def _bind(L):
     L.visma_icp_set_persistent.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_test_stall_command.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_get_sweep_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.visma_icp_set_ring_search.argtypes = [C.c_void_p, C.c_int]
+    L.visma_icp_get_ring_search.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.visma_icp_set_persistent_cu_share.argtypes = [C.c_double]
     L.visma_icp_get_persistent_info.argtypes = [C.c_void_p, C.POINTER(CPersistentInfo)]
     L.visma_icp_get_timing_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
@@ -550,10 +552,11 @@ class Context:
         return m.value
 
     def search_kernel_used(self):
-        """'brute' | 'serial' (lane-serial grid search) | 'warm' (warm-started wave-cooperative grid search)."""
+        """'brute' | 'serial' (lane-serial grid search) | 'warm' (warm-started wave-cooperative grid search) | 'ring' (cells
+        smaller than the radius, searched in rings: grid_ring.hip)."""
         v = C.c_int(0)
         self._chk(self.L.visma_icp_get_search_kernel_used(self._h, C.byref(v)))
-        return {0: "brute", 1: "serial", 2: "warm"}[v.value]
+        return {0: "brute", 1: "serial", 2: "warm", 3: "ring"}[v.value]
 
     def forget_winners(self):
         """The next pass runs like the first of a new registration (no warm start)."""
@@ -575,6 +578,16 @@ class Context:
         a, b = C.c_double(0.0), C.c_double(0.0)
         self._chk(self.L.visma_icp_get_sweep_info(self._h, C.byref(a), C.byref(b)))
         return {"launches": a.value, "aborts": b.value}
+
+    def set_ring_search(self, mode=-1):
+        """cells smaller than the radius, searched in rings (grid_ring.hip): -1 by occupancy, 0 never, 1 whenever possible"""
+        self._chk(self.L.visma_icp_set_ring_search(self._h, int(mode)))
+
+    def ring_search(self):
+        """what the current grid is (visma_icp_get_ring_search): rings > 0 = the ring search"""
+        r, c, o = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+        self._chk(self.L.visma_icp_get_ring_search(self._h, C.byref(r), C.byref(c), C.byref(o)))
+        return {"rings": r.value, "cell": c.value, "occupancy": o.value}
 
     def test_stall_command(self, nth, ms):
         self._chk(self.L.visma_icp_test_stall_command(self._h, int(nth), float(ms)))

@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libvisma_icp.so")
-SOURCES = ["kernels.hip", "grid.hip", "grid_coop.hip", "grid_wave.hip", "icp_loop.hip", "voxel.hip", "order.hip", "normals.hip", "mesh.hip", "hip_engine.cpp", "hip_engine_clouds.cpp", "hip_engine_passes.cpp", "hip_engine_comm.cpp", "driver.cpp", "aux_api.cpp", "corpus.cpp", "io.cpp"]
+SOURCES = ["kernels.hip", "grid.hip", "grid_coop.hip", "grid_wave.hip", "grid_ring.hip", "icp_loop.hip", "voxel.hip", "order.hip", "normals.hip", "mesh.hip", "hip_engine.cpp", "hip_engine_clouds.cpp", "hip_engine_passes.cpp", "hip_engine_comm.cpp", "driver.cpp", "aux_api.cpp", "corpus.cpp", "io.cpp"]
 HEADERS = ["kernels.h", "device_common.h", "so3.h", "host_math.hpp", "engine.hpp", "hip_engine.hpp", "driver_ctx.hpp", "grid_coop_probe.h", "plane_math.hpp",
            os.path.join("..", "..", "include", "visma_icp.h"), os.path.join("..", "..", "include", "visma_icp_testing.h")]
 

@@ -1035,6 +1035,20 @@ int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_persistent_info 
     return VISMA_ICP_OK;
 }
 
+int visma_icp_set_ring_search(visma_icp_ctx *ctx, int mode)
+{
+    CTX_CHECK();
+    ctx->eng->set_ring_search(mode);
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_get_ring_search(visma_icp_ctx *ctx, int *rings, double *cell, double *occupancy)
+{
+    CTX_CHECK();
+    ctx->eng->get_ring_search(rings, cell, occupancy);
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_get_sweep_info(visma_icp_ctx *ctx, double *launches, double *aborts)
 {
     CTX_CHECK();

@@ -277,6 +277,13 @@ public:
     // n passes (nn_pass + reduce, nothing else) -- an engine may then keep ONE launch alive across them (HipEngine:
     // the persistent certificate kernel).  loop_end() must follow on every path; LoopScope does that.
     virtual void set_persistent(int /*enabled*/, double /*timeout_ms*/) {}
+    virtual void set_ring_search(int /*mode*/) {}
+    virtual void get_ring_search(int *rings, double *cell, double *occupancy) const
+    {
+        if (rings) *rings = 0;
+        if (cell) *cell = 0.0;
+        if (occupancy) *occupancy = 0.0;
+    }
     virtual void get_persistent_info(visma_icp_persistent_info *out) const { (void)out; }
     virtual void get_sweep_info(double *launches, double *aborts) const { if (launches) *launches = 0.0; if (aborts) *aborts = 0.0; }
     virtual void stall_command(int /*nth*/, double /*ms*/) {}

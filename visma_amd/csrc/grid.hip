@@ -274,7 +274,46 @@ GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int6
     g.hs = g.sub == 2 ? 0.5f * h : h;
     g.inv_hs = 1.0f / g.hs;
     g.ncell = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
+    g.ring = 0;
+    g.pad_ = 0;
     return g;
+}
+
+// Cells of edge `cell` (smaller than the radius) for the ring search of grid_ring.hip: the table must fit like any other
+// (the edge grows until it does); g.ring = the largest ring of rows a radius can reach, + 1.  A cell that ends up as large
+// as the radius is the ordinary plan.
+GridParams grid_plan_ring(const float mn[3], const float mx[3], double max_dist, double cell, int64_t max_cells)
+{
+    GridParams g = grid_plan(mn, mx, max_dist, max_cells);
+    float h = (float)cell;
+    if (!(h > 0.f) || !isfinite(h) || !(h < g.h)) return g;
+    double ext[3];
+    for (int a = 0; a < 3; a++) {
+        ext[a] = (double)mx[a] - (double)mn[a];
+        if (!(ext[a] >= 0.0) || !isfinite(ext[a])) ext[a] = 0.0;
+    }
+    GridParams f = g;
+    for (;;) {
+        if (!(h < g.h)) return g;
+        double n = 1.0;
+        bool too_long = false;
+        for (int a = 0; a < 3; a++) {
+            const double d = floor(ext[a] / h) + 1.0;
+            if (d > (double)kGridMaxDim) too_long = true;      // (fp32 binning error below 1e-3 cell)
+            f.dim[a] = (int)std::min(d, 2.0e9);
+            n *= d;
+        }
+        if (n <= (double)max_cells && !too_long) break;
+        h *= 1.26f;
+    }
+    f.h = f.hs = h;
+    f.inv_h = f.inv_hs = 1.0f / h;
+    f.sub = 1;
+    f.ncell = (int64_t)f.dim[0] * f.dim[1] * f.dim[2];
+    const double rings = ceil(max_dist * 1.001 / (double)h) + 1.0;
+    if (rings > 256.0) return g;                              // (a radius of hundreds of cells: not this search's regime)
+    f.ring = (int)rings;
+    return f;
 }
 
 // cell_of: 2 * nt words (cell, rank of the point in its cell); bsum: grid_scan_blocks(g.ncell) + 1 words of scratch.
@@ -1006,6 +1045,15 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     int64_t want = (ns * G + kBlock - 1) / kBlock;
     int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
     if (nblocks < 1) nblocks = 1;
+    if (g.ring > 0) {
+        // cells smaller than the radius: the ring search (grid_ring.hip), eight lanes per query, f64 ranking
+        if (!src64 || G != 8 || persist) return hipErrorInvalidValue;
+        hipError_t e = launch_nn_ring(nblocks, nprob, (int)ns, src64, sorted64, start, g, tgt_normals, nrm64, T64, off, r2f,
+                                      point_to_plane, idx_out, d2_out, d64_out, prevq_io, warm & 1, partials, cand_count, st,
+                                      (long long)out_stride, fa, stream);
+        if (nblocks_out) *nblocks_out = nblocks;
+        return e;
+    }
     if (lanes_per_query == kCoopLanes) {
         if (src64 && exact && g.sub == 1 && prevq_io) {
             // the flattened exact search (grid_coop.hip): `sorted` is the packed 12-byte copy

@@ -32,7 +32,7 @@ public:
         for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_ru_); free_dev(d_partials_); free_dev(d_stats_);
         if (d_vox_out_) (void)hipFree(d_vox_out_);
-        free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_);
+        free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_); free_dev(d_occ_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_pos_); free_dev(bt_tgt_); free_dev(bt_sorted_);
@@ -248,6 +248,20 @@ public:
         persist_enabled_ = enabled != 0;
         persist_cooldown_ = 0;
         if (timeout_ms >= 0.5 && timeout_ms <= 5000.0) persist_timeout_ms_ = timeout_ms;
+    }
+    void set_ring_search(int mode) override
+    {
+        const int m = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+        if (m == ring_mode_) return;
+        if (sess_live_) (void)end_session();                 // (a launch that is alive searches the table that is about to go)
+        ring_mode_ = m;
+        grid_valid_ = false;                                 // the next pass plans its grid again
+    }
+    void get_ring_search(int *rings, double *cell, double *occupancy) const override
+    {
+        if (rings) *rings = grid_valid_ ? grid_.ring : 0;
+        if (cell) *cell = grid_valid_ ? (double)grid_.h : 0.0;
+        if (occupancy) *occupancy = grid_valid_ ? grid_occupancy_ : 0.0;
     }
     void get_sweep_info(double *launches, double *aborts) const override
     {
@@ -524,7 +538,8 @@ private:
     int cert_enabled_ = 1;       // VISMA_ICP_CERT=0: every query searched every pass (A/B timing)
     const Xform64 *cert_prev() const { return (cert_enabled_ && prev_T_valid_ && pos_fresh_) ? &prev_T_ : nullptr; }
     void note_state_pass(const Xform64 &T) { prev_T_ = T; prev_T_valid_ = true; }
-    int last_kernel_ = 0;        // what the last pass ran: 0 brute force, 1 lane-serial grid, 2 warm-started cooperative grid
+    int last_kernel_ = 0;        // what the last pass ran: 0 brute force, 1 lane-serial grid, 2 warm-started cooperative grid,
+                                 // 3 ring search over cells smaller than the radius (grid_ring.hip)
     int coop_enabled_ = 1;       // VISMA_ICP_COOP=0: every pass on the lane-serial kernel
     int invalidate_pos()
     {
@@ -537,14 +552,15 @@ private:
     bool coop_ok() const
     {
         // (the kernel addresses the candidate array with 32-bit byte offsets: 12 bytes per slot)
-        return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1 &&
+        return coop_enabled_ && exact_ && d_src64_ && d_sorted64_ && d_sorted12_ && d_pos_ && grid_.sub == 1 && grid_.ring == 0 &&
                (nt_ + kSortedSlack) * 12 < (1ll << 32);
     }
     // which kernel a lanes code selects (see launch_nn_grid_reduce)
-    int pass_kernel(int lanes) const { return (lanes == kCoopLanes && coop_ok()) ? 2 : 1; }
+    int pass_kernel(int lanes) const { return grid_.ring > 0 ? 3 : ((lanes == kCoopLanes && coop_ok()) ? 2 : 1); }
     // lanes code of the next grid pass over `nprob` problems sharing the clouds
     int pass_lanes(int nprob = 1) const
     {
+        if (grid_.ring > 0) return kRingLanes;               // cells smaller than the radius: the ring search, whatever is forced
         if (grid_lanes_ > 0) return grid_lanes_;
         if (coop_ok() && pos_fresh_) return kCoopLanes;
         // the FIRST pass of a large registration inside the persistent launch of its host loop (round 5, OPT-IN:
@@ -561,8 +577,18 @@ private:
     int cold_in_launch_ = 0;                 // VISMA_ICP_COLD_IN_LAUNCH=1: the first pass of large registrations inside the launch
     int64_t cold_in_launch_min_ns_ = 131072; // VISMA_ICP_COLD_IN_LAUNCH_MIN_NS (below: lane-serial 20 us vs 29 at 5 k)
     int grid_lanes_ = 0;   // lanes cooperating on one query; 0 = by source size (VISMA_ICP_GRID_LANES overrides)
+    // ---- radii that are large against the point spacing (grid_ring.hip): build_grid looks at the occupancy of the
+    // radius-sized table and, above ring_occ_min_ points per occupied cell, builds a finer one (ring_occ_target_ points per
+    // occupied cell, surfaces assumed: occupancy ~ edge^2) that the ring kernel searches.  VISMA_ICP_RING = 0 never,
+    // 1 whenever the f64 views exist and a finer table fits, unset: by occupancy.
+    static constexpr int kRingLanes = 208;   // lanes code of a ring pass: eight lanes per query (U unused)
+    int ring_mode_ = -1;
+    double ring_occ_min_ = 256.0, ring_occ_target_ = 8.0;
+    void *d_occ_ = nullptr;
+    double grid_occupancy_ = 0.0;            // points per occupied cell of the radius-sized table (0 = not measured)
     int grid_lanes(int nprob = 1) const
     {
+        if (grid_.ring > 0) return kRingLanes;
         if (grid_lanes_ > 0) return grid_lanes_;
         const int64_t q = ns_ * (int64_t)nprob;                  // queries of one launch
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality
@@ -598,7 +624,7 @@ private:
     bool use_tile() const
     {
 #ifdef VISMA_WITH_TILE
-        return tile_enabled_ && use_grid_ && exact_ && d_src64_ && d_sorted64_ && grid_.sub == 1 && !tshard_;
+        return tile_enabled_ && use_grid_ && exact_ && d_src64_ && d_sorted64_ && grid_.sub == 1 && grid_.ring == 0 && !tshard_;
 #else
         return false;
 #endif

@@ -58,6 +58,9 @@ int HipEngine::init()
     if (const char *e = std::getenv("VISMA_ICP_PERSIST")) persist_enabled_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_EARLY")) persist_early_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_SWEEP_PERSIST")) sweep_persist_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("VISMA_ICP_RING")) ring_mode_ = std::atoi(e) > 0 ? 1 : 0;
+    if (const char *e = std::getenv("VISMA_ICP_RING_OCCUPANCY")) { const double v = std::atof(e); if (v >= 1.0) ring_occ_min_ = v; }
+    if (const char *e = std::getenv("VISMA_ICP_RING_TARGET")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) ring_occ_target_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_RANKS")) persist_ranks_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH")) cold_in_launch_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_COLD_IN_LAUNCH_MIN_NS")) cold_in_launch_min_ns_ = std::max<long long>(0, std::atoll(e));
@@ -633,32 +636,68 @@ int HipEngine::build_grid(double max_dist)
         std::memcpy(mx, host_mx_, sizeof(mx));
     }
     grid_ = grid_plan(mn, mx, max_dist, kGridMaxCells, grid_sub_);
-    if ((int64_t)nt_ > sorted_cap_) {
-        free_dev(d_sorted_); free_dev(d_cell_of_);
-        HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * (nt_ + kSortedSlack)));   // batches read past a run's end
-        HIP_TRY(hipMalloc(&d_cell_of_, 2 * sizeof(unsigned) * nt_));   // (cell, rank in the cell)
-        sorted_cap_ = nt_;
+    grid_occupancy_ = 0.0;
+    // cells, counts, scan, scatter (+ the f64 and the packed copies) for the plan in grid_
+    auto build = [&]() -> int {
+        if ((int64_t)nt_ > sorted_cap_) {
+            free_dev(d_sorted_); free_dev(d_cell_of_);
+            HIP_TRY(hipMalloc(&d_sorted_, sizeof(float4) * (nt_ + kSortedSlack)));   // batches read past a run's end
+            HIP_TRY(hipMalloc(&d_cell_of_, 2 * sizeof(unsigned) * nt_));   // (cell, rank in the cell)
+            sorted_cap_ = nt_;
+        }
+        if (grid_.ncell + 1 > cell_cap_) {
+            free_dev(d_count_); free_dev(d_start_); free_dev(d_bsum_);
+            HIP_TRY(hipMalloc(&d_count_, sizeof(unsigned) * (grid_.ncell + 1)));
+            HIP_TRY(hipMalloc(&d_start_, sizeof(unsigned) * (grid_.ncell + 8)));    // (16-byte reads near the end)
+            HIP_TRY(hipMemsetAsync(d_start_, 0, sizeof(unsigned) * (grid_.ncell + 8), stream_));
+            HIP_TRY(hipMalloc(&d_bsum_, sizeof(unsigned) * (grid_scan_blocks(grid_.ncell) + 1)));
+            cell_cap_ = grid_.ncell + 1;
+        }
+        free_dev(d_sorted64_);
+        if (d_tgt64_ && d_src64_) { int prc = pool_alloc(&d_sorted64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt_, 1)); if (prc) return prc; }
+        HIP_TRY(launch_grid_build((const float4 *)d_tgt_, nt_, grid_, (unsigned *)d_cell_of_,
+                                  (unsigned *)d_count_, (unsigned *)d_bsum_, (unsigned *)d_start_,
+                                  (float4 *)d_sorted_, stream_, d_sorted64_ ? (const Pt64 *)d_tgt64_ : nullptr,
+                                  (Pt64 *)d_sorted64_));
+        // the exact search ranks on a packed copy: 12 bytes per candidate (grid.hip: P12)
+        free_dev(d_sorted12_);
+        if (d_sorted64_) {
+            int prc = pool_alloc(&d_sorted12_, sizeof(float) * 3 * (size_t)(nt_ + kSortedSlack));
+            if (prc) return prc;
+            HIP_TRY(launch_pack12((const float4 *)d_sorted_, (float *)d_sorted12_, nt_, stream_));
+        }
+        return VISMA_ICP_OK;
+    };
+    {
+        int brc = build();
+        if (brc) return brc;
     }
-    if (grid_.ncell + 1 > cell_cap_) {
-        free_dev(d_count_); free_dev(d_start_); free_dev(d_bsum_);
-        HIP_TRY(hipMalloc(&d_count_, sizeof(unsigned) * (grid_.ncell + 1)));
-        HIP_TRY(hipMalloc(&d_start_, sizeof(unsigned) * (grid_.ncell + 8)));    // (16-byte reads near the end)
-        HIP_TRY(hipMemsetAsync(d_start_, 0, sizeof(unsigned) * (grid_.ncell + 8), stream_));
-        HIP_TRY(hipMalloc(&d_bsum_, sizeof(unsigned) * (grid_scan_blocks(grid_.ncell) + 1)));
-        cell_cap_ = grid_.ncell + 1;
-    }
-    free_dev(d_sorted64_);
-    if (d_tgt64_ && d_src64_) { int prc = pool_alloc(&d_sorted64_, sizeof(Pt64) * (size_t)std::max<int64_t>(nt_, 1)); if (prc) return prc; }
-    HIP_TRY(launch_grid_build((const float4 *)d_tgt_, nt_, grid_, (unsigned *)d_cell_of_,
-                              (unsigned *)d_count_, (unsigned *)d_bsum_, (unsigned *)d_start_,
-                              (float4 *)d_sorted_, stream_, d_sorted64_ ? (const Pt64 *)d_tgt64_ : nullptr,
-                              (Pt64 *)d_sorted64_));
-    // the exact search ranks on a packed copy: 12 bytes per candidate (grid.hip: P12)
-    free_dev(d_sorted12_);
-    if (d_sorted64_) {
-        int prc = pool_alloc(&d_sorted12_, sizeof(float) * 3 * (size_t)(nt_ + kSortedSlack));
-        if (prc) return prc;
-        HIP_TRY(launch_pack12((const float4 *)d_sorted_, (float *)d_sorted12_, nt_, stream_));
+    // ---- a radius that is large against the point spacing?  (grid_ring.hip)  The radius-sized table tells: points per
+    // occupied cell.  Counted only where it can matter -- the count is a pass over the table and a round trip: a surface
+    // occupies a few n^2 of a table of n^3 cells, so its occupancy is at most ~n times the mean over ALL cells (C4:
+    // 0.08 x 428 = 34, not counted; r = 0.15 m on the same target: 524 x 20, counted: 2,800).
+    const bool ring_possible = ring_mode_ != 0 && d_tgt64_ && d_src64_ && nt_ > 0 && grid_sub_ <= 1 && grid_.sub == 1 &&
+                               nn_mode_ != VISMA_ICP_NN_BRUTE;
+    const double occ_guess = (double)nt_ / (double)std::max<int64_t>(grid_.ncell, 1) *
+                             (double)std::max(grid_.dim[0], std::max(grid_.dim[1], grid_.dim[2]));
+    if (ring_possible && (ring_mode_ > 0 || occ_guess >= ring_occ_min_)) {
+        if (!d_occ_) HIP_TRY(hipMalloc(&d_occ_, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(d_occ_, 0, sizeof(unsigned long long), stream_));
+        HIP_TRY(launch_count_occupied((const unsigned *)d_count_, grid_.ncell, (unsigned long long *)d_occ_, stream_));
+        unsigned long long occupied = 0ull;
+        HIP_TRY(hipMemcpyAsync(&occupied, d_occ_, sizeof(occupied), hipMemcpyDeviceToHost, stream_));
+        HIP_TRY(hipStreamSynchronize(stream_));
+        grid_occupancy_ = occupied ? (double)nt_ / (double)occupied : 0.0;
+        if (grid_occupancy_ > ring_occ_target_ && (ring_mode_ > 0 || grid_occupancy_ >= ring_occ_min_)) {
+            // surfaces: the occupancy falls with the square of the edge
+            const double cell = (double)grid_.h * std::sqrt(ring_occ_target_ / grid_occupancy_);
+            const GridParams fine = grid_plan_ring(mn, mx, max_dist, cell, kGridMaxCells);
+            if (fine.ring > 0) {
+                grid_ = fine;
+                int brc = build();
+                if (brc) return brc;
+            }
+        }
     }
     if (profiling_) { HIP_TRY(hipEventRecord(ev_[e0 + 1], stream_)); pending_.push_back({e0, 2}); }
     grid_valid_ = true;

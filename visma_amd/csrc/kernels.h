@@ -266,6 +266,9 @@ struct GridParams {
     int sub;          // 1, or 2: rows (y,z) at half pitch -- 25 thinner rows instead of 9
     float hs, inv_hs; // h / sub and its reciprocal
     int64_t ncell;
+    int ring;         // 0: cells at least as large as the search radius (27-cell neighbourhoods); > 0: cells SMALLER than
+                      // the radius, searched in rings of rows (grid_ring.hip) -- the largest ring a radius can reach, + 1
+    int pad_;
 };
 constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;        // at sub = 1
 constexpr int64_t kGridMaxCellsFine = 256ll * 1024 * 1024;   // at sub = 2 (1 GiB table)
@@ -333,6 +336,8 @@ hipError_t launch_grid_bbox(const float4 *tgt, int64_t nt, unsigned *box6, hipSt
 hipError_t launch_pack12(const float4 *src, float *dst, int64_t n, hipStream_t stream);   // (x,y,z,w) -> packed (x,y,z)
 void grid_decode_bbox(const unsigned box6[6], float mn[3], float mx[3]);
 GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int64_t max_cells, int max_sub = 1);
+// the same table with cells of edge `cell` < max_dist (enlarged until the table fits), for the ring search (grid_ring.hip)
+GridParams grid_plan_ring(const float mn[3], const float mx[3], double max_dist, double cell, int64_t max_cells);
 int grid_scan_blocks(int64_t ncell);
 
 // ---- mesh steps (mesh.hip): host arrays in, host arrays out -------------------
@@ -424,6 +429,16 @@ struct SweepArgs {
     int passes0;               // DevIcpState::passes of every problem when the launch begins (its first pass makes it passes0 + 1)
     long long wait_ticks;      // how long a workgroup waits for its problem's next transform (100 MHz ticks)
 };
+// ---- the ring search over cells smaller than the radius (grid_ring.hip; g.ring > 0): `nblocks` workgroups per problem,
+// eight lanes per query, candidates ranked in f64.  state_io: per query the winner's f64 point and original index (all bits
+// set = none), read when `warm`, always written.
+hipError_t launch_nn_ring(int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const unsigned *start,
+                          const GridParams &g, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64, const Offset64 &off,
+                          float r2f, int point_to_plane, int32_t *idx_out, float *d2_out, double *d64_out, Pt64 *state_io,
+                          int warm, double *partials, unsigned long long *cand_count, const DevIcpState *st,
+                          long long out_stride, const FoldArgs &fold, hipStream_t stream);
+// *out (device, zeroed by the caller) += the number of non-zero entries of count[0 .. n)
+hipError_t launch_count_occupied(const unsigned *count, int64_t n, unsigned long long *out, hipStream_t stream);
 int nn_wave_sweep_capacity();
 hipError_t launch_nn_wave_sweep(int bpp, int nprob, int ns, const float *s12, const unsigned *start, const GridParams &g,
                                 float r2f, int32_t *idx_out, float *d2_out, double *partials, unsigned long long *cand_count,
