@@ -115,7 +115,7 @@ ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffi
                  "cold_pass_avg_ms")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "ms_per_iter", "gpu_vs_cpu_rel_frobenius")
 CONFIG_KEYS = ("workload", "ns", "nt", "radius", "solver", "nn", "search", "problems", "work_items", "parallelism")
-SCALAR_EXTRAS = ("value_converged", "value_partial_overlap", "fitness", "inlier_rmse", "err_vs_T_gt",
+SCALAR_EXTRAS = ("value_converged", "value_partial_overlap", "value_literal_T_gt", "fitness", "inlier_rmse", "err_vs_T_gt",
                  "ranks_hold_identical_transforms", "matched_corr_per_sec", "problems_per_sec", "registrations_per_sec")
 
 
@@ -508,6 +508,10 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
     b_alg = queries * per_query + 16.0 * rows_per_launch + cand_bytes * cand_per_launch
     if exact and kernel in ("warm", "wave"):
         b_alg = warm_bytes(queries, certified_per_launch if kernel == "warm" else 0.0, rows_per_launch, cand_per_launch)
+    if kernel == "ring":
+        # grid_ring.hip, per query: source 32 B + state in 32 B + state out 32 B + (index, d2) 8 B + the f64 points of the
+        # rounding band 33.6 B; per row looked up two table words + its entry of the visiting order (16 B); 12 B per candidate
+        b_alg = queries * (32.0 + 32.0 + 32.0 + 8.0 + 33.6) + 16.0 * rows_per_launch + 12.0 * cand_per_launch
     comp = nt_total * cand_bytes + queries * (32.0 + 8.0 if exact else 24.0)
     # SURVEY 8d / BASELINE.md 3: B_alg = ceil(NS / S_TILE) NT 16 + NS 24 -- a search that reads the target once has
     # S_TILE = NS: B_min = NT 16 + NS 24.  Since round 4 `achieved` / `frac` are quoted on THESE bytes (the same formula
@@ -523,6 +527,8 @@ def grid_roofline(queries, nt_total, nn_ms, cand_per_launch, rows_per_launch, tr
                            "cells listed, one chunk list per workgroup ranked by all its waves; f64 re-rank; fold fused)",
                    "wave": "nn_wave_kernel (grid_wave.hip: round 3's warm-started wave-cooperative exact search, no certificates: "
                            "what batches and sweeps run after their first pass; fold fused)",
+                   "ring": "nn_ring_kernel (grid_ring.hip: cells smaller than the radius, rows visited nearest first and bounded "
+                           "by the best so far / the previous winner; fp32 ranking + f64 re-rank of the rounding band; fold fused)",
                    "serial": "nn_grid_reduce_kernel" + (" (exact: fp32 ranking + f64 re-rank of the rounding band; fold fused)"
                                                         if exact else "")}[kernel],
         "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS,
@@ -682,7 +688,7 @@ def kernel_roofline(ctx, ns_local, nt_local, tm, traffic_kind=None, persist_traf
     key = {"warm": "grid_warm", "serial": "grid"}.get(kind, "grid")
     r = grid_roofline(ns_local, nt_local, tm["nn_ms"] / nl, tm["grid_candidates"] / nl,
                       tm["grid_candidates_27cell"] / nl, load_traffic(traffic_kind or key, ns_local, nt_local),
-                      ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial") else "serial",
+                      ctx.search_mode_used() != "f32", kind if kind in ("warm", "serial", "ring") else "serial",
                       tm["grid_certified"] / nl)
     return persistent_launches(r, tm, ns_local if traffic_kind != "none" else 0, nt_local, persist_traffic_key)
 
@@ -1034,13 +1040,20 @@ def run_c4(R, args):
             out["value_partial_overlap_converged"] = out["partial_overlap"]["continuing"]["icp_iterations_per_sec"]
             out["value_partial_overlap_from_initial_pose"] = out["value_partial_overlap"]
             del psrc, ptgt
-            # SURVEY 8d's literal ground truth (5 deg yaw, 1 deg pitch, ~3 cm) needs a radius of 0.15 m to converge:
-            # twelve point spacings at 65,536 target points -- at 4,194,304 points that radius holds 15,000 points
-            # per query, outside what a radius-sized cell grid is for
-            lsrc, ltgt, lT, _ = synth.make_pair(16384, 65536, motion="fixed")
+            # SURVEY 8d's literal ground truth (5 deg yaw, 1 deg pitch, ~3 cm) needs a radius of 0.15 m to converge: at
+            # 4,194,304 target points that radius holds 15,000 points per query and 3,200 per occupied radius-sized cell --
+            # the regime of the ring search over cells of a few point spacings (grid_ring.hip, round 6; chosen by the
+            # library from the occupancy).  At the headline's sizes, and at 16,384 -> 65,536 (52 points per cell)
+            lsrc, ltgt, lT, _ = synth.make_pair(ns, nt, motion="fixed")
             out["literal_T_gt"] = c4_variant(R, R.local_rank, lsrc, ltgt, 0.15, lT, args.steps,
                                              "SURVEY 8d's T_gt = R_y(5 deg) R_x(1 deg), t = (0.02, -0.01, 0.015) on "
-                                             "S-surf 16,384 -> 65,536, radius 0.15")
+                                             "S-surf %d -> %d, radius 0.15" % (ns, nt))
+            out["value_literal_T_gt"] = out["literal_T_gt"]["from_initial_pose"]["icp_iterations_per_sec"]
+            del lsrc, ltgt
+            lsrc, ltgt, lT, _ = synth.make_pair(16384, 65536, motion="fixed")
+            out["literal_T_gt_small"] = c4_variant(R, R.local_rank, lsrc, ltgt, 0.15, lT, args.steps,
+                                                   "the same motion on S-surf 16,384 -> 65,536, radius 0.15")
+            del lsrc, ltgt
         if brute is not None:
             b = brute_roofline(ns_local, nt_local, brute["nn_ms"], tile, load_traffic("brute", ns_local, nt_local))
             b.update(steps=brute["steps"], ms_per_step=brute["ms_per_step"],

@@ -452,7 +452,7 @@ VISMA_ICP_API int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_pe
  * cells of a few point spacings instead and searches them in rings of rows around the query, nearest first, bounded by the
  * best candidate so far and, after the first pass, by the previous winner (grid_ring.hip): the same correspondences, bit
  * for bit; the cost of a query follows the number of points nearer than its nearest neighbour, not the radius.
- *  visma_icp_set_ring_search(ctx, mode): -1 (default) by the occupancy of the radius-sized cells (>= 256 points per
+ *  visma_icp_set_ring_search(ctx, mode): -1 (default) by the occupancy of the radius-sized cells (>= 48 points per
  *    occupied cell; VISMA_ICP_RING_OCCUPANCY), 0 never, 1 whenever the f64 views exist and a finer table fits (also
  *    VISMA_ICP_RING=0/1 when the context is created).  Takes effect at the next grid build (new target or radius).
  *  visma_icp_get_ring_search(ctx, ...): what the current grid is: *rings > 0 = ring search with that many rings at most,

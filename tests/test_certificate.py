@@ -67,6 +67,7 @@ def test_certified_passes_equal_searched_passes_bit_for_bit(lib, name, ns, nt, r
     c = _lib.Context(0)
     for x in (ref, nocert, c):
         x.set_nn_mode(lib.NN_GRID)
+        x.set_ring_search(0)       # (this test is about the certificate kernel: "big radius" would go to grid_ring.hip by itself)
         x.set_clouds_f64(src, tgt)
     c.set_profiling(1)
     # ICP-like: a pose near the truth, then motions decaying geometrically, a standstill, one jump, decay again

@@ -22,11 +22,16 @@ os.environ["VISMA_ICP_GRID_LANES"] = "801"
 serial = _lib.Context(0)                                 # the lane-serial kernel, one query per lane, every pass
 os.environ.pop("VISMA_ICP_COOP", None)
 os.environ.pop("VISMA_ICP_GRID_LANES", None)
-for c in (warm, serial):
+ring = _lib.Context(0)                                   # the ring search over cells smaller than the radius (grid_ring.hip),
+ring.set_ring_search(1)                                  # wherever a finer table than the radius-sized one exists
+for c in (warm, serial, ring):
     c.set_nn_mode(_lib.NN_GRID)
+for c in (warm, serial):
+    c.set_ring_search(0)                                 # (these two are about the radius-cell kernels)
 warm.set_profiling(1)
 queries = 0
 bad = 0
+ring_passes = ring_bad = 0
 used = {}
 for it in range(N):
     kind = int(rng.integers(0, 7))
@@ -62,7 +67,7 @@ for it in range(N):
     else:              # the bench's surface
         src, tgt, _, r = synth.make_pair(ns, max(nt, 8), seed_t=int(rng.integers(1 << 30)), seed_s=int(rng.integers(1 << 30)), motion="radius")
         r *= 10.0 ** rng.uniform(-0.5, 0.5)
-    for c in (warm, serial):
+    for c in (warm, serial, ring):
         c.set_clouds_f64(src, tgt)
     T = synth.make_T(synth.rot_y(rng.uniform(-0.2, 0.2)), rng.standard_normal(3) * r * 0.5)
     # in radii; pass 0 is the first (lane-serial on both); the decaying tail is what ICP does -- where the certificate
@@ -76,6 +81,21 @@ for it in range(N):
             c.nn_pass(T, r)
             st = c.reduce()
             out.append((c.correspondence_index(), c.get_correspondences()[2].view(np.uint32), st.view(np.uint64)))
+        # the ring search against the lane-serial kernel: indices and distances bit for bit, statistics to rounding
+        # (another summation order)
+        ring.nn_pass(T, r)
+        rst = ring.reduce()
+        ridx, rd2 = ring.correspondence_index(), ring.get_correspondences()[2].view(np.uint32)
+        if ring.search_kernel_used() == "ring":
+            ring_passes += 1
+            sst = out[1][2].view(np.float64)
+            tol = 1e-10 * np.maximum(np.abs(sst), np.abs(sst).max() * 1e-3 + 1e-300)
+            if not (np.array_equal(ridx, out[1][0]) and np.array_equal(rd2, out[1][1]) and rst[0] == sst[0] and
+                    np.all(np.abs(rst - sst) <= tol)):
+                ring_bad += 1
+                d = np.flatnonzero(ridx != out[1][0])
+                print("RING MISMATCH it=%d kind=%d pass=%d ns=%d nt=%d r=%g: %d indices differ (first %s), grid %s" %
+                      (it, kind, p, ns, nt, r, len(d), d[:5], ring.ring_search()), flush=True)
         queries += ns if p > 0 else 0
         k = warm.search_kernel_used()
         used[k] = used.get(k, 0) + 1
@@ -92,4 +112,5 @@ for it in range(N):
 cert = warm.get_timing()["grid_certified"]
 print("done: %d configurations x 13 passes, kernels used %s, %.1f %% of the warm passes' queries certified (no search), %d mismatches"
       % (N, used, 100.0 * cert / max(queries, 1), bad))
-sys.exit(1 if bad else 0)
+print("ring search (grid_ring.hip, forced wherever a finer table exists): %d passes, %d ring mismatches" % (ring_passes, ring_bad))
+sys.exit(1 if bad or ring_bad else 0)

@@ -275,7 +275,8 @@ GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int6
     g.inv_hs = 1.0f / g.hs;
     g.ncell = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
     g.ring = 0;
-    g.pad_ = 0;
+    g.ring_rows = 0;
+    g.ring_tab = nullptr;
     return g;
 }
 
@@ -287,6 +288,7 @@ GridParams grid_plan_ring(const float mn[3], const float mx[3], double max_dist,
     GridParams g = grid_plan(mn, mx, max_dist, max_cells);
     float h = (float)cell;
     if (!(h > 0.f) || !isfinite(h) || !(h < g.h)) return g;
+    h = std::max(h, (float)(max_dist * 1.001 / (double)(kRingMaxRings - 2)));   // (no more rings than the table holds)
     double ext[3];
     for (int a = 0; a < 3; a++) {
         ext[a] = (double)mx[a] - (double)mn[a];
@@ -311,8 +313,10 @@ GridParams grid_plan_ring(const float mn[3], const float mx[3], double max_dist,
     f.sub = 1;
     f.ncell = (int64_t)f.dim[0] * f.dim[1] * f.dim[2];
     const double rings = ceil(max_dist * 1.001 / (double)h) + 1.0;
-    if (rings > 256.0) return g;                              // (a radius of hundreds of cells: not this search's regime)
+    if (rings > (double)kRingMaxRings) return g;
     f.ring = (int)rings;
+    f.ring_rows = (2 * f.ring + 1) * (2 * f.ring + 1);
+    f.ring_tab = nullptr;                                     // (the caller's: build_ring_table)
     return f;
 }
 
@@ -1046,9 +1050,11 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     int nblocks = (int)(want > max_partial_blocks ? max_partial_blocks : want);
     if (nblocks < 1) nblocks = 1;
     if (g.ring > 0) {
-        // cells smaller than the radius: the ring search (grid_ring.hip), eight lanes per query, f64 ranking
-        if (!src64 || G != 8 || persist) return hipErrorInvalidValue;
-        hipError_t e = launch_nn_ring(nblocks, nprob, (int)ns, src64, sorted64, start, g, tgt_normals, nrm64, T64, off, r2f,
+        // cells smaller than the radius: the ring search (grid_ring.hip), G lanes per query
+        if (!src64 || persist) return hipErrorInvalidValue;
+        // (`sorted` is the packed 12-byte copy when the search is the exact one: HipEngine::search_sorted)
+        hipError_t e = launch_nn_ring(G, nblocks, nprob, (int)ns, src64, sorted64, exact ? (const float *)sorted : nullptr, start, g,
+                                      tgt_normals, nrm64, T64, off, r2f,
                                       point_to_plane, idx_out, d2_out, d64_out, prevq_io, warm & 1, partials, cand_count, st,
                                       (long long)out_stride, fa, stream);
         if (nblocks_out) *nblocks_out = nblocks;

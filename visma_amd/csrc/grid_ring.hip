@@ -19,24 +19,60 @@
 // (KDTreeFlann.cpp:184-185), ties go to the lowest original index -- the arithmetic of nn_grid_reduce_kernel<F64>.  Rows
 // and cells are pruned with the fp32 view and that kernel's margins (1e-3 cell on every slab distance, 1e-5 relative on
 // the squared bound, the bound rounded up), strictly: a pruned candidate is strictly farther than the best, so it could
-// neither win nor tie.  Eight lanes work on one query: each looks up one row of a ring, the octet then scans the eight
-// x-ranges side by side, eight candidates per step; the partial minima meet in a butterfly on (d2, index).
+// neither win nor tie.  With the packed fp32 copy of the target (12 B per candidate; the exact search's default) the walk
+// ranks in fp32 and keeps, per lane, the two best and the value of the third; the candidates inside the rounding band of
+// the octet's best (nn_grid_reduce_kernel<HYB>'s band) are then ranked in f64, and a lane that saw a third candidate inside
+// the band sends its query through the f64 walk -- the result is the f64 walk's either way.
+// Eight lanes work on one query: each looks up two rows of the ring sequence per step and scans their (short) x-ranges
+// itself -- sixteen independent streams per query; a long range (first rows of a cold pass, rows inside a surface) is
+// scanned by the octet, eight candidates per step; the partial minima meet in a butterfly on (d2, index).
 // Statistics, outputs, fold: as nn_grid_reduce_kernel (same accumulators, block_reduce_store, fused_fold).
 #include "device_common.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
 
 namespace visma {
 
 namespace {
 
-constexpr int kRingG = 8;                       // lanes per query
-constexpr int kRingU = 2;                       // 32-byte candidates in flight per lane
+// (lanes per query G and rows of the visiting order per lane and step R are template parameters: launch_nn_ring)
+constexpr int kRingLocal = 16;                  // a range up to this long is scanned by the lane that looked it up ...
+constexpr int kRingV = 2;                       // ... that many fp32 candidates of it in flight
+constexpr int kRingRowsLds = 512;               // rows of the visiting order kept in LDS (4 KB)
+constexpr int kRingU = 2;                       // 32-byte candidates in flight per lane (ranges scanned by the octet)
 constexpr unsigned kRingNone = 0xFFFFFFFFu;     // no winner (the largest index: loses every tie)
 constexpr unsigned kRingState = 0xFFFFFFFEu;    // the winner is the point the state holds (no slot known)
 
-template <bool PLANE>
+struct P12 { float x, y, z; };                  // fp32 rounding of a cell-sorted f64 target point (launch_pack12)
+
+// the two best (d2, slot) a lane has seen and the value of the third: every candidate not recorded is at least h2 away
+struct Top2 {
+    float h0, h1, h2;
+    unsigned p0, p1;
+    __device__ __forceinline__ void init(float lim)
+    {
+        h0 = h1 = h2 = lim;
+        p0 = p1 = kRingNone;
+    }
+    __device__ __forceinline__ void insert(float d, unsigned pos)
+    {
+        const bool c0 = d < h0, c1 = d < h1, c2 = d < h2;
+        h2 = c1 ? h1 : (c2 ? d : h2);
+        p1 = c0 ? p0 : (c1 ? pos : p1);
+        h1 = c0 ? h0 : (c1 ? d : h1);
+        p0 = c0 ? pos : p0;
+        h0 = c0 ? d : h0;
+    }
+};
+
+// ONE: every octet has at most one query (the launcher's geometry): the sums are formed after the search, nothing of
+// them is live during it.
+template <bool PLANE, bool ONE, int kRingG, int kRingR>
 __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
-    int ns, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64, const unsigned *__restrict__ start,
-    const GridParams g, const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, float r2f,
+    int ns, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64, const P12 *__restrict__ s12,
+    const unsigned *__restrict__ start, const GridParams g, const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, float r2f,
     int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ d64_out, Pt64 *__restrict__ state_io, int warm,
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count, const DevIcpState *__restrict__ st, int bpp,
     long long out_stride, const FoldArgs fold)
@@ -54,11 +90,10 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
     idx_out += (long long)prob * out_stride;
     d2_out += (long long)prob * out_stride;
     if (state_io) state_io += (long long)prob * out_stride;
-    double acc[NACC];
-#pragma unroll
-    for (int a = 0; a < NACC; a++) acc[a] = 0.0;
     unsigned long long ncand = 0ull, nrows_seen = 0ull;
 
+    static_assert(kRingG == 1 || kRingG == 2 || kRingG == 4 || kRingG == 8, "lanes per query");
+    constexpr unsigned long long kGroupMask = (1ull << kRingG) - 1ull;
     const int tid = (int)threadIdx.x, lane = tid & 63, l8 = lane & (kRingG - 1), obase = lane & ~(kRingG - 1);
     // the query -> octet map: nn_grid_reduce_kernel's (one contiguous eighth of the Morton-ordered queries per XCD)
     int vb = lb;
@@ -76,13 +111,21 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
     const float mgn = 1e-3f;                               // fp32 binning of query and candidates (kGridMaxDim)
     const float reach = (float)(K + 1);                    // cells: farther outside the table than this = no partner
 
-    int it = 0;
-    for (long long i = i_begin; i < i_end; i++, it++) {
-        // ---- the query: the reference's transform of a source point (PointCloud.cpp:75-80), in f64
+    // the head of the visiting order (what a converging registration reads) in LDS
+    __shared__ RingRow s_rows[kRingRowsLds];
+    const RingRow *tab = reinterpret_cast<const RingRow *>(g.ring_tab);
+    for (int n = tid; n < kRingRowsLds && n < g.ring_rows; n += kBlock) s_rows[n] = tab[n];
+    __syncthreads();
+    auto row_of = [&](int n) { return n < kRingRowsLds ? s_rows[n] : tab[n]; };
+
+    // ---- one query: its transformed point (pd), its winner (w8; false = none); outputs written by the octet's first lane
+    auto search = [&](long long i, double (&pd)[3], Pt64 &w8) -> bool {
+        // the reference's transform of a source point (PointCloud.cpp:75-80), in f64
         const Pt64 s8 = src64[i];
         const double pxd = T64.m[0] * s8.x + T64.m[1] * s8.y + T64.m[2] * s8.z + T64.m[3] * 1.0;
         const double pyd = T64.m[4] * s8.x + T64.m[5] * s8.y + T64.m[6] * s8.z + T64.m[7] * 1.0;
         const double pzd = T64.m[8] * s8.x + T64.m[9] * s8.y + T64.m[10] * s8.z + T64.m[11] * 1.0;
+        pd[0] = pxd; pd[1] = pyd; pd[2] = pzd;
         const float px = (float)pxd, py = (float)pyd, pz = (float)pzd;
         double bd = r2d;                                   // best d2 so far (strictly below r2d once set) ...
         unsigned bidx = kRingNone, bpos = kRingNone;       // ... its original index, its slot
@@ -104,50 +147,70 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
         Pt64 prev = Pt64{0.0, 0.0, 0.0, ~0ull};
         if (warm && state_io) prev = state_io[i];
         if ((unsigned)prev.w != kRingNone) rank(prev, kRingState);
+        const double bd0 = bd;
+        const unsigned bidx0 = bidx, bpos0 = bpos;
 
-        // the best so far as fp32, rounded UP a little, the smallest of the octet
-        auto octet_best = [&]() {
-            float f = (float)bd;
-            f += f * 1e-6f;
-#pragma unroll
-            for (int m = kRingG >> 1; m > 0; m >>= 1) f = fminf(f, __shfl_xor(f, m, 64));
-            return f;
-        };
+        // fp32 ranking (the packed 12-byte copy): rounding band as in nn_grid_reduce_kernel<HYB> -- p32 = fl(p64),
+        // q32 = fl(q64), E more than twice the bound of |d64 - sqrt(d2_32)| for candidates within the limit
+        const float r_f = sqrtf(r2f);
+        const float rup = r_f * (1.0f + 2.4e-7f);
+        const float E = 2.4e-7f * (fabsf(px) + fabsf(py) + fabsf(pz) + rup) + 4.8e-7f * rup;
+        Top2 top;
+        top.init(INFINITY);
+        // candidates at or beyond the limit never matter: the radius, or the previous winner's distance
+        const float sp = fminf(rup, sqrtf((float)bd) * (1.0f + 2.4e-7f)) + 2.0f * E;
+        const float lim = sp * sp * (1.0f + 6e-7f);
+
         const float ux = (px - g.mn[0]) * g.inv_h, uy = (py - g.mn[1]) * g.inv_h, uz = (pz - g.mn[2]) * g.inv_h;
         // (written so that a NaN query is outside)
         const bool inside = ux >= -reach && ux <= (float)g.dim[0] + reach && uy >= -reach && uy <= (float)g.dim[1] + reach &&
                             uz >= -reach && uz <= (float)g.dim[2] + reach;
-        if (inside) {
-            const float flx = floorf(ux), fly = floorf(uy), flz = floorf(uz);
-            const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
-            const float fx = ux - flx, fy = uy - fly, fz = uz - flz;      // position inside the cell, [0, 1)
-            const float lo_x = fmaxf(fx - mgn, 0.f), hi_x = fmaxf(1.0f - fx - mgn, 0.f);
-            const float lo_y = fmaxf(fy - mgn, 0.f), hi_y = fmaxf(1.0f - fy - mgn, 0.f);
-            const float lo_z = fmaxf(fz - mgn, 0.f), hi_z = fmaxf(1.0f - fz - mgn, 0.f);
-            const float face = fminf(fminf(lo_y, hi_y), fminf(lo_z, hi_z));
-            float gbest = octet_best();
-            for (int k = 0; k <= K; k++) {
-                if (k > 0) {
-                    // every row of ring k and beyond is at least (k - 1 + face) cells away in y or in z
-                    const float m = (float)(k - 1) + face;
-                    if (m * m * h2 > gbest) break;
+        const float flx = floorf(ux), fly = floorf(uy), flz = floorf(uz);
+        const int cx = (int)flx, cy = (int)fly, cz = (int)flz;
+        const float fx = ux - flx, fy = uy - fly, fz = uz - flz;          // position inside the cell, [0, 1)
+
+        // ---- the walk over the rows, ring by ring, sixteen rows of the sequence per step.  F32: candidates are the packed
+        // fp32 points, kept as the two best per lane + the value of the third; else: the f64 points, ranked at once.
+        auto walk = [&](auto f32_tag) {
+            constexpr bool F32 = decltype(f32_tag)::value;
+            // fp32 binning of query and candidates (kGridMaxDim) [+ the rounding band]
+            const float mg = F32 ? mgn + 4.0f * E * g.inv_h : mgn;
+            const float lo_x = fmaxf(fx - mg, 0.f), hi_x = fmaxf(1.0f - fx - mg, 0.f);
+            const float lo_y = fmaxf(fy - mg, 0.f), hi_y = fmaxf(1.0f - fy - mg, 0.f);
+            const float lo_z = fmaxf(fz - mg, 0.f), hi_z = fmaxf(1.0f - fz - mg, 0.f);
+            // what a candidate must not exceed to matter, as a squared fp32 distance rounded UP, the octet's smallest
+            auto octet_best = [&]() {
+                float f;
+                if constexpr (F32) {
+                    const float s1 = sqrtf(top.h0) + 2.0f * E;           // (nothing seen yet: inf)
+                    f = fminf(s1 * s1 * (1.0f + 4e-7f), lim);
+                } else {
+                    f = (float)bd;
+                    f += f * 1e-6f;
                 }
-                const int nrows = k == 0 ? 1 : 8 * k;
-                for (int r0 = 0; r0 < nrows; r0 += kRingG) {
-                    // ---- one row of the ring per lane: its slab bound, its x-extent, its range of the sorted target
-                    const int r = r0 + l8;
-                    int dy = 0, dz = 0;
-                    if (k > 0) {
-                        const int side = r / (2 * k), t = r - side * 2 * k;      // the ring's perimeter, once round
-                        dy = side == 0 ? -k + t : (side == 1 ? k : (side == 2 ? k - t : -k));
-                        dz = side == 0 ? -k : (side == 1 ? -k + t : (side == 2 ? k : k - t));
-                    }
+#pragma unroll
+                for (int m = kRingG >> 1; m > 0; m >>= 1) f = fminf(f, __shfl_xor(f, m, 64));
+                return f;
+            };
+            float gbest = octet_best();
+            const int total = g.ring_rows;
+#pragma unroll 1
+            for (int n0 = 0; n0 < total; n0 += kRingG * kRingR) {
+                // the rows come nearest first: every row from here on is at least sqrt(base) cells away
+                if (row_of(n0).base * h2 > gbest) break;
+                // ---- kRingR rows of the sequence per lane: slab bound, x-extent, range of the sorted target
+                unsigned rb[kRingR], re[kRingR];
+#pragma unroll
+                for (int u = 0; u < kRingR; u++) {
+                    const int n = n0 + u * kRingG + l8;
+                    const RingRow rr = row_of(n < total ? n : 0);
+                    const int dy = rr.dy, dz = rr.dz;
                     const float ey = dy == 0 ? 0.f : (dy < 0 ? lo_y + (float)(-dy - 1) : hi_y + (float)(dy - 1));
                     const float ez = dz == 0 ? 0.f : (dz < 0 ? lo_z + (float)(-dz - 1) : hi_z + (float)(dz - 1));
                     const float bound = (ey * ey + ez * ez) * h2;
                     const int y = cy + dy, z = cz + dz;
-                    const bool ok = r < nrows && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && !(bound > gbest);
-                    unsigned rb = 0u, re = 0u;
+                    const bool ok = n < total && y >= 0 && y < g.dim[1] && z >= 0 && z < g.dim[2] && !(bound > gbest);
+                    rb[u] = re[u] = 0u;
                     if (ok) {
                         // cells of the row that can hold a point within the bound: x-cell cx + d (d >= 1) is at least
                         // hi_x + d - 1 cells away, cx - d at least lo_x + d - 1 (one cell more never hurts)
@@ -157,37 +220,132 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
                         const int x0 = max(cx - dxm, 0), x1 = min(cx + dxp, g.dim[0] - 1);
                         if (x0 <= x1) {
                             const unsigned row = (unsigned)((z * g.dim[1] + y) * g.dim[0]);
-                            rb = start[row + (unsigned)x0];
-                            re = start[row + (unsigned)x1 + 1u];
+                            rb[u] = start[row + (unsigned)x0];
+                            re[u] = start[row + (unsigned)x1 + 1u];
                             nrows_seen += 1ull;
                         }
                     }
-                    // ---- the octet scans the eight ranges one after the other, eight candidates per step
+                }
+                // ---- short ranges (nearly all: a row of a few cells holds a few points): each lane scans its own,
+                // its rows side by side -- sixteen independent streams per octet, nothing crosses lanes
+                {
+                    unsigned b[kRingR], e[kRingR];
+                    bool more = false;
+#pragma unroll
+                    for (int u = 0; u < kRingR; u++) {
+                        const bool local = re[u] - rb[u] <= (unsigned)kRingLocal;
+                        b[u] = rb[u];
+                        e[u] = local ? re[u] : rb[u];
+                        ncand += (unsigned long long)(e[u] - b[u]);
+                        more = more || b[u] < e[u];
+                    }
 #pragma unroll 1
-                    for (int j = 0; j < kRingG; j++) {
-                        const unsigned b = (unsigned)__shfl((int)rb, obase + j, 64);
-                        const unsigned e = (unsigned)__shfl((int)re, obase + j, 64);
-                        const float bnd = __shfl(bound, obase + j, 64);
-                        if (b >= e || bnd > gbest) continue;        // (octet-uniform)
+                    while (more) {
+                        if constexpr (F32) {
+                            // (kRingV candidates of each row in flight: a range of kRingLocal is worked off in a few trips)
+                            P12 q[kRingR][kRingV];
+#pragma unroll
+                            for (int u = 0; u < kRingR; u++)
+#pragma unroll
+                                for (int v = 0; v < kRingV; v++) q[u][v] = s12[b[u] + (unsigned)v < e[u] ? b[u] + (unsigned)v : rb[0]];
+                            more = false;
+#pragma unroll
+                            for (int u = 0; u < kRingR; u++) {
+#pragma unroll
+                                for (int v = 0; v < kRingV; v++) {
+                                    const float d = sqdist_f32(make_float4(q[u][v].x, q[u][v].y, q[u][v].z, 0.f), px, py, pz);
+                                    const bool real = b[u] + (unsigned)v < e[u];
+                                    top.insert((real && d < lim) ? d : INFINITY, b[u] + (unsigned)v);
+                                }
+                                b[u] = min(b[u] + (unsigned)kRingV, e[u]);
+                                more = more || b[u] < e[u];
+                            }
+                        } else {
+                            Pt64 q[kRingR];
+#pragma unroll
+                            for (int u = 0; u < kRingR; u++) q[u] = sorted64[b[u] < e[u] ? b[u] : rb[0]];
+                            more = false;
+#pragma unroll
+                            for (int u = 0; u < kRingR; u++) {
+                                if (b[u] < e[u]) { rank(q[u], b[u]); b[u]++; }
+                                more = more || b[u] < e[u];
+                            }
+                        }
+                    }
+                }
+                // ---- long ranges (the first rows of a cold pass, rows that run inside a surface): the octet scans them
+                // one after the other, eight candidates per step
+#pragma unroll
+                for (int u = 0; u < kRingR; u++) {
+                    unsigned m8 = (unsigned)(__builtin_amdgcn_ballot_w64(re[u] - rb[u] > (unsigned)kRingLocal) >> obase) & (unsigned)kGroupMask;
+#pragma unroll 1
+                    while (m8) {
+                        const int j = __builtin_ctz(m8);
+                        m8 &= m8 - 1u;
+                        const unsigned b = (unsigned)__shfl((int)rb[u], obase + j, 64);
+                        const unsigned e = (unsigned)__shfl((int)re[u], obase + j, 64);
                         if (l8 == 0) ncand += (unsigned long long)(e - b);
 #pragma unroll 1
                         for (unsigned base = b; base < e; base += kRingG * kRingU) {
-                            Pt64 q[kRingU];
-                            unsigned jc[kRingU];
+                            if constexpr (F32) {
+                                P12 q[kRingU];
+                                unsigned jc[kRingU];
 #pragma unroll
-                            for (int u = 0; u < kRingU; u++) {
-                                // a slot past the end re-reads the range's first point: evaluating a candidate twice
-                                // cannot change the (d2, index) minimum
-                                const unsigned ju = base + (unsigned)(l8 + u * kRingG);
-                                jc[u] = ju < e ? ju : b;
-                                q[u] = sorted64[jc[u]];
+                                for (int v = 0; v < kRingU; v++) {
+                                    jc[v] = base + (unsigned)(l8 + v * kRingG);
+                                    q[v] = s12[jc[v] < e ? jc[v] : b];
+                                }
+#pragma unroll
+                                for (int v = 0; v < kRingU; v++) {
+                                    float d = sqdist_f32(make_float4(q[v].x, q[v].y, q[v].z, 0.f), px, py, pz);
+                                    d = (jc[v] < e && d < lim) ? d : INFINITY;   // (a padding slot is not a candidate)
+                                    top.insert(d, jc[v]);
+                                }
+                            } else {
+                                Pt64 q[kRingU];
+                                unsigned jc[kRingU];
+#pragma unroll
+                                for (int v = 0; v < kRingU; v++) {
+                                    // a slot past the end re-reads the range's first point: evaluating a candidate twice
+                                    // cannot change the (d2, index) minimum
+                                    const unsigned ju = base + (unsigned)(l8 + v * kRingG);
+                                    jc[v] = ju < e ? ju : b;
+                                    q[v] = sorted64[jc[v]];
+                                }
+#pragma unroll
+                                for (int v = 0; v < kRingU; v++) rank(q[v], jc[v]);
                             }
-#pragma unroll
-                            for (int u = 0; u < kRingU; u++) rank(q[u], jc[u]);
                         }
-                        gbest = octet_best();
                     }
                 }
+                gbest = octet_best();
+            }
+        };
+        if (inside) {
+            bool exact_walk = s12 == nullptr;
+            if (!exact_walk) {
+                walk(std::true_type{});
+                // ---- decisive?  every candidate inside the rounding band of the octet's best is ranked in f64; a lane
+                // that saw a third one inside the band does not know its position: the query is searched again in f64
+                float m = top.h0;
+#pragma unroll
+                for (int k = kRingG >> 1; k > 0; k >>= 1) m = fminf(m, __shfl_xor(m, k, 64));
+                const float s1 = sqrtf(m) + 2.0f * E;
+                const float s1sq = s1 * s1 * (1.0f + 4e-7f);
+                const bool over = top.h2 < INFINITY && top.h2 <= s1sq;   // (inf: no third candidate)
+                exact_walk = ((__builtin_amdgcn_ballot_w64(over) >> obase) & kGroupMask) != 0ull;
+                if (!exact_walk) {
+                    const bool in0 = top.h0 <= s1sq && top.h0 < INFINITY, in1 = top.h1 <= s1sq && top.h1 < INFINITY;
+                    Pt64 c0 = Pt64{0.0, 0.0, 0.0, 0ull}, c1 = Pt64{0.0, 0.0, 0.0, 0ull};
+                    if (in0) c0 = sorted64[top.p0];
+                    if (in1) c1 = sorted64[top.p1];
+                    if (in0) rank(c0, top.p0);
+                    if (in1) rank(c1, top.p1);
+                }
+            }
+            if (exact_walk) {
+                bd = bd0; bidx = bidx0; bpos = bpos0;
+                walk(std::false_type{});
             }
         }
         // ---- butterfly over the octet: smallest (d2, index) wins everywhere (none = the largest index: loses every tie)
@@ -200,7 +358,7 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
         }
         bpos = (unsigned)__shfl((int)bpos, obase, 64);       // (lanes that tie on (d2, index) may hold different slots of it)
         const bool found = bpos != kRingNone;
-        Pt64 w8 = prev;
+        w8 = prev;
         if (found && bpos != kRingState) w8 = sorted64[bpos];
         if (l8 == 0) {
             if (state_io) {
@@ -214,14 +372,36 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
             d2_out[i] = (float)bd;
             if (d64_out) d64_out[i] = bd;                    // (target-sharded ranks compare shards in f64)
         }
-        // lane (it mod 8) of the octet adds this query's correspondence to its sums
-        if (found && (it & (kRingG - 1)) == l8) {
-            double nx = 0.0, ny = 0.0, nz = 0.0;
-            if (PLANE) {
-                if (nrm64) { const Pt64 n8 = nrm64[(unsigned)w8.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
-                else { const float4 n4 = nrm[(unsigned)w8.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
-            }
-            accumulate_pq_d<PLANE>(acc, pxd, pyd, pzd, w8.x, w8.y, w8.z, nx, ny, nz, off);
+        return found;
+    };
+    auto add_pair = [&](double *acc, const double (&pd)[3], const Pt64 &w8) {
+        double nx = 0.0, ny = 0.0, nz = 0.0;
+        if (PLANE) {
+            if (nrm64) { const Pt64 n8 = nrm64[(unsigned)w8.w]; nx = n8.x; ny = n8.y; nz = n8.z; }
+            else { const float4 n4 = nrm[(unsigned)w8.w]; nx = n4.x; ny = n4.y; nz = n4.z; }
+        }
+        accumulate_pq_d<PLANE>(acc, pd[0], pd[1], pd[2], w8.x, w8.y, w8.z, nx, ny, nz, off);
+    };
+
+    double acc[NACC];
+    if constexpr (ONE) {
+        double pd[3] = {0.0, 0.0, 0.0};
+        Pt64 w8 = Pt64{0.0, 0.0, 0.0, ~0ull};
+        bool found = false;
+        if (i_begin < i_end) found = search(i_begin, pd, w8);
+#pragma unroll
+        for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+        if (found && l8 == 0) add_pair(acc, pd, w8);
+    } else {
+#pragma unroll
+        for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+        int it = 0;
+        for (long long i = i_begin; i < i_end; i++, it++) {
+            double pd[3];
+            Pt64 w8;
+            const bool found = search(i, pd, w8);
+            // lane (it mod 8) of the octet adds this query's correspondence to its sums
+            if (found && (it & (kRingG - 1)) == l8) add_pair(acc, pd, w8);
         }
     }
     block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
@@ -255,26 +435,65 @@ __global__ __launch_bounds__(256) void count_occupied_kernel(const unsigned *__r
 
 }  // namespace
 
-// `nblocks` workgroups per problem, `nprob` problems over shared clouds (st: their loop states or NULL); g.ring > 0.
+// `lanes` (1, 2, 4, 8) lanes per query, `nblocks` workgroups per problem, `nprob` problems over shared clouds (st: their loop
+// states or NULL); g.ring > 0.
 // state_io: per query the winner's f64 point and original index (all bits set = none), laid out like idx_out: read when
 // `warm` (every entry must be none or a point of THIS target), always written.
-hipError_t launch_nn_ring(int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const unsigned *start,
+hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const float *s12, const unsigned *start,
                           const GridParams &g, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64, const Offset64 &off,
                           float r2f, int point_to_plane, int32_t *idx_out, float *d2_out, double *d64_out, Pt64 *state_io,
                           int warm, double *partials, unsigned long long *cand_count, const DevIcpState *st,
                           long long out_stride, const FoldArgs &fold, hipStream_t stream)
 {
-    if (!src64 || !sorted64 || !start || g.ring < 1 || g.sub != 1 || nblocks < 1 || nprob < 1) return hipErrorInvalidValue;
+    if (!src64 || !sorted64 || !start || g.ring < 1 || g.sub != 1 || !g.ring_tab || g.ring_rows < 1 || nblocks < 1 || nprob < 1 ||
+        (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8))
+        return hipErrorInvalidValue;
     if (point_to_plane && !nrm && !nrm64) return hipErrorInvalidValue;
-    if (point_to_plane)
-        hipLaunchKernelGGL(nn_ring_kernel<true>, dim3(nblocks * nprob), dim3(kBlock), 0, stream, ns, src64, sorted64, start, g,
-                           nrm, nrm64, T64, off, r2f, idx_out, d2_out, d64_out, state_io, warm, partials, cand_count, st, nblocks,
-                           out_stride, fold);
-    else
-        hipLaunchKernelGGL(nn_ring_kernel<false>, dim3(nblocks * nprob), dim3(kBlock), 0, stream, ns, src64, sorted64, start, g,
-                           nrm, nrm64, T64, off, r2f, idx_out, d2_out, d64_out, state_io, warm, partials, cand_count, st, nblocks,
-                           out_stride, fold);
+    const bool one = (long long)nblocks * (kBlock / lanes) >= (long long)ns;       // at most one query per lane group
+#define VISMA_RING_LAUNCH(PLANE_, ONE_, G_, R_)                                                                                  \
+    hipLaunchKernelGGL((nn_ring_kernel<PLANE_, ONE_, G_, R_>), dim3(nblocks * nprob), dim3(kBlock), 0, stream, ns, src64,        \
+                       sorted64, reinterpret_cast<const P12 *>(s12), start, g, nrm, nrm64, T64, off, r2f, idx_out, d2_out,       \
+                       d64_out, state_io, warm, partials, cand_count, st, nblocks, out_stride, fold)
+#define VISMA_RING_CASE(G_, R_)                                                                                                  \
+    if (lanes == G_) {                                                                                                           \
+        if (point_to_plane) { if (one) VISMA_RING_LAUNCH(true, true, G_, R_); else VISMA_RING_LAUNCH(true, false, G_, R_); }     \
+        else { if (one) VISMA_RING_LAUNCH(false, true, G_, R_); else VISMA_RING_LAUNCH(false, false, G_, R_); }                  \
+    }
+    VISMA_RING_CASE(8, 2) VISMA_RING_CASE(4, 4) VISMA_RING_CASE(2, 4) VISMA_RING_CASE(1, 8)
+#undef VISMA_RING_CASE
+#undef VISMA_RING_LAUNCH
     return hipGetLastError();
+}
+
+// The visiting order of the rows around a query for `rings` rings: every offset (dy, dz) of the square, sorted by the squared
+// distance (in cells) that a point of the row is at least away from ANY point of the query's own row of cells -- the same
+// for every query, so the order is a table.  Ties: by |dy| + |dz|, then dy, then dz (any fixed order would do).
+hipError_t build_ring_table(int rings, void **d_tab, int *nrows)
+{
+    if (rings < 1 || rings > kRingMaxRings || !d_tab || !nrows) return hipErrorInvalidValue;
+    const int side = 2 * rings + 1;
+    std::vector<RingRow> rows;
+    rows.reserve((size_t)side * side);
+    for (int dz = -rings; dz <= rings; dz++)
+        for (int dy = -rings; dy <= rings; dy++) {
+            const int ay = std::max(std::abs(dy) - 1, 0), az = std::max(std::abs(dz) - 1, 0);
+            rows.push_back(RingRow{(short)dy, (short)dz, (float)(ay * ay + az * az)});
+        }
+    std::sort(rows.begin(), rows.end(), [](const RingRow &a, const RingRow &b) {
+        if (a.base != b.base) return a.base < b.base;
+        const int ma = std::abs((int)a.dy) + std::abs((int)a.dz), mb = std::abs((int)b.dy) + std::abs((int)b.dz);
+        if (ma != mb) return ma < mb;
+        if (a.dy != b.dy) return a.dy < b.dy;
+        return a.dz < b.dz;
+    });
+    void *d = nullptr;
+    hipError_t e = hipMalloc(&d, sizeof(RingRow) * rows.size());
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(d, rows.data(), sizeof(RingRow) * rows.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return e; }
+    *d_tab = d;
+    *nrows = (int)rows.size();
+    return hipSuccess;
 }
 
 // *out (device, zeroed by the caller) += the number of entries of count[0 .. n) that are not zero

@@ -32,7 +32,7 @@ public:
         for (int i = 0; i < 4; i++) if (pin_[i]) (void)hipHostFree(pin_[i]);
         free_dev(d_idx_); free_dev(d_d2_); free_dev(d_pos_); free_dev(d_ru_); free_dev(d_partials_); free_dev(d_stats_);
         if (d_vox_out_) (void)hipFree(d_vox_out_);
-        free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_); free_dev(d_occ_);
+        free_dev(d_box_); free_dev(d_sorted_); free_dev(d_cell_of_); free_dev(d_count_); free_dev(d_occ_); free_dev(d_ring_tab_);
         free_dev(d_start_); free_dev(d_bsum_); free_dev(d_cand_); free_dev(d_state_);
         free_dev(d_partials2_); free_dev(d_tickets_); free_dev(d_tstats_); free_dev(d_second_);
         free_dev(bt_src_); free_dev(bt_idx_); free_dev(bt_d2_); free_dev(bt_pos_); free_dev(bt_tgt_); free_dev(bt_sorted_);
@@ -513,6 +513,9 @@ private:
         // more workgroups keep it that way -- the fold of their partial rows costs less
         // than running the multi-round variant (1M sources: 0.12 vs 0.17 ms per iteration)
         if (grid_blocks_env_ > 0) return grid_blocks_env_;
+        // (the ring search works eight lanes per query and hides its dependent trips behind other waves: one query per
+        //  octet up to a million queries)
+        if (grid_.ring > 0) return (int)std::min<int64_t>(kGridMaxBlocks, std::max<int64_t>(1024, (ns_ * ring_lanes_ + kBlock - 1) / kBlock));
         if (ns_ <= 262144) return 1024;
         return (int)std::min<int64_t>(kGridMaxBlocks, (ns_ + kBlock - 1) / kBlock);
     }
@@ -560,7 +563,7 @@ private:
     // lanes code of the next grid pass over `nprob` problems sharing the clouds
     int pass_lanes(int nprob = 1) const
     {
-        if (grid_.ring > 0) return kRingLanes;               // cells smaller than the radius: the ring search, whatever is forced
+        if (grid_.ring > 0) return ring_lanes();             // cells smaller than the radius: the ring search, whatever is forced
         if (grid_lanes_ > 0) return grid_lanes_;
         if (coop_ok() && pos_fresh_) return kCoopLanes;
         // the FIRST pass of a large registration inside the persistent launch of its host loop (round 5, OPT-IN:
@@ -581,14 +584,19 @@ private:
     // radius-sized table and, above ring_occ_min_ points per occupied cell, builds a finer one (ring_occ_target_ points per
     // occupied cell, surfaces assumed: occupancy ~ edge^2) that the ring kernel searches.  VISMA_ICP_RING = 0 never,
     // 1 whenever the f64 views exist and a finer table fits, unset: by occupancy.
-    static constexpr int kRingLanes = 208;   // lanes code of a ring pass: eight lanes per query (U unused)
+    int ring_lanes_ = 8;                     // lanes per query of a ring pass (VISMA_ICP_RING_LANES: 1, 2, 4, 8)
+    int ring_lanes() const { return 200 + ring_lanes_; }   // (a lanes code: G + 100 U, U unused)
     int ring_mode_ = -1;
-    double ring_occ_min_ = 256.0, ring_occ_target_ = 8.0;
-    void *d_occ_ = nullptr;
+    // (48: measured, tools/ring_policy_probe.py -- single registrations gain from ~20 points per occupied cell on (1.5x at 21,
+    //  3.8x at 52, 7.6x at 84), yaw sweeps, whose far-off starts leave most queries without a partner -- the ring walk's
+    //  worst case: every row of the radius ball -- lose up to 3x below ~50 and gain 1.8-2x from there)
+    double ring_occ_min_ = 48.0, ring_occ_target_ = 8.0;
+    void *d_occ_ = nullptr, *d_ring_tab_ = nullptr;
+    int ring_tab_rings_ = 0;
     double grid_occupancy_ = 0.0;            // points per occupied cell of the radius-sized table (0 = not measured)
     int grid_lanes(int nprob = 1) const
     {
-        if (grid_.ring > 0) return kRingLanes;
+        if (grid_.ring > 0) return ring_lanes();
         if (grid_lanes_ > 0) return grid_lanes_;
         const int64_t q = ns_ * (int64_t)nprob;                  // queries of one launch
         // measured on MI355X: small clouds need the extra parallelism, large ones the locality

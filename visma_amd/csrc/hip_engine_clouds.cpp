@@ -59,6 +59,7 @@ int HipEngine::init()
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_EARLY")) persist_early_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_SWEEP_PERSIST")) sweep_persist_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_RING")) ring_mode_ = std::atoi(e) > 0 ? 1 : 0;
+    if (const char *e = std::getenv("VISMA_ICP_RING_LANES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) ring_lanes_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_RING_OCCUPANCY")) { const double v = std::atof(e); if (v >= 1.0) ring_occ_min_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_RING_TARGET")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) ring_occ_target_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_RANKS")) persist_ranks_ = std::atoi(e) != 0;
@@ -675,7 +676,7 @@ int HipEngine::build_grid(double max_dist)
     // ---- a radius that is large against the point spacing?  (grid_ring.hip)  The radius-sized table tells: points per
     // occupied cell.  Counted only where it can matter -- the count is a pass over the table and a round trip: a surface
     // occupies a few n^2 of a table of n^3 cells, so its occupancy is at most ~n times the mean over ALL cells (C4:
-    // 0.08 x 428 = 34, not counted; r = 0.15 m on the same target: 524 x 20, counted: 2,800).
+    // 0.08 x 428 = 34, not counted; r = 0.15 m on the same target: 524 x 20, counted: 3,200).
     const bool ring_possible = ring_mode_ != 0 && d_tgt64_ && d_src64_ && nt_ > 0 && grid_sub_ <= 1 && grid_.sub == 1 &&
                                nn_mode_ != VISMA_ICP_NN_BRUTE;
     const double occ_guess = (double)nt_ / (double)std::max<int64_t>(grid_.ncell, 1) *
@@ -693,7 +694,16 @@ int HipEngine::build_grid(double max_dist)
             const double cell = (double)grid_.h * std::sqrt(ring_occ_target_ / grid_occupancy_);
             const GridParams fine = grid_plan_ring(mn, mx, max_dist, cell, kGridMaxCells);
             if (fine.ring > 0) {
+                // the rows' visiting order around a query (the same for every query: a table per ring count)
+                if (!d_ring_tab_ || ring_tab_rings_ != fine.ring) {
+                    free_dev(d_ring_tab_);
+                    ring_tab_rings_ = 0;
+                    int nrows = 0;
+                    HIP_TRY(build_ring_table(fine.ring, &d_ring_tab_, &nrows));
+                    ring_tab_rings_ = fine.ring;
+                }
                 grid_ = fine;
+                grid_.ring_tab = d_ring_tab_;
                 int brc = build();
                 if (brc) return brc;
             }

@@ -268,8 +268,13 @@ struct GridParams {
     int64_t ncell;
     int ring;         // 0: cells at least as large as the search radius (27-cell neighbourhoods); > 0: cells SMALLER than
                       // the radius, searched in rings of rows (grid_ring.hip) -- the largest ring a radius can reach, + 1
-    int pad_;
+    int ring_rows;    // ... entries of ring_tab: (2 ring + 1)^2
+    const void *ring_tab;   // ... the row offsets (dy, dz) around a query, nearest first (device memory; RingRow[ring_rows])
 };
+// one row of the ring search's visiting order: its offset from the query's row and the squared distance (in cells) that
+// every point of it is at least away from any point of the query's cell row: max(|dy| - 1, 0)^2 + max(|dz| - 1, 0)^2
+struct RingRow { short dy, dz; float base; };
+constexpr int kRingMaxRings = 64;   // cells are enlarged until a radius spans no more rings than this
 constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;        // at sub = 1
 constexpr int64_t kGridMaxCellsFine = 256ll * 1024 * 1024;   // at sub = 2 (1 GiB table)
 constexpr int kGridMaxDim = 2048;   // per axis at sub = 1: keeps the fp32 binning error < 1e-3 cell
@@ -430,13 +435,16 @@ struct SweepArgs {
     long long wait_ticks;      // how long a workgroup waits for its problem's next transform (100 MHz ticks)
 };
 // ---- the ring search over cells smaller than the radius (grid_ring.hip; g.ring > 0): `nblocks` workgroups per problem,
-// eight lanes per query, candidates ranked in f64.  state_io: per query the winner's f64 point and original index (all bits
+// eight lanes per query; s12 (the packed fp32 copy of sorted64, 12 bytes per point) or NULL: candidates ranked in fp32 with
+// the f64 re-rank of the rounding band, or in f64 throughout -- same results.  state_io: per query the winner's f64 point and original index (all bits
 // set = none), read when `warm`, always written.
-hipError_t launch_nn_ring(int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const unsigned *start,
+hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const float *s12, const unsigned *start,
                           const GridParams &g, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64, const Offset64 &off,
                           float r2f, int point_to_plane, int32_t *idx_out, float *d2_out, double *d64_out, Pt64 *state_io,
                           int warm, double *partials, unsigned long long *cand_count, const DevIcpState *st,
                           long long out_stride, const FoldArgs &fold, hipStream_t stream);
+// the visiting order of a grid with g.ring = rings (a new device buffer the caller owns: hipFree); *nrows = (2 rings + 1)^2
+hipError_t build_ring_table(int rings, void **d_tab, int *nrows);
 // *out (device, zeroed by the caller) += the number of non-zero entries of count[0 .. n)
 hipError_t launch_count_occupied(const unsigned *count, int64_t n, unsigned long long *out, hipStream_t stream);
 int nn_wave_sweep_capacity();
