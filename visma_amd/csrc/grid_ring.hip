@@ -38,10 +38,20 @@ namespace visma {
 namespace {
 
 // (lanes per query G and rows of the visiting order per lane and step R are template parameters: launch_nn_ring)
-constexpr int kRingLocal = 16;                  // a range up to this long is scanned by the lane that looked it up ...
-constexpr int kRingV = 2;                       // ... that many fp32 candidates of it in flight
+#ifndef VISMA_RING_LOCAL
+#define VISMA_RING_LOCAL 4
+#endif
+#ifndef VISMA_RING_V
+#define VISMA_RING_V 2
+#endif
+#ifndef VISMA_RING_U
+#define VISMA_RING_U 2
+#endif
+constexpr int kRingLocal = VISMA_RING_LOCAL;    // a range up to this long is scanned by the lane that looked it up (4: measured,
+                                                // 240 -> 201 us per iteration against 16; 0 = every range by the octet: 204) ...
+constexpr int kRingV = VISMA_RING_V;                       // ... that many fp32 candidates of it in flight
 constexpr int kRingRowsLds = 512;               // rows of the visiting order kept in LDS (4 KB)
-constexpr int kRingU = 2;                       // 32-byte candidates in flight per lane (ranges scanned by the octet)
+constexpr int kRingU = VISMA_RING_U;                       // 32-byte candidates in flight per lane (ranges scanned by the octet)
 constexpr unsigned kRingNone = 0xFFFFFFFFu;     // no winner (the largest index: loses every tie)
 constexpr unsigned kRingState = 0xFFFFFFFEu;    // the winner is the point the state holds (no slot known)
 
