@@ -248,3 +248,59 @@ def test_target_shard_device_loop_through_rccl(lib, plane):
         assert synth.rel_frobenius(got.transformation_, want.transformation_) < (1e-7 if plane else 1e-12)
         assert np.array_equal(ctx.correspondence_index(), want_idx)
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shard", ["target", "source"])
+def test_sharded_ranks_through_the_ring_search(lib, shard, monkeypatch):
+    """Round 6: a radius that is large against the point spacing sends every rank's search to grid_ring.hip (forced here:
+    the shards of a target each see their own occupancy).  Target shards exchange the f64 distances the ring kernel writes
+    (d64_out) and the claimed indices; source shards only the sums.  The result must be the single context's on radius-sized
+    cells: identical correspondences, transform to summation order."""
+    src, tgt, T_gt, _ = synth.make_pair(6000, 50000, motion="fixed")
+    radius = 0.15
+    ref = _lib.Context(0)
+    ref.set_nn_mode(_lib.NN_GRID)
+    ref.set_ring_search(0)
+    ref.set_clouds_f64(src, tgt)
+    want = ref.run(None, radius, 10, 0, 0)
+    want_idx = ref.correspondence_index()
+    assert ref.search_kernel_used() != "ring"
+    monkeypatch.setenv("VISMA_ICP_RING", "1")                # (read when the ranks' contexts are created)
+    if shard == "target":
+        out, ex = run_sharded(src, tgt, radius, 10, _lib.NN_GRID, [0, 21111, len(tgt)])
+        assert ex.calls["sum"] == 11 and ex.calls["min"] == 22
+        for res, idx in out:
+            assert np.array_equal(idx, want_idx)
+            assert res.num_correspondences == want.num_correspondences
+            assert synth.rel_frobenius(res.transformation_, want.transformation_) < 1e-11
+        assert np.array_equal(out[0][0].transformation_, out[1][0].transformation_)
+        return
+    n = 2
+    ex = Exchange(n)
+    cuts = [0, 2500, len(src)]
+    out, kernels, err = [None] * n, [None] * n, []
+
+    def worker(rank):
+        try:
+            ctx = _lib.Context(0)
+            ctx.set_nn_mode(_lib.NN_GRID)
+            ctx.set_clouds_f64(src[cuts[rank]:cuts[rank + 1]], tgt)
+            ctx.set_global_source_count(len(src))
+            ctx.set_allreduce(ex.allreduce(rank), rank, n)
+            out[rank] = ctx.run(None, radius, 10, 0, 0)
+            kernels[rank] = (ctx.search_kernel_used(), ctx.correspondence_index())
+        except Exception as e:                  # pragma: no cover
+            err.append(e)
+            ex.barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not err, err
+    for r, res in enumerate(out):
+        assert kernels[r][0] == "ring"
+        assert np.array_equal(kernels[r][1], want_idx[cuts[r]:cuts[r + 1]])
+        assert res.num_correspondences == want.num_correspondences
+        assert synth.rel_frobenius(res.transformation_, want.transformation_) < 1e-11
+    assert np.array_equal(out[0].transformation_, out[1].transformation_)
