@@ -55,6 +55,8 @@ CASES = [
     ("seven targets", 300, 7, 0.5, 0, 1.0, ("small", "large")),
     ("several queries per octet", 300000, 100000, 0.1, 0, None, ("small", "large")),
     ("65k-1M r=0.1", 65536, 1048576, 0.1, 0, None, ("small", "small")),
+    # (more queries than lane groups: the launch's cap of 32,768 workgroups -- the variant that keeps its sums live)
+    ("1.2M queries", 1200000, 150000, 0.08, 0, None, ("small",)),
 ]
 
 
@@ -128,6 +130,20 @@ def test_registrations_agree(lib, loop):
     assert np.abs(a.transformation_ - b.transformation_).max() < 1e-10
     assert abs(a.fitness_ - b.fitness_) < 1e-12 and abs(a.inlier_rmse_ - b.inlier_rmse_) < 1e-10
     assert np.abs(b.transformation_ - T_gt).max() < 5e-3
+
+
+def test_device_loop_with_several_queries_per_lane_group(lib):
+    """Device-resident loops cap a problem at 1,024 workgroups: 100,000 queries are three per lane group."""
+    src, tgt, T_gt, _ = synth.make_pair(100000, 120000, motion="fixed")
+    ref, ring = pair_of_contexts(lib, src, tgt)
+    out = []
+    for c in (ref, ring):
+        c.set_device_loop(True)
+        out.append(c.run(None, 0.12, 12))
+    a, b = out
+    assert ring.search_kernel_used() == "ring" and a.iterations == b.iterations
+    assert np.abs(a.transformation_ - b.transformation_).max() < 1e-10 and abs(a.fitness_ - b.fitness_) < 1e-12
+    assert np.array_equal(ref.correspondence_index(), ring.correspondence_index())
 
 
 def test_yaw_sweep_and_point_to_plane_agree(lib):
