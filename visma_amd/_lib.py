@@ -192,8 +192,9 @@ def _bind(L):
     L.visma_icp_set_persistent.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_test_stall_command.argtypes = [C.c_void_p, C.c_int, C.c_double]
     L.visma_icp_get_sweep_info.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
-    L.visma_icp_set_ring_search.argtypes = [C.c_void_p, C.c_int]
-    L.visma_icp_get_ring_search.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    if hasattr(L, "visma_icp_set_ring_search"):          # (A/B runs load older builds through VISMA_ICP_LIB)
+        L.visma_icp_set_ring_search.argtypes = [C.c_void_p, C.c_int]
+        L.visma_icp_get_ring_search.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.visma_icp_set_persistent_cu_share.argtypes = [C.c_double]
     L.visma_icp_get_persistent_info.argtypes = [C.c_void_p, C.POINTER(CPersistentInfo)]
     L.visma_icp_get_timing_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

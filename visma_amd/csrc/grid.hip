@@ -275,8 +275,6 @@ GridParams grid_plan(const float mn[3], const float mx[3], double max_dist, int6
     g.inv_hs = 1.0f / g.hs;
     g.ncell = (int64_t)g.dim[0] * g.dim[1] * g.dim[2];
     g.ring = 0;
-    g.ring_rows = 0;
-    g.ring_tab = nullptr;
     return g;
 }
 
@@ -314,9 +312,7 @@ GridParams grid_plan_ring(const float mn[3], const float mx[3], double max_dist,
     f.ncell = (int64_t)f.dim[0] * f.dim[1] * f.dim[2];
     const double rings = ceil(max_dist * 1.001 / (double)h) + 1.0;
     if (rings > (double)kRingMaxRings) return g;
-    f.ring = (int)rings;
-    f.ring_rows = (2 * f.ring + 1) * (2 * f.ring + 1);
-    f.ring_tab = nullptr;                                     // (the caller's: build_ring_table)
+    f.ring = (int)rings;                                      // (its visiting order: build_ring_table)
     return f;
 }
 
@@ -1035,7 +1031,7 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  int nprob, int64_t out_stride, hipStream_t stream, const Pt64 *src64,
                                  const Pt64 *sorted64, double r2d, const Pt64 *nrm64, int exact,
                                  const FoldArgs *fold, double *d64_out, Pt64 *prevq_io, int warm, const Xform64 *Tprev,
-                                 const PersistArgs *persist, Pt64 *ru_io)
+                                 const PersistArgs *persist, Pt64 *ru_io, const RingTable *ring)
 {
     if ((src64 == nullptr) != (sorted64 == nullptr)) return hipErrorInvalidValue;
     // (the persistent launch exists for the certificate kernel only)
@@ -1051,10 +1047,10 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
     if (nblocks < 1) nblocks = 1;
     if (g.ring > 0) {
         // cells smaller than the radius: the ring search (grid_ring.hip), G lanes per query
-        if (!src64 || persist) return hipErrorInvalidValue;
+        if (!src64 || persist || !ring) return hipErrorInvalidValue;
         // (`sorted` is the packed 12-byte copy when the search is the exact one: HipEngine::search_sorted)
         hipError_t e = launch_nn_ring(G, nblocks, nprob, (int)ns, src64, sorted64, exact ? (const float *)sorted : nullptr, start, g,
-                                      tgt_normals, nrm64, T64, off, r2f,
+                                      *ring, tgt_normals, nrm64, T64, off, r2f,
                                       point_to_plane, idx_out, d2_out, d64_out, prevq_io, warm & 1, partials, cand_count, st,
                                       (long long)out_stride, fa, stream);
         if (nblocks_out) *nblocks_out = nblocks;

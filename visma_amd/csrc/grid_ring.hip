@@ -82,7 +82,8 @@ struct Top2 {
 template <bool PLANE, bool ONE, int kRingG, int kRingR>
 __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
     int ns, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64, const P12 *__restrict__ s12,
-    const unsigned *__restrict__ start, const GridParams g, const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, float r2f,
+    const unsigned *__restrict__ start, const GridParams g, const RingRow *__restrict__ tab, int ring_rows,
+    const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, float r2f,
     int *__restrict__ idx_out, float *__restrict__ d2_out, double *__restrict__ d64_out, Pt64 *__restrict__ state_io, int warm,
     double *__restrict__ partials, unsigned long long *__restrict__ cand_count, const DevIcpState *__restrict__ st, int bpp,
     long long out_stride, const FoldArgs fold)
@@ -123,8 +124,7 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
 
     // the head of the visiting order (what a converging registration reads) in LDS
     __shared__ RingRow s_rows[kRingRowsLds];
-    const RingRow *tab = reinterpret_cast<const RingRow *>(g.ring_tab);
-    for (int n = tid; n < kRingRowsLds && n < g.ring_rows; n += kBlock) s_rows[n] = tab[n];
+    for (int n = tid; n < kRingRowsLds && n < ring_rows; n += kBlock) s_rows[n] = tab[n];
     __syncthreads();
     auto row_of = [&](int n) { return n < kRingRowsLds ? s_rows[n] : tab[n]; };
 
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
                 return f;
             };
             float gbest = octet_best();
-            const int total = g.ring_rows;
+            const int total = ring_rows;
 #pragma unroll 1
             for (int n0 = 0; n0 < total; n0 += kRingG * kRingR) {
                 // the rows come nearest first: every row from here on is at least sqrt(base) cells away
@@ -450,19 +450,19 @@ __global__ __launch_bounds__(256) void count_occupied_kernel(const unsigned *__r
 // state_io: per query the winner's f64 point and original index (all bits set = none), laid out like idx_out: read when
 // `warm` (every entry must be none or a point of THIS target), always written.
 hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const float *s12, const unsigned *start,
-                          const GridParams &g, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64, const Offset64 &off,
-                          float r2f, int point_to_plane, int32_t *idx_out, float *d2_out, double *d64_out, Pt64 *state_io,
-                          int warm, double *partials, unsigned long long *cand_count, const DevIcpState *st,
+                          const GridParams &g, const RingTable &tab, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64,
+                          const Offset64 &off, float r2f, int point_to_plane, int32_t *idx_out, float *d2_out, double *d64_out,
+                          Pt64 *state_io, int warm, double *partials, unsigned long long *cand_count, const DevIcpState *st,
                           long long out_stride, const FoldArgs &fold, hipStream_t stream)
 {
-    if (!src64 || !sorted64 || !start || g.ring < 1 || g.sub != 1 || !g.ring_tab || g.ring_rows < 1 || nblocks < 1 || nprob < 1 ||
+    if (!src64 || !sorted64 || !start || g.ring < 1 || g.sub != 1 || !tab.rows || tab.nrows != (2 * g.ring + 1) * (2 * g.ring + 1) || nblocks < 1 || nprob < 1 ||
         (lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8))
         return hipErrorInvalidValue;
     if (point_to_plane && !nrm && !nrm64) return hipErrorInvalidValue;
     const bool one = (long long)nblocks * (kBlock / lanes) >= (long long)ns;       // at most one query per lane group
 #define VISMA_RING_LAUNCH(PLANE_, ONE_, G_, R_)                                                                                  \
     hipLaunchKernelGGL((nn_ring_kernel<PLANE_, ONE_, G_, R_>), dim3(nblocks * nprob), dim3(kBlock), 0, stream, ns, src64,        \
-                       sorted64, reinterpret_cast<const P12 *>(s12), start, g, nrm, nrm64, T64, off, r2f, idx_out, d2_out,       \
+                       sorted64, reinterpret_cast<const P12 *>(s12), start, g, tab.rows, tab.nrows, nrm, nrm64, T64, off, r2f, idx_out, d2_out,       \
                        d64_out, state_io, warm, partials, cand_count, st, nblocks, out_stride, fold)
 #define VISMA_RING_CASE(G_, R_)                                                                                                  \
     if (lanes == G_) {                                                                                                           \

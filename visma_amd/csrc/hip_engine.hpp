@@ -593,6 +593,9 @@ private:
     double ring_occ_min_ = 48.0, ring_occ_target_ = 8.0;
     void *d_occ_ = nullptr, *d_ring_tab_ = nullptr;
     int ring_tab_rings_ = 0;
+    RingTable ring_tab_{nullptr, 0};         // what a ring pass gets beside grid_ (launch_nn_grid_reduce: `ring`)
+    static int nrows_of_rings(int rings) { return (2 * rings + 1) * (2 * rings + 1); }
+    const RingTable *ring_table() const { return grid_.ring > 0 ? &ring_tab_ : nullptr; }
     double grid_occupancy_ = 0.0;            // points per occupied cell of the radius-sized table (0 = not measured)
     int grid_lanes(int nprob = 1) const
     {

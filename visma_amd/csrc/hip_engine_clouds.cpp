@@ -703,7 +703,7 @@ int HipEngine::build_grid(double max_dist)
                     ring_tab_rings_ = fine.ring;
                 }
                 grid_ = fine;
-                grid_.ring_tab = d_ring_tab_;
+                ring_tab_ = RingTable{(const RingRow *)d_ring_tab_, nrows_of_rings(fine.ring)};
                 int brc = build();
                 if (brc) return brc;
             }

@@ -369,7 +369,8 @@ int HipEngine::launch_grid_pass(const Xform64 &T64, bool plane, const double off
                                   &nblocks, lanes,
                                   prof ? (unsigned long long *)d_cand_ : nullptr, nullptr,
                                   1, 0, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
-                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1 | (persist ? persist_prio_ << 5 : 0), cert_prev(), persist, ru_state()));
+                                  exact_ ? 1 : 0, fused ? &fa : nullptr, shard_d64(), (Pt64 *)d_pos_, 1 | (persist ? persist_prio_ << 5 : 0), cert_prev(), persist, ru_state(),
+                                  ring_table()));
     if (!early) {
         // (an early persistent launch has run nothing yet: what its first pass leaves is noted when that pass has been seen)
         last_kernel_ = pass_kernel(lanes);
@@ -545,7 +546,7 @@ int HipEngine::get_correspondences(int32_t *idx, float *d2)
                                       (float *)d_d2_, (double *)d_partials_, reduce_max_blocks(),
                                       &nblocks, (last_kernel_ = pass_kernel(pass_lanes()), pass_lanes()), nullptr, nullptr, 1, 0, stream_,
                                       f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_, exact_ ? 1 : 0,
-                                      nullptr, nullptr, (Pt64 *)d_pos_, 1, cert_prev(), nullptr, ru_state()));
+                                      nullptr, nullptr, (Pt64 *)d_pos_, 1, cert_prev(), nullptr, ru_state(), ring_table()));
         pos_fresh_ = d_pos_ != nullptr;
         note_state_pass(T64);
         grid_pending_ = false;
@@ -749,7 +750,8 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
                                               profiling_ ? (unsigned long long *)d_cand_ : nullptr, st,
                                               nprob, loop_out_stride_, stream_, f64_src(), f64_sorted(), r2d_, (const Pt64 *)d_nrm64_,
                                               exact_ ? 1 : 0, fused ? &fa : nullptr, tshard_ ? shard_d64() : nullptr,
-                                              (Pt64 *)d_pos_, cert_enabled_ ? 1 : (1 | 8), nullptr, nullptr, nprob == 1 ? ru_state() : nullptr));
+                                              (Pt64 *)d_pos_, cert_enabled_ ? 1 : (1 | 8), nullptr, nullptr, nprob == 1 ? ru_state() : nullptr,
+                                              ring_table()));
                 last_kernel_ = pass_kernel(lanes);
                 pos_fresh_ = d_pos_ != nullptr;
                 prev_T_valid_ = false;                   // (the state's pose now lives in the device loop's state)

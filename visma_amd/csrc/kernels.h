@@ -265,15 +265,18 @@ struct GridParams {
     int dim[3];       // cells per axis (y and z counted in cells of edge h / sub)
     int sub;          // 1, or 2: rows (y,z) at half pitch -- 25 thinner rows instead of 9
     float hs, inv_hs; // h / sub and its reciprocal
-    int64_t ncell;
     int ring;         // 0: cells at least as large as the search radius (27-cell neighbourhoods); > 0: cells SMALLER than
                       // the radius, searched in rings of rows (grid_ring.hip) -- the largest ring a radius can reach, + 1
-    int ring_rows;    // ... entries of ring_tab: (2 ring + 1)^2
-    const void *ring_tab;   // ... the row offsets (dy, dz) around a query, nearest first (device memory; RingRow[ring_rows])
+                      // (in the 4 bytes the alignment of ncell left free: the structure every search kernel takes by value
+                      //  has the size it had -- 8 bytes more cost the persistent launch 0.25 us per pass)
+    int64_t ncell;
 };
+static_assert(sizeof(GridParams) == 56, "GridParams is a kernel argument of every search kernel");
 // one row of the ring search's visiting order: its offset from the query's row and the squared distance (in cells) that
 // every point of it is at least away from any point of the query's cell row: max(|dy| - 1, 0)^2 + max(|dz| - 1, 0)^2
 struct RingRow { short dy, dz; float base; };
+// ... the whole order for a grid with g.ring rings: (2 ring + 1)^2 entries, nearest first (device memory)
+struct RingTable { const RingRow *rows; int nrows; };
 constexpr int kRingMaxRings = 64;   // cells are enlarged until a radius spans no more rings than this
 constexpr int64_t kGridMaxCells = 64ll * 1024 * 1024;        // at sub = 1
 constexpr int64_t kGridMaxCellsFine = 256ll * 1024 * 1024;   // at sub = 2 (1 GiB table)
@@ -402,7 +405,9 @@ hipError_t launch_nn_grid_reduce(const float4 *src, int64_t ns, const float4 *so
                                  double r2d = 0.0, const Pt64 *nrm64 = nullptr, int exact = 0,
                                  const FoldArgs *fold = nullptr, double *d64_out = nullptr,
                                  Pt64 *wst_io = nullptr, int warm = 0, const Xform64 *Tprev = nullptr,
-                                 const PersistArgs *persist = nullptr, Pt64 *ru_io = nullptr);
+                                 const PersistArgs *persist = nullptr, Pt64 *ru_io = nullptr,
+                                 const RingTable *ring = nullptr);
+// ring: the visiting order of a grid with g.ring > 0 (grid_ring.hip).
 // persist: run the launch as the persistent certificate kernel (one problem, one query per lane, fused fold with
 // host publication; hipErrorInvalidValue where that does not apply -- ask coop_persist_capacity first).
 // wst_io (one Pt64 per query, laid out like idx_out): the exact searches leave their winners there (f64 point,
@@ -439,7 +444,7 @@ struct SweepArgs {
 // the f64 re-rank of the rounding band, or in f64 throughout -- same results.  state_io: per query the winner's f64 point and original index (all bits
 // set = none), read when `warm`, always written.
 hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 *src64, const Pt64 *sorted64, const float *s12, const unsigned *start,
-                          const GridParams &g, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64, const Offset64 &off,
+                          const GridParams &g, const RingTable &tab, const float4 *nrm, const Pt64 *nrm64, const Xform64 &T64, const Offset64 &off,
                           float r2f, int point_to_plane, int32_t *idx_out, float *d2_out, double *d64_out, Pt64 *state_io,
                           int warm, double *partials, unsigned long long *cand_count, const DevIcpState *st,
                           long long out_stride, const FoldArgs &fold, hipStream_t stream);
