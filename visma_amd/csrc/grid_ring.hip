@@ -38,6 +38,12 @@ namespace visma {
 namespace {
 
 // (lanes per query G and rows of the visiting order per lane and step R are template parameters: launch_nn_ring)
+#ifndef VISMA_RING_XP
+#define VISMA_RING_XP 0     /* timing experiments only (wrong results): 1 no sums / block reduction, 2 no walk, 4 no fold */
+#endif
+#ifndef VISMA_RING_ROWS_LDS
+#define VISMA_RING_ROWS_LDS 0
+#endif
 #ifndef VISMA_RING_LOCAL
 #define VISMA_RING_LOCAL 4
 #endif
@@ -50,7 +56,9 @@ namespace {
 constexpr int kRingLocal = VISMA_RING_LOCAL;    // a range up to this long is scanned by the lane that looked it up (4: measured,
                                                 // 240 -> 201 us per iteration against 16; 0 = every range by the octet: 204) ...
 constexpr int kRingV = VISMA_RING_V;                       // ... that many fp32 candidates of it in flight
-constexpr int kRingRowsLds = 512;               // rows of the visiting order kept in LDS (4 KB)
+#if VISMA_RING_ROWS_LDS
+constexpr int kRingRowsLds = 512;               // rows of the visiting order kept in LDS (4 KB; measured neutral: off)
+#endif
 constexpr int kRingU = VISMA_RING_U;                       // 32-byte candidates in flight per lane (ranges scanned by the octet)
 constexpr unsigned kRingNone = 0xFFFFFFFFu;     // no winner (the largest index: loses every tie)
 constexpr unsigned kRingState = 0xFFFFFFFEu;    // the winner is the point the state holds (no slot known)
@@ -122,11 +130,17 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
     const float mgn = 1e-3f;                               // fp32 binning of query and candidates (kGridMaxDim)
     const float reach = (float)(K + 1);                    // cells: farther outside the table than this = no partner
 
+#if VISMA_RING_ROWS_LDS
     // the head of the visiting order (what a converging registration reads) in LDS
     __shared__ RingRow s_rows[kRingRowsLds];
     for (int n = tid; n < kRingRowsLds && n < ring_rows; n += kBlock) s_rows[n] = tab[n];
     __syncthreads();
+#endif
+#if VISMA_RING_ROWS_LDS
     auto row_of = [&](int n) { return n < kRingRowsLds ? s_rows[n] : tab[n]; };
+#else
+    auto row_of = [&](int n) { return tab[n]; };        // (consecutive lanes, consecutive entries: the caches hold its head)
+#endif
 
     // ---- one query: its transformed point (pd), its winner (w8; false = none); outputs written by the octet's first lane
     auto search = [&](long long i, double (&pd)[3], Pt64 &w8) -> bool {
@@ -334,7 +348,9 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
         if (inside) {
             bool exact_walk = s12 == nullptr;
             if (!exact_walk) {
+#if !(VISMA_RING_XP & 2)
                 walk(std::true_type{});
+#endif
                 // ---- decisive?  every candidate inside the rounding band of the octet's best is ranked in f64; a lane
                 // that saw a third one inside the band does not know its position: the query is searched again in f64
                 float m = top.h0;
@@ -401,7 +417,9 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
         if (i_begin < i_end) found = search(i_begin, pd, w8);
 #pragma unroll
         for (int a = 0; a < NACC; a++) acc[a] = 0.0;
+#if !(VISMA_RING_XP & 1)
         if (found && l8 == 0) add_pair(acc, pd, w8);
+#endif
     } else {
 #pragma unroll
         for (int a = 0; a < NACC; a++) acc[a] = 0.0;
@@ -414,7 +432,9 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
             if (found && (it & (kRingG - 1)) == l8) add_pair(acc, pd, w8);
         }
     }
+#if !(VISMA_RING_XP & 1)
     block_reduce_store<NACC>(acc, partials, fold.tickets != nullptr);
+#endif
     if (cand_count) {
         // profiling only: candidates examined / rows of the cell table looked up (one slot pair per workgroup mod 4096)
         unsigned long long c = ncand, ca = nrows_seen;
@@ -429,7 +449,9 @@ __global__ __launch_bounds__(kBlock) void nn_ring_kernel(
             atomicAdd(slot + 1, ca);
         }
     }
+#if !(VISMA_RING_XP & 4)
     if (fold.tickets) fused_fold<PLANE, kBlock, false, kSolveInFold>(fold, partials, row0, lb, bpp, prob);
+#endif
 }
 
 // cells of a table that hold at least one point
