@@ -14,8 +14,11 @@ reference returned for
 A correspondence checksum is (sum of target indices, sum of (i + 1) * index mod 2^61 - 1): a swap of two
 partners or a single changed index moves the second one.
 
-    python tests/golden/gen_c4.py [--partial]      (--partial: tests/golden/c4_partial_ref.npz, the whole model
-                                                    against a scan of half of its surface: fitness ~ 0.5)
+    python tests/golden/gen_c4.py [--partial | --literal]
+                                                   (--partial: tests/golden/c4_partial_ref.npz, the whole model against
+                                                    a scan of half of its surface: fitness ~ 0.5;
+                                                    --literal: tests/golden/c4_literal_ref.npz, SURVEY 8d's literal
+                                                    ground truth with r = 0.15 m: the large-radius regime)
 Runs in THIS container only (needs oracle/_ref; ~1 minute on 8 cores); the .npz travels."""
 import os
 import sys
@@ -40,6 +43,14 @@ def clouds():
 def partial_clouds():
     """The partial-overlap variant of C4 (bench.py: `partial_overlap`): the whole model against half of its surface."""
     return synth.make_partial_pair(NS, NT, overlap=0.5)
+
+
+def literal_clouds():
+    """C4's sizes under SURVEY 8d's LITERAL ground truth (T_gt = R_y(5 deg) R_x(1 deg), t = (0.02, -0.01, 0.015)) with the
+    radius that motion needs (bench.py: `literal_T_gt`; the regime of visma_amd/csrc/grid_ring.hip: 3,200 points per
+    radius-sized cell)."""
+    src, tgt, T_gt, _ = synth.make_pair(NS, NT, motion="fixed")
+    return src, tgt, T_gt, 0.15
 
 
 def eval_pose(r):
@@ -74,13 +85,17 @@ def main():
     if "--partial" in sys.argv:
         src, tgt, T_gt, r = partial_clouds()
         name = "c4_partial_ref.npz"
+    elif "--literal" in sys.argv:
+        src, tgt, T_gt, r = literal_clouds()
+        name = "c4_literal_ref.npz"
     else:
         src, tgt, T_gt, r = clouds()
         name = "c4_ref.npz"
     out = {"ns": NS, "nt": NT, "radius": r, "iters": ITERS,
            "src_checksum": np.uint64(input_checksum(src)), "tgt_checksum": np.uint64(input_checksum(tgt))}
     t0 = time.time()
-    T0 = eval_pose(r)
+    # (--literal: a pose a tenth of the way to the ground truth -- most nearest neighbours centimetres away)
+    T0 = eval_pose(r) if "--literal" not in sys.argv else synth.make_T(synth.rot_y(np.deg2rad(0.5)), [0.002, -0.001, 0.0015])
     e = ref.evaluate_registration(src, tgt, r, T0)
     s1, s2, k = checksum(e.idx)
     assert k == e.k

@@ -178,3 +178,64 @@ def test_c4_partial_ten_iterations_equal_the_reference_run(lib, ctx, c4p, loop):
     assert e < 1e-9
     assert got.fitness_ == float(GP["ref_fitness"])
     assert abs(got.inlier_rmse_ - float(GP["ref_rmse"])) < 1e-12 * float(GP["ref_rmse"])
+
+
+# ---- SURVEY 8d's LITERAL ground truth (bench.py: `literal_T_gt`): T_gt = R_y(5 deg) R_x(1 deg), t = (0.02, -0.01, 0.015) at
+# C4's sizes with the radius that motion needs, 0.15 m -- 3,200 points per occupied radius-sized cell: the library goes to
+# the ring search over cells of a few point spacings by itself (visma_amd/csrc/grid_ring.hip, round 6)
+# (tests/golden/c4_literal_ref.npz, written by `gen_c4.py --literal` from the compiled reference).
+GL = np.load(os.path.join(HERE, "golden", "c4_literal_ref.npz"))
+
+
+@pytest.fixture(scope="module")
+def c4l():
+    src, tgt, T_gt, r = gen_c4.literal_clouds()
+    return src, tgt, r
+
+
+def test_literal_fixture_inputs_regenerate_bit_for_bit(c4l):
+    src, tgt, r = c4l
+    assert src.shape == (int(GL["ns"]), 3) and tgt.shape == (int(GL["nt"]), 3)
+    assert gen_c4.input_checksum(src) == int(GL["src_checksum"])
+    assert gen_c4.input_checksum(tgt) == int(GL["tgt_checksum"])
+    assert r == float(GL["radius"]) == 0.15
+    assert float(GL["ref_fitness"]) == 1.0 and float(GL["eval_rmse"]) > 0.02      # (nearest neighbours centimetres away)
+
+
+@pytest.mark.gpu
+def test_c4_literal_one_pass_equals_the_reference_evaluation(lib, ctx, c4l):
+    src, tgt, r = c4l
+    ctx.set_nn_mode(lib.NN_AUTO)
+    ctx.set_clouds_f64(src, tgt)
+    ctx.nn_pass(GL["eval_T"], r)
+    st = ctx.reduce()
+    idx = ctx.correspondence_index()
+    assert ctx.search_kernel_used() == "ring" and ctx.ring_search()["occupancy"] > 1000
+    s1, s2, k = gen_c4.checksum(idx)
+    assert k == int(GL["eval_k"]) == int(st[0])
+    assert (s1, s2) == (int(GL["eval_sum"]), int(GL["eval_wsum"]))
+    assert k / len(src) == float(GL["eval_fitness"])
+    rmse = np.sqrt(st[1] / st[0])
+    assert abs(rmse - float(GL["eval_rmse"])) < 1e-12 * float(GL["eval_rmse"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("loop", ["host", "device"])
+def test_c4_literal_ten_iterations_equal_the_reference_run(lib, ctx, c4l, loop):
+    """RegistrationICP from identity, criteria (0, 0, 10), every pass through the ring search (the first bounded by the
+    radius, the others by the previous winner): the reference's correspondences and, to 1e-9, its transform."""
+    src, tgt, r = c4l
+    ctx.set_nn_mode(lib.NN_AUTO)
+    ctx.set_device_loop(loop == "device")
+    ctx.set_clouds_f64(src, tgt)
+    got = ctx.run(np.eye(4), r, int(GL["iters"]), 0.0, 0.0)
+    ctx.set_device_loop(None)
+    assert ctx.nn_mode_used() == lib.NN_GRID and ctx.search_kernel_used() == "ring"
+    assert got.num_correspondences == int(GL["ref_k"])
+    s1, s2, k = gen_c4.checksum(ctx.correspondence_index())
+    assert (s1, s2, k) == (int(GL["ref_sum"]), int(GL["ref_wsum"]), int(GL["ref_k"]))
+    e = synth.rel_frobenius(got.transformation_, GL["ref_T"])
+    print("C4 literal motion vs compiled reference after %d iterations: %.3e" % (int(GL["iters"]), e))
+    assert e < 1e-9
+    assert got.fitness_ == float(GL["ref_fitness"])
+    assert abs(got.inlier_rmse_ - float(GL["ref_rmse"])) < 1e-12 * float(GL["ref_rmse"])
