@@ -1049,6 +1049,16 @@ def run_c4(R, args):
                                              "SURVEY 8d's T_gt = R_y(5 deg) R_x(1 deg), t = (0.02, -0.01, 0.015) on "
                                              "S-surf %d -> %d, radius 0.15" % (ns, nt))
             out["value_literal_T_gt"] = out["literal_T_gt"]["from_initial_pose"]["icp_iterations_per_sec"]
+            if R.world == 1 and not args.no_cpu_baseline:
+                # the compiled reference on the same pair and radius (its KD-tree does not care about the radius), one sample
+                lcb = cpu_baseline_c4(lsrc, ltgt, 0.15, args.cpu_iters, 1)
+                lc = _lib.Context(R.local_rank)
+                lc.set_clouds_f64(lsrc, ltgt)
+                lTg = lc.run(None, 0.15, 1 + args.cpu_iters, 0.0, 0.0)
+                lcb["gpu_vs_cpu_rel_frobenius"] = synth.rel_frobenius(lTg.transformation_, np.array(lcb.pop("T")))
+                lcb["gpu_search_kernel"] = lc.search_kernel_used()
+                lc.close()
+                out["literal_T_gt"]["cpu_baseline"] = lcb
             del lsrc, ltgt
             lsrc, ltgt, lT, _ = synth.make_pair(16384, 65536, motion="fixed")
             out["literal_T_gt_small"] = c4_variant(R, R.local_rank, lsrc, ltgt, 0.15, lT, args.steps,
