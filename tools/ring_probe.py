@@ -29,7 +29,7 @@ def main():
         info = c.ring_search()
         # per-pass times, profiled
         c.set_profiling(1)
-        per, cand, rows = [], [], []
+        per, cand, rows, rmse = [], [], [], []
         T = np.eye(4)
         for k in range(iters):
             c.get_timing(True)
@@ -38,6 +38,7 @@ def main():
             per.append(round(tm.get("nn_ms", 0.0) * 1e3, 1))
             cand.append(round(tm.get("grid_candidates", 0.0) / ns, 1))
             rows.append(round(tm.get("grid_candidates_27cell", 0.0) / ns, 1))
+            rmse.append(round(res.inlier_rmse_ / max(info["cell"], 1e-30), 3))
         c.set_profiling(0)
         reps = []
         for _ in range(3):
@@ -46,7 +47,7 @@ def main():
             reps.append((time.perf_counter() - t0) / iters * 1e6)
         print(json.dumps({"ns": ns, "nt": nt, "radius": r, "ring_mode": mode, "grid": info, "kernel": c.search_kernel_used(),
                           "setup_and_first_pass_ms": round(t_first * 1e3, 2), "us_per_iteration": [round(x, 1) for x in reps],
-                          "kernel_us_by_pass": per, "candidates_per_query_by_pass": cand, "rows_per_query_by_pass": rows, "fitness": res2.fitness_, "rmse": res2.inlier_rmse_,
+                          "kernel_us_by_pass": per, "candidates_per_query_by_pass": cand, "rows_per_query_by_pass": rows, "rmse_in_cells_by_pass": rmse, "fitness": res2.fitness_, "rmse": res2.inlier_rmse_,
                           "err_vs_T_gt": float(np.abs(T2 - T_gt).max())}), flush=True)
         c.close()
 

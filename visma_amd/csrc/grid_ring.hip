@@ -87,8 +87,13 @@ struct Top2 {
 
 // ONE: every octet has at most one query (the launcher's geometry): the sums are formed after the search, nothing of
 // them is live during it.
+#ifdef VISMA_RING_WAVES   /* occupancy experiments: waves per SIMD the register allocation must allow */
+#define VISMA_RING_OCCUPANCY __attribute__((amdgpu_waves_per_eu(VISMA_RING_WAVES, VISMA_RING_WAVES)))
+#else
+#define VISMA_RING_OCCUPANCY
+#endif
 template <bool PLANE, bool ONE, int kRingG, int kRingR>
-__global__ __launch_bounds__(kBlock) void nn_ring_kernel(
+__global__ __launch_bounds__(kBlock) VISMA_RING_OCCUPANCY void nn_ring_kernel(
     int ns, const Pt64 *__restrict__ src64, const Pt64 *__restrict__ sorted64, const P12 *__restrict__ s12,
     const unsigned *__restrict__ start, const GridParams g, const RingRow *__restrict__ tab, int ring_rows,
     const float4 *__restrict__ nrm, const Pt64 *__restrict__ nrm64, Xform64 T64, Offset64 off, float r2f,

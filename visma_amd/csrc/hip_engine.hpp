@@ -287,6 +287,7 @@ public:
         loop_budget_ = max_passes;
         loop_persist_passes_ = 0;
         if (persist_cooldown_ > 0) persist_cooldown_--;
+        if (ring_lanes_auto_) ring_lanes_ = 8;               // (a new loop knows nothing about how far its start is from the end)
     }
     bool loop_across_ranks_ok() const override { return persist_ranks_ok(); }
     int loop_end() override
@@ -515,7 +516,7 @@ private:
         if (grid_blocks_env_ > 0) return grid_blocks_env_;
         // (the ring search works eight lanes per query and hides its dependent trips behind other waves: one query per
         //  octet up to a million queries)
-        if (grid_.ring > 0) return (int)std::min<int64_t>(kGridMaxBlocks, std::max<int64_t>(1024, (ns_ * ring_lanes_ + kBlock - 1) / kBlock));
+        if (grid_.ring > 0) return (int)std::min<int64_t>(kGridMaxBlocks, std::max<int64_t>(1024, (ns_ * (ring_lanes() - 200) + kBlock - 1) / kBlock));
         if (ns_ <= 262144) return 1024;
         return (int)std::min<int64_t>(kGridMaxBlocks, (ns_ + kBlock - 1) / kBlock);
     }
@@ -584,8 +585,27 @@ private:
     // radius-sized table and, above ring_occ_min_ points per occupied cell, builds a finer one (ring_occ_target_ points per
     // occupied cell, surfaces assumed: occupancy ~ edge^2) that the ring kernel searches.  VISMA_ICP_RING = 0 never,
     // 1 whenever the f64 views exist and a finer table fits, unset: by occupancy.
-    int ring_lanes_ = 8;                     // lanes per query of a ring pass (VISMA_ICP_RING_LANES: 1, 2, 4, 8)
-    int ring_lanes() const { return 200 + ring_lanes_; }   // (a lanes code: G + 100 U, U unused)
+    // lanes per query of a ring pass.  Many rows to visit (first passes: the nearest neighbour is several cells away) want
+    // eight lanes per query, a converged registration (a handful of rows around the previous winner) four or two: the host
+    // loop picks from the last pass's rmse in cells (measured at C4's sizes, literal motion: pass 20 119 / 99 / 88 us with
+    // 8 / 4 / 2 lanes, pass 1 369 / 502 / 787).  VISMA_ICP_RING_LANES = 1, 2, 4, 8 fixes it.  Device-resident loops, whose
+    // statistics never reach the host between passes, keep eight.
+    int ring_lanes_ = 8;
+    bool ring_lanes_auto_ = true;
+    double ring_lanes_t84_ = 1.6, ring_lanes_t42_ = 0.8;    // rmse / cell edge below which 4 / 2 lanes take over (VISMA_ICP_RING_T84 / _T42:
+                                                            // where the per-pass times of the fixed settings cross, profiles/r06_ring_search_probe.txt)
+    int ring_lanes() const { return 200 + ((ring_lanes_auto_ && !pos_fresh_) ? 8 : ring_lanes_); }   // (a lanes code: G + 100 U, U unused)
+    void note_ring_stats(const double *stats)
+    {
+        if (!ring_lanes_auto_ || grid_.ring <= 0) return;
+        ring_lanes_ = 8;
+        if (stats[0] > 0.0 && stats[1] >= 0.0 && loop_scope_) {
+            const double cells = std::sqrt(stats[1] / stats[0]) / (double)grid_.h;
+            ring_lanes_ = cells < ring_lanes_t42_ ? 2 : (cells < ring_lanes_t84_ ? 4 : 8);
+            // (fewer lanes per query are fewer waves: only where they still fill the device -- 8,192 waves)
+            while (ring_lanes_ < 8 && ns_ * ring_lanes_ < 8192 * 64) ring_lanes_ *= 2;
+        }
+    }
     int ring_mode_ = -1;
     // (48: measured, tools/ring_policy_probe.py -- single registrations gain from ~20 points per occupied cell on (1.5x at 21,
     //  3.8x at 52, 7.6x at 84), yaw sweeps, whose far-off starts leave most queries without a partner -- the ring walk's

@@ -59,7 +59,9 @@ int HipEngine::init()
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_EARLY")) persist_early_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_SWEEP_PERSIST")) sweep_persist_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("VISMA_ICP_RING")) ring_mode_ = std::atoi(e) > 0 ? 1 : 0;
-    if (const char *e = std::getenv("VISMA_ICP_RING_LANES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) ring_lanes_ = v; }
+    if (const char *e = std::getenv("VISMA_ICP_RING_LANES")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { ring_lanes_ = v; ring_lanes_auto_ = false; } }
+    if (const char *e = std::getenv("VISMA_ICP_RING_T84")) { const double v = std::atof(e); if (v >= 0.0) ring_lanes_t84_ = v; }
+    if (const char *e = std::getenv("VISMA_ICP_RING_T42")) { const double v = std::atof(e); if (v >= 0.0) ring_lanes_t42_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_RING_OCCUPANCY")) { const double v = std::atof(e); if (v >= 1.0) ring_occ_min_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_RING_TARGET")) { const double v = std::atof(e); if (v >= 1.0 && v <= 1024.0) ring_occ_target_ = v; }
     if (const char *e = std::getenv("VISMA_ICP_PERSIST_RANKS")) persist_ranks_ = std::atoi(e) != 0;

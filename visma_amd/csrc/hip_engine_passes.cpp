@@ -321,6 +321,7 @@ int HipEngine::reduce(const Mat4 &Tc, bool plane, const double offset[3], double
         const unsigned long long v = g[2 * i];
         std::memcpy(&stats[i], &v, sizeof(double));
     }
+    note_ring_stats(stats);                                  // (ring passes: lanes per query of the next one)
     return sess_live_ ? VISMA_ICP_OK : maybe_collect_timing();   // (no stream synchronisation while a session waits for the host)
 }
 
@@ -575,6 +576,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
     if (sess_live_) { int src = end_session(); if (src) return src; }
     if (nprob < 1) { err_ = "nprob < 1"; return VISMA_ICP_ERR_INVALID; }
     if (!d_src_ || !d_tgt_) { err_ = "clouds not set"; return VISMA_ICP_ERR_STATE; }
+    if (ring_lanes_auto_) ring_lanes_ = 8;                   // (no statistics reach the host between the passes of this loop)
     last_was_batch_ = false;
     if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
     int rc = choose_mode(lp.max_dist);
