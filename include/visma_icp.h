@@ -453,7 +453,8 @@ VISMA_ICP_API int visma_icp_get_persistent_info(visma_icp_ctx *ctx, visma_icp_pe
  * best candidate so far and, after the first pass, by the previous winner (grid_ring.hip): the same correspondences, bit
  * for bit; the cost of a query follows the number of points nearer than its nearest neighbour, not the radius.
  *  visma_icp_set_ring_search(ctx, mode): -1 (default) by the occupancy of the radius-sized cells (>= 48 points per
- *    occupied cell; VISMA_ICP_RING_OCCUPANCY), 0 never, 1 whenever the f64 views exist and a finer table fits (also
+ *    occupied cell for yaw sweeps, whose far-off starts leave most queries without a partner -- the ring walk's worst
+ *    case --, >= 20 for one registration at a time; VISMA_ICP_RING_OCCUPANCY sets the first), 0 never, 1 whenever the f64 views exist and a finer table fits (also
  *    VISMA_ICP_RING=0/1 when the context is created).  Takes effect at the next grid build (new target or radius).
  *  visma_icp_get_ring_search(ctx, ...): what the current grid is: *rings > 0 = ring search with that many rings at most,
  *    *cell = the cell edge, *occupancy = points per occupied radius-sized cell as counted (0 = not counted).  Any pointer may

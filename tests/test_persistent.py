@@ -20,6 +20,8 @@ def pair_of_contexts(src, tgt, normals=False):
     nrm = persist.estimate_normals(tgt, knn=12) if normals else None
     for c in (per_pass, persist):
         c.set_nn_mode(_lib.NN_GRID)
+        c.set_ring_search(0)       # (these tests are about the persistent launch of the certificate kernel: a larger radius --
+                                   #  20 points per radius-sized cell and more -- would send a registration to grid_ring.hip)
         c.set_clouds_f64(src, tgt)
         if normals:
             c.set_target_normals_f64(nrm)

@@ -114,6 +114,32 @@ def test_the_occupancy_rule_switches_by_itself(lib):
     assert np.array_equal(c.correspondence_index(), idx_ring)
 
 
+def test_between_the_thresholds_the_table_follows_the_caller(lib):
+    """20 <= points per occupied radius-sized cell < 48: one registration at a time takes the ring search, a yaw sweep
+    radius-sized cells (its far-off starts leave most queries without a partner); a context that alternates re-plans
+    three times, the third time for good: radius-sized cells for that target.  Results do not depend on any of it."""
+    src, tgt, T_gt, _ = synth.make_pair(20000, 262144, motion="fixed")
+    r = 0.05
+    c = _lib.Context(0)
+    c.set_nn_mode(lib.NN_GRID)
+    c.set_clouds_f64(src, tgt)
+    a = c.run(None, r, 8)
+    info = c.ring_search()
+    assert 20 <= info["occupancy"] < 48 and info["rings"] >= 2 and c.search_kernel_used() == "ring", info
+    sw = c.run_yaw_sweep(4, r, 6)
+    assert c.ring_search()["rings"] == 0 and c.search_kernel_used() != "ring"
+    b = c.run(None, r, 8)
+    assert c.ring_search()["rings"] >= 2 and c.search_kernel_used() == "ring"
+    assert np.abs(a.transformation_ - b.transformation_).max() < 1e-12
+    sw2 = c.run_yaw_sweep(4, r, 6)                               # (the third change of caller: settled on ...)
+    kept = c.ring_search()["rings"]
+    d = c.run(None, r, 8)
+    assert c.ring_search()["rings"] == kept == 0                  # (... radius-sized cells)
+    assert np.abs(a.transformation_ - d.transformation_).max() < 1e-10
+    for x, y in zip(sw[2], sw2[2]):
+        assert x.iterations == y.iterations and np.abs(x.transformation_ - y.transformation_).max() < 1e-10
+
+
 @pytest.mark.parametrize("loop", ["host", "device"])
 def test_registrations_agree(lib, loop):
     """A whole registration from the literal motion's start: ring search == radius cells to rounding, and the literal

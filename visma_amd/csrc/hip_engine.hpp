@@ -611,6 +611,20 @@ private:
     //  3.8x at 52, 7.6x at 84), yaw sweeps, whose far-off starts leave most queries without a partner -- the ring walk's
     //  worst case: every row of the radius ball -- lose up to 3x below ~50 and gain 1.8-2x from there)
     double ring_occ_min_ = 48.0, ring_occ_target_ = 8.0;
+    // ... and ONE registration at a time (host loop, device loop, the per-pass API) from 20 on: between the two thresholds the
+    // table depends on who asks.  caller_sweep_: the pass about to run belongs to a sweep over several starts;
+    // ring_for_sweep_: what the current table was planned for.  A context whose callers alternate re-plans at most three
+    // times per target (1 ms each at 4 M points): the third time for good, to radius-sized cells.
+    double ring_occ_min_single_ = 20.0;
+    bool caller_sweep_ = false, ring_for_sweep_ = false;
+    int ring_flips_ = 0;
+    double ring_threshold() const { return (caller_sweep_ || ring_flips_ >= 3) ? ring_occ_min_ : std::min(ring_occ_min_single_, ring_occ_min_); }
+    bool ring_replan_needed() const
+    {
+        if (ring_mode_ != -1 || !(grid_occupancy_ > 0.0) || ring_flips_ >= 3) return false;   // fixed / never counted / settled
+        if (!(grid_occupancy_ >= ring_occ_min_single_ && grid_occupancy_ < ring_occ_min_)) return false;   // both callers agree
+        return ring_for_sweep_ != caller_sweep_;
+    }
     void *d_occ_ = nullptr, *d_ring_tab_ = nullptr;
     int ring_tab_rings_ = 0;
     RingTable ring_tab_{nullptr, 0};         // what a ring pass gets beside grid_ (launch_nn_grid_reduce: `ring`)

@@ -571,6 +571,7 @@ int HipEngine::ensure_target(int64_t nt)
     HIP_TRY(launch_fill_inf((float4 *)d_tgt_ + nt, nt_pad_ - nt, stream_));
     nt_ = nt;
     grid_valid_ = false;
+    ring_flips_ = 0;
     have_pass_ = false;
     return VISMA_ICP_OK;
 }
@@ -596,6 +597,11 @@ int HipEngine::choose_mode(double max_dist)
     {
         int rc = ensure_f64_views();
         if (rc) return rc;
+    }
+    if (grid_valid_ && grid_radius_ == max_dist && ring_replan_needed()) {
+        // (between the two occupancy thresholds a single registration wants the ring search, a sweep radius-sized cells)
+        ring_flips_++;
+        grid_valid_ = false;
     }
     if (!(grid_valid_ && grid_radius_ == max_dist)) {
         int rc = build_grid(max_dist);
@@ -683,6 +689,7 @@ int HipEngine::build_grid(double max_dist)
                                nn_mode_ != VISMA_ICP_NN_BRUTE;
     const double occ_guess = (double)nt_ / (double)std::max<int64_t>(grid_.ncell, 1) *
                              (double)std::max(grid_.dim[0], std::max(grid_.dim[1], grid_.dim[2]));
+    ring_for_sweep_ = caller_sweep_;
     if (ring_possible && (ring_mode_ > 0 || occ_guess >= ring_occ_min_)) {
         if (!d_occ_) HIP_TRY(hipMalloc(&d_occ_, sizeof(unsigned long long)));
         HIP_TRY(hipMemsetAsync(d_occ_, 0, sizeof(unsigned long long), stream_));
@@ -691,7 +698,7 @@ int HipEngine::build_grid(double max_dist)
         HIP_TRY(hipMemcpyAsync(&occupied, d_occ_, sizeof(occupied), hipMemcpyDeviceToHost, stream_));
         HIP_TRY(hipStreamSynchronize(stream_));
         grid_occupancy_ = occupied ? (double)nt_ / (double)occupied : 0.0;
-        if (grid_occupancy_ > ring_occ_target_ && (ring_mode_ > 0 || grid_occupancy_ >= ring_occ_min_)) {
+        if (grid_occupancy_ > ring_occ_target_ && (ring_mode_ > 0 || grid_occupancy_ >= ring_threshold())) {
             // surfaces: the occupancy falls with the square of the edge
             const double cell = (double)grid_.h * std::sqrt(ring_occ_target_ / grid_occupancy_);
             const GridParams fine = grid_plan_ring(mn, mx, max_dist, cell, kGridMaxCells);

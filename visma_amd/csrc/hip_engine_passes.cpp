@@ -26,6 +26,7 @@ int HipEngine::nn_pass(const Mat4 &Tc, double max_dist)
     for (int i = 0; i < 12; i++) { T32_.m[i] = (float)Tc.m[i]; T64_last_.m[i] = Tc.m[i]; }
     r2f_ = (float)(max_dist * max_dist);
     r2d_ = (double)r2f_;                                     // (double)(float)(r*r): KDTreeFlann.cpp:184-185
+    caller_sweep_ = false;
     int rc = choose_mode(max_dist);
     if (rc) return rc;
     view_offset_ = 0;
@@ -579,6 +580,7 @@ int HipEngine::run_loop(const LoopParams &lp, const Mat4 *Tc0s, int nprob, LoopR
     if (ring_lanes_auto_) ring_lanes_ = 8;                   // (no statistics reach the host between the passes of this loop)
     last_was_batch_ = false;
     if (lp.plane && !d_nrm_) { err_ = "point-to-plane needs target normals"; return VISMA_ICP_ERR_STATE; }
+    caller_sweep_ = nprob > 1;
     int rc = choose_mode(lp.max_dist);
     if (rc) return rc;
     // Many problems advancing together fill the chip whatever the cloud size: AUTO then
