@@ -16,6 +16,7 @@ print("checker:", type(o).__name__)
 ctx = _lib.Context(0)
 ctx.set_search_precision(sys.argv[3] if len(sys.argv) > 3 else "f32")      # f32 | auto | f64
 errs = []
+kernels = {}
 for it in range(N):
     ns = int(rng.integers(500, 8000)); nt = int(rng.integers(2000, 40000))
     src, tgt, T_gt, r = synth.make_pair(ns, nt, seed_t=int(rng.integers(1 << 30)), seed_s=int(rng.integers(1 << 30)),
@@ -30,7 +31,8 @@ for it in range(N):
     got = ctx.run(init, r, iters, 1e-6, 1e-6)
     e = synth.rel_frobenius(got.transformation_, want.T)
     errs.append(e)
+    kernels[ctx.search_kernel_used()] = kernels.get(ctx.search_kernel_used(), 0) + 1
     if e > 1e-5 or got.num_correspondences != want.k:
         print("it=%d ns=%d nt=%d r=%.4g iters=%d/%d: rel %.3g  K %d vs %d" % (it, ns, nt, r, got.iterations, iters, e, got.num_correspondences, want.k))
 errs = np.array(errs)
-print("N=%d  median %.2g  p99 %.2g  max %.2g  (tolerance 1e-5)" % (N, np.median(errs), np.quantile(errs, 0.99), errs.max()))
+print("N=%d  median %.2g  p99 %.2g  max %.2g  (tolerance 1e-5); search kernel of the last pass: %s" % (N, np.median(errs), np.quantile(errs, 0.99), errs.max(), kernels))
