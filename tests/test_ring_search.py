@@ -206,3 +206,30 @@ def test_literal_ground_truth_against_the_oracle(lib, oracle):
     res = c.run(None, r, 30)
     want = oracle.registration_icp(src, tgt, r, None, 30)
     assert np.abs(res.transformation_ - want.T).max() < 1e-9 and res.iterations == want.iters
+
+
+def test_empty_and_tiny_clouds_with_the_ring_search_asked_for(lib):
+    """An empty source, an empty target, one point against one point: nothing to match or one pair, whatever is asked for."""
+    src, tgt, _, _ = synth.make_pair(2000, 30000, motion="fixed")
+    c = _lib.Context(0)
+    c.set_ring_search(1)
+    c.set_nn_mode(lib.NN_GRID)
+    c.set_clouds_f64(np.zeros((0, 3)), tgt)
+    c.nn_pass(np.eye(4), 0.2)
+    assert c.reduce()[0] == 0.0
+    c.set_clouds_f64(src, np.zeros((0, 3)))
+    c.nn_pass(np.eye(4), 0.2)
+    assert c.reduce()[0] == 0.0 and np.all(c.correspondence_index() == -1)
+    c.set_clouds_f64(src[:1], tgt[:1] * 0.0 + src[:1] + 0.01)
+    c.nn_pass(np.eye(4), 0.2)
+    st = c.reduce()
+    assert st[0] == 1.0 and c.correspondence_index()[0] == 0 and abs(st[1] - 3 * 0.01 ** 2) < 1e-12
+    # and a registration over a real pair afterwards is the one a fresh context computes
+    c.set_clouds_f64(src, tgt)
+    a = c.run(None, 0.2, 5)
+    d = _lib.Context(0)
+    d.set_ring_search(1)
+    d.set_nn_mode(lib.NN_GRID)
+    d.set_clouds_f64(src, tgt)
+    b = d.run(None, 0.2, 5)
+    assert c.search_kernel_used() == "ring" and np.array_equal(a.transformation_, b.transformation_)

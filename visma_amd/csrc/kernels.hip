@@ -801,7 +801,7 @@ hipError_t launch_reduce(const float4 *src, int64_t ns, const float4 *tgt,
         if (pend.count) {
             // the undecided queries: two sweeps of the target by all workgroups, then their moments into a
             // second set of partial rows (the fold sums 2 * nblocks rows)
-            const int rblocks = (int)std::min<int64_t>(2048, (ex->nt + 255) / 256);
+            const int rblocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (ex->nt + 255) / 256));   // (an empty target: one idle workgroup)
             hipLaunchKernelGGL(brute_rescan_kernel<0>, dim3(rblocks), dim3(256), 0, stream, tgt, ex->tgt64, (int)ex->nt, pend, st);
             hipLaunchKernelGGL(brute_rescan_kernel<1>, dim3(rblocks), dim3(256), 0, stream, tgt, ex->tgt64, (int)ex->nt, pend, st);
             double *p2 = partials + (size_t)nblocks * kReduceAcc;
