@@ -64,6 +64,18 @@ VISMA_ICP_API int visma_icp_test_stall_command(visma_icp_ctx *ctx, int nth, doub
  * context was created.  Either pointer may be NULL. */
 VISMA_ICP_API int visma_icp_get_sweep_info(visma_icp_ctx *ctx, double *launches, double *aborts);
 
+/* (round 6, host logic of the ring search -- visma_amd/csrc/grid_ring.hip --, no device needed)
+ * visma_icp_plan_ring_grid: the cell table the library would plan for a target with bounding box [mn, mx], search radius
+ *   max_dist and a wished cell edge `cell` < max_dist: cells per axis, the edge it ends up with (grown until the table fits
+ *   64 M cells, 2048 per axis and 64 rings), *rings = the largest ring of rows a radius can reach + 1 (0: the ordinary plan
+ *   with radius-sized cells -- the wished edge was not smaller than the radius).
+ * visma_icp_ring_visiting_order: the rows' visiting order for `rings` rings, (2 rings + 1)^2 entries nearest first: offsets
+ *   (dy, dz) and base = max(|dy| - 1, 0)^2 + max(|dz| - 1, 0)^2; writes min(capacity, *nrows) entries.  Any pointer may be NULL.
+ * Replace nothing in the reference. */
+VISMA_ICP_API int visma_icp_plan_ring_grid(const float mn[3], const float mx[3], double max_dist, double cell, int dims[3],
+                                           double *cell_out, int *rings);
+VISMA_ICP_API int visma_icp_ring_visiting_order(int rings, int capacity, short *dy, short *dz, float *base, int *nrows);
+
 /* Compile-time tile constants, for roofline accounting: S_TILE source points
  * per workgroup, target chunk staged per LDS fill, workgroup size. */
 VISMA_ICP_API int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block);

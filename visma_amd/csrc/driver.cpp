@@ -1089,6 +1089,29 @@ int visma_icp_get_timing_sized(visma_icp_ctx *ctx, void *out, size_t struct_size
     return VISMA_ICP_OK;
 }
 
+int visma_icp_plan_ring_grid(const float mn[3], const float mx[3], double max_dist, double cell, int dims[3], double *cell_out, int *rings)
+{
+    if (!mn || !mx) return VISMA_ICP_ERR_INVALID;
+    const visma::GridParams g = visma::grid_plan_ring(mn, mx, max_dist, cell, visma::kGridMaxCells);
+    if (dims) for (int a = 0; a < 3; a++) dims[a] = g.dim[a];
+    if (cell_out) *cell_out = (double)g.h;
+    if (rings) *rings = g.ring;
+    return VISMA_ICP_OK;
+}
+
+int visma_icp_ring_visiting_order(int rings, int capacity, short *dy, short *dz, float *base, int *nrows)
+{
+    const std::vector<visma::RingRow> rows = visma::ring_visiting_order(rings);
+    if (nrows) *nrows = (int)rows.size();
+    if (rows.empty()) return VISMA_ICP_ERR_INVALID;
+    for (int k = 0; k < (int)rows.size() && k < capacity; k++) {
+        if (dy) dy[k] = rows[k].dy;
+        if (dz) dz[k] = rows[k].dz;
+        if (base) base[k] = rows[k].base;
+    }
+    return VISMA_ICP_OK;
+}
+
 int visma_icp_get_tile_config(int *s_tile, int *t_chunk, int *block)
 {
     if (s_tile) *s_tile = kSTile;

@@ -505,11 +505,11 @@ hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 
 // The visiting order of the rows around a query for `rings` rings: every offset (dy, dz) of the square, sorted by the squared
 // distance (in cells) that a point of the row is at least away from ANY point of the query's own row of cells -- the same
 // for every query, so the order is a table.  Ties: by |dy| + |dz|, then dy, then dz (any fixed order would do).
-hipError_t build_ring_table(int rings, void **d_tab, int *nrows)
+std::vector<RingRow> ring_visiting_order(int rings)
 {
-    if (rings < 1 || rings > kRingMaxRings || !d_tab || !nrows) return hipErrorInvalidValue;
-    const int side = 2 * rings + 1;
     std::vector<RingRow> rows;
+    if (rings < 1 || rings > kRingMaxRings) return rows;
+    const int side = 2 * rings + 1;
     rows.reserve((size_t)side * side);
     for (int dz = -rings; dz <= rings; dz++)
         for (int dy = -rings; dy <= rings; dy++) {
@@ -523,6 +523,13 @@ hipError_t build_ring_table(int rings, void **d_tab, int *nrows)
         if (a.dy != b.dy) return a.dy < b.dy;
         return a.dz < b.dz;
     });
+    return rows;
+}
+
+hipError_t build_ring_table(int rings, void **d_tab, int *nrows)
+{
+    if (rings < 1 || rings > kRingMaxRings || !d_tab || !nrows) return hipErrorInvalidValue;
+    const std::vector<RingRow> rows = ring_visiting_order(rings);
     void *d = nullptr;
     hipError_t e = hipMalloc(&d, sizeof(RingRow) * rows.size());
     if (e != hipSuccess) return e;

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace visma {
 
@@ -450,6 +451,8 @@ hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 
                           long long out_stride, const FoldArgs &fold, hipStream_t stream);
 // the visiting order of a grid with g.ring = rings (a new device buffer the caller owns: hipFree); *nrows = (2 rings + 1)^2
 hipError_t build_ring_table(int rings, void **d_tab, int *nrows);
+// ... the same order on the host (empty for rings outside 1 .. kRingMaxRings)
+std::vector<RingRow> ring_visiting_order(int rings);
 // *out (device, zeroed by the caller) += the number of non-zero entries of count[0 .. n)
 hipError_t launch_count_occupied(const unsigned *count, int64_t n, unsigned long long *out, hipStream_t stream);
 int nn_wave_sweep_capacity();
