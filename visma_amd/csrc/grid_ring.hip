@@ -8,8 +8,9 @@
 //
 // Here the cell edge is decoupled from the radius (GridParams::ring > 0: cells of a few point spacings, chosen by
 // HipEngine::build_grid from the occupancy of the radius-sized grid) and a query visits the rows (y, z) of the cell table
-// in RINGS around its own row, nearest ring first, each row only over the x-extent that can still hold a candidate nearer
-// than the best so far, and stops when the next ring lies beyond the best.  The best so far starts at the radius -- or, for
+// around its own row NEAREST FIRST -- ring by ring; the order is the same for every query, so it is a table of offsets
+// sorted by their lower bound (ring_visiting_order) --, each row only over the x-extent that can still hold a candidate nearer
+// than the best so far, and stops when the next row's bound lies beyond the best.  The best so far starts at the radius -- or, for
 // every pass after the first, at the distance to the previous pass's winner under the new transform (the state of the
 // cooperative kernels, same buffer), so a converging registration visits the few cells around its winner.  The cost of a
 // query follows the number of target points nearer than its nearest neighbour's distance, not the radius.
@@ -23,9 +24,11 @@
 // ranks in fp32 and keeps, per lane, the two best and the value of the third; the candidates inside the rounding band of
 // the octet's best (nn_grid_reduce_kernel<HYB>'s band) are then ranked in f64, and a lane that saw a third candidate inside
 // the band sends its query through the f64 walk -- the result is the f64 walk's either way.
-// Eight lanes work on one query: each looks up two rows of the ring sequence per step and scans their (short) x-ranges
+// G lanes work on one query (eight; four or two once a host loop's registration has converged to within a cell or so:
+// HipEngine::note_ring_stats): each looks up R rows of the visiting order per step and scans their (short) x-ranges
 // itself -- sixteen independent streams per query; a long range (first rows of a cold pass, rows inside a surface) is
-// scanned by the octet, eight candidates per step; the partial minima meet in a butterfly on (d2, index).
+// scanned by the group, G candidates per step and two in flight; the partial minima meet in a butterfly on (d2, index).
+// One query per lane group wherever the launch may have that many workgroups: the sums are formed after the search.
 // Statistics, outputs, fold: as nn_grid_reduce_kernel (same accumulators, block_reduce_store, fused_fold).
 #include "device_common.h"
 
