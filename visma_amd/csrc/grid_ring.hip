@@ -499,7 +499,10 @@ hipError_t launch_nn_ring(int lanes, int nblocks, int nprob, int ns, const Pt64 
         if (point_to_plane) { if (one) VISMA_RING_LAUNCH(true, true, G_, R_); else VISMA_RING_LAUNCH(true, false, G_, R_); }     \
         else { if (one) VISMA_RING_LAUNCH(false, true, G_, R_); else VISMA_RING_LAUNCH(false, false, G_, R_); }                  \
     }
-    VISMA_RING_CASE(8, 2) VISMA_RING_CASE(4, 4) VISMA_RING_CASE(2, 4) VISMA_RING_CASE(1, 8)
+#ifndef VISMA_RING_R8
+#define VISMA_RING_R8 2     /* rows of the visiting order per lane and step with eight lanes per query (A/B: 1, 3, 4) */
+#endif
+    VISMA_RING_CASE(8, VISMA_RING_R8) VISMA_RING_CASE(4, 4) VISMA_RING_CASE(2, 4) VISMA_RING_CASE(1, 8)
 #undef VISMA_RING_CASE
 #undef VISMA_RING_LAUNCH
     return hipGetLastError();
